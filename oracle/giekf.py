@@ -1,0 +1,125 @@
+"""ORACLE (test infrastructure only -- never imported by the product path).
+
+Line-by-line CPU restatement of the reference's globally-iterated EKF filter + RTS smoother.
+PARITY UNPINNED (no reference fixtures, no MATLAB); self-pinned by tests/test_oracle_selfpins.py
+(Jacobian vs finite differences; linear measurement model == Kalman filter).
+
+Follows (file:line under /root/reference/matlab):
+  ekf_update1.m:103-109, iekf_update1.m:110-117
+  gf_giekf_modulator_nmf.m:55-106 (set-up, balance ON), :108-291 (predict mode), :445-459 (h, Jacobian)
+  gf_giekf_modulator_nmf_constraints.m:144-327 (P reset every global iteration, :163-168),
+      :492-502 (corrected Jacobian  dy = partials'*H, used for BOTH variants here, SURVEY C-13)
+The nlml/gradient mode (:296-439) is not restated.
+"""
+import numpy as np
+from . import ss as ssm
+from .gf_ep import merge_inputs, rts_step, assemble
+
+
+def linkf(x):
+    return np.log(1.0 + np.exp(x))
+
+
+def dlinkf(x):
+    return np.exp(x) / (np.exp(x) + 1.0)
+
+
+def funh(x, H, D, N, W):
+    """gf_giekf_modulator_nmf.m:445-449."""
+    return float((H[:D] @ x) @ W @ linkf(H[D:D + N] @ x))
+
+
+def funhd(x, H, D, N, W):
+    """gf_giekf_modulator_nmf_constraints.m:497-502 (dy = partials'*H)."""
+    g = H[D:D + N] @ x
+    partials = np.concatenate([W @ linkf(g), ((H[:D] @ x) @ W) * dlinkf(g)])
+    return partials @ H
+
+
+def ekf_update1(M, P, y, Hfun, R, hfun):
+    """ekf_update1.m:103-109 (scalar measurement)."""
+    H_ = Hfun(M); MU = hfun(M)
+    S = R + H_ @ P @ H_
+    K = P @ H_ / S
+    M = M + K * (y - MU)
+    P = P - np.outer(K, K) * S
+    return M, P, K, MU, S
+
+
+def iekf_update1(M, P, y, Hfun, R, hfun, iters=5):
+    """iekf_update1.m:110-117 (not the textbook IEKF -- reproduced as written)."""
+    for _ in range(iters):
+        H_ = Hfun(M); MU = hfun(M)
+        S = R + H_ @ P @ H_
+        K = P @ H_ / S
+        M = M + K * (y - MU)
+    P = P - np.outer(K, K) * S
+    return M, P, K, MU, S
+
+
+def run_predict(model, yall, D, N, g_iter, l_iter, constraints_variant=False):
+    """gf_giekf_modulator_nmf.m:108-291."""
+    A, Q, H, Pinf, Wnmf, lik_param = (model[k] for k in ('A', 'Q', 'H', 'Pinf', 'Wnmf', 'lik_param'))
+    S = A.shape[0]; T = yall.size
+    sigma2 = float(np.exp(np.ravel(lik_param)[0]))
+    MS = np.zeros((S, T)); PS = np.zeros((T, S, S))
+    hfun = lambda x: funh(x, H, D, N, Wnmf)
+    Hfun = lambda x: funhd(x, H, D, N, Wnmf)
+    counters = {}
+    mdP = np.zeros(g_iter)
+    m = None; P = None
+    for itt in range(1, g_iter + 1):
+        if itt == 1:
+            m = np.zeros(S); P = Pinf.copy()
+        if constraints_variant:
+            P = Pinf.copy()                                   # _constraints.m:168
+        maxDiffP = 0.0; PSP = PS.copy()
+        for k in range(T):
+            if k > 0:
+                m = A @ m; P = A @ P @ A.T + Q
+            if not np.isnan(yall[k]):
+                m, P, *_ = iekf_update1(m, P, yall[k], Hfun, sigma2, hfun, l_iter)
+            MS[:, k] = m; PS[k] = P
+        MF = MS.copy(); PF = PS.copy()
+        for k in range(T - 2, -1, -1):
+            m, P = rts_step(A, Q, PS[k], MS[:, k], m, P, counters)
+            MS[:, k] = m; PS[k] = P
+            maxDiffP = max(maxDiffP, np.max(np.abs(H @ PSP[k] @ H.T - H @ P @ H.T)))
+        mdP[itt - 1] = maxDiffP
+    Eft = H @ MS
+    Varft = np.stack([np.diag(H @ PS[k] @ H.T) for k in range(T)], axis=1)
+    return dict(Eft=Eft, Varft=Varft, MS=MS, PS=PS, MF=MF, PF=PF, maxDiffP=mdP, counters=counters)
+
+
+def gf_giekf_modulator_nmf(w, x, y, ss, mom, xt, kernel1, kernel2, num_lik_params, D, N, g_iter, l_iter,
+                           GradObj='off', nargout=6):
+    """gf_giekf_modulator_nmf.m:1-2 (predict mode)."""
+    yall, return_ind = merge_inputs(x, y, xt)
+    lik_param, param1, param2, Wnmf = ssm.unpack_log(w, num_lik_params, D, N)
+    model = assemble(lik_param, param1, param2, Wnmf, kernel1, kernel2, balance=True)
+    if xt is None or np.size(xt) == 0:
+        raise NotImplementedError('EKF nlml/gradient mode not restated (SURVEY f-4)')
+    res = run_predict(model, yall, D, N, g_iter, l_iter, constraints_variant=False)
+    return _outputs(res, return_ind, nargout)
+
+
+def gf_giekf_modulator_nmf_constraints(w, x, y, ss, mom, xt, kernel1, kernel2, num_lik_params, D, N, g_iter, l_iter,
+                                       constraints, w_fixed, tune_hypers, GradObj='off', nargout=6):
+    """gf_giekf_modulator_nmf_constraints.m:1-2 (predict mode)."""
+    yall, return_ind = merge_inputs(x, y, xt)
+    lik_param, param1, param2, Wnmf = ssm.unpack_constraints(w, w_fixed, tune_hypers, constraints, num_lik_params, D, N)
+    model = assemble(lik_param, param1, param2, Wnmf, kernel1, kernel2, balance=True)
+    if xt is None or np.size(xt) == 0:
+        raise NotImplementedError('EKF nlml/gradient mode not restated (SURVEY f-4)')
+    res = run_predict(model, yall, D, N, g_iter, l_iter, constraints_variant=True)
+    return _outputs(res, return_ind, nargout)
+
+
+def _outputs(res, return_ind, nargout):
+    Eft = res['Eft'][:, return_ind]; Varft = res['Varft'][:, return_ind]
+    if nargout <= 1:
+        return Eft
+    if nargout <= 3:
+        return Eft, Varft
+    lb = Eft - 1.96 * np.sqrt(Varft); ub = Eft + 1.96 * np.sqrt(Varft)
+    return Eft, Varft, None, lb, ub, res

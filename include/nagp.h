@@ -1,0 +1,181 @@
+/*
+ * nagp.h -- C ABI of libnagp.so: MI355X-native (gfx950, HIP) Kalman-filter / RTS-smoother /
+ * Power-EP / iterated-EKF inference loops of the GT-NMF audio model.
+ *
+ * The reference (AaltoML/nonstationary-audio-gp) is 100 % MATLAB and has no FFI; the entry points
+ * below are what a MEX gateway (or ctypes / any FFI) binds to replace the per-time-step loops of
+ *
+ *   nagp_*_KIND_GF_EP   -> matlab/gf_ep_modulator.m:113-283 (predict) / :383-522 (nlml)
+ *                          matlab/gf_ep_modulator_nmf.m:113-283 / :384-522
+ *                          matlab/gf_ep_modulator_nmf_constraints.m:148-334 / :436-573
+ *   nagp_*_KIND_IHGP    -> matlab/ihgp_ep_modulator_nmf.m:223-454,
+ *                          matlab/ihgp_ep_modulator_nmf_constraints.m:257-480
+ *   nagp_*_KIND_GIEKF   -> matlab/gf_giekf_modulator_nmf.m:126-221 (+ iekf_update1.m:110-117,
+ *                          ekf_update1.m:106-109), matlab/gf_giekf_modulator_nmf_constraints.m:162-257
+ *   mom callbacks       -> matlab/likModulatorPower.m:25-100, likModulatorNMFPower.m:28-87,
+ *                          experiments/likModulatorPreCalcwn.m:28-86 (selected by lik_kind)
+ *
+ * Everything outside those loops (parameter unpacking, ss_modulators*, balance, lti_disc, DARE
+ * tables, sigma-point tables) stays on the host side of the boundary and arrives here as plain
+ * arrays.  All matrices are column-major IEEE doubles (MATLAB layout); all pointers are HOST
+ * pointers owned by the caller; inputs are read-only; outputs are caller-allocated and may be
+ * NULL (= not wanted).  No exceptions cross the ABI: every function returns 0 or a negative
+ * nagp_status.  Single caller thread per plan; safe to call repeatedly from a long-lived process.
+ */
+#ifndef NAGP_H
+#define NAGP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NAGP_VERSION 100 /* 0.1.0 */
+
+typedef enum nagp_status {
+  NAGP_OK = 0,
+  NAGP_EINVAL = -1,       /* bad argument / inconsistent sizes */
+  NAGP_EUNSUPPORTED = -2, /* shape outside what the kernels handle (e.g. block size > 4) */
+  NAGP_EHIP = -3,         /* HIP runtime error (see nagp_last_error) */
+  NAGP_ENOMEM = -4,       /* device memory exhausted */
+  NAGP_ENODEVICE = -5,    /* no gfx950 device visible */
+  NAGP_ENOTPD = -6        /* Cholesky failed even after the jitter retry */
+} nagp_status;
+
+typedef enum nagp_kind { NAGP_KIND_GF_EP = 0, NAGP_KIND_IHGP = 1, NAGP_KIND_GIEKF = 2 } nagp_kind;
+typedef enum nagp_mode { NAGP_MODE_PREDICT = 0, NAGP_MODE_NLML = 1 } nagp_mode;
+/* mom callbacks of the reference, by file */
+typedef enum nagp_lik {
+  NAGP_LIK_POWER = 0,          /* likModulatorPower.m        (W = I, jitter 1e-8)  */
+  NAGP_LIK_POWER_NMF = 1,      /* likModulatorNMFPower.m     (jitter 1e-10, pEP_const = 1) */
+  NAGP_LIK_POWER_NMF_SQRT = 2  /* experiments/likModulatorPreCalcwn.m (sqrt amplitude, true pEP_const) */
+} nagp_lik;
+/* link functions seen in the drivers: log(1+exp(g-shift)) and exp(g) */
+typedef enum nagp_link { NAGP_LINK_SOFTPLUS = 0, NAGP_LINK_EXP = 1 } nagp_link;
+
+/* flags (nagp_opts.flags) */
+#define NAGP_FLAG_IHGP_CONSTRAINTS 0x1u /* ihgp_ep_modulator_nmf_constraints.m: R starts at 0, no abs(Varft) */
+#define NAGP_FLAG_EKF_RESET_P      0x2u /* gf_giekf_modulator_nmf_constraints.m:168: P=Pinf every global iteration */
+#define NAGP_FLAG_WANT_PS          0x4u /* keep the smoothed covariances so that nagp_out.PS can be filled */
+
+/* Discrete-time model of ONE problem (segment / hyper-parameter replica).
+ * State ordering and block structure as built by ss_modulators_nmf.m:128-132: M diagonal blocks,
+ * block n spanning states block_offsets[n] .. block_offsets[n+1]-1 (0-based); A, Q, Pinf are
+ * block-diagonal with these blocks (only the diagonal blocks are read); row n of H has its single
+ * non-zero h_val[n] at column block_offsets[n] (1 before `balance`, a power of two after). */
+typedef struct nagp_model {
+  int32_t S;                    /* state dimension */
+  int32_t M;                    /* sites per step: D+N (NMF) or 2*D (gf_ep_modulator) */
+  int32_t D;                    /* sub-bands */
+  int32_t N;                    /* modulators / NMF components */
+  const int32_t* block_offsets; /* M+1 */
+  const double* A;              /* S x S */
+  const double* Q;              /* S x S */
+  const double* Pinf;           /* S x S */
+  const double* h_val;          /* M */
+  const double* Wnmf;           /* D x N, or NULL for NAGP_LIK_POWER */
+  double lik_param;             /* w(1): log observation-noise variance */
+} nagp_model;
+
+/* IHGP look-up tables of one problem (ihgp_ep_modulator_nmf.m:107-134, 150-191), n_grid rows each,
+ * channel-major: PPlist[n] is n_grid x b_n^2 (column-major b x b per row, as MATLAB's PP(:)'),
+ * PGlist[n] is n_grid x 2 b_n^2 = [PS2(:)' G(:)'].  Stored flat: channel n starts at
+ * pp_offsets[n] / pg_offsets[n] (in doubles), row stride b_n^2 / 2 b_n^2. */
+typedef struct nagp_ihgp_tables {
+  int32_t n_grid;          /* 200 in the reference */
+  const double* r_grid;    /* n_grid ascending (logspace(-2,4,200)) */
+  const double* PPlist;
+  const int64_t* pp_offsets; /* M */
+  const double* PGlist;
+  const int64_t* pg_offsets; /* M */
+} nagp_ihgp_tables;
+
+typedef struct nagp_opts {
+  int32_t kind;            /* nagp_kind */
+  int32_t mode;            /* nagp_mode (NLML: GF_EP only) */
+  int32_t lik_kind;        /* nagp_lik */
+  int32_t link_kind;       /* nagp_link */
+  double link_shift;       /* softplus shift (mod_sparsity) */
+  int32_t n_pts;           /* sigma points */
+  int32_t cub_dim;         /* N (NMF) or D (POWER) */
+  const double* wn;        /* n_pts weights  (utp_ws / mvhermgauss) */
+  const double* xn_unscaled; /* cub_dim x n_pts unit sigma points, column-major */
+  double ep_fraction;      /* power-EP alpha */
+  int32_t ep_itts;         /* EP sweeps (GIEKF: g_iter) */
+  const double* ep_damping; /* ep_itts values */
+  int32_t l_iter;          /* GIEKF inner iterations (iekf_update1 `iters`) */
+  int32_t predict_at_k1;   /* gf_ep_modulator.m:131-133 predicts at k=1 in predict mode */
+  uint32_t flags;
+  int32_t device;          /* HIP device ordinal */
+  int32_t chunk;           /* smoother chunk length (0 = default) */
+} nagp_opts;
+
+/* Caller-allocated outputs of ONE problem; any pointer may be NULL. */
+typedef struct nagp_out {
+  double* Eft;      /* M x T   H*MS                                  */
+  double* Varft;    /* M x T   diag(H*PS_k*H')  (IHGP: time-constant) */
+  double* MS;       /* S x T   smoothed means                        */
+  double* PS;       /* S x S x T smoothed covariances (GF_EP / GIEKF) */
+  double* ttau;     /* M x T */
+  double* tnu;      /* M x T */
+  double* R;        /* M x T */
+  double* lZ;       /* T      (GF_EP: per-step log Z as left by the last pass) */
+  double* nlZ;      /* ep_itts (predict) ; nlZ[0] = edata in NLML mode */
+  double* maxDiffM; /* ep_itts */
+  double* maxDiffP; /* ep_itts */
+  int64_t* counters; /* NAGP_N_COUNTERS: chol retries, clamped sites, NaN observations, not-PD */
+} nagp_out;
+
+#define NAGP_N_COUNTERS 4
+#define NAGP_CNT_CHOL_RETRY 0
+#define NAGP_CNT_CLAMPED 1
+#define NAGP_CNT_NAN_OBS 2
+#define NAGP_CNT_NOTPD 3
+
+/* Per-kernel device time of the last nagp_plan_execute, measured with HIP events on the plan's
+ * own stream (ms, summed over launches) and launch counts. */
+#define NAGP_N_KERNELS 8
+#define NAGP_K_FILTER 0      /* gf/ekf forward filter  | ihgp ADF filter          */
+#define NAGP_K_GAIN 1        /* RTS gain (PSkp, Cholesky, G)                       */
+#define NAGP_K_SCAN 2        /* RTS backward recursion | ihgp backward mean scan  */
+#define NAGP_K_EPSITE 3      /* cavity + mom + site update (parallel over k)      */
+#define NAGP_K_REDUCE 4      /* nlZ / maxDiff reductions                          */
+#define NAGP_K_FILTER_LIN 5  /* ihgp fixed-site (linear) filter of sweeps >= 2    */
+#define NAGP_K_OUTPUT 6      /* output formatting (tile-major -> column-major)    */
+#define NAGP_K_OTHER 7
+typedef struct nagp_timings {
+  double ms[NAGP_N_KERNELS];
+  int64_t launches[NAGP_N_KERNELS];
+  double total_ms; /* whole execute, events on the same stream */
+} nagp_timings;
+
+typedef struct nagp_plan nagp_plan; /* opaque */
+
+int nagp_version(void);
+int nagp_device_count(void);
+const char* nagp_strerror(int status);
+const char* nagp_last_error(void); /* text of the last HIP failure on this thread */
+
+/* One-shot host-buffer entry points (create + upload + execute + download + destroy).  The three
+ * names mirror the reference's function families; `tables` only for IHGP. */
+int nagp_ep_run(const nagp_model* model, const double* y, int64_t T, const nagp_opts* opts, nagp_out* out);
+int nagp_ihgp_run(const nagp_model* model, const nagp_ihgp_tables* tables, const double* y, int64_t T,
+                  const nagp_opts* opts, nagp_out* out);
+int nagp_giekf_run(const nagp_model* model, const double* y, int64_t T, const nagp_opts* opts, nagp_out* out);
+
+/* Batched / device-resident form: n_problems independent problems of identical shape
+ * (S, M, block structure, T) -- audio segments or hyper-parameter replicas -- run concurrently. */
+int nagp_plan_create(nagp_plan** plan, int32_t n_problems, const nagp_model* models,
+                     const nagp_ihgp_tables* tables /* n_problems or NULL */, int64_t T, const nagp_opts* opts);
+int nagp_plan_upload_y(nagp_plan* plan, const double* const* ys); /* n_problems pointers to T doubles (NaN = missing) */
+int nagp_plan_execute(nagp_plan* plan);                          /* enqueue all sweeps; returns after stream sync */
+int nagp_plan_timings(const nagp_plan* plan, nagp_timings* t);
+int nagp_plan_download(nagp_plan* plan, nagp_out* outs);          /* n_problems outs */
+int64_t nagp_plan_device_bytes(const nagp_plan* plan);
+void nagp_plan_destroy(nagp_plan* plan);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NAGP_H */

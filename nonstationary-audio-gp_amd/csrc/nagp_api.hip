@@ -1,0 +1,743 @@
+// nagp_api.hip -- C ABI (include/nagp.h) and host orchestration of the HIP kernels.
+// One plan = n_problems independent problems of identical shape; everything between
+// nagp_plan_upload_y and nagp_plan_download stays in HBM.  The sweep structure follows
+// matlab/gf_ep_modulator_nmf.m:113-283 (predict) / :384-522 (nlml), ihgp_ep_modulator_nmf.m:223-454
+// and gf_giekf_modulator_nmf.m:126-221.
+#include "nagp_ihgp.hpp"
+#include "../../include/nagp.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace nagp;
+
+static thread_local std::string g_last_error;
+
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess) {                                                                   \
+      char _b[512];                                                                           \
+      snprintf(_b, sizeof _b, "%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      g_last_error = _b;                                                                      \
+      return (_e == hipErrorOutOfMemory) ? NAGP_ENOMEM : NAGP_EHIP;                           \
+    }                                                                                         \
+  } while (0)
+
+#define FAIL(code, ...)                          \
+  do {                                           \
+    char _b[512];                                \
+    snprintf(_b, sizeof _b, __VA_ARGS__);        \
+    g_last_error = _b;                           \
+    return (code);                               \
+  } while (0)
+
+struct EvRec { int kid; hipEvent_t a, b; };
+
+struct nagp_plan {
+  Shape sh{};
+  nagp_opts opts{};
+  std::vector<double> damping;
+  int B = 0;
+  int TPT = 1, NT = 256, NT_f = 256, NT_ih = 256;
+  int chunk = 2048, LP = 4;
+  int DG_f = 1, DG_ep = 1;
+  bool want_PS = false;
+  bool need_PF = false;
+  hipStream_t stream = nullptr;
+  Bufs b{};
+  MomCfg mc{};
+  IhgpTabs tb{};
+  double* d_model = nullptr; double* d_y = nullptr; double* d_wn = nullptr; double* d_xi = nullptr;
+  double* d_xbuf = nullptr; double* d_lZs = nullptr; double* d_vprev = nullptr; double* d_tab = nullptr; double* d_r = nullptr;
+  std::vector<void*> allocs;
+  int64_t dev_bytes = 0;
+  std::vector<double> nlZ, mdM, mdP;   // [B][ep_itts]
+  std::vector<EvRec> evs;
+  std::vector<hipEvent_t> ev_pool; size_t ev_next = 0;
+  hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
+  nagp_timings tim{};
+  std::vector<double> h_hval;          // [B][M]
+  size_t lds_filter = 0, lds_gain = 0, lds_scan = 0, lds_ep = 0, lds_ih = 0;
+};
+
+extern "C" int nagp_version(void) { return NAGP_VERSION; }
+extern "C" int nagp_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+extern "C" const char* nagp_last_error(void) { return g_last_error.c_str(); }
+extern "C" const char* nagp_strerror(int s) {
+  switch (s) {
+    case NAGP_OK: return "ok";
+    case NAGP_EINVAL: return "invalid argument";
+    case NAGP_EUNSUPPORTED: return "unsupported shape";
+    case NAGP_EHIP: return "HIP runtime error";
+    case NAGP_ENOMEM: return "out of device memory";
+    case NAGP_ENODEVICE: return "no HIP device";
+    case NAGP_ENOTPD: return "matrix not positive definite";
+    default: return "unknown";
+  }
+}
+
+static int dalloc(nagp_plan* p, double** ptr, size_t n_doubles, bool zero = true) {
+  void* v = nullptr;
+  const size_t bytes = (n_doubles ? n_doubles : 1) * sizeof(double);
+  HIP_TRY(hipMalloc(&v, bytes));
+  p->allocs.push_back(v);
+  p->dev_bytes += (int64_t)bytes;
+  if (zero) HIP_TRY(hipMemsetAsync(v, 0, bytes, p->stream));
+  *ptr = static_cast<double*>(v);
+  return NAGP_OK;
+}
+
+static int roundup64(int x) { return ((x + 63) / 64) * 64; }
+
+static int pick_DG(int n_pts, int NT, int D) {
+  int dg = 1;
+  while (dg * 2 <= 16 && dg * 2 <= D && (long long)n_pts * dg * 2 <= NT) dg *= 2;
+  return dg;
+}
+
+static hipEvent_t next_event(nagp_plan* p) {
+  if (p->ev_next == p->ev_pool.size()) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    p->ev_pool.push_back(e);
+  }
+  return p->ev_pool[p->ev_next++];
+}
+struct Timed {
+  nagp_plan* p; int kid; hipEvent_t a, b;
+  Timed(nagp_plan* p_, int kid_) : p(p_), kid(kid_) {
+    a = next_event(p); b = next_event(p);
+    if (a) (void)hipEventRecord(a, p->stream);
+  }
+  ~Timed() {
+    if (b) (void)hipEventRecord(b, p->stream);
+    if (a && b) p->evs.push_back({kid, a, b});
+  }
+};
+
+template <typename K>
+static int set_lds(K kernel, size_t bytes) {
+  if (bytes > 160 * 1024) FAIL(NAGP_EUNSUPPORTED, "kernel needs %zu B of LDS (> 160 KiB)", bytes);
+  if (bytes > 48 * 1024)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return NAGP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* models, const nagp_ihgp_tables* tables,
+                                int64_t T, const nagp_opts* o) {
+  if (!out || !models || !o || B < 1 || T < 1) FAIL(NAGP_EINVAL, "null/empty argument");
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) FAIL(NAGP_ENODEVICE, "no HIP device visible");
+  if (o->device < 0 || o->device >= ndev) FAIL(NAGP_EINVAL, "device ordinal %d out of range", o->device);
+  const nagp_model& m0 = models[0];
+  if (m0.M < 1 || m0.M > MAXM) FAIL(NAGP_EUNSUPPORTED, "M=%d outside 1..%d", m0.M, MAXM);
+  if (m0.S < m0.M || m0.S > 1024) FAIL(NAGP_EUNSUPPORTED, "S=%d unsupported", m0.S);
+  if (o->kind != NAGP_KIND_GF_EP && o->kind != NAGP_KIND_IHGP && o->kind != NAGP_KIND_GIEKF) FAIL(NAGP_EINVAL, "kind");
+  if (o->kind != NAGP_KIND_GF_EP && o->mode != NAGP_MODE_PREDICT)
+    FAIL(NAGP_EUNSUPPORTED, "nlml mode exists only for gf_ep (SURVEY C-11, f-4)");
+  if (o->ep_itts < 1) FAIL(NAGP_EINVAL, "ep_itts < 1");
+  const bool ekf = (o->kind == NAGP_KIND_GIEKF);
+  if (!ekf) {
+    if (!o->wn || !o->xn_unscaled || o->n_pts < 1 || !o->ep_damping) FAIL(NAGP_EINVAL, "cubature/damping missing");
+    if (o->lik_kind == NAGP_LIK_POWER) {
+      if (m0.M != 2 * m0.D || o->cub_dim != m0.D) FAIL(NAGP_EINVAL, "POWER likelihood needs M=2D, cub_dim=D");
+    } else {
+      if (m0.M != m0.D + m0.N || o->cub_dim != m0.N || !m0.Wnmf) FAIL(NAGP_EINVAL, "NMF likelihood needs M=D+N, cub_dim=N, Wnmf");
+      if (m0.N > 8) FAIL(NAGP_EUNSUPPORTED, "N=%d > 8 NMF components", m0.N);
+    }
+  } else {
+    if (m0.M != m0.D + m0.N || !m0.Wnmf || o->l_iter < 1) FAIL(NAGP_EINVAL, "EKF needs M=D+N, Wnmf, l_iter>=1");
+  }
+  if (o->kind == NAGP_KIND_IHGP && !tables) FAIL(NAGP_EINVAL, "IHGP tables missing");
+
+  nagp_plan* p = new nagp_plan();
+  p->opts = *o;
+  p->B = B;
+  Shape& sh = p->sh;
+  sh.S = m0.S; sh.M = m0.M; sh.D = m0.D; sh.N = (o->lik_kind == NAGP_LIK_POWER && !ekf) ? m0.D : m0.N;
+  sh.T = T; sh.ntiles = m0.M * m0.M;
+  for (int n = 0; n <= m0.M; ++n) sh.off[n] = m0.block_offsets[n];
+  for (int n = 0; n < m0.M; ++n) {
+    sh.bsz[n] = sh.off[n + 1] - sh.off[n];
+    if (sh.bsz[n] < 1 || sh.bsz[n] > 4) { delete p; FAIL(NAGP_EUNSUPPORTED, "block %d has size %d (supported: 1..4)", n, sh.bsz[n]); }
+  }
+  if (sh.off[0] != 0 || sh.off[m0.M] != m0.S) { delete p; FAIL(NAGP_EINVAL, "block_offsets do not span 0..S"); }
+  for (int q = 1; q < B; ++q) {
+    const nagp_model& mq = models[q];
+    bool same = mq.S == m0.S && mq.M == m0.M && mq.D == m0.D && mq.N == m0.N;
+    for (int n = 0; same && n <= m0.M; ++n) same = mq.block_offsets[n] == m0.block_offsets[n];
+    if (!same) { delete p; FAIL(NAGP_EINVAL, "problem %d has a different shape", q); }
+  }
+  if (!ekf) p->damping.assign(o->ep_damping, o->ep_damping + o->ep_itts);
+  p->want_PS = true;   // smoothed covariances are cheap to keep only if asked; decided at download (see below)
+
+#define PLAN_TRY(expr) do { int _s = (expr); if (_s != NAGP_OK) { nagp_plan_destroy(p); return _s; } } while (0)
+#define PLAN_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { char _b[512]; snprintf(_b, sizeof _b, "%s -> %s", #expr, hipGetErrorString(_e)); g_last_error = _b; nagp_plan_destroy(p); return _e == hipErrorOutOfMemory ? NAGP_ENOMEM : NAGP_EHIP; } } while (0)
+
+  PLAN_HIP(hipSetDevice(o->device));
+  PLAN_HIP(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+  PLAN_HIP(hipEventCreate(&p->ev_t0));
+  PLAN_HIP(hipEventCreate(&p->ev_t1));
+
+  // ---- launch geometry
+  const int nt = sh.ntiles;
+  p->TPT = (nt + 511) / 512;   // <= 512 threads per workgroup: 256 VGPRs per lane for the register-resident tiles
+  if (p->TPT > 4 || sh.S > 512) { nagp_plan_destroy(p); FAIL(NAGP_EUNSUPPORTED, "M=%d / S=%d: more than 2048 tiles or 512 states", sh.M, sh.S); }
+  p->NT = std::max(roundup64((nt + p->TPT - 1) / p->TPT), std::max(roundup64(sh.S), 128));
+  p->NT_f = p->NT;
+  p->want_PS = (o->flags & 0x4u) != 0;
+  p->need_PF = (o->kind != NAGP_KIND_IHGP) && !(o->mode == NAGP_MODE_NLML && o->ep_itts == 1);
+
+  // ---- model packing
+  const size_t msz = mdl_size(sh);
+  std::vector<double> hm((size_t)B * msz, 0.0);
+  p->h_hval.resize((size_t)B * sh.M);
+  for (int q = 0; q < B; ++q) {
+    const nagp_model& mq = models[q];
+    double* d = hm.data() + (size_t)q * msz;
+    const int S = sh.S;
+    for (int n = 0; n < sh.M; ++n) {
+      const int o0 = sh.off[n], bs = sh.bsz[n];
+      for (int i = 0; i < bs; ++i)
+        for (int j = 0; j < bs; ++j) {
+          const size_t src = (size_t)(o0 + i) + (size_t)S * (o0 + j);   // column-major
+          d[mdl_A(sh) + (size_t)n * 16 + 4 * i + j] = mq.A[src];
+          d[mdl_Q(sh) + (size_t)n * 16 + 4 * i + j] = mq.Q[src];
+          d[mdl_P(sh) + (size_t)n * 16 + 4 * i + j] = mq.Pinf[src];
+        }
+      d[mdl_h(sh) + n] = mq.h_val[n];
+      p->h_hval[(size_t)q * sh.M + n] = mq.h_val[n];
+    }
+    if (mq.Wnmf)
+      for (int dd = 0; dd < sh.D; ++dd)
+        for (int j = 0; j < sh.N; ++j) d[mdl_W(sh) + (size_t)dd * sh.N + j] = mq.Wnmf[dd + (size_t)sh.D * j];
+    d[mdl_sn2(sh)] = std::exp(mq.lik_param);
+  }
+  PLAN_TRY(dalloc(p, &p->d_model, hm.size(), false));
+  PLAN_HIP(hipMemcpyAsync(p->d_model, hm.data(), hm.size() * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  PLAN_HIP(hipStreamSynchronize(p->stream));
+
+  // ---- cubature tables (point-major)
+  MomCfg& mc = p->mc;
+  if (!ekf) {
+    std::vector<double> xi((size_t)o->n_pts * o->cub_dim);
+    for (int pt = 0; pt < o->n_pts; ++pt)
+      for (int j = 0; j < o->cub_dim; ++j) xi[(size_t)pt * o->cub_dim + j] = o->xn_unscaled[j + (size_t)o->cub_dim * pt];
+    PLAN_TRY(dalloc(p, &p->d_wn, o->n_pts, false));
+    PLAN_TRY(dalloc(p, &p->d_xi, xi.size(), false));
+    PLAN_HIP(hipMemcpyAsync(p->d_wn, o->wn, (size_t)o->n_pts * sizeof(double), hipMemcpyHostToDevice, p->stream));
+    PLAN_HIP(hipMemcpyAsync(p->d_xi, xi.data(), xi.size() * sizeof(double), hipMemcpyHostToDevice, p->stream));
+    PLAN_HIP(hipStreamSynchronize(p->stream));
+    mc.lik_kind = o->lik_kind; mc.link_kind = o->link_kind; mc.link_shift = o->link_shift;
+    mc.n_pts = o->n_pts; mc.cdim = o->cub_dim; mc.D = sh.D; mc.wn = p->d_wn; mc.xi = p->d_xi;
+    mc.jitter = (o->lik_kind == NAGP_LIK_POWER) ? 1e-8 : 1e-10;
+    mc.DG = 1;
+  }
+
+  // ---- buffers
+  const size_t BT = (size_t)B * T;
+  Bufs& b = p->b;
+  b.model = p->d_model;
+  PLAN_TRY(dalloc(p, &p->d_y, BT)); b.y = p->d_y;
+  PLAN_TRY(dalloc(p, &b.ttau, BT * sh.M));
+  PLAN_TRY(dalloc(p, &b.tnu, BT * sh.M));
+  PLAN_TRY(dalloc(p, &b.R, BT * sh.M));
+  PLAN_TRY(dalloc(p, &b.lZ, BT));
+  PLAN_TRY(dalloc(p, &b.MF, BT * sh.S));
+  PLAN_TRY(dalloc(p, &b.MS, BT * sh.S));
+  PLAN_TRY(dalloc(p, &b.fm, BT * sh.M));
+  PLAN_TRY(dalloc(p, &b.fv, BT * sh.M));
+  PLAN_TRY(dalloc(p, &b.sm, BT * sh.M));
+  PLAN_TRY(dalloc(p, &b.sv, BT * sh.M));
+  PLAN_TRY(dalloc(p, &b.state, (size_t)B * ((size_t)nt * 16 + sh.S)));
+  PLAN_TRY(dalloc(p, &b.red, (size_t)B * 8));
+  { double* c = nullptr; PLAN_TRY(dalloc(p, &c, (size_t)B * 4)); b.counters = reinterpret_cast<unsigned long long*>(c); }
+  p->chunk = (o->chunk > 0) ? o->chunk : 2048;
+  if (p->chunk > T) p->chunk = (int)T;
+  if (o->kind != NAGP_KIND_IHGP) {
+    // keep the (G, Delta) chunk buffer under ~8 GiB
+    const double per_step = (double)B * 2.0 * nt * 128.0;
+    while (p->chunk > 64 && per_step * p->chunk > 8.0 * 1073741824.0) p->chunk /= 2;
+    if (p->need_PF) PLAN_TRY(dalloc(p, &b.PF, BT * nt * 16, false));
+    if (p->want_PS) PLAN_TRY(dalloc(p, &b.PSs, BT * nt * 16, false));
+    PLAN_TRY(dalloc(p, &b.Gbuf, (size_t)B * p->chunk * 2 * nt * 16, false));
+    PLAN_TRY(dalloc(p, &b.dbuf, (size_t)B * p->chunk * sh.S, false));
+    PLAN_TRY(dalloc(p, &p->d_xbuf, (size_t)B * nt * 16));
+    int LP = (int)((80.0 * 1024.0) / (512.0 * sh.M));
+    p->LP = std::max(1, std::min(LP, sh.M));
+  } else {
+    PLAN_TRY(dalloc(p, &p->d_lZs, BT));
+    PLAN_TRY(dalloc(p, &p->d_vprev, (size_t)B * sh.M));
+    // ---- IHGP tables: MATLAB layout -> device layout (see nagp_ihgp.hpp)
+    const int NG = tables[0].n_grid;
+    if (NG < 2) { nagp_plan_destroy(p); FAIL(NAGP_EINVAL, "n_grid < 2"); }
+    const size_t tsz = itab_size(sh, NG);
+    std::vector<double> ht((size_t)B * tsz, 0.0);
+    for (int q = 0; q < B; ++q) {
+      const nagp_ihgp_tables& tq = tables[q];
+      if (tq.n_grid != NG) { nagp_plan_destroy(p); FAIL(NAGP_EINVAL, "n_grid differs between problems"); }
+      double* d = ht.data() + (size_t)q * tsz;
+      const nagp_model& mq = models[q];
+      for (int n = 0; n < sh.M; ++n) {
+        const int bs = sh.bsz[n], o0 = sh.off[n];
+        const double h = mq.h_val[n];
+        const double* pp = tq.PPlist + tq.pp_offsets[n];
+        const double* pg = tq.PGlist + tq.pg_offsets[n];
+        for (int g = 0; g < NG; ++g) {
+          const double* ppr = pp + (size_t)g * bs * bs;          // column-major bs x bs
+          d[itab_hph(sh, NG) + (size_t)n * NG + g] = h * h * ppr[0];
+          for (int i = 0; i < bs; ++i) d[itab_wcol(sh, NG) + ((size_t)n * NG + g) * 4 + i] = h * ppr[i];
+          const double* pgr = pg + (size_t)g * 2 * bs * bs;      // [PS2(:)' G(:)']
+          d[itab_v(sh, NG) + (size_t)n * NG + g] = h * h * pgr[0];
+          for (int i = 0; i < bs; ++i)
+            for (int j = 0; j < bs; ++j)
+              d[itab_g(sh, NG) + ((size_t)n * NG + g) * 16 + 4 * i + j] = pgr[bs * bs + i + bs * j];
+        }
+        d[itab_hph0(sh, NG) + n] = h * h * mq.Pinf[(size_t)o0 + (size_t)sh.S * o0];
+        for (int i = 0; i < bs; ++i) d[itab_wcol0(sh, NG) + (size_t)n * 4 + i] = h * mq.Pinf[(size_t)(o0 + i) + (size_t)sh.S * o0];
+      }
+    }
+    PLAN_TRY(dalloc(p, &p->d_tab, ht.size(), false));
+    PLAN_TRY(dalloc(p, &p->d_r, NG, false));
+    PLAN_HIP(hipMemcpyAsync(p->d_tab, ht.data(), ht.size() * sizeof(double), hipMemcpyHostToDevice, p->stream));
+    PLAN_HIP(hipMemcpyAsync(p->d_r, tables[0].r_grid, (size_t)NG * sizeof(double), hipMemcpyHostToDevice, p->stream));
+    PLAN_HIP(hipStreamSynchronize(p->stream));
+    p->tb.NG = NG; p->tb.r = p->d_r; p->tb.base = p->d_tab;
+    p->tb.lr0 = std::log10(tables[0].r_grid[0]);
+    p->tb.inv_dlr = (double)(NG - 1) / (std::log10(tables[0].r_grid[NG - 1]) - p->tb.lr0);
+  }
+
+  // ---- LDS sizes / kernel attributes
+  if (o->kind == NAGP_KIND_IHGP) {
+    p->NT_ih = std::min(512, std::max(256, roundup64(o->n_pts)));
+    p->DG_f = pick_DG(o->n_pts, p->NT_ih, sh.D);
+    MomCfg t = mc; t.DG = p->DG_f;
+    p->lds_ih = ihgp_filter_lds_doubles(sh, t) * sizeof(double);
+    PLAN_TRY(set_lds(ihgp_filter_kernel, p->lds_ih));
+  } else {
+    if (!ekf) p->DG_f = pick_DG(o->n_pts, p->NT_f, sh.D);
+    MomCfg t = mc; t.DG = p->DG_f;
+    p->lds_filter = filter_lds_doubles(sh, t, ekf ? 1 : 0) * sizeof(double);
+    p->lds_gain = gain_lds_doubles(sh) * sizeof(double);
+    p->lds_scan = scan_lds_doubles(sh, p->LP) * sizeof(double);
+    switch (p->TPT) {
+      case 1:
+        PLAN_TRY(ekf ? set_lds(gf_filter_kernel<1, 1>, p->lds_filter) : set_lds(gf_filter_kernel<1, 0>, p->lds_filter));
+        PLAN_TRY(set_lds(rts_gain_kernel<1>, p->lds_gain)); PLAN_TRY(set_lds(rts_scan_kernel<1>, p->lds_scan)); break;
+      case 2:
+        PLAN_TRY(ekf ? set_lds(gf_filter_kernel<2, 1>, p->lds_filter) : set_lds(gf_filter_kernel<2, 0>, p->lds_filter));
+        PLAN_TRY(set_lds(rts_gain_kernel<2>, p->lds_gain)); PLAN_TRY(set_lds(rts_scan_kernel<2>, p->lds_scan)); break;
+      case 3:
+        PLAN_TRY(ekf ? set_lds(gf_filter_kernel<3, 1>, p->lds_filter) : set_lds(gf_filter_kernel<3, 0>, p->lds_filter));
+        PLAN_TRY(set_lds(rts_gain_kernel<3>, p->lds_gain)); PLAN_TRY(set_lds(rts_scan_kernel<3>, p->lds_scan)); break;
+      default:
+        PLAN_TRY(ekf ? set_lds(gf_filter_kernel<4, 1>, p->lds_filter) : set_lds(gf_filter_kernel<4, 0>, p->lds_filter));
+        PLAN_TRY(set_lds(rts_gain_kernel<4>, p->lds_gain)); PLAN_TRY(set_lds(rts_scan_kernel<4>, p->lds_scan)); break;
+    }
+  }
+  if (!ekf) {
+    p->DG_ep = pick_DG(o->n_pts, 256, sh.D);
+    MomCfg t = mc; t.DG = p->DG_ep;
+    p->lds_ep = ep_lds_doubles(sh, t) * sizeof(double);
+    PLAN_TRY(set_lds(ep_site_kernel, p->lds_ep));
+  }
+  p->nlZ.assign((size_t)B * o->ep_itts, 0.0);
+  p->mdM.assign((size_t)B * o->ep_itts, 0.0);
+  p->mdP.assign((size_t)B * o->ep_itts, 0.0);
+  PLAN_HIP(hipStreamSynchronize(p->stream));
+  *out = p;
+  return NAGP_OK;
+}
+
+extern "C" void nagp_plan_destroy(nagp_plan* p) {
+  if (!p) return;
+  if (p->stream) (void)hipStreamSynchronize(p->stream);
+  for (void* v : p->allocs) (void)hipFree(v);
+  for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
+  if (p->ev_t0) (void)hipEventDestroy(p->ev_t0);
+  if (p->ev_t1) (void)hipEventDestroy(p->ev_t1);
+  if (p->stream) (void)hipStreamDestroy(p->stream);
+  delete p;
+}
+
+extern "C" int64_t nagp_plan_device_bytes(const nagp_plan* p) { return p ? p->dev_bytes : 0; }
+
+extern "C" int nagp_plan_upload_y(nagp_plan* p, const double* const* ys) {
+  if (!p || !ys) FAIL(NAGP_EINVAL, "null argument");
+  HIP_TRY(hipSetDevice(p->opts.device));
+  for (int q = 0; q < p->B; ++q)
+    HIP_TRY(hipMemcpyAsync(p->d_y + (size_t)q * p->sh.T, ys[q], (size_t)p->sh.T * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return NAGP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+static int launch_filter(nagp_plan* p, const FilterPar& fp) {
+  const bool ekf = p->opts.kind == NAGP_KIND_GIEKF;
+  MomCfg mc = p->mc; mc.DG = p->DG_f;
+  Timed t(p, NAGP_K_FILTER);
+  dim3 g(p->B), bl(p->NT_f);
+#define LF(TP, ME) hipLaunchKernelGGL((gf_filter_kernel<TP, ME>), g, bl, p->lds_filter, p->stream, p->sh, p->b, mc, fp)
+  switch (p->TPT) {
+    case 1: if (ekf) LF(1, 1); else LF(1, 0); break;
+    case 2: if (ekf) LF(2, 1); else LF(2, 0); break;
+    case 3: if (ekf) LF(3, 1); else LF(3, 0); break;
+    default: if (ekf) LF(4, 1); else LF(4, 0); break;
+  }
+#undef LF
+  HIP_TRY(hipGetLastError());
+  return NAGP_OK;
+}
+
+static int launch_smoother(nagp_plan* p, bool write_PSs) {
+  const Shape& sh = p->sh;
+  const int64_t nsm = sh.T - 1;   // smoothing steps k = 0 .. T-2
+  bool first = true;
+  for (int64_t k1 = nsm; k1 > 0;) {
+    const int nk = (int)std::min<int64_t>(p->chunk, k1);
+    const int64_t k0 = k1 - nk;
+    GainPar gp{k0, nk, p->chunk};
+    {
+      Timed t(p, NAGP_K_GAIN);
+      dim3 g(nk, p->B), bl(p->NT);
+      switch (p->TPT) {
+        case 1: hipLaunchKernelGGL((rts_gain_kernel<1>), g, bl, p->lds_gain, p->stream, sh, p->b, gp); break;
+        case 2: hipLaunchKernelGGL((rts_gain_kernel<2>), g, bl, p->lds_gain, p->stream, sh, p->b, gp); break;
+        case 3: hipLaunchKernelGGL((rts_gain_kernel<3>), g, bl, p->lds_gain, p->stream, sh, p->b, gp); break;
+        default: hipLaunchKernelGGL((rts_gain_kernel<4>), g, bl, p->lds_gain, p->stream, sh, p->b, gp); break;
+      }
+    }
+    HIP_TRY(hipGetLastError());
+    ScanPar sp{k0, nk, p->chunk, p->LP, first ? 1 : 0, write_PSs ? 1 : 0, 1};
+    {
+      Timed t(p, NAGP_K_SCAN);
+      dim3 g(p->B), bl(p->NT);
+      switch (p->TPT) {
+        case 1: hipLaunchKernelGGL((rts_scan_kernel<1>), g, bl, p->lds_scan, p->stream, sh, p->b, sp, p->d_xbuf); break;
+        case 2: hipLaunchKernelGGL((rts_scan_kernel<2>), g, bl, p->lds_scan, p->stream, sh, p->b, sp, p->d_xbuf); break;
+        case 3: hipLaunchKernelGGL((rts_scan_kernel<3>), g, bl, p->lds_scan, p->stream, sh, p->b, sp, p->d_xbuf); break;
+        default: hipLaunchKernelGGL((rts_scan_kernel<4>), g, bl, p->lds_scan, p->stream, sh, p->b, sp, p->d_xbuf); break;
+      }
+    }
+    HIP_TRY(hipGetLastError());
+    first = false;
+    k1 = k0;
+  }
+  return NAGP_OK;
+}
+
+static int launch_ep(nagp_plan* p, double alpha, double damp, int clamp, int write_R, double* lZ_out) {
+  const Shape& sh = p->sh;
+  if (sh.T < 2) return NAGP_OK;
+  MomCfg mc = p->mc; mc.DG = p->DG_ep;
+  EpPar ep{};
+  ep.k_end = sh.T - 1;
+  ep.steps_per_wg = (int)std::max<int64_t>(1, (ep.k_end + 4095) / 4096);
+  ep.alpha = alpha; ep.ep_damp = damp; ep.clamp = clamp; ep.write_R = write_R; ep.lZ_out = lZ_out;
+  Timed t(p, NAGP_K_EPSITE);
+  dim3 g((unsigned)((ep.k_end + ep.steps_per_wg - 1) / ep.steps_per_wg), p->B), bl(256);
+  hipLaunchKernelGGL(ep_site_kernel, g, bl, p->lds_ep, p->stream, sh, p->b, mc, ep);
+  HIP_TRY(hipGetLastError());
+  return NAGP_OK;
+}
+
+static int reduce_sum(nagp_plan* p, const double* v, int64_t k_lo, int64_t k_hi, int slot) {
+  Timed t(p, NAGP_K_REDUCE);
+  hipLaunchKernelGGL(sum_kernel, dim3(p->B), dim3(1024), 0, p->stream, v, p->sh.T, k_lo, k_hi, p->b.red, slot);
+  HIP_TRY(hipGetLastError());
+  return NAGP_OK;
+}
+
+static int fetch_red(nagp_plan* p, std::vector<double>& h) {
+  h.resize((size_t)p->B * 8);
+  HIP_TRY(hipMemcpyAsync(h.data(), p->b.red, h.size() * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return NAGP_OK;
+}
+
+// copy the filtered marginals / mean of the last step into the smoothed arrays (the smoother never
+// visits k = T-1: gf_ep_modulator_nmf.m:207)
+static int seed_last_step(nagp_plan* p) {
+  const Shape& sh = p->sh;
+  for (int q = 0; q < p->B; ++q) {
+    const size_t o = ((size_t)q * sh.T + (sh.T - 1));
+    HIP_TRY(hipMemcpyAsync(p->b.sm + o * sh.M, p->b.fm + o * sh.M, sh.M * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
+    if (p->opts.kind != NAGP_KIND_IHGP)
+      HIP_TRY(hipMemcpyAsync(p->b.sv + o * sh.M, p->b.fv + o * sh.M, sh.M * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
+    HIP_TRY(hipMemcpyAsync(p->b.MS + o * sh.S, p->b.MF + o * sh.S, sh.S * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
+  }
+  return NAGP_OK;
+}
+
+#define RUN(expr) do { int _s = (expr); if (_s != NAGP_OK) return _s; } while (0)
+
+static int zero_async(nagp_plan* p, void* ptr, size_t bytes) {
+  HIP_TRY(hipMemsetAsync(ptr, 0, bytes, p->stream));
+  return NAGP_OK;
+}
+
+static int exec_gf(nagp_plan* p) {
+  const Shape& sh = p->sh; const nagp_opts& o = p->opts; const int I = o.ep_itts, B = p->B;
+  const bool nlml = (o.mode == NAGP_MODE_NLML);
+  std::vector<double> red;
+  for (int itt = 1; itt <= I; ++itt) {
+    const bool run_filter = !nlml || itt == 1 || itt < I;
+    if (run_filter) {
+      FilterPar fp{};
+      fp.itt = itt; fp.ep_damp = p->damping[itt - 1]; fp.mom_all = (itt == 1);
+      fp.legacy_update = nlml; fp.clamp_always = nlml; fp.write_R = !nlml;
+      fp.predict_k1 = (!nlml && o.predict_at_k1) ? 1 : 0;
+      fp.store_PF = p->need_PF ? 1 : 0; fp.l_iter = 0;
+      RUN(launch_filter(p, fp));
+    }
+    if (itt == 1 && !nlml) {
+      RUN(reduce_sum(p, p->b.lZ, 0, sh.T, 0));
+      RUN(fetch_red(p, red));
+      for (int q = 0; q < B; ++q) p->nlZ[(size_t)q * I] = -red[(size_t)q * 8];
+    }
+    const bool run_smoother = !nlml || itt < I;
+    if (run_smoother && run_filter) {
+      RUN(zero_async(p, p->b.red, (size_t)B * 8 * sizeof(double)));
+      RUN(seed_last_step(p));
+      RUN(launch_smoother(p, p->want_PS && itt == I));
+      if (itt < I) {
+        RUN(launch_ep(p, o.ep_fraction, p->damping[itt], nlml ? 0 : 1, nlml ? 0 : 1, p->b.lZ));
+        if (!nlml) RUN(reduce_sum(p, p->b.lZ, 0, sh.T, 0));
+      }
+      RUN(fetch_red(p, red));
+      for (int q = 0; q < B; ++q) {
+        if (itt < I && !nlml) p->nlZ[(size_t)q * I + itt] = -red[(size_t)q * 8];
+        p->mdM[(size_t)q * I + itt - 1] = red[(size_t)q * 8 + 1];
+        p->mdP[(size_t)q * I + itt - 1] = red[(size_t)q * 8 + 2];
+      }
+    }
+  }
+  if (nlml) {
+    RUN(reduce_sum(p, p->b.lZ, 0, sh.T, 0));
+    RUN(fetch_red(p, red));
+    for (int q = 0; q < B; ++q) p->nlZ[(size_t)q * I] = -red[(size_t)q * 8];
+  }
+  return NAGP_OK;
+}
+
+static int exec_giekf(nagp_plan* p) {
+  const Shape& sh = p->sh; const nagp_opts& o = p->opts; const int I = o.ep_itts, B = p->B;
+  std::vector<double> red;
+  for (int itt = 1; itt <= I; ++itt) {
+    FilterPar fp{};
+    fp.itt = itt; fp.store_PF = 1; fp.l_iter = o.l_iter;
+    fp.init_from_state = (itt > 1); fp.reset_P = (o.flags & NAGP_FLAG_EKF_RESET_P) ? 1 : 0;
+    RUN(launch_filter(p, fp));
+    RUN(zero_async(p, p->b.red, (size_t)B * 8 * sizeof(double)));
+    RUN(seed_last_step(p));
+    if (sh.T == 1) {   // no smoothing step: the restart state is the filtered one
+      for (int q = 0; q < B; ++q) {
+        double* st = p->b.state + (size_t)q * ((size_t)sh.ntiles * 16 + sh.S);
+        HIP_TRY(hipMemcpyAsync(st, p->b.PF + (size_t)q * sh.ntiles * 16, (size_t)sh.ntiles * 128, hipMemcpyDeviceToDevice, p->stream));
+        HIP_TRY(hipMemcpyAsync(st + (size_t)sh.ntiles * 16, p->b.MF + (size_t)q * sh.S, sh.S * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
+      }
+    }
+    RUN(launch_smoother(p, p->want_PS && itt == I));
+    RUN(fetch_red(p, red));
+    for (int q = 0; q < B; ++q) {
+      p->mdM[(size_t)q * I + itt - 1] = red[(size_t)q * 8 + 1];
+      p->mdP[(size_t)q * I + itt - 1] = red[(size_t)q * 8 + 2];
+    }
+  }
+  return NAGP_OK;
+}
+
+__global__ void fill_kernel(double* p, size_t n, double v) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+static int exec_ihgp(nagp_plan* p) {
+  const Shape& sh = p->sh; const nagp_opts& o = p->opts; const int I = o.ep_itts, B = p->B;
+  std::vector<double> red;
+  const bool cv = (o.flags & NAGP_FLAG_IHGP_CONSTRAINTS) != 0;
+  // R = exp(lik) .* ones (ihgp_ep_modulator_nmf.m:209) or zeros (constraints variant :243); problem-wise value
+  for (int q = 0; q < B; ++q) {
+    double sn2 = 0.0;
+    if (!cv) HIP_TRY(hipMemcpyAsync(&sn2, p->d_model + (size_t)q * mdl_size(sh) + mdl_sn2(sh), sizeof(double), hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, p->stream, p->b.R + (size_t)q * sh.T * sh.M, (size_t)sh.T * sh.M, cv ? 0.0 : sn2);
+    // PSP of sweep 1 = Pinf  ->  vprev = h^2 Pinf(c,c)
+    HIP_TRY(hipMemcpyAsync(p->d_vprev + (size_t)q * sh.M, p->d_tab + (size_t)q * itab_size(sh, p->tb.NG) + itab_hph0(sh, p->tb.NG),
+                           sh.M * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
+  }
+  MomCfg mcf = p->mc; mcf.DG = p->DG_f;
+  for (int itt = 1; itt <= I; ++itt) {
+    IhgpPar ip{itt, p->damping[itt - 1], itt == 1 ? 1 : 0, 0.0};
+    {
+      Timed t(p, itt == 1 ? NAGP_K_FILTER : NAGP_K_FILTER_LIN);
+      hipLaunchKernelGGL(ihgp_filter_kernel, dim3(B), dim3(p->NT_ih), p->lds_ih, p->stream, sh, p->b, mcf, p->tb, ip);
+    }
+    HIP_TRY(hipGetLastError());
+    RUN(reduce_sum(p, p->b.lZ, itt == 1 ? 0 : sh.T - 1, sh.T, 0));
+    RUN(seed_last_step(p));
+    {
+      Timed t(p, NAGP_K_SCAN);
+      hipLaunchKernelGGL(ihgp_scan_kernel, dim3(B), dim3(64), 0, p->stream, sh, p->b, p->tb, p->d_vprev);
+    }
+    HIP_TRY(hipGetLastError());
+    if (itt < I) {
+      RUN(zero_async(p, p->d_lZs, (size_t)B * sh.T * sizeof(double)));
+      RUN(launch_ep(p, o.ep_fraction, p->damping[itt], 0, 2, p->d_lZs));
+      RUN(reduce_sum(p, p->d_lZs, 0, sh.T, 3));
+    }
+    RUN(fetch_red(p, red));
+    for (int q = 0; q < B; ++q) {
+      const double sumF = red[(size_t)q * 8], sumS = red[(size_t)q * 8 + 3];
+      if (itt == 1) p->nlZ[(size_t)q * I] = -sumF;
+      if (itt < I) p->nlZ[(size_t)q * I + itt] = -(sumF + (itt > 1 ? sumS : 0.0));
+      p->mdM[(size_t)q * I + itt - 1] = red[(size_t)q * 8 + 1];
+      p->mdP[(size_t)q * I + itt - 1] = red[(size_t)q * 8 + 2];
+    }
+  }
+  return NAGP_OK;
+}
+
+extern "C" int nagp_plan_execute(nagp_plan* p) {
+  if (!p) FAIL(NAGP_EINVAL, "null plan");
+  HIP_TRY(hipSetDevice(p->opts.device));
+  const Shape& sh = p->sh; const size_t BT = (size_t)p->B * sh.T;
+  p->evs.clear(); p->ev_next = 0;
+  HIP_TRY(hipEventRecord(p->ev_t0, p->stream));
+  // every call starts from the reference's initial state (sites zero, MS zero, ...)
+  RUN(zero_async(p, p->b.ttau, BT * sh.M * 8)); RUN(zero_async(p, p->b.tnu, BT * sh.M * 8));
+  RUN(zero_async(p, p->b.R, BT * sh.M * 8)); RUN(zero_async(p, p->b.lZ, BT * 8));
+  RUN(zero_async(p, p->b.sm, BT * sh.M * 8)); RUN(zero_async(p, p->b.sv, BT * sh.M * 8));
+  RUN(zero_async(p, p->b.MS, BT * sh.S * 8)); RUN(zero_async(p, p->b.red, (size_t)p->B * 64));
+  RUN(zero_async(p, p->b.counters, (size_t)p->B * 32));
+  RUN(zero_async(p, p->b.state, (size_t)p->B * ((size_t)sh.ntiles * 16 + sh.S) * 8));
+  std::fill(p->nlZ.begin(), p->nlZ.end(), 0.0);
+  std::fill(p->mdM.begin(), p->mdM.end(), 0.0);
+  std::fill(p->mdP.begin(), p->mdP.end(), 0.0);
+  int st;
+  switch (p->opts.kind) {
+    case NAGP_KIND_GF_EP: st = exec_gf(p); break;
+    case NAGP_KIND_IHGP: st = exec_ihgp(p); break;
+    default: st = exec_giekf(p); break;
+  }
+  if (st != NAGP_OK) return st;
+  HIP_TRY(hipEventRecord(p->ev_t1, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  HIP_TRY(hipGetLastError());
+  memset(&p->tim, 0, sizeof p->tim);
+  for (const EvRec& e : p->evs) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) { p->tim.ms[e.kid] += ms; p->tim.launches[e.kid] += 1; }
+  }
+  float tot = 0.f;
+  (void)hipEventElapsedTime(&tot, p->ev_t0, p->ev_t1);
+  p->tim.total_ms = tot;
+  return NAGP_OK;
+}
+
+extern "C" int nagp_plan_timings(const nagp_plan* p, nagp_timings* t) {
+  if (!p || !t) FAIL(NAGP_EINVAL, "null argument");
+  *t = p->tim;
+  return NAGP_OK;
+}
+
+extern "C" int nagp_plan_download(nagp_plan* p, nagp_out* outs) {
+  if (!p || !outs) FAIL(NAGP_EINVAL, "null argument");
+  HIP_TRY(hipSetDevice(p->opts.device));
+  const Shape& sh = p->sh; const int64_t T = sh.T; const int M = sh.M, S = sh.S, I = p->opts.ep_itts;
+  const bool ihgp = p->opts.kind == NAGP_KIND_IHGP;
+  std::vector<double> tmp;
+  for (int q = 0; q < p->B; ++q) {
+    nagp_out& o = outs[q];
+    const size_t oM = (size_t)q * T * M, oS = (size_t)q * T * S;
+#define D2H(dst, src, n) do { if (dst) HIP_TRY(hipMemcpyAsync(dst, src, (size_t)(n) * sizeof(double), hipMemcpyDeviceToHost, p->stream)); } while (0)
+    D2H(o.Eft, p->b.sm + oM, T * M);
+    D2H(o.MS, p->b.MS + oS, T * S);
+    D2H(o.ttau, p->b.ttau + oM, T * M);
+    D2H(o.tnu, p->b.tnu + oM, T * M);
+    D2H(o.R, p->b.R + oM, T * M);
+    D2H(o.lZ, p->b.lZ + (size_t)q * T, T);
+    if (!ihgp) D2H(o.Varft, p->b.sv + oM, T * M);
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    if (ihgp && o.Varft) {
+      // Varft = repmat(diag(H*P*H')) with the blocks last looked up (k = 0); abs() unless constraints variant
+      std::vector<double> v0(M, 0.0);
+      if (T > 1) { HIP_TRY(hipMemcpy(v0.data(), p->b.sv + oM, M * sizeof(double), hipMemcpyDeviceToHost)); }
+      const bool cv = (p->opts.flags & NAGP_FLAG_IHGP_CONSTRAINTS) != 0;
+      for (int64_t k = 0; k < T; ++k)
+        for (int n = 0; n < M; ++n) o.Varft[(size_t)k * M + n] = cv ? v0[n] : std::fabs(v0[n]);
+    }
+    if (o.PS) {
+      if (ihgp || !p->want_PS) FAIL(NAGP_EINVAL, "PS requested but the plan was created without NAGP flag 0x4 (or IHGP)");
+      const size_t tl = (size_t)sh.ntiles * 16;
+      const int64_t KB = 256;
+      tmp.resize((size_t)KB * tl);
+      for (int64_t k0 = 0; k0 < T; k0 += KB) {
+        const int64_t nk = std::min<int64_t>(KB, T - k0);
+        // smoothed tiles for k < T-1; the last step is the filtered one
+        const int64_t nsm = std::min<int64_t>(nk, std::max<int64_t>(0, (T - 1) - k0));
+        if (nsm > 0) HIP_TRY(hipMemcpy(tmp.data(), p->b.PSs + ((size_t)q * T + k0) * tl, (size_t)nsm * tl * 8, hipMemcpyDeviceToHost));
+        if (nsm < nk) HIP_TRY(hipMemcpy(tmp.data() + (size_t)nsm * tl, p->b.PF + ((size_t)q * T + (T - 1)) * tl, tl * 8, hipMemcpyDeviceToHost));
+        for (int64_t kk = 0; kk < nk; ++kk) {
+          double* dst = o.PS + (size_t)(k0 + kk) * S * S;
+          const double* src = tmp.data() + (size_t)kk * tl;
+          for (int Ib = 0; Ib < M; ++Ib)
+            for (int Jb = 0; Jb < M; ++Jb) {
+              const double* t16 = src + ((size_t)Ib * M + Jb) * 16;
+              for (int i = 0; i < sh.bsz[Ib]; ++i)
+                for (int j = 0; j < sh.bsz[Jb]; ++j) dst[(size_t)(sh.off[Ib] + i) + (size_t)S * (sh.off[Jb] + j)] = t16[4 * i + j];
+            }
+        }
+      }
+    }
+    if (o.nlZ) for (int i = 0; i < I; ++i) o.nlZ[i] = p->nlZ[(size_t)q * I + i];
+    if (o.maxDiffM) for (int i = 0; i < I; ++i) o.maxDiffM[i] = p->mdM[(size_t)q * I + i];
+    if (o.maxDiffP) for (int i = 0; i < I; ++i) o.maxDiffP[i] = p->mdP[(size_t)q * I + i];
+    if (o.counters) {
+      unsigned long long c[4];
+      HIP_TRY(hipMemcpy(c, p->b.counters + (size_t)q * 4, sizeof c, hipMemcpyDeviceToHost));
+      for (int i = 0; i < 4; ++i) o.counters[i] = (int64_t)c[i];
+    }
+  }
+  return NAGP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+static int run_one(const nagp_model* model, const nagp_ihgp_tables* tables, const double* y, int64_t T,
+                   const nagp_opts* opts, nagp_out* out) {
+  if (!model || !y || !opts || !out) FAIL(NAGP_EINVAL, "null argument");
+  nagp_opts o = *opts;
+  if (out->PS) o.flags |= 0x4u;
+  nagp_plan* p = nullptr;
+  int st = nagp_plan_create(&p, 1, model, tables, T, &o);
+  if (st != NAGP_OK) return st;
+  const double* ys[1] = {y};
+  st = nagp_plan_upload_y(p, ys);
+  if (st == NAGP_OK) st = nagp_plan_execute(p);
+  if (st == NAGP_OK) st = nagp_plan_download(p, out);
+  nagp_plan_destroy(p);
+  return st;
+}
+
+extern "C" int nagp_ep_run(const nagp_model* model, const double* y, int64_t T, const nagp_opts* opts, nagp_out* out) {
+  if (opts && opts->kind != NAGP_KIND_GF_EP) FAIL(NAGP_EINVAL, "nagp_ep_run needs kind = NAGP_KIND_GF_EP");
+  return run_one(model, nullptr, y, T, opts, out);
+}
+extern "C" int nagp_ihgp_run(const nagp_model* model, const nagp_ihgp_tables* tables, const double* y, int64_t T,
+                             const nagp_opts* opts, nagp_out* out) {
+  if (opts && opts->kind != NAGP_KIND_IHGP) FAIL(NAGP_EINVAL, "nagp_ihgp_run needs kind = NAGP_KIND_IHGP");
+  return run_one(model, tables, y, T, opts, out);
+}
+extern "C" int nagp_giekf_run(const nagp_model* model, const double* y, int64_t T, const nagp_opts* opts, nagp_out* out) {
+  if (opts && opts->kind != NAGP_KIND_GIEKF) FAIL(NAGP_EINVAL, "nagp_giekf_run needs kind = NAGP_KIND_GIEKF");
+  return run_one(model, nullptr, y, T, opts, out);
+}

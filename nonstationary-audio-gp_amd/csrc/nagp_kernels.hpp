@@ -1,0 +1,895 @@
+// nagp_kernels.hpp -- HIP kernels of the full-covariance path (gf_ep_* / gf_giekf_*):
+//   gf_filter_kernel   forward ADF/Kalman (or EKF) filter, one workgroup per problem, P resident in registers
+//   rts_gain_kernel    per-step smoother gain (PSkp, Cholesky, G), one workgroup per (step, problem)
+//   rts_scan_kernel    backward recursion E <- G (E+Delta) G', e <- G (e+delta), one workgroup per problem
+//   ep_site_kernel     cavity + mom + damped power-EP site update, parallel over steps
+//   reduce kernels     nlZ = -sum(lZ), maxDiff
+// Reference lines: matlab/gf_ep_modulator_nmf.m:126-184 (filter), :207-234 (RTS), :236-268 (EP),
+// matlab/iekf_update1.m:110-117 + gf_giekf_modulator_nmf_constraints.m:492-502 (EKF update).
+#pragma once
+#include "nagp_dev.hpp"
+
+namespace nagp {
+
+constexpr int LDS_INT_DOUBLES = 66;  // (2*MAXM+2) ints rounded up to an even number of doubles
+
+struct Shape {
+  int S, M, D, N;
+  int ntiles;  // M*M
+  int64_t T;
+  int off[MAXM + 1];
+  int bsz[MAXM];
+};
+
+// per-problem packed model (doubles): A blocks [M][16] | Q blocks [M][16] | Pinf blocks [M][16] |
+// h_val [M] | W [D][N] row-major | sn2
+__host__ __device__ inline size_t mdl_A(const Shape&) { return 0; }
+__host__ __device__ inline size_t mdl_Q(const Shape& s) { return (size_t)s.M * 16; }
+__host__ __device__ inline size_t mdl_P(const Shape& s) { return (size_t)s.M * 32; }
+__host__ __device__ inline size_t mdl_h(const Shape& s) { return (size_t)s.M * 48; }
+__host__ __device__ inline size_t mdl_W(const Shape& s) { return (size_t)s.M * 49; }
+__host__ __device__ inline size_t mdl_sn2(const Shape& s) { return (size_t)s.M * 49 + (size_t)s.D * s.N; }
+__host__ __device__ inline size_t mdl_size(const Shape& s) { return ((mdl_sn2(s) + 1 + 1) / 2) * 2; }
+
+struct Bufs {
+  const double* model;  // [B][mdl_size]
+  const double* y;      // [B][T]
+  double* ttau;         // [B][T][M]
+  double* tnu;          // [B][T][M]
+  double* R;            // [B][T][M]
+  double* lZ;           // [B][T]
+  double* MF;           // [B][T][S]  filtered means
+  double* MS;           // [B][T][S]  smoothed means
+  double* PF;           // [B][T][ntiles][16] filtered covariances (tile-major), may be null (nlml, 1 sweep)
+  double* PSs;          // [B][T][ntiles][16] smoothed covariances, optional (null unless requested)
+  double* fm;           // [B][T][M] filtered marginal mean  H m
+  double* fv;           // [B][T][M] filtered marginal var   diag(H P H')
+  double* sm;           // [B][T][M] smoothed marginals
+  double* sv;
+  double* Gbuf;         // [B][chunk][2][ntiles][16]  (G, Delta) of the current smoother chunk
+  double* dbuf;         // [B][chunk][S]              delta of the current chunk
+  double* state;        // [B][ntiles*16 + S]         scan state (E, e) between chunks; smoothed (P,m) at k=0 for EKF
+  double* red;          // [B][8] reduction outputs (sum lZ, maxDiffM, maxDiffP, ...)
+  unsigned long long* counters;  // [B][4]
+};
+
+struct FilterPar {
+  int itt;            // 1-based sweep
+  double ep_damp;
+  int mom_all;        // call mom at every step (itt==1) -- otherwise only at k==T-1
+  int legacy_update;  // nlml mode single-branch update (gf_ep_modulator_nmf.m:428-439)
+  int clamp_always;   // nlml mode clamps ttau at every step (:425)
+  int write_R;        // predict mode writes R
+  int predict_k1;     // gf_ep_modulator.m:131-133
+  int store_PF;
+  int init_from_state;  // EKF sweeps >= 2: start from the smoothed (m,P) at k=0
+  int reset_P;          // with init_from_state: P <- Pinf anyway (constraints variant)
+  int l_iter;           // EKF inner iterations
+};
+
+// thread tid owns tiles t = tid + q*NT (q < TPT)
+template <int TPT>
+struct TileOwner {
+  int I[TPT], J[TPT];
+  bool ok[TPT];
+  __device__ void init(int M, int ntiles) {
+#pragma unroll
+    for (int q = 0; q < TPT; ++q) {
+      const int t = threadIdx.x + q * blockDim.x;
+      ok[q] = t < ntiles;
+      const int tt = ok[q] ? t : 0;
+      I[q] = tt / M;
+      J[q] = tt - I[q] * M;
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Forward filter.  MEAS = 0: Power-EP / ADF sites (gf_ep_modulator*.m), MEAS = 1: EKF (gf_giekf_*).
+// LDS (doubles): sA[M*16] sh[M] sW[D*N] m[S] Wl[M*S] HPl[M*S] fmu[M] HPH[M] tt[M] tn[M] cA[M] cm[M]
+//                dl[M] d2l[M] misc[8] | mom workspace | EKF: part[M] PJ[S]
+__host__ __device__ inline size_t filter_lds_doubles(const Shape& s, const MomCfg& mc, int meas) {
+  size_t n = LDS_INT_DOUBLES + (size_t)s.M * 16 + s.M + (size_t)s.D * s.N + s.S + 2 * (size_t)s.M * s.S +
+             8 * (size_t)s.M + 8;
+  n += (meas == 0) ? mom_lds_doubles(mc) : (size_t)(s.M + s.S);
+  return (n + 1) & ~(size_t)1;
+}
+
+template <int TPT, int MEAS>
+__global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg mc, FilterPar fp) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int tid = threadIdx.x, NT = blockDim.x;
+  const int S = sh.S, M = sh.M, D = sh.D;
+  const int64_t T = sh.T;
+  const int pb = blockIdx.x;
+  const double* mdl = b.model + (size_t)pb * mdl_size(sh);
+
+  int* ioff = reinterpret_cast<int*>(lds);          // [MAXM+1]
+  int* ibsz = ioff + (MAXM + 1);                     // [MAXM]   (fixed 2*MAXM+2 ints = 65 doubles + pad)
+  double* sA = lds + LDS_INT_DOUBLES;
+  double* shv = sA + (size_t)M * 16;
+  double* sW = shv + M;
+  double* m = sW + (size_t)sh.D * sh.N;
+  double* Wl = m + S;
+  double* HPl = Wl + (size_t)M * S;
+  double* fmu = HPl + (size_t)M * S;
+  double* HPH = fmu + M;
+  double* tt = HPH + M;
+  double* tn = tt + M;
+  double* cA = tn + M;
+  double* cm = cA + M;
+  double* dl = cm + M;
+  double* d2l = dl + M;
+  double* misc = d2l + M;  // [0]=lZ
+  double* ws = misc + 8;   // mom workspace | EKF: part[M], PJ[S]
+
+  for (int i = tid; i <= M; i += NT) ioff[i] = sh.off[i];
+  for (int i = tid; i < M; i += NT) ibsz[i] = sh.bsz[i];
+  for (int i = tid; i < M * 16; i += NT) sA[i] = mdl[mdl_A(sh) + i];
+  for (int i = tid; i < M; i += NT) shv[i] = mdl[mdl_h(sh) + i];
+  for (int i = tid; i < sh.D * sh.N; i += NT) sW[i] = mdl[mdl_W(sh) + i];
+  const double sn2 = mdl[mdl_sn2(sh)];
+
+  TileOwner<TPT> own;
+  own.init(M, sh.ntiles);
+  double P[TPT][16];
+  const double* st = b.state + (size_t)pb * ((size_t)sh.ntiles * 16 + S);
+#pragma unroll
+  for (int q = 0; q < TPT; ++q) {
+    tile_zero(P[q]);
+    if (own.ok[q]) {
+      if (fp.init_from_state && !fp.reset_P)
+        tile_load(P[q], st + (size_t)(own.I[q] * M + own.J[q]) * 16);
+      else if (own.I[q] == own.J[q])
+        tile_load(P[q], mdl + mdl_P(sh) + (size_t)own.I[q] * 16);
+    }
+  }
+  for (int i = tid; i < S; i += NT) m[i] = fp.init_from_state ? st[(size_t)sh.ntiles * 16 + i] : 0.0;
+  __syncthreads();
+  // which block / row-in-block does state i (= tid) belong to
+  int myblk = 0, myrow = 0;
+  if (tid < S) {
+    while (ioff[myblk + 1] <= tid) ++myblk;
+    myrow = tid - ioff[myblk];
+  }
+
+  const double* yv = b.y + (size_t)pb * T;
+  double* g_tt = b.ttau + (size_t)pb * T * M;
+  double* g_tn = b.tnu + (size_t)pb * T * M;
+  double* g_R = b.R + (size_t)pb * T * M;
+  double* g_lZ = b.lZ + (size_t)pb * T;
+  double* g_MF = b.MF + (size_t)pb * T * S;
+  double* g_fm = b.fm + (size_t)pb * T * M;
+  double* g_fv = b.fv + (size_t)pb * T * M;
+  double* g_PF = b.PF ? b.PF + (size_t)pb * T * sh.ntiles * 16 : nullptr;
+  unsigned long long n_clamped = 0, n_nan = 0;
+
+  for (int64_t k = 0; k < T; ++k) {
+    const double yk = yv[k];
+    const bool pred = (k > 0) || fp.predict_k1;
+    // ---- S0: prediction (registers), publish W = P H', H P, diag(H P H'), fmu = H m
+    double rm = 0.0;
+    if (tid < S) {
+      if (pred) {
+        const double* a = sA + (size_t)myblk * 16 + 4 * myrow;
+        const double* mb = m + ioff[myblk];
+        const int bs = ibsz[myblk];
+        for (int l = 0; l < bs; ++l) rm = fma(a[l], mb[l], rm);
+      } else {
+        rm = m[tid];
+      }
+      if (myrow == 0) fmu[myblk] = shv[myblk] * rm;
+    }
+#pragma unroll
+    for (int q = 0; q < TPT; ++q) {
+      if (own.ok[q]) {
+        const int I = own.I[q], J = own.J[q];
+        if (pred) {
+          tile_congruence(P[q], sA + (size_t)I * 16, sA + (size_t)J * 16);
+          if (I == J) {
+            const double* Qb = mdl + mdl_Q(sh) + (size_t)I * 16;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) P[q][e] += Qb[e];
+          }
+        }
+        const double hJ = shv[J], hI = shv[I];
+        const int oI = ioff[I], oJ = ioff[J], bI = ibsz[I], bJ = ibsz[J];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (i < bI) Wl[(size_t)J * S + oI + i] = hJ * P[q][4 * i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (j < bJ) HPl[(size_t)I * S + oJ + j] = hI * P[q][j];
+        if (I == J) HPH[I] = hI * hI * P[q][0];
+      }
+    }
+    __syncthreads();  // B1
+    if (tid < S) m[tid] = rm;
+
+    if (!(yk != yk)) {  // ~isnan(y_k)
+      if (MEAS == 0) {
+        const bool do_mom = fp.mom_all || (k == T - 1);
+        if (do_mom) {
+          mom_eval(mc, sW, sn2, 1.0, yk, fmu, HPH, ws, &misc[0], dl, d2l);
+          if (tid < M) {
+            const double d2 = d2l[tid], d1 = dl[tid], hp = HPH[tid], f = fmu[tid];
+            double t_old = g_tt[(size_t)k * M + tid], n_old = g_tn[(size_t)k * M + tid];
+            double tnew = (1.0 - fp.ep_damp) * t_old + fp.ep_damp * (-d2 / (1.0 + d2 * hp));
+            double nnew = (1.0 - fp.ep_damp) * n_old + fp.ep_damp * ((d1 - f * d2) / (1.0 + d2 * hp));
+            if (!(tnew > 0.0)) ++n_clamped;
+            tnew = max0(tnew);
+            tt[tid] = tnew; tn[tid] = nnew;
+            g_tt[(size_t)k * M + tid] = tnew; g_tn[(size_t)k * M + tid] = nnew;
+            if (fp.write_R) g_R[(size_t)k * M + tid] = 1.0 / tnew;
+          }
+          if (tid == 0) g_lZ[k] = misc[0];
+        } else if (tid < M) {
+          double t_old = g_tt[(size_t)k * M + tid];
+          if (fp.clamp_always) { t_old = max0(t_old); g_tt[(size_t)k * M + tid] = t_old; }
+          tt[tid] = t_old; tn[tid] = g_tn[(size_t)k * M + tid];
+        }
+        if (fp.legacy_update) __syncthreads();
+        if (tid < M) {
+          const double t = tt[tid], n = tn[tid], hp = HPH[tid], f = fmu[tid];
+          bool formA = (t == 0.0);
+          if (fp.legacy_update) {
+            double mn = tt[0];
+            for (int q = 1; q < M; ++q) mn = fmin(mn, tt[q]);   // MATLAB min ignores NaN like fmin
+            formA = (mn == 0.0);
+          }
+          if (formA) {   // z = t*hp+1; K = W*(t/z); v = t*f - n; m -= W*(v/z); P -= K*W'
+            const double z = t * hp + 1.0;
+            cA[tid] = t / z;
+            cm[tid] = -(t * f - n) / z;
+          } else {       // K = W/(hp+1/t); v = n/t - f; m += K*v; P -= K*H*P
+            const double s = 1.0 / (hp + 1.0 / t);
+            cA[tid] = s;
+            cm[tid] = s * (n / t - f);
+          }
+          if (tid == 0) misc[1] = formA ? 1.0 : 0.0;
+        }
+        __syncthreads();  // B4
+        const bool legacyA = fp.legacy_update && (misc[1] != 0.0);
+        if (tid < S) {
+          double acc = rm;
+          for (int n = 0; n < M; ++n) acc = fma(Wl[(size_t)n * S + tid], cm[n], acc);
+          rm = acc;
+          m[tid] = acc;
+        }
+        // P -= sum_n (W[:,n] cA[n]) * R_n,   R_n = (H P)[n,:]  (or W[:,n]' in the legacy form)
+        const double* Rt = legacyA ? Wl : HPl;
+#pragma unroll
+        for (int q = 0; q < TPT; ++q) {
+          if (own.ok[q]) {
+            const int oI = ioff[own.I[q]], oJ = ioff[own.J[q]];
+            for (int n = 0; n < M; ++n) {
+              const double c = cA[n];
+              if (c == 0.0) continue;
+              const double* wr = Wl + (size_t)n * S + oI;
+              const double* rr = Rt + (size_t)n * S + oJ;
+              double r4[4], w4[4];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) r4[j] = rr[j];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) w4[i] = -(wr[i] * c);
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) P[q][4 * i + j] = fma(w4[i], r4[j], P[q][4 * i + j]);
+            }
+            // keep the zero padding clean (Wl/HPl beyond the block width belong to neighbours)
+            const int bI = ibsz[own.I[q]], bJ = ibsz[own.J[q]];
+            if (bI < 4 || bJ < 4) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                  if (i >= bI || j >= bJ) P[q][4 * i + j] = 0.0;
+            }
+          }
+        }
+      } else {
+        // ---------------- EKF measurement update (iekf_update1.m:110-117)
+        double* part = ws;
+        double* PJ = ws + M;
+        const int N = sh.N;
+        double Sx = 1.0, MU = 0.0;
+        for (int it = 0; it < fp.l_iter; ++it) {
+          if (it > 0) {
+            if (tid < M) fmu[tid] = shv[tid] * m[ioff[tid]];
+            __syncthreads();
+          }
+          if (tid < M) {   // partials of h = z' W softplus(g)
+            double pv = 0.0;
+            if (tid < D) {
+              for (int j = 0; j < N; ++j) pv = fma(sW[tid * N + j], log(1.0 + exp(fmu[D + j])), pv);
+            } else {
+              const int j = tid - D;
+              double zw = 0.0;
+              for (int d = 0; d < D; ++d) zw = fma(fmu[d], sW[d * N + j], zw);
+              const double eg = exp(fmu[D + j]);
+              pv = zw * (eg / (eg + 1.0));
+            }
+            part[tid] = pv;
+          }
+          __syncthreads();
+          if (tid < S) {
+            double acc = 0.0;
+            for (int n = 0; n < M; ++n) acc = fma(Wl[(size_t)n * S + tid], part[n], acc);
+            PJ[tid] = acc;
+          }
+          __syncthreads();
+          double jpj = 0.0;
+          MU = 0.0;
+          for (int n = 0; n < M; ++n) jpj = fma(part[n] * shv[n], PJ[ioff[n]], jpj);
+          for (int d = 0; d < D; ++d) MU = fma(fmu[d], part[d], MU);
+          Sx = sn2 + jpj;
+          if (tid < S) { rm = rm + (PJ[tid] / Sx) * (yk - MU); }
+          __syncthreads();   // all reads of m/fmu for this iteration done
+          if (tid < S) m[tid] = rm;
+          if (it + 1 < fp.l_iter) __syncthreads();
+        }
+        // P -= K S K'
+#pragma unroll
+        for (int q = 0; q < TPT; ++q) {
+          if (own.ok[q]) {
+            const int oI = ioff[own.I[q]], oJ = ioff[own.J[q]];
+            const int bI = ibsz[own.I[q]], bJ = ibsz[own.J[q]];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                if (i < bI && j < bJ) {
+                  const double Ki = PJ[oI + i] / Sx, Kj = PJ[oJ + j] / Sx;
+                  P[q][4 * i + j] -= (Ki * Sx) * Kj;
+                }
+          }
+        }
+      }
+    } else {
+      ++n_nan;
+    }
+    // ---- store
+    if (tid < S) {
+      g_MF[(size_t)k * S + tid] = rm;
+      if (myrow == 0) g_fm[(size_t)k * M + myblk] = shv[myblk] * rm;
+    }
+#pragma unroll
+    for (int q = 0; q < TPT; ++q)
+      if (own.ok[q] && own.I[q] == own.J[q])
+        g_fv[(size_t)k * M + own.I[q]] = shv[own.I[q]] * shv[own.I[q]] * P[q][0];
+    if (g_PF && fp.store_PF) {
+#pragma unroll
+      for (int q = 0; q < TPT; ++q)
+        if (own.ok[q]) tile_store(g_PF + ((size_t)k * sh.ntiles + tid + q * NT) * 16, P[q]);
+    }
+    __syncthreads();  // B5
+  }
+  // final filtered state -> scan state (E = 0, e = 0 is implied; the smoother starts from MF/PF at T-1)
+  if (tid < M && n_clamped) atomicAdd(&b.counters[(size_t)pb * 4 + 1], n_clamped);
+  if (tid == 0 && n_nan) atomicAdd(&b.counters[(size_t)pb * 4 + 2], n_nan);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// RTS gain.  One workgroup per (step, problem) of the current chunk:
+//   B = PS_k A' ; PSkp = A B + Q ; L = chol(PSkp,'lower') (jitter retry) ; G = B / L' / L
+//   Delta_k = PS_{k+1} - PSkp ; delta_k = MF_{k+1} - A MF_k          (gf_ep_modulator_nmf.m:210-230)
+// Right-looking blocked algorithms on the 4x4 tiles; every thread keeps its B/X/G tile and its
+// L tile in registers; panels travel through LDS (double buffered).
+struct GainPar {
+  int64_t k0;   // first step of the chunk
+  int nk;       // steps in the chunk
+  int chunk;    // chunk capacity (buffer stride)
+};
+
+__host__ __device__ inline size_t gain_lds_doubles(const Shape& s) {
+  return LDS_INT_DOUBLES + (size_t)s.M * 16 * 2 + 4 * (size_t)s.M * 16 + 8;
+}
+
+// in-place Cholesky of the leading bs x bs lower triangle of a 4x4 tile; padding -> identity.
+__device__ __forceinline__ bool tile_chol(double* t, int bs) {
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (j < bs) {
+      double s = t[4 * j + j];
+#pragma unroll
+      for (int l = 0; l < 4; ++l)
+        if (l < j) s = fma(-t[4 * j + l], t[4 * j + l], s);
+      if (!(s > 0.0)) ok = false;
+      const double d = sqrt(s);
+      t[4 * j + j] = d;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (i > j && i < bs) {
+          double v = t[4 * i + j];
+#pragma unroll
+          for (int l = 0; l < 4; ++l)
+            if (l < j) v = fma(-t[4 * i + l], t[4 * j + l], v);
+          t[4 * i + j] = v / d;
+        }
+    } else {
+      t[4 * j + j] = 1.0;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (i < j) t[4 * i + j] = 0.0;   // upper part
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (i > j && (i >= bs || j >= bs)) t[4 * i + j] = 0.0;
+  }
+  return ok;
+}
+// rows of t:  x * L' = t   (forward substitution, L lower 4x4 with unit padding)
+__device__ __forceinline__ void tile_solve_Lt(double* t, const double* L) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      double v = t[4 * i + c];
+#pragma unroll
+      for (int l = 0; l < 4; ++l)
+        if (l < c) v = fma(-t[4 * i + l], L[4 * c + l], v);
+      t[4 * i + c] = v / L[4 * c + c];
+    }
+}
+// rows of t:  x * L = t   (backward substitution)
+__device__ __forceinline__ void tile_solve_L(double* t, const double* L) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int c = 3; c >= 0; --c) {
+      double v = t[4 * i + c];
+#pragma unroll
+      for (int l = 0; l < 4; ++l)
+        if (l > c) v = fma(-t[4 * i + l], L[4 * l + c], v);
+      t[4 * i + c] = v / L[4 * c + c];
+    }
+}
+
+template <int TPT>
+__global__ void __launch_bounds__(512) rts_gain_kernel(Shape sh, Bufs b, GainPar gp) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int tid = threadIdx.x, NT = blockDim.x;
+  const int S = sh.S, M = sh.M;
+  const int64_t T = sh.T;
+  const int kk = blockIdx.x, pb = blockIdx.y;
+  const int64_t k = gp.k0 + kk;
+  const double* mdl = b.model + (size_t)pb * mdl_size(sh);
+
+  int* ioff = reinterpret_cast<int*>(lds);
+  int* ibsz = ioff + (MAXM + 1);
+  double* sA = lds + LDS_INT_DOUBLES;          // [M][16]
+  double* sLd = sA + (size_t)M * 16;           // [M][16] diagonal Cholesky factors
+  double* bufX = sLd + (size_t)M * 16;         // [2][M][16]
+  double* bufP = bufX + 2 * (size_t)M * 16;    // [2][M][16]
+  int* flag = reinterpret_cast<int*>(bufP + 2 * (size_t)M * 16);
+
+  for (int i = tid; i <= M; i += NT) ioff[i] = sh.off[i];
+  for (int i = tid; i < M; i += NT) ibsz[i] = sh.bsz[i];
+  for (int i = tid; i < M * 16; i += NT) sA[i] = mdl[mdl_A(sh) + i];
+  if (tid == 0) { flag[0] = 0; flag[1] = 0; }
+  __syncthreads();
+
+  TileOwner<TPT> own;
+  own.init(M, sh.ntiles);
+  const double* PFk = b.PF + ((size_t)pb * T + k) * sh.ntiles * 16;
+  const double* PFk1 = PFk + (size_t)sh.ntiles * 16;
+  double* Gout = b.Gbuf + (((size_t)pb * gp.chunk + kk) * 2) * sh.ntiles * 16;
+  double* Dout = Gout + (size_t)sh.ntiles * 16;
+
+  double Bt[TPT][16], Lt[TPT][16];
+#pragma unroll
+  for (int q = 0; q < TPT; ++q) {
+    tile_zero(Bt[q]); tile_zero(Lt[q]);
+    if (own.ok[q]) {
+      const int I = own.I[q], J = own.J[q], t = tid + q * NT;
+      double ps[16];
+      tile_load(ps, PFk + (size_t)t * 16);
+      tile_mma_nt(Bt[q], ps, sA + (size_t)J * 16);          // B = PS A'
+      tile_mma(Lt[q], sA + (size_t)I * 16, Bt[q]);          // PSkp = A B (+Q)
+      if (I == J) {
+        const double* Qb = mdl + mdl_Q(sh) + (size_t)I * 16;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) Lt[q][e] += Qb[e];
+      }
+      double d[16];
+      tile_load(d, PFk1 + (size_t)t * 16);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) d[e] -= Lt[q][e];
+      tile_store(Dout + (size_t)t * 16, d);                 // Delta_k
+    }
+  }
+  // delta_k = MF_{k+1} - A MF_k
+  if (tid < S) {
+    int blk = 0;
+    while (ioff[blk + 1] <= tid) ++blk;
+    const int row = tid - ioff[blk];
+    const double* mf = b.MF + ((size_t)pb * T + k) * S;
+    double acc = mf[S + tid];
+    for (int l = 0; l < ibsz[blk]; ++l) acc = fma(-sA[(size_t)blk * 16 + 4 * row + l], mf[ioff[blk] + l], acc);
+    b.dbuf[((size_t)pb * gp.chunk + kk) * S + tid] = acc;
+  }
+
+  // ---- Cholesky of the lower triangle (two attempts: plain, then + jitter, SURVEY C-7)
+  bool failed = false;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    if (attempt == 1) {
+#pragma unroll
+      for (int q = 0; q < TPT; ++q)
+        if (own.ok[q]) {
+          const int I = own.I[q], J = own.J[q];
+          tile_zero(Lt[q]);
+          tile_mma(Lt[q], sA + (size_t)I * 16, Bt[q]);
+          if (I == J) {
+            const double* Qb = mdl + mdl_Q(sh) + (size_t)I * 16;
+            // sqrt(1e-4)*diag(rand): deterministic 0.5 in place of rand
+#pragma unroll
+            for (int e = 0; e < 16; ++e) Lt[q][e] += Qb[e];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (i < ibsz[I]) Lt[q][5 * i] += 0.01 * 0.5;
+          }
+        }
+    }
+    for (int jb = 0; jb < M; ++jb) {
+      const int par = jb & 1;
+#pragma unroll
+      for (int q = 0; q < TPT; ++q)
+        if (own.ok[q] && own.I[q] == jb && own.J[q] == jb) {
+          if (!tile_chol(Lt[q], ibsz[jb])) flag[attempt] = 1;
+          tile_store(sLd + (size_t)jb * 16, Lt[q]);
+        }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < TPT; ++q)
+        if (own.ok[q] && own.J[q] == jb && own.I[q] > jb) {
+          tile_solve_Lt(Lt[q], sLd + (size_t)jb * 16);
+          tile_store(bufP + ((size_t)par * M + own.I[q]) * 16, Lt[q]);
+        }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < TPT; ++q)
+        if (own.ok[q] && own.J[q] > jb && own.I[q] >= own.J[q])
+          tile_mms_nt(Lt[q], bufP + ((size_t)par * M + own.I[q]) * 16, bufP + ((size_t)par * M + own.J[q]) * 16);
+    }
+    __syncthreads();
+    failed = (flag[attempt] != 0);
+    if (!failed) break;
+  }
+  if (tid == 0) {
+    if (flag[0]) atomicAdd(&b.counters[(size_t)pb * 4 + 0], 1ull);
+    if (flag[0] && flag[1]) atomicAdd(&b.counters[(size_t)pb * 4 + 3], 1ull);
+  }
+
+  // ---- X L' = B  (forward over block columns)
+  for (int jb = 0; jb < M; ++jb) {
+    const int par = jb & 1;
+#pragma unroll
+    for (int q = 0; q < TPT; ++q)
+      if (own.ok[q] && own.J[q] == jb) {
+        tile_solve_Lt(Bt[q], sLd + (size_t)jb * 16);
+        tile_store(bufX + ((size_t)par * M + own.I[q]) * 16, Bt[q]);
+        if (own.I[q] > jb) tile_store(bufP + ((size_t)par * M + own.I[q]) * 16, Lt[q]);
+      }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < TPT; ++q)
+      if (own.ok[q] && own.J[q] > jb)
+        tile_mms_nt(Bt[q], bufX + ((size_t)par * M + own.I[q]) * 16, bufP + ((size_t)par * M + own.J[q]) * 16);
+  }
+  __syncthreads();
+  // ---- G L = X  (backward over block columns)
+  for (int jb = M - 1; jb >= 0; --jb) {
+    const int par = jb & 1;
+#pragma unroll
+    for (int q = 0; q < TPT; ++q)
+      if (own.ok[q]) {
+        if (own.J[q] == jb) {
+          tile_solve_L(Bt[q], sLd + (size_t)jb * 16);
+          tile_store(bufX + ((size_t)par * M + own.I[q]) * 16, Bt[q]);
+        }
+        if (own.I[q] == jb && own.J[q] < jb) tile_store(bufP + ((size_t)par * M + own.J[q]) * 16, Lt[q]);
+      }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < TPT; ++q)
+      if (own.ok[q] && own.J[q] < jb)
+        tile_mms(Bt[q], bufX + ((size_t)par * M + own.I[q]) * 16, bufP + ((size_t)par * M + own.J[q]) * 16);
+  }
+#pragma unroll
+  for (int q = 0; q < TPT; ++q)
+    if (own.ok[q]) {
+      // clean padding, then store G
+      const int bI = ibsz[own.I[q]], bJ = ibsz[own.J[q]];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (i >= bI || j >= bJ) Bt[q][4 * i + j] = 0.0;
+      tile_store(Gout + (size_t)(tid + q * NT) * 16, Bt[q]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// RTS backward recursion over one chunk, one workgroup per problem (sequential in k):
+//   Y = E + Delta_k ; X = G_k Y ; E <- X G_k' ; e <- G_k (e + delta_k)
+//   (E_k = P^s_k - PS_k, e_k = m^s_k - MF_k: gf_ep_modulator_nmf.m:229-230 in difference form)
+// Panel GEMM on 4x4 register tiles: operands streamed global -> registers -> LDS panels (double
+// buffered, one barrier per panel); state E/X live in global scratch (L2 resident).
+struct ScanPar {
+  int64_t k0;
+  int nk;
+  int chunk;
+  int LP;          // panel width in tiles
+  int first;       // first chunk of the sweep: E = 0, e = 0
+  int write_PSs;   // also store smoothed covariances PF_k + E_k
+  int last_state;  // at k == 0 store the smoothed (P, m) into `state` (EKF restart) -- always done
+};
+
+__host__ __device__ inline size_t scan_lds_doubles(const Shape& s, int LP) {
+  return LDS_INT_DOUBLES + (size_t)s.M + 2 * (size_t)s.S + 4 * (size_t)s.M * LP * 16 + 8;
+}
+
+template <int TPT>
+__global__ void __launch_bounds__(512) rts_scan_kernel(Shape sh, Bufs b, ScanPar sp, double* xbuf /* [B][ntiles*16] */) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int tid = threadIdx.x, NT = blockDim.x;
+  const int S = sh.S, M = sh.M, LP = sp.LP;
+  const int64_t T = sh.T;
+  const int pb = blockIdx.x;
+  const double* mdl = b.model + (size_t)pb * mdl_size(sh);
+  const int ntl = sh.ntiles;
+
+  int* ioff = reinterpret_cast<int*>(lds);
+  int* ibsz = ioff + (MAXM + 1);
+  double* shv = lds + LDS_INT_DOUBLES;   // [M]
+  double* ev = shv + M;                  // [S] e + delta
+  double* en = ev + S;                   // [S] new e
+  double* pan = en + S;                  // [2][2][M*LP][16]   (buffer, operand, tile)
+  const size_t panOp = (size_t)M * LP * 16;
+
+  for (int i = tid; i <= M; i += NT) ioff[i] = sh.off[i];
+  for (int i = tid; i < M; i += NT) ibsz[i] = sh.bsz[i];
+  for (int i = tid; i < M; i += NT) shv[i] = mdl[mdl_h(sh) + i];
+  double* Est = b.state + (size_t)pb * ((size_t)ntl * 16 + S);
+  double* est = Est + (size_t)ntl * 16;
+  double* Xb = xbuf + (size_t)pb * ntl * 16;
+  if (sp.first) {
+    for (int i = tid; i < ntl * 16; i += NT) Est[i] = 0.0;
+    for (int i = tid; i < S; i += NT) est[i] = 0.0;
+  }
+  __syncthreads();
+  int myblk = 0, myrow = 0;
+  if (tid < S) {
+    while (ioff[myblk + 1] <= tid) ++myblk;
+    myrow = tid - ioff[myblk];
+  }
+  TileOwner<TPT> own;
+  own.init(M, ntl);
+  const int npan = (M + LP - 1) / LP;
+  double mxM = 0.0, mxP = 0.0;
+
+  for (int kk = sp.nk - 1; kk >= 0; --kk) {
+    const int64_t k = sp.k0 + kk;
+    const double* Gk = b.Gbuf + (((size_t)pb * sp.chunk + kk) * 2) * ntl * 16;
+    const double* Dk = Gk + (size_t)ntl * 16;
+    const double* dk = b.dbuf + ((size_t)pb * sp.chunk + kk) * S;
+    if (tid < S) ev[tid] = est[tid] + dk[tid];
+
+    double acc[TPT][16];
+    // ================= GEMM 1: X = G (E + Delta)
+#pragma unroll
+    for (int q = 0; q < TPT; ++q) tile_zero(acc[q]);
+    for (int p = 0; p < npan; ++p) {
+      const int l0 = p * LP, lw = (M - l0 < LP) ? (M - l0) : LP;
+      double* pg = pan + (size_t)(p & 1) * 2 * panOp;   // G[:, panel]   tile (I,l) at (I*LP+l)
+      double* py = pg + panOp;                           // Y[panel, :]   tile (l,J) at (l*M+J)
+      for (int it = tid; it < 2 * M * lw; it += NT) {
+        double t16[16];
+        if (it < M * lw) {
+          const int I = it / lw, l = it - I * lw;
+          tile_load(t16, Gk + ((size_t)I * M + l0 + l) * 16);
+          tile_store(pg + ((size_t)I * LP + l) * 16, t16);
+        } else {
+          const int it2 = it - M * lw;
+          const int l = it2 / M, J = it2 - l * M;
+          double d16[16];
+          const size_t tix = ((size_t)(l0 + l) * M + J) * 16;
+          tile_load(t16, Est + tix);
+          tile_load(d16, Dk + tix);
+#pragma unroll
+          for (int e = 0; e < 16; ++e) t16[e] += d16[e];
+          tile_store(py + ((size_t)l * M + J) * 16, t16);
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < TPT; ++q)
+        if (own.ok[q])
+          for (int l = 0; l < lw; ++l)
+            tile_mma(acc[q], pg + ((size_t)own.I[q] * LP + l) * 16, py + ((size_t)l * M + own.J[q]) * 16);
+    }
+#pragma unroll
+    for (int q = 0; q < TPT; ++q)
+      if (own.ok[q]) tile_store(Xb + (size_t)(tid + q * NT) * 16, acc[q]);
+    // e' = G (e + delta)   (row `tid` of G)
+    if (tid < S) {
+      double a = 0.0;
+      for (int J = 0; J < M; ++J) {
+        const double* g = Gk + ((size_t)myblk * M + J) * 16 + 4 * myrow;
+        const double* v = ev + ioff[J];
+        for (int j = 0; j < ibsz[J]; ++j) a = fma(g[j], v[j], a);
+      }
+      en[tid] = a;
+    }
+    __syncthreads();   // X visible to the whole workgroup; all GEMM-1 panel reads done
+    // ================= GEMM 2: E' = X G'
+#pragma unroll
+    for (int q = 0; q < TPT; ++q) tile_zero(acc[q]);
+    for (int p = 0; p < npan; ++p) {
+      const int l0 = p * LP, lw = (M - l0 < LP) ? (M - l0) : LP;
+      double* px = pan + (size_t)(p & 1) * 2 * panOp;   // X[:, panel]  tile (I,l) at (I*LP+l)
+      double* pg = px + panOp;                           // G[:, panel]  tile (J,l) at (J*LP+l)
+      for (int it = tid; it < 2 * M * lw; it += NT) {
+        double t16[16];
+        const int it2 = (it < M * lw) ? it : it - M * lw;
+        const int I = it2 / lw, l = it2 - I * lw;
+        const double* src = (it < M * lw) ? Xb : Gk;
+        tile_load(t16, src + ((size_t)I * M + l0 + l) * 16);
+        tile_store(((it < M * lw) ? px : pg) + ((size_t)I * LP + l) * 16, t16);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < TPT; ++q)
+        if (own.ok[q])
+          for (int l = 0; l < lw; ++l)
+            tile_mma_nt(acc[q], px + ((size_t)own.I[q] * LP + l) * 16, pg + ((size_t)own.J[q] * LP + l) * 16);
+    }
+    // ---- store E', outputs
+    const double* PFk = b.PF + ((size_t)pb * T + k) * ntl * 16;
+#pragma unroll
+    for (int q = 0; q < TPT; ++q)
+      if (own.ok[q]) {
+        const int t = tid + q * NT;
+        tile_store(Est + (size_t)t * 16, acc[q]);
+        if (own.I[q] == own.J[q]) {
+          const int n = own.I[q];
+          const size_t ix = ((size_t)pb * T + k) * M + n;
+          const double vnew = b.fv[ix] + shv[n] * shv[n] * acc[q][0];
+          mxP = fmax(mxP, fabs(b.sv[ix] - vnew));
+          b.sv[ix] = vnew;
+        }
+        if (sp.write_PSs || k == 0) {
+          double ps[16];
+          tile_load(ps, PFk + (size_t)t * 16);
+#pragma unroll
+          for (int e = 0; e < 16; ++e) ps[e] += acc[q][e];
+          if (sp.write_PSs) tile_store(b.PSs + (((size_t)pb * T + k) * ntl + t) * 16, ps);
+          if (k == 0) tile_store(Xb + (size_t)t * 16, ps);   // staged; copied into `state` after the loop
+        }
+      }
+    if (tid < S) {
+      const double e1 = en[tid];
+      est[tid] = e1;
+      const double ms = b.MF[((size_t)pb * T + k) * S + tid] + e1;
+      b.MS[((size_t)pb * T + k) * S + tid] = ms;
+      if (myrow == 0) {
+        const size_t ix = ((size_t)pb * T + k) * M + myblk;
+        const double mnew = shv[myblk] * ms;
+        mxM = fmax(mxM, fabs(b.sm[ix] - mnew));
+        b.sm[ix] = mnew;
+      }
+    }
+    __syncthreads();   // E', e' visible before the next step reads them
+  }
+  // running maxima -> red[1], red[2] (accumulated over chunks with atomics on the bit pattern: values >= 0)
+  mxM = wave_max(mxM);
+  mxP = wave_max(mxP);
+  if ((tid & 63) == 0) {
+    atomicMax(reinterpret_cast<unsigned long long*>(&b.red[(size_t)pb * 8 + 1]), (unsigned long long)__double_as_longlong(mxM));
+    atomicMax(reinterpret_cast<unsigned long long*>(&b.red[(size_t)pb * 8 + 2]), (unsigned long long)__double_as_longlong(mxP));
+  }
+  if (sp.k0 == 0) {
+    // smoothed (P, m) at k = 0 -> state (restart point of the non-resetting EKF variant)
+    __syncthreads();
+    for (int i = tid; i < ntl * 16; i += NT) Est[i] = Xb[i];
+    if (tid < S) est[tid] = b.MS[((size_t)pb * T) * S + tid];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Power-EP site refresh, parallel over steps (gf_ep_modulator_nmf.m:236-268,
+// ihgp_ep_modulator_nmf.m:397-436): cavity from the smoothed marginals, mom(alpha), damped update.
+struct EpPar {
+  int64_t k_end;       // steps 0 .. k_end-1 are refreshed (T-1)
+  int steps_per_wg;
+  double alpha;
+  double ep_damp;
+  int clamp;           // gf predict mode: ttau = max(ttau,0) after the update, R = 1/ttau for all sites
+  int write_R;         // 0: none (nlml), 1: all sites (gf predict), 2: updated sites only (ihgp)
+  double* lZ_out;      // [B][T] where the per-step log Z goes (gf: b.lZ ; ihgp: separate array)
+  int const_var;       // ihgp: marginal variance is read from sv[k] as usual (kept for clarity)
+};
+
+__host__ __device__ inline size_t ep_lds_doubles(const Shape& s, const MomCfg& mc) {
+  return (size_t)s.D * s.N + 4 * (size_t)s.M + 8 + mom_lds_doubles(mc);
+}
+
+__global__ void __launch_bounds__(256) ep_site_kernel(Shape sh, Bufs b, MomCfg mc, EpPar ep) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int tid = threadIdx.x, NT = blockDim.x;
+  const int M = sh.M;
+  const int64_t T = sh.T;
+  const int pb = blockIdx.y;
+  const double* mdl = b.model + (size_t)pb * mdl_size(sh);
+  double* sW = lds;
+  double* mc_ = sW + (size_t)sh.D * sh.N;   // m_cav [M]
+  double* vc_ = mc_ + M;                    // v_cav [M]
+  double* dl = vc_ + M;
+  double* d2l = dl + M;
+  double* misc = d2l + M;
+  double* ws = misc + 8;
+  for (int i = tid; i < sh.D * sh.N; i += NT) sW[i] = mdl[mdl_W(sh) + i];
+  const double sn2 = mdl[mdl_sn2(sh)];
+  __syncthreads();
+  const int64_t kb = (int64_t)blockIdx.x * ep.steps_per_wg;
+  unsigned long long n_clamped = 0;
+  for (int64_t k = kb; k < kb + ep.steps_per_wg && k < ep.k_end; ++k) {
+    const double yk = b.y[(size_t)pb * T + k];
+    if (yk != yk) continue;   // isnan(y_k): no EP update (uniform)
+    const size_t ix = ((size_t)pb * T + k) * M + tid;
+    double t_old = 0.0, n_old = 0.0, vcav = 0.0, mcav = 0.0;
+    if (tid < M) {
+      t_old = b.ttau[ix]; n_old = b.tnu[ix];
+      const double vm = b.sv[ix], mm = b.sm[ix];
+      vcav = 1.0 / (1.0 / vm - ep.alpha * t_old);
+      mcav = vcav * (mm / vm - ep.alpha * n_old);
+      mc_[tid] = mcav; vc_[tid] = vcav;
+    }
+    __syncthreads();
+    mom_eval(mc, sW, sn2, ep.alpha, yk, mc_, vc_, ws, &misc[0], dl, d2l);
+    if (tid < M) {
+      const bool upd = vcav > 0.0;
+      double tnew = t_old, nnew = n_old;
+      if (upd) {
+        const double d1 = dl[tid], d2 = d2l[tid];
+        tnew = (1.0 - ep.ep_damp * ep.alpha) * t_old + ep.ep_damp * (-d2 / (1.0 + d2 * vcav));
+        nnew = (1.0 - ep.ep_damp * ep.alpha) * n_old + ep.ep_damp * ((d1 - mcav * d2) / (1.0 + d2 * vcav));
+      }
+      if (ep.clamp) { if (!(tnew > 0.0)) ++n_clamped; tnew = max0(tnew); }
+      b.ttau[ix] = tnew; b.tnu[ix] = nnew;
+      if (ep.write_R == 1 || (ep.write_R == 2 && upd)) b.R[ix] = 1.0 / tnew;
+    }
+    if (tid == 0) ep.lZ_out[(size_t)pb * T + k] = misc[0];
+    __syncthreads();
+  }
+  if (tid < M && n_clamped) atomicAdd(&b.counters[(size_t)pb * 4 + 1], n_clamped);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Deterministic reductions: out[pb*8 + slot] = sum_{k in [k_lo,k_hi)} v[pb][k]   (skipping nothing:
+// entries that were never written are zero, like the reference's zeros(1,T) initialisation).
+__global__ void __launch_bounds__(1024) sum_kernel(const double* v, int64_t T, int64_t k_lo, int64_t k_hi, double* out, int slot) {
+  __shared__ double part[16];
+  const int tid = threadIdx.x, NT = blockDim.x, pb = blockIdx.x;
+  const double* p = v + (size_t)pb * T;
+  // fixed blocking: thread t sums a contiguous slice in order, then a fixed tree
+  const int64_t n = k_hi - k_lo;
+  const int64_t per = (n + NT - 1) / NT;
+  const int64_t a = k_lo + (int64_t)tid * per;
+  const int64_t e = (a + per < k_hi) ? a + per : k_hi;
+  double s = 0.0;
+  for (int64_t k = a; k < e; ++k) s += p[k];
+  s = wave_sum(s);
+  if ((tid & 63) == 0) part[tid >> 6] = s;
+  __syncthreads();
+  if (tid == 0) {
+    double tot = 0.0;
+    for (int w = 0; w < (NT >> 6); ++w) tot += part[w];
+    out[(size_t)pb * 8 + slot] = tot;
+  }
+}
+
+}  // namespace nagp

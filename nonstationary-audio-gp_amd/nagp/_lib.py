@@ -1,0 +1,130 @@
+"""ctypes binding of libnagp.so (include/nagp.h).  No torch types cross this boundary.
+
+The library is built in-tree by `__graft_entry__.build()` (hipcc --offload-arch=gfx950).  There is
+no CPU fallback: if the shared object is missing or no GPU is visible every entry point raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PKG_ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(PKG_ROOT, 'libnagp.so')
+CSRC = os.path.join(PKG_ROOT, 'csrc')
+INCLUDE = os.path.join(os.path.dirname(PKG_ROOT), 'include')
+
+NAGP_OK = 0
+KIND_GF_EP, KIND_IHGP, KIND_GIEKF = 0, 1, 2
+MODE_PREDICT, MODE_NLML = 0, 1
+LIK_POWER, LIK_POWER_NMF, LIK_POWER_NMF_SQRT = 0, 1, 2
+LINK_SOFTPLUS, LINK_EXP = 0, 1
+FLAG_IHGP_CONSTRAINTS, FLAG_EKF_RESET_P, FLAG_WANT_PS = 0x1, 0x2, 0x4
+N_KERNELS = 8
+KERNEL_NAMES = ['filter', 'gain', 'scan', 'epsite', 'reduce', 'filter_lin', 'output', 'other']
+
+c_dp = C.POINTER(C.c_double)
+c_ip = C.POINTER(C.c_int32)
+c_lp = C.POINTER(C.c_int64)
+
+
+class Model(C.Structure):
+    _fields_ = [('S', C.c_int32), ('M', C.c_int32), ('D', C.c_int32), ('N', C.c_int32),
+                ('block_offsets', c_ip), ('A', c_dp), ('Q', c_dp), ('Pinf', c_dp), ('h_val', c_dp),
+                ('Wnmf', c_dp), ('lik_param', C.c_double)]
+
+
+class IhgpTables(C.Structure):
+    _fields_ = [('n_grid', C.c_int32), ('r_grid', c_dp), ('PPlist', c_dp), ('pp_offsets', c_lp),
+                ('PGlist', c_dp), ('pg_offsets', c_lp)]
+
+
+class Opts(C.Structure):
+    _fields_ = [('kind', C.c_int32), ('mode', C.c_int32), ('lik_kind', C.c_int32), ('link_kind', C.c_int32),
+                ('link_shift', C.c_double), ('n_pts', C.c_int32), ('cub_dim', C.c_int32), ('wn', c_dp),
+                ('xn_unscaled', c_dp), ('ep_fraction', C.c_double), ('ep_itts', C.c_int32),
+                ('ep_damping', c_dp), ('l_iter', C.c_int32), ('predict_at_k1', C.c_int32),
+                ('flags', C.c_uint32), ('device', C.c_int32), ('chunk', C.c_int32)]
+
+
+class Out(C.Structure):
+    _fields_ = [('Eft', c_dp), ('Varft', c_dp), ('MS', c_dp), ('PS', c_dp), ('ttau', c_dp), ('tnu', c_dp),
+                ('R', c_dp), ('lZ', c_dp), ('nlZ', c_dp), ('maxDiffM', c_dp), ('maxDiffP', c_dp),
+                ('counters', c_lp)]
+
+
+class Timings(C.Structure):
+    _fields_ = [('ms', C.c_double * N_KERNELS), ('launches', C.c_int64 * N_KERNELS), ('total_ms', C.c_double)]
+
+
+EXPORTS = ['nagp_version', 'nagp_device_count', 'nagp_strerror', 'nagp_last_error', 'nagp_ep_run',
+           'nagp_ihgp_run', 'nagp_giekf_run', 'nagp_plan_create', 'nagp_plan_upload_y', 'nagp_plan_execute',
+           'nagp_plan_timings', 'nagp_plan_download', 'nagp_plan_device_bytes', 'nagp_plan_destroy']
+
+
+class NagpError(RuntimeError):
+    pass
+
+
+def build(force=False, verbose=False):
+    """Compile csrc/nagp_api.hip -> libnagp.so for gfx950 (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(INCLUDE, 'nagp.h')]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
+        return LIB_PATH
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    cmd = [hipcc, '-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-shared', '-I', INCLUDE,
+           '-o', LIB_PATH, os.path.join(CSRC, 'nagp_api.hip')]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or r.returncode != 0:
+        print(' '.join(cmd)); print(r.stdout); print(r.stderr)
+    if r.returncode != 0:
+        raise NagpError('hipcc failed building libnagp.so')
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load libnagp.so (raises NagpError when it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NagpError('libnagp.so is missing (%s): run __graft_entry__.build() -- there is no CPU fallback' % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.nagp_version.restype = C.c_int
+    L.nagp_device_count.restype = C.c_int
+    L.nagp_strerror.restype = C.c_char_p; L.nagp_strerror.argtypes = [C.c_int]
+    L.nagp_last_error.restype = C.c_char_p
+    L.nagp_ep_run.argtypes = [C.POINTER(Model), c_dp, C.c_int64, C.POINTER(Opts), C.POINTER(Out)]
+    L.nagp_ihgp_run.argtypes = [C.POINTER(Model), C.POINTER(IhgpTables), c_dp, C.c_int64, C.POINTER(Opts), C.POINTER(Out)]
+    L.nagp_giekf_run.argtypes = [C.POINTER(Model), c_dp, C.c_int64, C.POINTER(Opts), C.POINTER(Out)]
+    L.nagp_plan_create.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(Model), C.POINTER(IhgpTables),
+                                   C.c_int64, C.POINTER(Opts)]
+    L.nagp_plan_upload_y.argtypes = [C.c_void_p, C.POINTER(c_dp)]
+    L.nagp_plan_execute.argtypes = [C.c_void_p]
+    L.nagp_plan_timings.argtypes = [C.c_void_p, C.POINTER(Timings)]
+    L.nagp_plan_download.argtypes = [C.c_void_p, C.POINTER(Out)]
+    L.nagp_plan_device_bytes.argtypes = [C.c_void_p]; L.nagp_plan_device_bytes.restype = C.c_int64
+    L.nagp_plan_destroy.argtypes = [C.c_void_p]; L.nagp_plan_destroy.restype = None
+    for f in ('nagp_ep_run', 'nagp_ihgp_run', 'nagp_giekf_run', 'nagp_plan_create', 'nagp_plan_upload_y',
+              'nagp_plan_execute', 'nagp_plan_timings', 'nagp_plan_download'):
+        getattr(L, f).restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(status):
+    if status != NAGP_OK:
+        L = lib()
+        raise NagpError('libnagp: %s (%d): %s' % (L.nagp_strerror(status).decode(), status, L.nagp_last_error().decode()))
+
+
+def dptr(a):
+    return a.ctypes.data_as(c_dp) if a is not None else c_dp()
+
+
+def f64(a, order='F'):
+    return np.require(np.asarray(a, dtype=np.float64), requirements=['A', 'O', 'W'] + (['F'] if order == 'F' else ['C']))

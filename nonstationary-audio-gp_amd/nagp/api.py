@@ -1,0 +1,317 @@
+"""Host-side mirror of the reference's operator interface for the hot path.
+
+Same names, positional argument lists and return conventions as the MATLAB functions
+(matlab/gf_ep_modulator.m:1, gf_ep_modulator_nmf.m:1, gf_ep_modulator_nmf_constraints.m:1-2,
+ihgp_ep_modulator_nmf.m:1, ihgp_ep_modulator_nmf_constraints.m:1-2, gf_giekf_modulator_nmf.m:1-2,
+gf_giekf_modulator_nmf_constraints.m:1-2); `nargout` stands in for MATLAB's nargout.  Everything up
+to the discrete-time model runs here on the host (as it would in the .m wrapper); the per-time-step
+loops run in libnagp.so on the GPU.  There is no CPU fallback.
+
+The two function handles of the reference become:
+  ss  -- any callable ss(x, p1, p2, k1, k2) -> (F, L, Qc, H, Pinf) with block-diagonal F (one block per
+         row of H); `nagp.ss_modulators_nmf` / `nagp.ss_modulators` wrapped by SSHandle are the shipped ones
+  mom -- a `Mom` descriptor (the wrapper inspects it the way the MEX wrapper inspects
+         functions(mom).workspace{1}: likfunc, link, p_cubature or precomputed wn/xn_unscaled)
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from . import cubature, ihgp_tables
+from . import ss as ssm
+
+
+class Mom:
+    """Descriptor of the reference's `mom` closure (demo_toy_modulators_nmf.m:81, demo_toy_modulators.m:81,
+    experiments/train_GTFNMF.m:149)."""
+    _KINDS = {'likModulatorPower': L.LIK_POWER, 'likModulatorNMFPower': L.LIK_POWER_NMF,
+              'likModulatorPreCalcwn': L.LIK_POWER_NMF_SQRT}
+
+    def __init__(self, likfunc='likModulatorNMFPower', link='softplus', link_shift=0.0, p_cubature=9,
+                 wn=None, xn_unscaled=None, quirks=True):
+        if likfunc not in self._KINDS:
+            raise ValueError('unknown likelihood %r (shipped: %s)' % (likfunc, ', '.join(self._KINDS)))
+        if link not in ('softplus', 'exp'):
+            raise ValueError("link must be 'softplus' (log(1+exp(g-shift))) or 'exp'")
+        self.likfunc, self.kind = likfunc, self._KINDS[likfunc]
+        self.link, self.link_shift, self.p, self.quirks = link, float(link_shift), p_cubature, quirks
+        self.wn, self.xn_unscaled = wn, xn_unscaled
+        if self.kind == L.LIK_POWER_NMF_SQRT and (wn is None or xn_unscaled is None):
+            raise ValueError('likModulatorPreCalcwn needs precomputed wn, xn_unscaled')
+
+    def tables(self, dim):
+        if self.wn is not None:
+            wn = np.asarray(self.wn, float).ravel(); xn = np.asarray(self.xn_unscaled, float)
+            if xn.shape != (dim, wn.size):
+                raise ValueError('xn_unscaled must be %d x %d' % (dim, wn.size))
+            return wn, xn
+        return cubature.sigma_points(self.p, dim, self.quirks)
+
+
+class SSHandle:
+    """ss = @(x,p1,p2,k1,k2) ss_modulators_nmf(p1,p2,k1,k2)  /  @(x,p,k1,k2) ss_modulators(p,k1,k2)."""
+
+    def __init__(self, name='ss_modulators_nmf'):
+        self.name = name
+
+    def __call__(self, x, *a):
+        if self.name == 'ss_modulators_nmf':
+            return ssm.ss_modulators_nmf(*a)
+        return ssm.ss_modulators(*a)
+
+
+def _merge_inputs(x, y, xt):
+    """gf_ep_modulator_nmf.m:58-66."""
+    x = np.asarray(x, float).ravel(); y = np.asarray(y, float).ravel()
+    xt = np.zeros(0) if xt is None else np.asarray(xt, float).ravel()
+    xall = np.concatenate([x, xt]); yall = np.concatenate([y, np.full(xt.size, np.nan)])
+    _, first, inv = np.unique(xall, return_index=True, return_inverse=True)
+    return np.ascontiguousarray(yall[first]), inv[xall.size - xt.size:]
+
+
+def _blocks_from_dense(F, L_, Qc, H, Pinf, D, N):
+    """Recover the per-block form from what an `ss` handle returned (block starts = non-zero columns
+    of H, ihgp_ep_modulator_nmf.m:104)."""
+    H = np.asarray(H, float); F = np.asarray(F, float); Pinf = np.asarray(Pinf, float)
+    LQL = np.asarray(L_, float) @ np.atleast_2d(Qc) @ np.asarray(L_, float).T
+    M, S = H.shape
+    starts = np.nonzero(np.abs(H).sum(axis=0))[0]
+    if starts.size != M or not all(np.count_nonzero(H[n]) == 1 and H[n, starts[n]] != 0 for n in range(M)):
+        raise ValueError('H must have exactly one non-zero per row, at the start of its block')
+    off = np.concatenate([starts, [S]])
+    mask = np.zeros((S, S), bool)
+    Fs, Qs, Ps = [], [], []
+    for n in range(M):
+        o, e = off[n], off[n + 1]
+        mask[o:e, o:e] = True
+        Fs.append(F[o:e, o:e].copy()); Qs.append(LQL[o:e, o:e].copy()); Ps.append(Pinf[o:e, o:e].copy())
+    if np.any(F[~mask] != 0) or np.any(LQL[~mask] != 0) or np.any(Pinf[~mask] != 0):
+        raise ValueError('the state-space model is not block diagonal with the blocks of H')
+    blk = ssm.BlockSS(Fs, Qs, Ps, D, N)
+    blk.h_val = H[np.arange(M), starts].copy()
+    return blk
+
+
+def _damping(ep_damping, ep_itts):
+    d = np.atleast_1d(np.asarray(ep_damping, float)).ravel()
+    if d.size == 1:                        # SURVEY C-15: drivers pass scalars with ep_itts > 1
+        d = np.full(max(int(ep_itts), 1), d[0])
+    if d.size < ep_itts:
+        raise ValueError('ep_damping has fewer than ep_itts entries')
+    return np.ascontiguousarray(d[:ep_itts])
+
+
+class _Problem:
+    """Everything the C ABI needs for one call, with the numpy arrays kept alive."""
+
+    def __init__(self, blk, Wnmf, lik_param, symmetrize_Q=False):
+        self.blk = blk
+        A, Q, P = ssm.discretise(blk, symmetrize_Q)
+        self.A, self.Q, self.Pinf = L.f64(A), L.f64(Q), L.f64(P)
+        self.h_val = L.f64(blk.h_val)
+        self.offsets = np.ascontiguousarray(blk.offsets, dtype=np.int32)
+        self.W = None if Wnmf is None else L.f64(Wnmf)
+        self.model = L.Model(S=blk.S, M=blk.M, D=blk.D, N=blk.N,
+                             block_offsets=self.offsets.ctypes.data_as(L.c_ip), A=L.dptr(self.A), Q=L.dptr(self.Q),
+                             Pinf=L.dptr(self.Pinf), h_val=L.dptr(self.h_val), Wnmf=L.dptr(self.W),
+                             lik_param=float(np.ravel(lik_param)[0]))
+
+
+class _Outputs:
+    def __init__(self, M, S, T, I, want_PS=False, want_MS=True):
+        self.Eft = np.zeros((M, T), order='F'); self.Varft = np.zeros((M, T), order='F')
+        self.MS = np.zeros((S, T), order='F') if want_MS else None
+        self.PS = np.zeros((S, S, T), order='F') if want_PS else None
+        self.ttau = np.zeros((M, T), order='F'); self.tnu = np.zeros((M, T), order='F'); self.R = np.zeros((M, T), order='F')
+        self.lZ = np.zeros(T); self.nlZ = np.zeros(I); self.maxDiffM = np.zeros(I); self.maxDiffP = np.zeros(I)
+        self.counters = np.zeros(4, dtype=np.int64)
+        self.c = L.Out(Eft=L.dptr(self.Eft), Varft=L.dptr(self.Varft), MS=L.dptr(self.MS), PS=L.dptr(self.PS),
+                       ttau=L.dptr(self.ttau), tnu=L.dptr(self.tnu), R=L.dptr(self.R), lZ=L.dptr(self.lZ),
+                       nlZ=L.dptr(self.nlZ), maxDiffM=L.dptr(self.maxDiffM), maxDiffP=L.dptr(self.maxDiffP),
+                       counters=self.counters.ctypes.data_as(L.c_lp))
+
+    def as_dict(self):
+        d = dict(tnu=self.tnu, ttau=self.ttau, lZ=self.lZ, R=self.R, MS=self.MS, PS=self.PS, nlZ=self.nlZ,
+                 maxDiffM=self.maxDiffM, maxDiffP=self.maxDiffP,
+                 counters=dict(chol_retries=int(self.counters[0]), clamped=int(self.counters[1]),
+                               nan_obs=int(self.counters[2]), not_pd=int(self.counters[3])),
+                 Eft=self.Eft, Varft=self.Varft)
+        return d
+
+
+def make_opts(kind, mode, mom, dim, ep_fraction, damping, ep_itts, l_iter=0, predict_at_k1=0, flags=0, device=0, chunk=0):
+    keep = {}
+    o = L.Opts(kind=kind, mode=mode, ep_fraction=float(ep_fraction), ep_itts=int(ep_itts), l_iter=int(l_iter),
+               predict_at_k1=int(predict_at_k1), flags=int(flags), device=int(device), chunk=int(chunk))
+    if mom is not None and kind != L.KIND_GIEKF:
+        wn, xn = mom.tables(dim)
+        keep['wn'] = L.f64(wn, 'C'); keep['xn'] = L.f64(xn)
+        o.lik_kind = mom.kind; o.link_kind = L.LINK_SOFTPLUS if mom.link == 'softplus' else L.LINK_EXP
+        o.link_shift = mom.link_shift; o.n_pts = keep['wn'].size; o.cub_dim = dim
+        o.wn = L.dptr(keep['wn']); o.xn_unscaled = L.dptr(keep['xn'])
+    if damping is not None:
+        keep['damp'] = L.f64(damping, 'C'); o.ep_damping = L.dptr(keep['damp'])
+    return o, keep
+
+
+def _returns(out, return_ind, nargout, predict_extra=None):
+    Eft = out.Eft[:, return_ind]; Varft = out.Varft[:, return_ind]
+    if nargout <= 1:
+        return Eft
+    if nargout == 2:
+        return Eft, Varft
+    lb = Eft - 1.96 * np.sqrt(Varft); ub = Eft + 1.96 * np.sqrt(Varft)
+    res = (Eft, Varft, None, lb, ub, out.as_dict())
+    return res[:max(nargout, 3)] if nargout < 6 else res
+
+
+def _unpack_log(w, num_lik_params, D, N):
+    w = np.asarray(w, float).ravel(); n0 = num_lik_params
+    return (w[:n0], np.exp(w[n0:n0 + 3 * D]), np.exp(w[n0 + 3 * D:n0 + 3 * D + 2 * N]),
+            np.exp(w[n0 + 3 * D + 2 * N:]).reshape((D, N), order='F'))
+
+
+def _unpack_constraints(w, w_fixed, tune_hypers, constraints, num_lik_params, D, N):
+    """gf_ep_modulator_nmf_constraints.m:75-110."""
+    w = np.asarray(w, float).ravel(); wf = np.asarray(w_fixed, float).ravel(); cons = np.asarray(constraints, float)
+    pos = {True: 0, False: 0}
+    src = {True: w, False: wf}
+
+    def take(tuned, cnt):
+        tuned = bool(tuned); a = pos[tuned]; pos[tuned] = a + cnt
+        return src[tuned][a:a + cnt]
+
+    lik_param = take(tune_hypers[0], num_lik_params)
+    groups = [ssm.sigmoid(take(tune_hypers[i], D if i <= 3 else N), cons[i - 1]) for i in range(1, 6)]
+    t7 = bool(tune_hypers[6])
+    Wnmf = ssm.sigmoid(src[t7][pos[t7]:], cons[5]).reshape((D, N), order='F')
+    return lik_param, np.concatenate(groups[:3]), np.concatenate(groups[3:]), Wnmf
+
+
+def _run_gf(blk, Wnmf, lik_param, yall, return_ind, mom, ep_fraction, ep_damping, ep_itts, predict, nargout,
+            predict_at_k1=0, device=0):
+    prob = _Problem(blk, Wnmf, lik_param)
+    dim = blk.D if mom.kind == L.LIK_POWER else blk.N
+    damp = _damping(ep_damping, ep_itts)
+    want_PS = predict and nargout >= 6
+    opts, keep = make_opts(L.KIND_GF_EP, L.MODE_PREDICT if predict else L.MODE_NLML, mom, dim, ep_fraction, damp,
+                           ep_itts, predict_at_k1=predict_at_k1, flags=L.FLAG_WANT_PS if want_PS else 0, device=device)
+    out = _Outputs(blk.M, blk.S, yall.size, ep_itts, want_PS=want_PS)
+    L.check(L.lib().nagp_ep_run(C.byref(prob.model), L.dptr(yall), yall.size, C.byref(opts), C.byref(out.c)))
+    return out
+
+
+def gf_ep_modulator_nmf(w, x, y, ss, mom, xt=None, kernel1='matern32', kernel2='matern52', num_lik_params=1, D=None, N=None,
+                        ep_fraction=0.5, ep_damping=None, ep_itts=30, nargout=2, device=0):
+    """[Eft,Varft,Covft,lb,ub,out] (xt given) or [e,eg] (xt empty) -- matlab/gf_ep_modulator_nmf.m:1."""
+    yall, return_ind = _merge_inputs(x, y, xt)
+    lik_param, p1, p2, Wnmf = _unpack_log(w, num_lik_params, D, N)
+    blk = _blocks_from_dense(*ss(x, p1, p2, kernel1, kernel2), D, N)           # balance OFF (:80 `if false`)
+    predict = xt is not None and np.size(xt) > 0
+    out = _run_gf(blk, Wnmf, lik_param, yall, return_ind, mom, ep_fraction, ep_damping, ep_itts, predict, nargout, device=device)
+    if predict:
+        return _returns(out, return_ind, nargout)
+    return float(out.nlZ[0]), np.zeros(np.size(w))                             # eg is all zeros (:363, :531)
+
+
+def gf_ep_modulator_nmf_constraints(w, x, y, ss, mom, xt, kernel1, kernel2, num_lik_params, D, N, ep_fraction, ep_damping,
+                                    ep_itts, constraints, w_fixed, tune_hypers, nargout=2, device=0):
+    """matlab/gf_ep_modulator_nmf_constraints.m:1-2 (sigmoid-constrained parameters, balance ON :115)."""
+    yall, return_ind = _merge_inputs(x, y, xt)
+    lik_param, p1, p2, Wnmf = _unpack_constraints(w, w_fixed, tune_hypers, constraints, num_lik_params, D, N)
+    blk = ssm.balance_blocks(_blocks_from_dense(*ss(x, p1, p2, kernel1, kernel2), D, N))
+    predict = xt is not None and np.size(xt) > 0
+    out = _run_gf(blk, Wnmf, lik_param, yall, return_ind, mom, ep_fraction, ep_damping, ep_itts, predict, nargout, device=device)
+    if predict:
+        return _returns(out, return_ind, nargout)
+    return float(out.nlZ[0]), np.zeros(np.size(w))
+
+
+def gf_ep_modulator(w, x, y, ss, mom, xt=None, kernel1='matern32', kernel2='matern52', num_lik_params=1,
+                    ep_fraction=0.5, ep_damping=None, ep_itts=30, nargout=2, device=0):
+    """matlab/gf_ep_modulator.m:1 (one modulator per sub-band; balance ON :75; predicts at k=1 in
+    predict mode :131-133)."""
+    yall, return_ind = _merge_inputs(x, y, xt)
+    w = np.asarray(w, float).ravel()
+    lik_param = w[:num_lik_params]; param = np.exp(w[num_lik_params:])
+    D = param.size // 5
+    blk = ssm.balance_blocks(_blocks_from_dense(*ss(x, param, kernel1, kernel2), D, D))
+    predict = xt is not None and np.size(xt) > 0
+    out = _run_gf(blk, None, lik_param, yall, return_ind, mom, ep_fraction, ep_damping, ep_itts, predict, nargout,
+                  predict_at_k1=1, device=device)
+    if predict:
+        return _returns(out, return_ind, nargout)
+    return float(out.nlZ[0]), np.zeros(np.size(w))
+
+
+def _run_ihgp(blk, Wnmf, lik_param, yall, mom, ep_fraction, ep_damping, ep_itts, constraints_variant, device=0):
+    prob = _Problem(blk, Wnmf, lik_param, symmetrize_Q=True)                    # :97  Q=(Q+Q')/2
+    r, PP, ppo, PG, pgo = ihgp_tables.build_tables(prob.A, prob.Q, blk.offsets, blk.h_val)
+    r = L.f64(r, 'C'); PP = L.f64(PP, 'C'); PG = L.f64(PG, 'C')
+    tabs = L.IhgpTables(n_grid=r.size, r_grid=L.dptr(r), PPlist=L.dptr(PP), pp_offsets=ppo.ctypes.data_as(L.c_lp),
+                        PGlist=L.dptr(PG), pg_offsets=pgo.ctypes.data_as(L.c_lp))
+    damp = _damping(ep_damping, ep_itts)
+    opts, keep = make_opts(L.KIND_IHGP, L.MODE_PREDICT, mom, blk.N, ep_fraction, damp, ep_itts,
+                           flags=L.FLAG_IHGP_CONSTRAINTS if constraints_variant else 0, device=device)
+    out = _Outputs(blk.M, blk.S, yall.size, ep_itts)
+    L.check(L.lib().nagp_ihgp_run(C.byref(prob.model), C.byref(tabs), L.dptr(yall), yall.size, C.byref(opts), C.byref(out.c)))
+    return out
+
+
+def ihgp_ep_modulator_nmf(w, x, y, ss, mom, xt, kernel1, kernel2, num_lik_params, D, N, ep_fraction=0.5, ep_damping=None,
+                          ep_itts=30, nargout=2, device=0):
+    """matlab/ihgp_ep_modulator_nmf.m:1 (predict mode; the reference's nlml mode is broken, SURVEY C-11)."""
+    if xt is None or np.size(xt) == 0:
+        raise NotImplementedError('ihgp nlml mode is broken in the reference (P undefined, ihgp_ep_modulator_nmf.m:555)')
+    yall, return_ind = _merge_inputs(x, y, xt)
+    lik_param, p1, p2, Wnmf = _unpack_log(w, num_lik_params, D, N)
+    blk = ssm.balance_blocks(_blocks_from_dense(*ss(x, p1, p2, kernel1, kernel2), D, N))   # :81 `if true`
+    out = _run_ihgp(blk, Wnmf, lik_param, yall, mom, ep_fraction, ep_damping, ep_itts, False, device)
+    return _returns(out, return_ind, nargout)
+
+
+def ihgp_ep_modulator_nmf_constraints(w, x, y, ss, mom, xt, kernel1, kernel2, num_lik_params, D, N, ep_fraction, ep_damping,
+                                      ep_itts, constraints, w_fixed, tune_hypers, nargout=2, device=0):
+    """matlab/ihgp_ep_modulator_nmf_constraints.m:1-2."""
+    if xt is None or np.size(xt) == 0:
+        raise NotImplementedError('ihgp nlml mode is broken in the reference (SURVEY C-11)')
+    yall, return_ind = _merge_inputs(x, y, xt)
+    lik_param, p1, p2, Wnmf = _unpack_constraints(w, w_fixed, tune_hypers, constraints, num_lik_params, D, N)
+    blk = ssm.balance_blocks(_blocks_from_dense(*ss(x, p1, p2, kernel1, kernel2), D, N))
+    out = _run_ihgp(blk, Wnmf, lik_param, yall, mom, ep_fraction, ep_damping, ep_itts, True, device)
+    return _returns(out, return_ind, nargout)
+
+
+def _run_giekf(blk, Wnmf, lik_param, yall, g_iter, l_iter, reset_P, nargout, device=0):
+    prob = _Problem(blk, Wnmf, lik_param)
+    want_PS = nargout >= 6
+    flags = (L.FLAG_EKF_RESET_P if reset_P else 0) | (L.FLAG_WANT_PS if want_PS else 0)
+    opts, keep = make_opts(L.KIND_GIEKF, L.MODE_PREDICT, None, blk.N, 0.0, None, g_iter, l_iter=l_iter, flags=flags, device=device)
+    out = _Outputs(blk.M, blk.S, yall.size, g_iter, want_PS=want_PS)
+    L.check(L.lib().nagp_giekf_run(C.byref(prob.model), L.dptr(yall), yall.size, C.byref(opts), C.byref(out.c)))
+    return out
+
+
+def gf_giekf_modulator_nmf(w, x, y, ss, mom, xt, kernel1, kernel2, num_lik_params, D, N, g_iter, l_iter, GradObj='off',
+                           nargout=2, device=0):
+    """matlab/gf_giekf_modulator_nmf.m:1-2 (predict mode; `mom` is accepted and unused, as in the reference :13)."""
+    if xt is None or np.size(xt) == 0:
+        raise NotImplementedError('EKF nlml/gradient mode (gf_giekf_modulator_nmf.m:296-439) is a "next" row (SURVEY f-4)')
+    yall, return_ind = _merge_inputs(x, y, xt)
+    lik_param, p1, p2, Wnmf = _unpack_log(w, num_lik_params, D, N)
+    blk = ssm.balance_blocks(_blocks_from_dense(*ss(x, p1, p2, kernel1, kernel2), D, N))   # :78 `if true`
+    out = _run_giekf(blk, Wnmf, lik_param, yall, g_iter, l_iter, False, nargout, device)
+    return _returns(out, return_ind, nargout)
+
+
+def gf_giekf_modulator_nmf_constraints(w, x, y, ss, mom, xt, kernel1, kernel2, num_lik_params, D, N, g_iter, l_iter,
+                                       constraints, w_fixed, tune_hypers, GradObj='off', nargout=2, device=0):
+    """matlab/gf_giekf_modulator_nmf_constraints.m:1-2."""
+    if xt is None or np.size(xt) == 0:
+        raise NotImplementedError('EKF nlml/gradient mode is a "next" row (SURVEY f-4)')
+    yall, return_ind = _merge_inputs(x, y, xt)
+    lik_param, p1, p2, Wnmf = _unpack_constraints(w, w_fixed, tune_hypers, constraints, num_lik_params, D, N)
+    blk = ssm.balance_blocks(_blocks_from_dense(*ss(x, p1, p2, kernel1, kernel2), D, N))
+    out = _run_giekf(blk, Wnmf, lik_param, yall, g_iter, l_iter, True, nargout, device)
+    return _returns(out, return_ind, nargout)

@@ -1,0 +1,76 @@
+"""Device-resident, batched form of the C ABI (nagp_plan_*): B independent problems of identical shape
+(audio segments / hyper-parameter replicas) with inputs and all intermediates kept in HBM."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from .api import _Outputs, _Problem, make_opts, _damping
+from . import ihgp_tables
+
+
+class Plan:
+    def __init__(self, kind, problems, T, mom=None, ep_fraction=0.5, ep_damping=None, ep_itts=3, mode=L.MODE_PREDICT,
+                 l_iter=1, predict_at_k1=0, flags=0, device=0, chunk=0):
+        """problems: list of (BlockSS, Wnmf, lik_param) -- already balanced if the variant balances."""
+        self.kind, self.T, self.I = kind, int(T), int(ep_itts)
+        sym = kind == L.KIND_IHGP
+        self.probs = [_Problem(b, W, lp, symmetrize_Q=sym) for (b, W, lp) in problems]
+        self.B = len(self.probs)
+        blk0 = problems[0][0]
+        self.M, self.S = blk0.M, blk0.S
+        dim = None
+        if mom is not None:
+            dim = blk0.D if mom.kind == L.LIK_POWER else blk0.N
+        damp = _damping(ep_damping, ep_itts) if ep_damping is not None else None
+        self.opts, self._keep = make_opts(kind, mode, mom, dim, ep_fraction, damp, ep_itts, l_iter=l_iter,
+                                          predict_at_k1=predict_at_k1, flags=flags, device=device, chunk=chunk)
+        models = (L.Model * self.B)(*[p.model for p in self.probs])
+        tabs_arr = None
+        self._tabkeep = []
+        if kind == L.KIND_IHGP:
+            tl = []
+            for p in self.probs:
+                r, PP, ppo, PG, pgo = ihgp_tables.build_tables(p.A, p.Q, p.blk.offsets, p.blk.h_val)
+                r = L.f64(r, 'C'); PP = L.f64(PP, 'C'); PG = L.f64(PG, 'C')
+                self._tabkeep.append((r, PP, ppo, PG, pgo))
+                tl.append(L.IhgpTables(n_grid=r.size, r_grid=L.dptr(r), PPlist=L.dptr(PP), pp_offsets=ppo.ctypes.data_as(L.c_lp),
+                                       PGlist=L.dptr(PG), pg_offsets=pgo.ctypes.data_as(L.c_lp)))
+            tabs_arr = (L.IhgpTables * self.B)(*tl)
+        self._h = C.c_void_p()
+        L.check(L.lib().nagp_plan_create(C.byref(self._h), self.B, models, tabs_arr, self.T, C.byref(self.opts)))
+
+    def upload(self, ys):
+        ys = [L.f64(y, 'C') for y in ys]
+        assert len(ys) == self.B and all(y.size == self.T for y in ys)
+        arr = (L.c_dp * self.B)(*[L.dptr(y) for y in ys])
+        L.check(L.lib().nagp_plan_upload_y(self._h, arr))
+
+    def execute(self):
+        L.check(L.lib().nagp_plan_execute(self._h))
+
+    def timings(self):
+        t = L.Timings()
+        L.check(L.lib().nagp_plan_timings(self._h, C.byref(t)))
+        return dict(ms={k: t.ms[i] for i, k in enumerate(L.KERNEL_NAMES)},
+                    launches={k: int(t.launches[i]) for i, k in enumerate(L.KERNEL_NAMES)}, total_ms=t.total_ms)
+
+    def download(self, want_PS=False, want_MS=True):
+        outs = [_Outputs(self.M, self.S, self.T, self.I, want_PS=want_PS, want_MS=want_MS) for _ in range(self.B)]
+        arr = (L.Out * self.B)(*[o.c for o in outs])
+        L.check(L.lib().nagp_plan_download(self._h, arr))
+        return outs
+
+    def device_bytes(self):
+        return int(L.lib().nagp_plan_device_bytes(self._h))
+
+    def close(self):
+        if self._h:
+            L.lib().nagp_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -273,7 +273,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     PLAN_TRY(dalloc(p, &b.Gbuf, (size_t)B * p->chunk * 2 * nt * 16, false));
     PLAN_TRY(dalloc(p, &b.dbuf, (size_t)B * p->chunk * sh.S, false));
     PLAN_TRY(dalloc(p, &p->d_xbuf, (size_t)B * nt * 16));
-    int LP = (int)((80.0 * 1024.0) / (512.0 * sh.M));
+    int LP = (int)((80.0 * 1024.0) / (4.0 * TS * 8.0 * sh.M));
     p->LP = std::max(1, std::min(LP, sh.M));
   } else {
     PLAN_TRY(dalloc(p, &p->d_lZs, BT));

@@ -11,7 +11,8 @@
 
 namespace nagp {
 
-constexpr int LDS_INT_DOUBLES = 66;  // (2*MAXM+2) ints rounded up to an even number of doubles
+constexpr int LDS_INT_DOUBLES = 66;
+constexpr int TS = 18;  // LDS tile stride in doubles (16 + 2 pad): consecutive tiles start 36 banks apart -> conflict-free b64/b128 reads  // (2*MAXM+2) ints rounded up to an even number of doubles
 
 struct Shape {
   int S, M, D, N;
@@ -89,7 +90,7 @@ struct TileOwner {
 // LDS (doubles): sA[M*16] sh[M] sW[D*N] m[S] Wl[M*S] HPl[M*S] fmu[M] HPH[M] tt[M] tn[M] cA[M] cm[M]
 //                dl[M] d2l[M] misc[8] | mom workspace | EKF: part[M] PJ[S]
 __host__ __device__ inline size_t filter_lds_doubles(const Shape& s, const MomCfg& mc, int meas) {
-  size_t n = LDS_INT_DOUBLES + (size_t)s.M * 16 + s.M + (size_t)s.D * s.N + s.S + 2 * (size_t)s.M * s.S +
+  size_t n = LDS_INT_DOUBLES + (size_t)s.M * 16 + s.M + (size_t)s.D * s.N + s.S + 8 * (size_t)s.M * s.M +
              8 * (size_t)s.M + 8;
   n += (meas == 0) ? mom_lds_doubles(mc) : (size_t)(s.M + s.S);
   return (n + 1) & ~(size_t)1;
@@ -111,8 +112,8 @@ __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg
   double* sW = shv + M;
   double* m = sW + (size_t)sh.D * sh.N;
   double* Wl = m + S;
-  double* HPl = Wl + (size_t)M * S;
-  double* fmu = HPl + (size_t)M * S;
+  double* HPl = Wl + (size_t)M * 4 * M;   // Wl[n][i][I] = h_n P(off_I+i, c_n) ; HPl[n][j][J] = h_n P(c_n, off_J+j)
+  double* fmu = HPl + (size_t)M * 4 * M;
   double* HPH = fmu + M;
   double* tt = HPH + M;
   double* tn = tt + M;
@@ -193,13 +194,10 @@ __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg
           }
         }
         const double hJ = shv[J], hI = shv[I];
-        const int oI = ioff[I], oJ = ioff[J], bI = ibsz[I], bJ = ibsz[J];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (i < bI) Wl[(size_t)J * S + oI + i] = hJ * P[q][4 * i];
+        for (int i = 0; i < 4; ++i) Wl[((size_t)J * 4 + i) * M + I] = hJ * P[q][4 * i];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (j < bJ) HPl[(size_t)I * S + oJ + j] = hI * P[q][j];
+        for (int j = 0; j < 4; ++j) HPl[((size_t)I * 4 + j) * M + J] = hI * P[q][j];
         if (I == J) HPH[I] = hI * hI * P[q][0];
       }
     }
@@ -252,7 +250,7 @@ __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg
         const bool legacyA = fp.legacy_update && (misc[1] != 0.0);
         if (tid < S) {
           double acc = rm;
-          for (int n = 0; n < M; ++n) acc = fma(Wl[(size_t)n * S + tid], cm[n], acc);
+          for (int n = 0; n < M; ++n) acc = fma(Wl[((size_t)n * 4 + myrow) * M + myblk], cm[n], acc);
           rm = acc;
           m[tid] = acc;
         }
@@ -261,30 +259,20 @@ __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg
 #pragma unroll
         for (int q = 0; q < TPT; ++q) {
           if (own.ok[q]) {
-            const int oI = ioff[own.I[q]], oJ = ioff[own.J[q]];
             for (int n = 0; n < M; ++n) {
               const double c = cA[n];
               if (c == 0.0) continue;
-              const double* wr = Wl + (size_t)n * S + oI;
-              const double* rr = Rt + (size_t)n * S + oJ;
+              const double* wr = Wl + (size_t)n * 4 * M + own.I[q];
+              const double* rr = Rt + (size_t)n * 4 * M + own.J[q];
               double r4[4], w4[4];
 #pragma unroll
-              for (int j = 0; j < 4; ++j) r4[j] = rr[j];
+              for (int j = 0; j < 4; ++j) r4[j] = rr[j * M];
 #pragma unroll
-              for (int i = 0; i < 4; ++i) w4[i] = -(wr[i] * c);
+              for (int i = 0; i < 4; ++i) w4[i] = -(wr[i * M] * c);
 #pragma unroll
               for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) P[q][4 * i + j] = fma(w4[i], r4[j], P[q][4 * i + j]);
-            }
-            // keep the zero padding clean (Wl/HPl beyond the block width belong to neighbours)
-            const int bI = ibsz[own.I[q]], bJ = ibsz[own.J[q]];
-            if (bI < 4 || bJ < 4) {
-#pragma unroll
-              for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                  if (i >= bI || j >= bJ) P[q][4 * i + j] = 0.0;
             }
           }
         }
@@ -315,7 +303,7 @@ __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg
           __syncthreads();
           if (tid < S) {
             double acc = 0.0;
-            for (int n = 0; n < M; ++n) acc = fma(Wl[(size_t)n * S + tid], part[n], acc);
+            for (int n = 0; n < M; ++n) acc = fma(Wl[((size_t)n * 4 + myrow) * M + myblk], part[n], acc);
             PJ[tid] = acc;
           }
           __syncthreads();
@@ -384,7 +372,7 @@ struct GainPar {
 };
 
 __host__ __device__ inline size_t gain_lds_doubles(const Shape& s) {
-  return LDS_INT_DOUBLES + (size_t)s.M * 16 * 2 + 4 * (size_t)s.M * 16 + 8;
+  return LDS_INT_DOUBLES + (size_t)s.M * 16 * 2 + 4 * (size_t)s.M * TS + 8;
 }
 
 // in-place Cholesky of the leading bs x bs lower triangle of a 4x4 tile; padding -> identity.
@@ -462,9 +450,9 @@ __global__ void __launch_bounds__(512) rts_gain_kernel(Shape sh, Bufs b, GainPar
   int* ibsz = ioff + (MAXM + 1);
   double* sA = lds + LDS_INT_DOUBLES;          // [M][16]
   double* sLd = sA + (size_t)M * 16;           // [M][16] diagonal Cholesky factors
-  double* bufX = sLd + (size_t)M * 16;         // [2][M][16]
-  double* bufP = bufX + 2 * (size_t)M * 16;    // [2][M][16]
-  int* flag = reinterpret_cast<int*>(bufP + 2 * (size_t)M * 16);
+  double* bufX = sLd + (size_t)M * 16;         // [2][M][TS]
+  double* bufP = bufX + 2 * (size_t)M * TS;    // [2][M][TS]
+  int* flag = reinterpret_cast<int*>(bufP + 2 * (size_t)M * TS);
 
   for (int i = tid; i <= M; i += NT) ioff[i] = sh.off[i];
   for (int i = tid; i < M; i += NT) ibsz[i] = sh.bsz[i];
@@ -546,13 +534,13 @@ __global__ void __launch_bounds__(512) rts_gain_kernel(Shape sh, Bufs b, GainPar
       for (int q = 0; q < TPT; ++q)
         if (own.ok[q] && own.J[q] == jb && own.I[q] > jb) {
           tile_solve_Lt(Lt[q], sLd + (size_t)jb * 16);
-          tile_store(bufP + ((size_t)par * M + own.I[q]) * 16, Lt[q]);
+          tile_store(bufP + ((size_t)par * M + own.I[q]) * TS, Lt[q]);
         }
       __syncthreads();
 #pragma unroll
       for (int q = 0; q < TPT; ++q)
         if (own.ok[q] && own.J[q] > jb && own.I[q] >= own.J[q])
-          tile_mms_nt(Lt[q], bufP + ((size_t)par * M + own.I[q]) * 16, bufP + ((size_t)par * M + own.J[q]) * 16);
+          tile_mms_nt(Lt[q], bufP + ((size_t)par * M + own.I[q]) * TS, bufP + ((size_t)par * M + own.J[q]) * TS);
     }
     __syncthreads();
     failed = (flag[attempt] != 0);
@@ -570,14 +558,14 @@ __global__ void __launch_bounds__(512) rts_gain_kernel(Shape sh, Bufs b, GainPar
     for (int q = 0; q < TPT; ++q)
       if (own.ok[q] && own.J[q] == jb) {
         tile_solve_Lt(Bt[q], sLd + (size_t)jb * 16);
-        tile_store(bufX + ((size_t)par * M + own.I[q]) * 16, Bt[q]);
-        if (own.I[q] > jb) tile_store(bufP + ((size_t)par * M + own.I[q]) * 16, Lt[q]);
+        tile_store(bufX + ((size_t)par * M + own.I[q]) * TS, Bt[q]);
+        if (own.I[q] > jb) tile_store(bufP + ((size_t)par * M + own.I[q]) * TS, Lt[q]);
       }
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < TPT; ++q)
       if (own.ok[q] && own.J[q] > jb)
-        tile_mms_nt(Bt[q], bufX + ((size_t)par * M + own.I[q]) * 16, bufP + ((size_t)par * M + own.J[q]) * 16);
+        tile_mms_nt(Bt[q], bufX + ((size_t)par * M + own.I[q]) * TS, bufP + ((size_t)par * M + own.J[q]) * TS);
   }
   __syncthreads();
   // ---- G L = X  (backward over block columns)
@@ -588,15 +576,15 @@ __global__ void __launch_bounds__(512) rts_gain_kernel(Shape sh, Bufs b, GainPar
       if (own.ok[q]) {
         if (own.J[q] == jb) {
           tile_solve_L(Bt[q], sLd + (size_t)jb * 16);
-          tile_store(bufX + ((size_t)par * M + own.I[q]) * 16, Bt[q]);
+          tile_store(bufX + ((size_t)par * M + own.I[q]) * TS, Bt[q]);
         }
-        if (own.I[q] == jb && own.J[q] < jb) tile_store(bufP + ((size_t)par * M + own.J[q]) * 16, Lt[q]);
+        if (own.I[q] == jb && own.J[q] < jb) tile_store(bufP + ((size_t)par * M + own.J[q]) * TS, Lt[q]);
       }
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < TPT; ++q)
       if (own.ok[q] && own.J[q] < jb)
-        tile_mms(Bt[q], bufX + ((size_t)par * M + own.I[q]) * 16, bufP + ((size_t)par * M + own.J[q]) * 16);
+        tile_mms(Bt[q], bufX + ((size_t)par * M + own.I[q]) * TS, bufP + ((size_t)par * M + own.J[q]) * TS);
   }
 #pragma unroll
   for (int q = 0; q < TPT; ++q)
@@ -629,7 +617,7 @@ struct ScanPar {
 };
 
 __host__ __device__ inline size_t scan_lds_doubles(const Shape& s, int LP) {
-  return LDS_INT_DOUBLES + (size_t)s.M + 2 * (size_t)s.S + 4 * (size_t)s.M * LP * 16 + 8;
+  return LDS_INT_DOUBLES + (size_t)s.M + 1 + 2 * (size_t)(s.S + 1) + 4 * (size_t)s.M * LP * TS + 8;
 }
 
 template <int TPT>
@@ -645,10 +633,10 @@ __global__ void __launch_bounds__(512) rts_scan_kernel(Shape sh, Bufs b, ScanPar
   int* ioff = reinterpret_cast<int*>(lds);
   int* ibsz = ioff + (MAXM + 1);
   double* shv = lds + LDS_INT_DOUBLES;   // [M]
-  double* ev = shv + M;                  // [S] e + delta
-  double* en = ev + S;                   // [S] new e
-  double* pan = en + S;                  // [2][2][M*LP][16]   (buffer, operand, tile)
-  const size_t panOp = (size_t)M * LP * 16;
+  double* ev = shv + ((M + 1) & ~1);     // [S] e + delta
+  double* en = ev + ((S + 1) & ~1);      // [S] new e
+  double* pan = en + ((S + 1) & ~1);     // [2][2][LP*M][TS]   (buffer, operand, tile) -- 16-B aligned
+  const size_t panOp = (size_t)M * LP * TS;
 
   for (int i = tid; i <= M; i += NT) ioff[i] = sh.off[i];
   for (int i = tid; i < M; i += NT) ibsz[i] = sh.bsz[i];
@@ -684,14 +672,14 @@ __global__ void __launch_bounds__(512) rts_scan_kernel(Shape sh, Bufs b, ScanPar
     for (int q = 0; q < TPT; ++q) tile_zero(acc[q]);
     for (int p = 0; p < npan; ++p) {
       const int l0 = p * LP, lw = (M - l0 < LP) ? (M - l0) : LP;
-      double* pg = pan + (size_t)(p & 1) * 2 * panOp;   // G[:, panel]   tile (I,l) at (I*LP+l)
+      double* pg = pan + (size_t)(p & 1) * 2 * panOp;   // G[:, panel]   tile (I,l) at (l*M+I)
       double* py = pg + panOp;                           // Y[panel, :]   tile (l,J) at (l*M+J)
       for (int it = tid; it < 2 * M * lw; it += NT) {
         double t16[16];
         if (it < M * lw) {
           const int I = it / lw, l = it - I * lw;
           tile_load(t16, Gk + ((size_t)I * M + l0 + l) * 16);
-          tile_store(pg + ((size_t)I * LP + l) * 16, t16);
+          tile_store(pg + ((size_t)l * M + I) * TS, t16);
         } else {
           const int it2 = it - M * lw;
           const int l = it2 / M, J = it2 - l * M;
@@ -701,7 +689,7 @@ __global__ void __launch_bounds__(512) rts_scan_kernel(Shape sh, Bufs b, ScanPar
           tile_load(d16, Dk + tix);
 #pragma unroll
           for (int e = 0; e < 16; ++e) t16[e] += d16[e];
-          tile_store(py + ((size_t)l * M + J) * 16, t16);
+          tile_store(py + ((size_t)l * M + J) * TS, t16);
         }
       }
       __syncthreads();
@@ -709,7 +697,7 @@ __global__ void __launch_bounds__(512) rts_scan_kernel(Shape sh, Bufs b, ScanPar
       for (int q = 0; q < TPT; ++q)
         if (own.ok[q])
           for (int l = 0; l < lw; ++l)
-            tile_mma(acc[q], pg + ((size_t)own.I[q] * LP + l) * 16, py + ((size_t)l * M + own.J[q]) * 16);
+            tile_mma(acc[q], pg + ((size_t)l * M + own.I[q]) * TS, py + ((size_t)l * M + own.J[q]) * TS);
     }
 #pragma unroll
     for (int q = 0; q < TPT; ++q)
@@ -730,22 +718,22 @@ __global__ void __launch_bounds__(512) rts_scan_kernel(Shape sh, Bufs b, ScanPar
     for (int q = 0; q < TPT; ++q) tile_zero(acc[q]);
     for (int p = 0; p < npan; ++p) {
       const int l0 = p * LP, lw = (M - l0 < LP) ? (M - l0) : LP;
-      double* px = pan + (size_t)(p & 1) * 2 * panOp;   // X[:, panel]  tile (I,l) at (I*LP+l)
-      double* pg = px + panOp;                           // G[:, panel]  tile (J,l) at (J*LP+l)
+      double* px = pan + (size_t)(p & 1) * 2 * panOp;   // X[:, panel]  tile (I,l) at (l*M+I)
+      double* pg = px + panOp;                           // G[:, panel]  tile (J,l) at (l*M+J)
       for (int it = tid; it < 2 * M * lw; it += NT) {
         double t16[16];
         const int it2 = (it < M * lw) ? it : it - M * lw;
         const int I = it2 / lw, l = it2 - I * lw;
         const double* src = (it < M * lw) ? Xb : Gk;
         tile_load(t16, src + ((size_t)I * M + l0 + l) * 16);
-        tile_store(((it < M * lw) ? px : pg) + ((size_t)I * LP + l) * 16, t16);
+        tile_store(((it < M * lw) ? px : pg) + ((size_t)l * M + I) * TS, t16);
       }
       __syncthreads();
 #pragma unroll
       for (int q = 0; q < TPT; ++q)
         if (own.ok[q])
           for (int l = 0; l < lw; ++l)
-            tile_mma_nt(acc[q], px + ((size_t)own.I[q] * LP + l) * 16, pg + ((size_t)own.J[q] * LP + l) * 16);
+            tile_mma_nt(acc[q], px + ((size_t)l * M + own.I[q]) * TS, pg + ((size_t)l * M + own.J[q]) * TS);
     }
     // ---- store E', outputs
     const double* PFk = b.PF + ((size_t)pb * T + k) * ntl * 16;

@@ -1,0 +1,57 @@
+"""Multi-GPU layer: one process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on ROCm,
+"gloo" on CPU for tests).  The path shards by PROBLEM (audio segments / hyper-parameter replicas,
+SURVEY 8e): rank r owns problems r, r+W, r+2W, ... ; there is no data-path collective -- the only
+exchange is the all-reduce of the per-sweep negative log marginal likelihood
+nlZ[itt] = -sum_k lZ_k (gf_ep_modulator_nmf.m:187, 277, 525) over all problems.
+"""
+import os
+
+import numpy as np
+
+
+def env_world():
+    return int(os.environ.get('RANK', 0)), int(os.environ.get('LOCAL_RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
+
+
+def shard(n_problems, rank, world):
+    """Round-robin problem -> rank map (problem i -> rank i mod W)."""
+    return list(range(rank, n_problems, world))
+
+
+def init(backend=None):
+    import torch.distributed as dist
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        dist.init_process_group(backend=backend or 'nccl', rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def allreduce_nlz(nlz_local, device=None):
+    """Sum the (n_local_problems x ep_itts) partial nlZ over problems and ranks -> (ep_itts,) total."""
+    import torch
+    import torch.distributed as dist
+    part = torch.as_tensor(np.asarray(nlz_local, dtype=np.float64).reshape(-1, np.shape(nlz_local)[-1]).sum(axis=0))
+    if device is not None:
+        part = part.to(device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(part, op=dist.ReduceOp.SUM)
+    return part.cpu().numpy()
+
+
+def allreduce_max(x, device=None):
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([float(x)], dtype=torch.float64)
+    if device is not None:
+        t = t.to(device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.cpu()[0])
+
+
+def barrier():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

@@ -35,7 +35,7 @@ def build_tables(A, Q, offsets, h_val, n_grid=200, n_knots=32):
                 PP = sla.solve_discrete_are(Ab.T, Hn.T, Qb, np.array([[rj]]))
             except Exception:
                 continue                                   # :118-126: failed grid points are dropped
-            S = float(Hn @ PP @ Hn.T) + rj
+            S = float((Hn @ PP @ Hn.T)[0, 0]) + rj
             K = PP @ Hn.T / S
             P = PP - rj * (K @ K.T)
             PSkp = Ab @ P @ Ab.T + Qb

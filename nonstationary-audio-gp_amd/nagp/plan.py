@@ -61,6 +61,13 @@ class Plan:
         L.check(L.lib().nagp_plan_download(self._h, arr))
         return outs
 
+    def download_nlz(self):
+        """(B, ep_itts) negative log marginal likelihoods only (nothing else crosses PCIe)."""
+        nlz = np.zeros((self.B, self.I))
+        arr = (L.Out * self.B)(*[L.Out(nlZ=nlz[q].ctypes.data_as(L.c_dp)) for q in range(self.B)])
+        L.check(L.lib().nagp_plan_download(self._h, arr))
+        return nlz
+
     def device_bytes(self):
         return int(L.lib().nagp_plan_device_bytes(self._h))
 

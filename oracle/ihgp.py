@@ -109,13 +109,20 @@ def nearest_index(r, Rv):
     return int(np.nanargmin(d))
 
 
-def run_predict(model, yall, mom, ep_fraction, ep_damping, ep_itts, constraints_variant=False, verbose=False):
-    """ihgp_ep_modulator_nmf.m:99-524 on an assembled (balanced, Q-symmetrised) model."""
-    A, Q, H, Pinf, Wnmf, lik_param = (model[k] for k in ('A', 'Q', 'H', 'Pinf', 'Wnmf', 'lik_param'))
-    S = A.shape[0]; M = H.shape[0]; T = yall.size
+def build_tables(model):
+    """The DARE set-up of ihgp_ep_modulator_nmf.m:99-191 (host side, once per call)."""
+    A, Q, H = model['A'], model['Q'], model['H']
     ilist = ssm.block_starts(H)
     r, PPlist, PPlisto, ro_list = forward_tables(A, Q, H, ilist)
     PGlist = smoother_tables(A, Q, H, ilist, r, PPlisto, ro_list)
+    return ilist, r, PPlist, PGlist
+
+
+def run_predict(model, yall, mom, ep_fraction, ep_damping, ep_itts, constraints_variant=False, verbose=False, tables=None):
+    """ihgp_ep_modulator_nmf.m:99-524 on an assembled (balanced, Q-symmetrised) model."""
+    A, Q, H, Pinf, Wnmf, lik_param = (model[k] for k in ('A', 'Q', 'H', 'Pinf', 'Wnmf', 'lik_param'))
+    S = A.shape[0]; M = H.shape[0]; T = yall.size
+    ilist, r, PPlist, PGlist = tables if tables is not None else build_tables(model)
     blocks = [slice(ilist[n], ilist[n + 1]) for n in range(M)]
     bs = [ilist[n + 1] - ilist[n] for n in range(M)]
 

@@ -1,0 +1,206 @@
+"""GPU (-m gpu): parity of the HIP path against the CPU oracle and the committed golden vectors,
+called through the product's public interface (reference-named functions -> C ABI -> HIP kernels).
+
+Stated tolerances (north_star: |dlogZ|/|logZ| < 1e-5): filtered/smoothed means and variances within
+1e-7 of the largest magnitude of the array, site parameters 1e-6, |dlogZ|/|logZ| < 1e-8.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import nagp
+from nagp import harness, Mom, SSHandle, Plan, _lib as L
+from nagp import ss as pss
+from oracle import gf_ep as ogf, ihgp as oih, giekf as oek, lik as olik
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+TOL_MEAN, TOL_SITE, TOL_LOGZ = 1e-7, 1e-6, 1e-8
+
+
+def rel(a, b):
+    a = np.asarray(a, float); b = np.asarray(b, float)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert np.array_equal(np.isnan(a), np.isnan(b))
+    return float(np.nanmax(np.abs(a - b)) / (np.nanmax(np.abs(b)) + 1e-300)) if a.size else 0.0
+
+
+def relz(a, b):
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b)) / np.abs(np.asarray(b))))
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _lib(nagp_lib):
+    assert nagp_lib.nagp_device_count() >= 1
+    return nagp_lib
+
+
+def gold(name):
+    return np.load(os.path.join(GOLD, name + '.npz'))
+
+
+def test_golden_cfg1_gf_ep_modulator_full_size():
+    g = gold('cfg1_gf_ep_modulator'); T = g['y'].size; t = np.arange(1, T + 1.0)
+    mom = Mom('likModulatorPower', p_cubature=9)
+    Eft, Varft, _, lb, ub, out = nagp.gf_ep_modulator(g['w'], t, g['y'], SSHandle('ss_modulators'), mom, t, 'matern32', 'matern52', 1,
+                                                      0.5, g['ep_damping'], 5, nargout=6)
+    assert rel(Eft, g['Eft']) < TOL_MEAN and rel(Varft, g['Varft']) < TOL_MEAN
+    assert relz(out['nlZ'], g['nlZ']) < TOL_LOGZ
+    assert rel(out['ttau'], g['ttau']) < TOL_SITE and rel(out['tnu'], g['tnu']) < TOL_SITE
+    assert rel(out['lZ'], g['lZ']) < 1e-7
+    assert rel(out['maxDiffM'], g['maxDiffM']) < 1e-6 and rel(out['maxDiffP'], g['maxDiffP']) < 1e-6
+    assert np.allclose(lb, Eft - 1.96 * np.sqrt(Varft)) and np.allclose(ub, Eft + 1.96 * np.sqrt(Varft))
+    e, eg = nagp.gf_ep_modulator(g['w'], t, g['y'], SSHandle('ss_modulators'), mom, None, 'matern32', 'matern52', 1, 0.5, g['ep_damping'], 3)
+    assert abs(e - float(g['edata_I3'])) < TOL_LOGZ * abs(e) and not np.any(eg)
+
+
+def test_golden_cfg2_gf_ep_modulator_nmf_with_missing_data():
+    g = gold('cfg2_gf_ep_modulator_nmf'); D, N = int(g['D']), int(g['N']); T = g['y'].size; t = np.arange(1, T + 1.0)
+    mom = Mom('likModulatorNMFPower', p_cubature=9); d = 0.5 * np.ones(3)
+    Eft, Varft, _, _, _, out = nagp.gf_ep_modulator_nmf(g['w'], t, g['y'], SSHandle(), mom, t, 'matern32', 'matern52', 1, D, N, 0.5, d, 3, nargout=6)
+    assert rel(Eft, g['Eft']) < TOL_MEAN and rel(Varft, g['Varft']) < TOL_MEAN and relz(out['nlZ'], g['nlZ']) < TOL_LOGZ
+    assert rel(out['ttau'], g['ttau']) < TOL_SITE and rel(out['tnu'], g['tnu']) < TOL_SITE
+    assert out['counters']['nan_obs'] == 3 * 60 and out['counters']['chol_retries'] == 0
+    for I, key in ((1, 'edata_I1'), (3, 'edata_I3')):
+        e, _ = nagp.gf_ep_modulator_nmf(g['w'], t, g['y'], SSHandle(), mom, None, 'matern32', 'matern52', 1, D, N, 0.5, d, I)
+        assert abs(e - float(g[key])) < TOL_LOGZ * abs(e)
+
+
+def test_golden_cfg3_ihgp():
+    g = gold('cfg3_ihgp_ep_modulator_nmf'); D, N = int(g['D']), int(g['N']); T = g['y'].size; t = np.arange(1, T + 1.0)
+    mom = Mom('likModulatorNMFPower', p_cubature=7); d = 0.5 * np.ones(3)
+    Eft, Varft, _, _, _, out = nagp.ihgp_ep_modulator_nmf(g['w'], t, g['y'], SSHandle(), mom, t, 'matern32', 'matern52', 1, D, N, 0.5, d, 3, nargout=6)
+    assert rel(Eft, g['Eft']) < TOL_MEAN and rel(Varft, g['Varft']) < TOL_MEAN and relz(out['nlZ'], g['nlZ']) < TOL_LOGZ
+    assert rel(out['ttau'], g['ttau']) < TOL_SITE
+    assert np.array_equal(np.isinf(out['R']), np.isinf(g['R']))
+    fin = np.isfinite(g['R'])
+    assert rel(out['R'][fin], g['R'][fin]) < TOL_SITE
+    assert np.all(Varft == Varft[:, :1])                                   # time-constant (SURVEY C-10)
+
+
+def test_golden_cfg4_giekf_both_variants():
+    g = gold('cfg4_gf_giekf_modulator_nmf'); D, N = int(g['D']), int(g['N']); T = g['y'].size; t = np.arange(1, T + 1.0)
+    Eft, Varft, _, _, _, out = nagp.gf_giekf_modulator_nmf_constraints(g['w'], t, g['y'], SSHandle(), None, t, 'matern32', 'matern52', 1, D, N,
+                                                                       3, 1, g['constraints'], g['w_fixed'], list(g['tune_hypers']), nargout=6)
+    assert rel(Eft, g['Eft']) < TOL_MEAN and rel(Varft, g['Varft']) < TOL_MEAN and rel(out['maxDiffP'], g['maxDiffP']) < 1e-6
+    Eft, Varft, _, _, _, out = nagp.gf_giekf_modulator_nmf(g['w_log'], t, g['y'], SSHandle(), None, t, 'matern32', 'matern52', 1, D, N, 2, 2, nargout=6)
+    assert rel(Eft, g['Eft_plain']) < TOL_MEAN and rel(Varft, g['Varft_plain']) < TOL_MEAN
+    assert rel(out['maxDiffP'], g['maxDiffP_plain']) < 1e-6
+
+
+def test_golden_cfg5_constraints_S146():
+    g = gold('cfg5_gf_ep_modulator_nmf_constraints'); D, N = int(g['D']), int(g['N']); T = g['y'].size; t = np.arange(1, T + 1.0)
+    mom = Mom('likModulatorNMFPower', p_cubature=7); d = 0.5 * np.ones(3)
+    Eft, Varft, _, _, _, out = nagp.gf_ep_modulator_nmf_constraints(g['w'], t, g['y'], SSHandle(), mom, t, 'matern32', 'matern52', 1, D, N, 0.5, d, 3,
+                                                                    g['constraints'], g['w_fixed'], list(g['tune_hypers']), nargout=6)
+    assert rel(Eft, g['Eft']) < TOL_MEAN and rel(Varft, g['Varft']) < TOL_MEAN and relz(out['nlZ'], g['nlZ']) < TOL_LOGZ
+    assert rel(out['ttau'], g['ttau']) < TOL_SITE and rel(out['tnu'], g['tnu']) < TOL_SITE
+
+
+def test_golden_precalcwn_sqrt_likelihood_exp_subbands_shifted_link():
+    g = gold('precalcwn_exp_subbands'); D, N = int(g['D']), int(g['N']); T = g['y'].size; t = np.arange(1, T + 1.0)
+    mom = Mom('likModulatorPreCalcwn', link='softplus', link_shift=1.0, wn=g['wn'], xn_unscaled=g['xn_unscaled'])
+    Eft, Varft, _, _, _, out = nagp.gf_ep_modulator_nmf(g['w'], t, g['y'], SSHandle(), mom, t, 'exp', 'matern52', 1, D, N, 0.75, 0.1 * np.ones(4), 4, nargout=6)
+    assert rel(Eft, g['Eft']) < TOL_MEAN and rel(Varft, g['Varft']) < TOL_MEAN and relz(out['nlZ'], g['nlZ']) < TOL_LOGZ
+
+
+@pytest.mark.parametrize('T,nanpos', [(1, []), (2, []), (3, [0]), (40, [39]), (40, list(range(40))), (65, [0, 1, 2, 63, 64])])
+def test_edge_lengths_and_missing_patterns_against_oracle(T, nanpos):
+    """T = 1/2, NaN at the first / last step, everything missing, chunk-boundary lengths."""
+    D, N = 3, 2
+    pr = harness.nmf_problem(D, N, T, 5); y = pr['y'].copy(); y[nanpos] = np.nan
+    t = np.arange(1, T + 1.0); d = np.array([0.4, 0.6])
+    Eft, Varft, _, _, _, out = nagp.gf_ep_modulator_nmf(pr['w'], t, y, SSHandle(), Mom('likModulatorNMFPower', p_cubature=5), t, 'matern32', 'matern52',
+                                                        1, D, N, 0.5, d, 2, nargout=6)
+    o = ogf.gf_ep_modulator_nmf(pr['w'], t, y, None, olik.Mom(olik.LIK_POWER_NMF, p=5), t, 'matern32', 'matern52', 1, D, N, 0.5, d, 2)
+    assert rel(Eft, o[0]) < TOL_MEAN and rel(Varft, o[1]) < TOL_MEAN
+    assert np.allclose(out['nlZ'], o[5]['nlZ'], rtol=TOL_LOGZ, atol=1e-12)
+    assert rel(out['PS'], np.transpose(o[5]['PS'], (1, 2, 0))) < TOL_MEAN and rel(out['MS'], o[5]['MS']) < TOL_MEAN
+    # the other two families on the same input
+    r2 = nagp.ihgp_ep_modulator_nmf(pr['w'], t, y, SSHandle(), Mom('likModulatorNMFPower', p_cubature=5), t, 'matern32', 'matern52', 1, D, N, 0.5, d, 2, nargout=6)
+    o2 = oih.ihgp_ep_modulator_nmf(pr['w'], t, y, None, olik.Mom(olik.LIK_POWER_NMF, p=5), t, 'matern32', 'matern52', 1, D, N, 0.5, d, 2)
+    assert rel(r2[0], o2[0]) < TOL_MEAN and rel(r2[1], o2[1]) < TOL_MEAN and np.allclose(r2[5]['nlZ'], o2[5]['nlZ'], rtol=TOL_LOGZ, atol=1e-12)
+    r3 = nagp.gf_giekf_modulator_nmf(pr['w'], t, y, SSHandle(), None, t, 'matern32', 'matern52', 1, D, N, 2, 2, nargout=2)
+    o3 = oek.gf_giekf_modulator_nmf(pr['w'], t, y, None, None, t, 'matern32', 'matern52', 1, D, N, 2, 2)
+    assert rel(r3[0], o3[0]) < TOL_MEAN and rel(r3[1], o3[1]) < TOL_MEAN
+
+
+def test_test_inputs_subset_and_unsorted_inputs():
+    """xt a subset of x, x unsorted: return_ind / unique('first') semantics (gf_ep_modulator_nmf.m:58-66)."""
+    D, N, T = 3, 2, 60
+    pr = harness.nmf_problem(D, N, T, 8)
+    perm = np.random.default_rng(0).permutation(T); x = (np.arange(1, T + 1.0))[perm]; y = pr['y'][perm]
+    xt = np.array([5.0, 17.0, 3.0, 60.0, 61.0, 62.5])
+    mom = Mom('likModulatorNMFPower', p_cubature=5)
+    Eft, Varft = nagp.gf_ep_modulator_nmf(pr['w'], x, y, SSHandle(), mom, xt, 'matern32', 'matern52', 1, D, N, 0.5, [0.5, 0.5], 2, nargout=2)
+    o = ogf.gf_ep_modulator_nmf(pr['w'], x, y, None, olik.Mom(olik.LIK_POWER_NMF, p=5), xt, 'matern32', 'matern52', 1, D, N, 0.5, [0.5, 0.5], 2)
+    assert Eft.shape == (D + N, xt.size) and rel(Eft, o[0]) < TOL_MEAN and rel(Varft, o[1]) < TOL_MEAN
+
+
+def test_ihgp_constraints_variant_and_exp_link():
+    D, N, T = 4, 2, 150
+    pr = harness.nmf_problem(D, N, T, 21, 'constraints'); t = np.arange(1, T + 1.0)
+    cons = harness.CONSTRAINTS_DEMO(D); w, wf = harness.constrained_vectors(pr, cons, harness.TUNE_DEMO)
+    mom = Mom('likModulatorNMFPower', link='exp', p_cubature=7)
+    r = nagp.ihgp_ep_modulator_nmf_constraints(w, t, pr['y'], SSHandle(), mom, t, 'matern32', 'matern52', 1, D, N, 0.5, 0.3, 3, cons, wf, harness.TUNE_DEMO, nargout=6)
+    o = oih.ihgp_ep_modulator_nmf_constraints(w, t, pr['y'], None, olik.Mom(olik.LIK_POWER_NMF, link=olik.exp_link(), p=7), t, 'matern32', 'matern52',
+                                              1, D, N, 0.5, 0.3, 3, cons, wf, harness.TUNE_DEMO)
+    assert rel(r[0], o[0]) < TOL_MEAN and rel(r[1], o[1]) < TOL_MEAN and relz(r[5]['nlZ'], o[5]['nlZ']) < TOL_LOGZ
+
+
+def _plan_problems(D, N, T, seeds, balance):
+    probs, ys = [], []
+    for s in seeds:
+        pr = harness.nmf_problem(D, N, T, s)
+        blk = pss.ss_blocks_nmf(pr['param1'], pr['param2'], 'matern32', 'matern52')
+        probs.append((pss.balance_blocks(blk) if balance else blk, pr['W'], np.log(pr['w_lik']))); ys.append(pr['y'])
+    return probs, ys
+
+
+def test_batched_plan_equals_single_runs_and_is_deterministic_and_chunk_invariant():
+    D, N, T = 5, 2, 300
+    probs, ys = _plan_problems(D, N, T, [1, 2, 3], False)
+    mom = Mom('likModulatorNMFPower', p_cubature=7); kw = dict(mom=mom, ep_fraction=0.5, ep_damping=[0.5, 0.5], ep_itts=2)
+    plan = Plan(L.KIND_GF_EP, probs, T, **kw); plan.upload(ys); plan.execute(); a = plan.download()
+    plan.execute(); b = plan.download()                                   # re-execution: bitwise identical
+    small = Plan(L.KIND_GF_EP, probs, T, chunk=64, **kw); small.upload(ys); small.execute(); c = small.download()
+    for q in range(3):
+        assert np.array_equal(a[q].Eft, b[q].Eft) and np.array_equal(a[q].nlZ, b[q].nlZ) and np.array_equal(a[q].ttau, b[q].ttau)
+        assert np.array_equal(a[q].Eft, c[q].Eft) and np.array_equal(a[q].Varft, c[q].Varft)      # chunk length does not matter
+        one = Plan(L.KIND_GF_EP, probs[q:q + 1], T, **kw); one.upload(ys[q:q + 1]); one.execute(); o = one.download()[0]
+        assert np.array_equal(a[q].Eft, o.Eft) and np.array_equal(a[q].Varft, o.Varft) and np.array_equal(a[q].nlZ, o.nlZ)
+        one.close()
+    assert np.allclose(plan.download_nlz(), np.array([x.nlZ for x in a]))
+    t = plan.timings(); assert t['launches']['filter'] == 2 and t['ms']['scan'] > 0
+    plan.close(); small.close()
+
+
+def test_full_length_cfg2_prefix_property_and_finiteness():
+    """BASELINE size (T = 84 010, S = 73) through a size-independent property: with one sweep the sites of
+    step k depend only on y(1..k), so the first 1500 columns must equal the truncated golden run's filter
+    pass; outputs finite; variances positive."""
+    g = gold('cfg2_gf_ep_modulator_nmf'); D, N = int(g['D']), int(g['N'])
+    T = 84010
+    pr = harness.nmf_problem(D, N, T, 100)             # same seed -> same model as the fixture; prior sample differs in length only
+    y = np.concatenate([g['y'], pr['y'][g['y'].size:]])
+    blk = pss.ss_blocks_nmf(pr['param1'], pr['param2'], 'matern32', 'matern52')
+    mom = Mom('likModulatorNMFPower', p_cubature=9)
+    plan = Plan(L.KIND_GF_EP, [(blk, pr['W'], np.log(pr['w_lik']))], T, mom=mom, ep_fraction=0.5, ep_damping=[0.5], ep_itts=1)
+    plan.upload([y]); plan.execute(); out = plan.download(want_MS=False)[0]; plan.close()
+    Tg = g['y'].size
+    ref = Plan(L.KIND_GF_EP, [(blk, pr['W'], np.log(pr['w_lik']))], Tg, mom=mom, ep_fraction=0.5, ep_damping=[0.5], ep_itts=1)
+    ref.upload([g['y']]); ref.execute(); o = ref.download(want_MS=False)[0]; ref.close()
+    assert np.array_equal(out.ttau[:, :Tg - 1], o.ttau[:, :Tg - 1]) and np.array_equal(out.lZ[:Tg - 1], o.lZ[:Tg - 1])
+    o1 = ogf.gf_ep_modulator_nmf(g['w'], np.arange(1, 201.0), g['y'][:200], None, olik.Mom(olik.LIK_POWER_NMF, p=9), np.arange(1, 201.0),
+                                 'matern32', 'matern52', 1, D, N, 0.5, [0.5], 1)
+    assert rel(out.ttau[:, :199], o1[5]['ttau'][:, :199]) < TOL_SITE
+    assert np.all(np.isfinite(out.Eft)) and np.all(out.Varft > 0) and np.isfinite(out.nlZ[0])
+
+
+def test_unsupported_shapes_are_refused_not_emulated():
+    D, N, T = 2, 1, 20
+    pr = harness.nmf_problem(D, N, T, 1, kernel1='matern52')              # 6-state sub-band blocks
+    t = np.arange(1, T + 1.0)
+    with pytest.raises(nagp.NagpError, match='unsupported'):
+        nagp.gf_ep_modulator_nmf(pr['w'], t, pr['y'], SSHandle(), Mom('likModulatorNMFPower', p_cubature=5), t, 'matern52', 'matern52', 1, D, N, 0.5, [0.5], 1)

@@ -1,0 +1,84 @@
+"""Generate tests/golden/*.npz: inputs and expected outputs of the hot path, produced by the CPU
+oracle (oracle/, a restatement of the MATLAB reference -- the reference itself cannot run here:
+no MATLAB/Octave).  Fixtures hold data only (inputs + expected outputs).
+
+    python tools/make_golden.py
+"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'nonstationary-audio-gp_amd'))
+import numpy as np
+from nagp import harness, cubature as pcub
+from oracle import gf_ep as ogf, ihgp as oih, giekf as oek, lik as olik
+
+OUT = os.path.join(ROOT, 'tests', 'golden')
+os.makedirs(OUT, exist_ok=True)
+
+
+def save(name, **kw):
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **kw)
+    print('wrote %s (%.0f KB)' % (name, os.path.getsize(os.path.join(OUT, name + '.npz')) / 1024)); sys.stdout.flush()
+
+
+def keep(res, keys=('nlZ', 'ttau', 'tnu', 'maxDiffM', 'maxDiffP')):
+    return {k: res[k] for k in keys if k in res}
+
+
+t0 = time.time()
+# cfg1: gf_ep_modulator, 1k samples, 4 channels (full size)
+c = harness.cfg1(T=1000)
+t = np.arange(1, 1001.0)
+o = ogf.gf_ep_modulator(c['w'], t, c['y'], None, olik.Mom(olik.LIK_POWER, p=9), t, 'matern32', 'matern52', 1, 0.5, c['ep_damping'], 5)
+e, _ = ogf.gf_ep_modulator(c['w'], t, c['y'], None, olik.Mom(olik.LIK_POWER, p=9), None, 'matern32', 'matern52', 1, 0.5, c['ep_damping'], 3)
+save('cfg1_gf_ep_modulator', w=c['w'], y=c['y'], ep_damping=c['ep_damping'], Eft=o[0], Varft=o[1], edata_I3=e, lZ=o[5]['lZ'], **keep(o[5]))
+
+# cfg2 shape: gf_ep_modulator_nmf, 16 ch / 3 NMF, p=9, truncated, with a missing stretch
+D, N, T = 16, 3, 1500
+pr = harness.nmf_problem(D, N, T, 100); y = pr['y'].copy(); y[400:460] = np.nan
+t = np.arange(1, T + 1.0); d = 0.5 * np.ones(3)
+om = olik.Mom(olik.LIK_POWER_NMF, p=9)
+o = ogf.gf_ep_modulator_nmf(pr['w'], t, y, None, om, t, 'matern32', 'matern52', 1, D, N, 0.5, d, 3)
+e1, _ = ogf.gf_ep_modulator_nmf(pr['w'], t, y, None, om, None, 'matern32', 'matern52', 1, D, N, 0.5, d, 1)
+e3, _ = ogf.gf_ep_modulator_nmf(pr['w'], t, y, None, om, None, 'matern32', 'matern52', 1, D, N, 0.5, d, 3)
+save('cfg2_gf_ep_modulator_nmf', w=pr['w'], y=y, D=D, N=N, Eft=o[0], Varft=o[1], edata_I1=e1, edata_I3=e3, lZ=o[5]['lZ'], **keep(o[5]))
+
+# cfg3 shape: ihgp, 32 ch / 6 NMF, p=7, truncated
+D, N, T = 32, 6, 1200
+pr = harness.nmf_problem(D, N, T, 2019, 'constraints'); y = pr['y'].copy(); y[700:720] = np.nan
+t = np.arange(1, T + 1.0)
+om = olik.Mom(olik.LIK_POWER_NMF, p=7)
+o = oih.ihgp_ep_modulator_nmf(pr['w'], t, y, None, om, t, 'matern32', 'matern52', 1, D, N, 0.5, d, 3)
+save('cfg3_ihgp_ep_modulator_nmf', w=pr['w'], y=y, D=D, N=N, Eft=o[0], Varft=o[1], R=o[5]['R'], **keep(o[5]))
+
+# cfg4 shape: giekf (constraints variant), 24 ch / 3 NMF
+D, N, T = 24, 3, 800
+pr = harness.nmf_problem(D, N, T, 312); y = pr['y'].copy(); y[100:110] = np.nan
+t = np.arange(1, T + 1.0)
+cons = np.array([[0.001, 0.1], [20.0, 800.0], [0.0, 2 * np.pi], [2.0, 12.0], [100.0, 2000.0], [0.0, 1.0]])
+tune = [1, 0, 1, 0, 1, 1, 0]
+w, wf = harness.constrained_vectors(pr, cons, tune)
+o = oek.gf_giekf_modulator_nmf_constraints(w, t, y, None, None, t, 'matern32', 'matern52', 1, D, N, 3, 1, cons, wf, tune)
+o2 = oek.gf_giekf_modulator_nmf(pr['w'], t, y, None, None, t, 'matern32', 'matern52', 1, D, N, 2, 2)
+save('cfg4_gf_giekf_modulator_nmf', w=w, w_fixed=wf, w_log=pr['w'], y=y, D=D, N=N, constraints=cons, tune_hypers=np.array(tune),
+     Eft=o[0], Varft=o[1], maxDiffP=o[5]['maxDiffP'], Eft_plain=o2[0], Varft_plain=o2[1], maxDiffP_plain=o2[5]['maxDiffP'])
+
+# cfg5 shape: gf_ep_modulator_nmf_constraints, 32 ch / 6 NMF (S = 146), p=7
+D, N, T = 32, 6, 500
+pr = harness.nmf_problem(D, N, T, 5000, 'constraints'); y = pr['y'].copy()
+t = np.arange(1, T + 1.0)
+cons = harness.CONSTRAINTS_DEMO(D); cons[0] = [0.01, 0.1]
+w, wf = harness.constrained_vectors(pr, cons, harness.TUNE_DEMO)
+om = olik.Mom(olik.LIK_POWER_NMF, p=7)
+o = ogf.gf_ep_modulator_nmf_constraints(w, t, y, None, om, t, 'matern32', 'matern52', 1, D, N, 0.5, d, 3, cons, wf, harness.TUNE_DEMO)
+save('cfg5_gf_ep_modulator_nmf_constraints', w=w, w_fixed=wf, y=y, D=D, N=N, constraints=cons, tune_hypers=np.array(harness.TUNE_DEMO),
+     Eft=o[0], Varft=o[1], lZ=o[5]['lZ'], **keep(o[5]))
+
+# likModulatorPreCalcwn (sqrt-amplitude likelihood, precomputed sigma points), exp kernel sub-bands, shifted softplus
+D, N, T = 6, 2, 400
+pr = harness.nmf_problem(D, N, T, 77, kernel1='exp'); y = np.abs(pr['y']) + 0.05
+t = np.arange(1, T + 1.0)
+wn, xn = pcub.utp_ws(7, N)
+om = olik.Mom(olik.LIK_POWER_NMF_SQRT, link=olik.softplus_link(1.0), wn=wn, xn_unscaled=xn)
+o = ogf.gf_ep_modulator_nmf(pr['w'], t, y, None, om, t, 'exp', 'matern52', 1, D, N, 0.75, 0.1 * np.ones(4), 4)
+save('precalcwn_exp_subbands', w=pr['w'], y=y, D=D, N=N, wn=wn, xn_unscaled=xn, Eft=o[0], Varft=o[1], lZ=o[5]['lZ'], **keep(o[5]))
+print('done in %.0fs' % (time.time() - t0))

@@ -43,8 +43,9 @@ struct nagp_plan {
   std::vector<double> damping;
   int B = 0;
   int TPT = 1, NT = 256, NT_f = 256, NT_ih = 256;
-  int chunk = 2048, LP = 4;
-  int DG_f = 1, DG_ep = 1;
+  int chunk = 2048, LP1 = 1, LP2 = 1, ns_max = 1;
+  SpanPar spar{};
+  int DG_f = 1, DG_ep = 1, cache_f = 0, cache_ep = 0;
   bool want_PS = false;
   bool need_PF = false;
   hipStream_t stream = nullptr;
@@ -52,7 +53,7 @@ struct nagp_plan {
   MomCfg mc{};
   IhgpTabs tb{};
   double* d_model = nullptr; double* d_y = nullptr; double* d_wn = nullptr; double* d_xi = nullptr;
-  double* d_xbuf = nullptr; double* d_lZs = nullptr; double* d_vprev = nullptr; double* d_tab = nullptr; double* d_r = nullptr;
+  double* d_lZs = nullptr; double* d_vprev = nullptr; double* d_tab = nullptr; double* d_r = nullptr;
   std::vector<void*> allocs;
   int64_t dev_bytes = 0;
   std::vector<double> nlZ, mdM, mdP;   // [B][ep_itts]
@@ -241,7 +242,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     mc.lik_kind = o->lik_kind; mc.link_kind = o->link_kind; mc.link_shift = o->link_shift;
     mc.n_pts = o->n_pts; mc.cdim = o->cub_dim; mc.D = sh.D; mc.wn = p->d_wn; mc.xi = p->d_xi;
     mc.jitter = (o->lik_kind == NAGP_LIK_POWER) ? 1e-8 : 1e-10;
-    mc.DG = 1;
+    mc.DG = 1; mc.cache_tabs = 0;
   }
 
   // ---- buffers
@@ -262,19 +263,31 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
   PLAN_TRY(dalloc(p, &b.state, (size_t)B * ((size_t)nt * 16 + sh.S)));
   PLAN_TRY(dalloc(p, &b.red, (size_t)B * 8));
   { double* c = nullptr; PLAN_TRY(dalloc(p, &c, (size_t)B * 4)); b.counters = reinterpret_cast<unsigned long long*>(c); }
-  p->chunk = (o->chunk > 0) ? o->chunk : 2048;
+  p->chunk = (o->chunk > 0) ? o->chunk : (int)std::min<int64_t>(T, 1 << 20);
   if (p->chunk > T) p->chunk = (int)T;
   if (o->kind != NAGP_KIND_IHGP) {
     // keep the (G, Delta) chunk buffer under ~8 GiB
     const double per_step = (double)B * 2.0 * nt * 128.0;
-    while (p->chunk > 64 && per_step * p->chunk > 8.0 * 1073741824.0) p->chunk /= 2;
+    while (p->chunk > 64 && per_step * p->chunk > 24.0 * 1073741824.0) p->chunk = (p->chunk + 1) / 2;
     if (p->need_PF) PLAN_TRY(dalloc(p, &b.PF, BT * nt * 16, false));
     if (p->want_PS) PLAN_TRY(dalloc(p, &b.PSs, BT * nt * 16, false));
     PLAN_TRY(dalloc(p, &b.Gbuf, (size_t)B * p->chunk * 2 * nt * 16, false));
     PLAN_TRY(dalloc(p, &b.dbuf, (size_t)B * p->chunk * sh.S, false));
-    PLAN_TRY(dalloc(p, &p->d_xbuf, (size_t)B * nt * 16));
-    int LP = (int)((80.0 * 1024.0) / (4.0 * TS * 8.0 * sh.M));
-    p->LP = std::max(1, std::min(LP, sh.M));
+    // panel widths: one tile per thread per operand panel, panels (double buffered) within 72 KiB of LDS
+    const double cap = 72.0 * 1024.0;
+    p->LP1 = std::max(1, std::min(std::min(sh.M, p->NT / (3 * sh.M)), (int)(cap / (2.0 * 3 * sh.M * TS * 8))));
+    p->LP2 = std::max(1, std::min(std::min(sh.M, p->NT / (2 * sh.M)), (int)(cap / (2.0 * 2 * sh.M * TS * 8))));
+    // spans per chunk: pass 2 is sequential in the span count, passes 1+3 in the span length
+    {
+      const int per_prob = std::max(1, 1024 / std::min(B, 1024));
+      int ns = (int)std::lround(std::sqrt(2.5 * (double)p->chunk));
+      ns = std::max(1, std::min(std::min(ns, per_prob), (p->chunk + 7) / 8));
+      p->ns_max = ns;
+    }
+    PLAN_TRY(dalloc(p, &p->spar.spanbuf, (size_t)B * p->ns_max * 2 * nt * 16, false));
+    PLAN_TRY(dalloc(p, &p->spar.spanvec, (size_t)B * p->ns_max * sh.S, false));
+    PLAN_TRY(dalloc(p, &p->spar.bnd, (size_t)B * p->ns_max * ((size_t)nt * 16 + sh.S), false));
+    PLAN_TRY(dalloc(p, &p->spar.xbuf, (size_t)B * p->ns_max * nt * 16, false));
   } else {
     PLAN_TRY(dalloc(p, &p->d_lZs, BT));
     PLAN_TRY(dalloc(p, &p->d_vprev, (size_t)B * sh.M));
@@ -319,35 +332,41 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
 
   // ---- LDS sizes / kernel attributes
   if (o->kind == NAGP_KIND_IHGP) {
-    p->NT_ih = std::min(512, std::max(256, roundup64(o->n_pts)));
+    p->NT_ih = 512;
     p->DG_f = pick_DG(o->n_pts, p->NT_ih, sh.D);
-    MomCfg t = mc; t.DG = p->DG_f;
+    MomCfg t = mc; t.DG = p->DG_f; t.cache_tabs = 1;
+    if (ihgp_filter_lds_doubles(sh, t) * sizeof(double) > 150 * 1024) t.cache_tabs = 0;
+    p->cache_f = t.cache_tabs;
     p->lds_ih = ihgp_filter_lds_doubles(sh, t) * sizeof(double);
     PLAN_TRY(set_lds(ihgp_filter_kernel, p->lds_ih));
   } else {
     if (!ekf) p->DG_f = pick_DG(o->n_pts, p->NT_f, sh.D);
-    MomCfg t = mc; t.DG = p->DG_f;
+    MomCfg t = mc; t.DG = p->DG_f; t.cache_tabs = ekf ? 0 : 1;
+    if (filter_lds_doubles(sh, t, ekf ? 1 : 0) * sizeof(double) > 150 * 1024) t.cache_tabs = 0;
+    p->cache_f = t.cache_tabs;
     p->lds_filter = filter_lds_doubles(sh, t, ekf ? 1 : 0) * sizeof(double);
     p->lds_gain = gain_lds_doubles(sh) * sizeof(double);
-    p->lds_scan = scan_lds_doubles(sh, p->LP) * sizeof(double);
+    p->lds_scan = span_lds_doubles(sh, p->LP1, p->LP2) * sizeof(double);
     switch (p->TPT) {
       case 1:
         PLAN_TRY(ekf ? set_lds(gf_filter_kernel<1, 1>, p->lds_filter) : set_lds(gf_filter_kernel<1, 0>, p->lds_filter));
-        PLAN_TRY(set_lds(rts_gain_kernel<1>, p->lds_gain)); PLAN_TRY(set_lds(rts_scan_kernel<1>, p->lds_scan)); break;
+        PLAN_TRY(set_lds(rts_gain_kernel<1>, p->lds_gain)); PLAN_TRY(set_lds(rts_compose_kernel<1>, p->lds_scan)); PLAN_TRY(set_lds(rts_boundary_kernel<1>, p->lds_scan)); PLAN_TRY(set_lds(rts_apply_kernel<1>, p->lds_scan)); break;
       case 2:
         PLAN_TRY(ekf ? set_lds(gf_filter_kernel<2, 1>, p->lds_filter) : set_lds(gf_filter_kernel<2, 0>, p->lds_filter));
-        PLAN_TRY(set_lds(rts_gain_kernel<2>, p->lds_gain)); PLAN_TRY(set_lds(rts_scan_kernel<2>, p->lds_scan)); break;
+        PLAN_TRY(set_lds(rts_gain_kernel<2>, p->lds_gain)); PLAN_TRY(set_lds(rts_compose_kernel<2>, p->lds_scan)); PLAN_TRY(set_lds(rts_boundary_kernel<2>, p->lds_scan)); PLAN_TRY(set_lds(rts_apply_kernel<2>, p->lds_scan)); break;
       case 3:
         PLAN_TRY(ekf ? set_lds(gf_filter_kernel<3, 1>, p->lds_filter) : set_lds(gf_filter_kernel<3, 0>, p->lds_filter));
-        PLAN_TRY(set_lds(rts_gain_kernel<3>, p->lds_gain)); PLAN_TRY(set_lds(rts_scan_kernel<3>, p->lds_scan)); break;
+        PLAN_TRY(set_lds(rts_gain_kernel<3>, p->lds_gain)); PLAN_TRY(set_lds(rts_compose_kernel<3>, p->lds_scan)); PLAN_TRY(set_lds(rts_boundary_kernel<3>, p->lds_scan)); PLAN_TRY(set_lds(rts_apply_kernel<3>, p->lds_scan)); break;
       default:
         PLAN_TRY(ekf ? set_lds(gf_filter_kernel<4, 1>, p->lds_filter) : set_lds(gf_filter_kernel<4, 0>, p->lds_filter));
-        PLAN_TRY(set_lds(rts_gain_kernel<4>, p->lds_gain)); PLAN_TRY(set_lds(rts_scan_kernel<4>, p->lds_scan)); break;
+        PLAN_TRY(set_lds(rts_gain_kernel<4>, p->lds_gain)); PLAN_TRY(set_lds(rts_compose_kernel<4>, p->lds_scan)); PLAN_TRY(set_lds(rts_boundary_kernel<4>, p->lds_scan)); PLAN_TRY(set_lds(rts_apply_kernel<4>, p->lds_scan)); break;
     }
   }
   if (!ekf) {
     p->DG_ep = pick_DG(o->n_pts, 256, sh.D);
-    MomCfg t = mc; t.DG = p->DG_ep;
+    MomCfg t = mc; t.DG = p->DG_ep; t.cache_tabs = 1;
+    if (ep_lds_doubles(sh, t) * sizeof(double) > 64 * 1024) t.cache_tabs = 0;
+    p->cache_ep = t.cache_tabs;
     p->lds_ep = ep_lds_doubles(sh, t) * sizeof(double);
     PLAN_TRY(set_lds(ep_site_kernel, p->lds_ep));
   }
@@ -384,7 +403,7 @@ extern "C" int nagp_plan_upload_y(nagp_plan* p, const double* const* ys) {
 // ---------------------------------------------------------------------------------------------
 static int launch_filter(nagp_plan* p, const FilterPar& fp) {
   const bool ekf = p->opts.kind == NAGP_KIND_GIEKF;
-  MomCfg mc = p->mc; mc.DG = p->DG_f;
+  MomCfg mc = p->mc; mc.DG = p->DG_f; mc.cache_tabs = p->cache_f;
   Timed t(p, NAGP_K_FILTER);
   dim3 g(p->B), bl(p->NT_f);
 #define LF(TP, ME) hipLaunchKernelGGL((gf_filter_kernel<TP, ME>), g, bl, p->lds_filter, p->stream, p->sh, p->b, mc, fp)
@@ -418,16 +437,24 @@ static int launch_smoother(nagp_plan* p, bool write_PSs) {
       }
     }
     HIP_TRY(hipGetLastError());
-    ScanPar sp{k0, nk, p->chunk, p->LP, first ? 1 : 0, write_PSs ? 1 : 0, 1};
+    SpanPar sp = p->spar;
+    sp.k0 = k0; sp.nk = nk; sp.chunk = p->chunk; sp.ns_max = p->ns_max; sp.LP1 = p->LP1; sp.LP2 = p->LP2;
+    sp.first = first ? 1 : 0; sp.write_PSs = write_PSs ? 1 : 0;
+    {
+      int ns = (int)std::lround(std::sqrt(2.5 * (double)nk));
+      ns = std::max(1, std::min(std::min(ns, p->ns_max), (nk + 7) / 8));
+      sp.L = (nk + ns - 1) / ns;
+      sp.ns = (nk + sp.L - 1) / sp.L;
+    }
     {
       Timed t(p, NAGP_K_SCAN);
-      dim3 g(p->B), bl(p->NT);
-      switch (p->TPT) {
-        case 1: hipLaunchKernelGGL((rts_scan_kernel<1>), g, bl, p->lds_scan, p->stream, sh, p->b, sp, p->d_xbuf); break;
-        case 2: hipLaunchKernelGGL((rts_scan_kernel<2>), g, bl, p->lds_scan, p->stream, sh, p->b, sp, p->d_xbuf); break;
-        case 3: hipLaunchKernelGGL((rts_scan_kernel<3>), g, bl, p->lds_scan, p->stream, sh, p->b, sp, p->d_xbuf); break;
-        default: hipLaunchKernelGGL((rts_scan_kernel<4>), g, bl, p->lds_scan, p->stream, sh, p->b, sp, p->d_xbuf); break;
-      }
+      dim3 g(sp.ns, p->B), g2(p->B), bl(p->NT);
+#define LS(TP) do { \
+        hipLaunchKernelGGL((rts_compose_kernel<TP>), g, bl, p->lds_scan, p->stream, sh, p->b, sp); \
+        hipLaunchKernelGGL((rts_boundary_kernel<TP>), g2, bl, p->lds_scan, p->stream, sh, p->b, sp); \
+        hipLaunchKernelGGL((rts_apply_kernel<TP>), g, bl, p->lds_scan, p->stream, sh, p->b, sp); } while (0)
+      switch (p->TPT) { case 1: LS(1); break; case 2: LS(2); break; case 3: LS(3); break; default: LS(4); break; }
+#undef LS
     }
     HIP_TRY(hipGetLastError());
     first = false;
@@ -439,7 +466,7 @@ static int launch_smoother(nagp_plan* p, bool write_PSs) {
 static int launch_ep(nagp_plan* p, double alpha, double damp, int clamp, int write_R, double* lZ_out) {
   const Shape& sh = p->sh;
   if (sh.T < 2) return NAGP_OK;
-  MomCfg mc = p->mc; mc.DG = p->DG_ep;
+  MomCfg mc = p->mc; mc.DG = p->DG_ep; mc.cache_tabs = p->cache_ep;
   EpPar ep{};
   ep.k_end = sh.T - 1;
   ep.steps_per_wg = (int)std::max<int64_t>(1, (ep.k_end + 4095) / 4096);
@@ -575,7 +602,7 @@ static int exec_ihgp(nagp_plan* p) {
     HIP_TRY(hipMemcpyAsync(p->d_vprev + (size_t)q * sh.M, p->d_tab + (size_t)q * itab_size(sh, p->tb.NG) + itab_hph0(sh, p->tb.NG),
                            sh.M * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
   }
-  MomCfg mcf = p->mc; mcf.DG = p->DG_f;
+  MomCfg mcf = p->mc; mcf.DG = p->DG_f; mcf.cache_tabs = p->cache_f;
   for (int itt = 1; itt <= I; ++itt) {
     IhgpPar ip{itt, p->damping[itt - 1], itt == 1 ? 1 : 0, 0.0};
     {

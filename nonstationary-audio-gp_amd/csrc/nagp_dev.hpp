@@ -53,6 +53,10 @@ __device__ __forceinline__ double wave_max(double v) {
   return fmax(fmax(readlane_d(v, 0), readlane_d(v, 16)), fmax(readlane_d(v, 32), readlane_d(v, 48)));
 }
 
+// Workgroup barrier for LDS hand-offs only: waits for this wave's LDS traffic, NOT for outstanding
+// global loads/stores (a __syncthreads() would drain vmcnt and expose HBM store latency every step).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // MATLAB max(x,0): NaN -> 0 (SURVEY C-3)
 __device__ __forceinline__ double max0(double x) { return (x > 0.0) ? x : 0.0; }
 
@@ -140,6 +144,7 @@ struct MomCfg {
   const double* wn;  // [n_pts]
   const double* xi;  // [n_pts][cdim] unit sigma points, point-major
   double jitter;
+  int cache_tabs;    // copy wn / xi into LDS at kernel start (when the workgroup's LDS budget allows)
 };
 
 // LDS workspace (doubles) needed by mom_eval for a chunk of CH points
@@ -147,7 +152,17 @@ __host__ __device__ inline int mom_chunk(const MomCfg& c) { return c.n_pts < 102
 __host__ __device__ inline size_t mom_lds_doubles(const MomCfg& c) {
   const int CH = mom_chunk(c);
   // lk[CH][cdim] + c0,c1,c2[CH] + sg[cdim] + sums1,sums2 [D+cdim+1]
-  return (size_t)CH * (c.cdim + 3) + c.cdim + 2 * (size_t)(c.D + c.cdim + 1) + 2;
+  return (size_t)CH * (c.cdim + 3) + c.cdim + 2 * (size_t)(c.D + c.cdim + 1) + 2 +
+         (c.cache_tabs ? (size_t)c.n_pts * (c.cdim + 1) : 0);
+}
+// kernels call this once after carving `ws`: returns where the cached tables live (end of the workspace)
+__device__ inline void mom_cache_tables(const MomCfg& c, double* ws) {
+  if (!c.cache_tabs) return;
+  const int CH = mom_chunk(c);
+  double* tw = ws + (size_t)CH * (c.cdim + 3) + c.cdim + 2 * (size_t)(c.D + c.cdim + 1) + 2;
+  double* tx = tw + c.n_pts;
+  for (int i = threadIdx.x; i < c.n_pts; i += blockDim.x) tw[i] = c.wn[i];
+  for (int i = threadIdx.x; i < c.n_pts * c.cdim; i += blockDim.x) tx[i] = c.xi[i];
 }
 
 __device__ __forceinline__ double link_eval(int kind, double shift, double g) {
@@ -184,9 +199,10 @@ __device__ __forceinline__ void mom_p1_nmf(const MomCfg& c, const double* Wl, co
 //   Wl     : LDS D x N row-major NMF weights (ignored for POWER)
 //   out    : dl[M], d2l[M] (LDS) and *lZ (LDS scalar) valid after the function returns
 //            (the function ends with a __syncthreads()).
-__device__ inline void mom_eval(const MomCfg& c, const double* Wl, double sn2, double alpha, double y,
-                                const double* mu, const double* s2, double* ws, double* lZ, double* dl,
-                                double* d2l) {
+template <bool TL>
+__device__ __forceinline__ void mom_eval_t(const MomCfg& c, const double* Wl, double sn2, double alpha, double y,
+                                           const double* mu, const double* s2, double* ws, double* lZ, double* dl,
+                                           double* d2l) {
   const int tid = threadIdx.x, NT = blockDim.x;
   const int lane = tid & 63, wave = tid >> 6, nwaves = NT >> 6;
   const int D = c.D, cd = c.cdim, CH = mom_chunk(c);
@@ -200,6 +216,8 @@ __device__ inline void mom_eval(const MomCfg& c, const double* Wl, double sn2, d
   double* sg = c2 + CH;               // [cd] sqrt(s2_g)
   double* sums1 = sg + cd;            // [nout]
   double* sums2 = sums1 + nout;       // [nout]
+  const double* t_wn = TL ? (sums2 + nout + 2) : c.wn;       // cached tables sit right behind the workspace
+  const double* t_xi = TL ? (sums2 + nout + 2 + c.n_pts) : c.xi;
   const double* mu_z = mu;
   const double* mu_g = mu + D;
   const double* s2_z = s2;
@@ -207,7 +225,7 @@ __device__ inline void mom_eval(const MomCfg& c, const double* Wl, double sn2, d
 
   if (tid < cd) sg[tid] = sqrt(s2_g[tid]);
   if (tid < nout) { sums1[tid] = 0.0; sums2[tid] = 0.0; }
-  __syncthreads();
+  lds_barrier();
 
   const int DG = c.DG;
   const double sn2a = sn2 / alpha;
@@ -217,7 +235,7 @@ __device__ inline void mom_eval(const MomCfg& c, const double* Wl, double sn2, d
     for (int item = tid; item < npc * DG; item += NT) {
       const int pl = item / DG, sub = item - pl * DG;
       const int p = base + pl;
-      const double* xip = c.xi + (size_t)p * cd;
+      const double* xip = t_xi + (size_t)p * cd;
       double sa2 = 0.0, sam = 0.0;
       if (nmf) {
         switch (cd) {
@@ -246,14 +264,14 @@ __device__ inline void mom_eval(const MomCfg& c, const double* Wl, double sn2, d
         const double sd = sqrt(sig2);
         const double r = (y - sam) / sd;
         const double pdf = exp(-0.5 * r * r) / (kSqrt2Pi * sd);
-        const double w0 = c.wn[p] * pdf;
+        const double w0 = t_wn[p] * pdf;
         const double q = (y - sam) / sig2;
         c0[pl] = w0;
         c1[pl] = w0 * q;
         c2[pl] = w0 * (q * q - 1.0 / sig2);
       }
     }
-    __syncthreads();
+    lds_barrier();
     // ---- phase 2: one output per wave pass, lanes stride over the points of the chunk
     for (int o = wave; o < nout; o += nwaves) {
       double a1 = 0.0, a2 = 0.0;
@@ -274,7 +292,7 @@ __device__ inline void mom_eval(const MomCfg& c, const double* Wl, double sn2, d
         const int j = o - D;
         const double mg = mu_g[j], s2g = s2_g[j], sgj = sg[j];
         for (int pl = lane; pl < npc; pl += 64) {
-          const double xn = mg + sgj * c.xi[(size_t)(base + pl) * cd + j];
+          const double xn = mg + sgj * t_xi[(size_t)(base + pl) * cd + j];
           const double xg = (xn - mg) / s2g;
           a1 = fma(xg, c0[pl], a1);
           a2 = fma(xg * xg - 1.0 / s2g, c0[pl], a2);
@@ -286,7 +304,7 @@ __device__ inline void mom_eval(const MomCfg& c, const double* Wl, double sn2, d
       a2 = wave_sum(a2);
       if (lane == 0) { sums1[o] += a1; sums2[o] += a2; }
     }
-    __syncthreads();
+    lds_barrier();
   }
   // ---- phase 3
   {
@@ -302,7 +320,14 @@ __device__ inline void mom_eval(const MomCfg& c, const double* Wl, double sn2, d
     }
     if (tid == 0) *lZ = log(Z);
   }
-  __syncthreads();
+  lds_barrier();
+}
+
+__device__ __forceinline__ void mom_eval(const MomCfg& c, const double* Wl, double sn2, double alpha, double y,
+                                         const double* mu, const double* s2, double* ws, double* lZ, double* dl,
+                                         double* d2l) {
+  if (c.cache_tabs) mom_eval_t<true>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l);
+  else mom_eval_t<false>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l);
 }
 
 }  // namespace nagp

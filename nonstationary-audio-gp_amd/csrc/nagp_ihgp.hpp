@@ -82,7 +82,8 @@ __global__ void __launch_bounds__(512) ihgp_filter_kernel(Shape sh, Bufs b, MomC
   for (int i = tid; i < M; i += NT) ibsz[i] = sh.bsz[i];
   for (int i = tid; i < sh.D * sh.N; i += NT) sW[i] = mdl[mdl_W(sh) + i];
   const double sn2 = mdl[mdl_sn2(sh)];
-  __syncthreads();
+  mom_cache_tables(mc, ws);
+  lds_barrier();
 
   // thread n < M owns block n
   const int n = tid;
@@ -109,8 +110,14 @@ __global__ void __launch_bounds__(512) ihgp_filter_kernel(Shape sh, Bufs b, MomC
   double Rprev = 0.0;
   unsigned long long n_clamped = 0;
 
+  double y_nx = yv[0], tt_nx = 0.0, tn_nx = 0.0, R_nx = 0.0;
+  if (act) { tt_nx = g_tt[n]; tn_nx = g_tn[n]; R_nx = g_R[n]; }
   for (int64_t k = 0; k < T; ++k) {
-    const double yk = yv[k];
+    const double yk = y_nx, tt_k = tt_nx, tn_k = tn_nx, R_k = R_nx;
+    if (k + 1 < T) {
+      y_nx = yv[k + 1];
+      if (act) { tt_nx = g_tt[(size_t)(k + 1) * M + n]; tn_nx = g_tn[(size_t)(k + 1) * M + n]; R_nx = g_R[(size_t)(k + 1) * M + n]; }
+    }
     double hph = 0.0, wc[4] = {0, 0, 0, 0}, Am[4] = {0, 0, 0, 0}, fmun = 0.0;
     if (act) {
       if (k > 0) {
@@ -138,19 +145,19 @@ __global__ void __launch_bounds__(512) ihgp_filter_kernel(Shape sh, Bufs b, MomC
     const bool do_mom = ip.mom_all || (k == T - 1);
     double tnew = 0.0, nnew = 0.0, Rn = 0.0;
     if (do_mom) {
-      __syncthreads();
+      lds_barrier();
       mom_eval(mc, sW, sn2, 1.0, yk, fmu, HPH, ws, &misc[0], dl, d2l);
       if (act) {
         const double d1 = dl[n], d2 = d2l[n];
-        const double t_old = g_tt[(size_t)k * M + n], n_old = g_tn[(size_t)k * M + n];
+        const double t_old = tt_k, n_old = tn_k;
         tnew = (1.0 - ip.ep_damp) * t_old + ip.ep_damp * (-d2 / (1.0 + d2 * hph));
         nnew = (1.0 - ip.ep_damp) * n_old + ip.ep_damp * ((d1 - fmun * d2) / (1.0 + d2 * hph));
         Rn = 1.0 / tnew;                      // before the clamp (:269)
       }
       if (tid == 0) g_lZ[k] = misc[0];
     } else if (act) {
-      tnew = g_tt[(size_t)k * M + n]; nnew = g_tn[(size_t)k * M + n];
-      Rn = g_R[(size_t)k * M + n];
+      tnew = tt_k; nnew = tn_k;
+      Rn = R_k;
     }
     if (act) {
       if (!(tnew > 0.0)) ++n_clamped;
@@ -170,7 +177,7 @@ __global__ void __launch_bounds__(512) ihgp_filter_kernel(Shape sh, Bufs b, MomC
       g_fm[(size_t)k * M + n] = hn * mreg[0];
       Rprev = Rn;
     }
-    if (do_mom) __syncthreads();   // fmu/HPH/dl reuse
+    if (do_mom) lds_barrier();   // fmu/HPH/dl reuse
   }
   if (act && n_clamped) atomicAdd(&b.counters[(size_t)pb * 4 + 1], n_clamped);
 }

@@ -130,6 +130,7 @@ __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg
   for (int i = tid; i < M; i += NT) shv[i] = mdl[mdl_h(sh) + i];
   for (int i = tid; i < sh.D * sh.N; i += NT) sW[i] = mdl[mdl_W(sh) + i];
   const double sn2 = mdl[mdl_sn2(sh)];
+  if (MEAS == 0) mom_cache_tables(mc, ws);
 
   TileOwner<TPT> own;
   own.init(M, sh.ntiles);
@@ -146,7 +147,7 @@ __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg
     }
   }
   for (int i = tid; i < S; i += NT) m[i] = fp.init_from_state ? st[(size_t)sh.ntiles * 16 + i] : 0.0;
-  __syncthreads();
+  lds_barrier();
   // which block / row-in-block does state i (= tid) belong to
   int myblk = 0, myrow = 0;
   if (tid < S) {
@@ -165,8 +166,15 @@ __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg
   double* g_PF = b.PF ? b.PF + (size_t)pb * T * sh.ntiles * 16 : nullptr;
   unsigned long long n_clamped = 0, n_nan = 0;
 
+  // software prefetch of the per-step global inputs (one step ahead; no barrier drains vmcnt)
+  double y_nx = yv[0], tt_nx = 0.0, tn_nx = 0.0;
+  if (MEAS == 0 && tid < M) { tt_nx = g_tt[tid]; tn_nx = g_tn[tid]; }
   for (int64_t k = 0; k < T; ++k) {
-    const double yk = yv[k];
+    const double yk = y_nx, tt_k = tt_nx, tn_k = tn_nx;
+    if (k + 1 < T) {
+      y_nx = yv[k + 1];
+      if (MEAS == 0 && tid < M) { tt_nx = g_tt[(size_t)(k + 1) * M + tid]; tn_nx = g_tn[(size_t)(k + 1) * M + tid]; }
+    }
     const bool pred = (k > 0) || fp.predict_k1;
     // ---- S0: prediction (registers), publish W = P H', H P, diag(H P H'), fmu = H m
     double rm = 0.0;
@@ -201,7 +209,7 @@ __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg
         if (I == J) HPH[I] = hI * hI * P[q][0];
       }
     }
-    __syncthreads();  // B1
+    lds_barrier();  // B1
     if (tid < S) m[tid] = rm;
 
     if (!(yk != yk)) {  // ~isnan(y_k)
@@ -211,7 +219,7 @@ __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg
           mom_eval(mc, sW, sn2, 1.0, yk, fmu, HPH, ws, &misc[0], dl, d2l);
           if (tid < M) {
             const double d2 = d2l[tid], d1 = dl[tid], hp = HPH[tid], f = fmu[tid];
-            double t_old = g_tt[(size_t)k * M + tid], n_old = g_tn[(size_t)k * M + tid];
+            double t_old = tt_k, n_old = tn_k;
             double tnew = (1.0 - fp.ep_damp) * t_old + fp.ep_damp * (-d2 / (1.0 + d2 * hp));
             double nnew = (1.0 - fp.ep_damp) * n_old + fp.ep_damp * ((d1 - f * d2) / (1.0 + d2 * hp));
             if (!(tnew > 0.0)) ++n_clamped;
@@ -222,11 +230,11 @@ __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg
           }
           if (tid == 0) g_lZ[k] = misc[0];
         } else if (tid < M) {
-          double t_old = g_tt[(size_t)k * M + tid];
+          double t_old = tt_k;
           if (fp.clamp_always) { t_old = max0(t_old); g_tt[(size_t)k * M + tid] = t_old; }
-          tt[tid] = t_old; tn[tid] = g_tn[(size_t)k * M + tid];
+          tt[tid] = t_old; tn[tid] = tn_k;
         }
-        if (fp.legacy_update) __syncthreads();
+        if (fp.legacy_update) lds_barrier();
         if (tid < M) {
           const double t = tt[tid], n = tn[tid], hp = HPH[tid], f = fmu[tid];
           bool formA = (t == 0.0);
@@ -246,7 +254,7 @@ __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg
           }
           if (tid == 0) misc[1] = formA ? 1.0 : 0.0;
         }
-        __syncthreads();  // B4
+        lds_barrier();  // B4
         const bool legacyA = fp.legacy_update && (misc[1] != 0.0);
         if (tid < S) {
           double acc = rm;
@@ -285,7 +293,7 @@ __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg
         for (int it = 0; it < fp.l_iter; ++it) {
           if (it > 0) {
             if (tid < M) fmu[tid] = shv[tid] * m[ioff[tid]];
-            __syncthreads();
+            lds_barrier();
           }
           if (tid < M) {   // partials of h = z' W softplus(g)
             double pv = 0.0;
@@ -300,22 +308,22 @@ __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg
             }
             part[tid] = pv;
           }
-          __syncthreads();
+          lds_barrier();
           if (tid < S) {
             double acc = 0.0;
             for (int n = 0; n < M; ++n) acc = fma(Wl[((size_t)n * 4 + myrow) * M + myblk], part[n], acc);
             PJ[tid] = acc;
           }
-          __syncthreads();
+          lds_barrier();
           double jpj = 0.0;
           MU = 0.0;
           for (int n = 0; n < M; ++n) jpj = fma(part[n] * shv[n], PJ[ioff[n]], jpj);
           for (int d = 0; d < D; ++d) MU = fma(fmu[d], part[d], MU);
           Sx = sn2 + jpj;
           if (tid < S) { rm = rm + (PJ[tid] / Sx) * (yk - MU); }
-          __syncthreads();   // all reads of m/fmu for this iteration done
+          lds_barrier();   // all reads of m/fmu for this iteration done
           if (tid < S) m[tid] = rm;
-          if (it + 1 < fp.l_iter) __syncthreads();
+          if (it + 1 < fp.l_iter) lds_barrier();
         }
         // P -= K S K'
 #pragma unroll
@@ -351,7 +359,7 @@ __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg
       for (int q = 0; q < TPT; ++q)
         if (own.ok[q]) tile_store(g_PF + ((size_t)k * sh.ntiles + tid + q * NT) * 16, P[q]);
     }
-    __syncthreads();  // B5
+    lds_barrier();  // B5
   }
   // final filtered state -> scan state (E = 0, e = 0 is implied; the smoother starts from MF/PF at T-1)
   if (tid < M && n_clamped) atomicAdd(&b.counters[(size_t)pb * 4 + 1], n_clamped);
@@ -458,7 +466,7 @@ __global__ void __launch_bounds__(512) rts_gain_kernel(Shape sh, Bufs b, GainPar
   for (int i = tid; i < M; i += NT) ibsz[i] = sh.bsz[i];
   for (int i = tid; i < M * 16; i += NT) sA[i] = mdl[mdl_A(sh) + i];
   if (tid == 0) { flag[0] = 0; flag[1] = 0; }
-  __syncthreads();
+  lds_barrier();
 
   TileOwner<TPT> own;
   own.init(M, sh.ntiles);
@@ -529,20 +537,20 @@ __global__ void __launch_bounds__(512) rts_gain_kernel(Shape sh, Bufs b, GainPar
           if (!tile_chol(Lt[q], ibsz[jb])) flag[attempt] = 1;
           tile_store(sLd + (size_t)jb * 16, Lt[q]);
         }
-      __syncthreads();
+      lds_barrier();
 #pragma unroll
       for (int q = 0; q < TPT; ++q)
         if (own.ok[q] && own.J[q] == jb && own.I[q] > jb) {
           tile_solve_Lt(Lt[q], sLd + (size_t)jb * 16);
           tile_store(bufP + ((size_t)par * M + own.I[q]) * TS, Lt[q]);
         }
-      __syncthreads();
+      lds_barrier();
 #pragma unroll
       for (int q = 0; q < TPT; ++q)
         if (own.ok[q] && own.J[q] > jb && own.I[q] >= own.J[q])
           tile_mms_nt(Lt[q], bufP + ((size_t)par * M + own.I[q]) * TS, bufP + ((size_t)par * M + own.J[q]) * TS);
     }
-    __syncthreads();
+    lds_barrier();
     failed = (flag[attempt] != 0);
     if (!failed) break;
   }
@@ -561,13 +569,13 @@ __global__ void __launch_bounds__(512) rts_gain_kernel(Shape sh, Bufs b, GainPar
         tile_store(bufX + ((size_t)par * M + own.I[q]) * TS, Bt[q]);
         if (own.I[q] > jb) tile_store(bufP + ((size_t)par * M + own.I[q]) * TS, Lt[q]);
       }
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int q = 0; q < TPT; ++q)
       if (own.ok[q] && own.J[q] > jb)
         tile_mms_nt(Bt[q], bufX + ((size_t)par * M + own.I[q]) * TS, bufP + ((size_t)par * M + own.J[q]) * TS);
   }
-  __syncthreads();
+  lds_barrier();
   // ---- G L = X  (backward over block columns)
   for (int jb = M - 1; jb >= 0; --jb) {
     const int par = jb & 1;
@@ -580,7 +588,7 @@ __global__ void __launch_bounds__(512) rts_gain_kernel(Shape sh, Bufs b, GainPar
         }
         if (own.I[q] == jb && own.J[q] < jb) tile_store(bufP + ((size_t)par * M + own.J[q]) * TS, Lt[q]);
       }
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int q = 0; q < TPT; ++q)
       if (own.ok[q] && own.J[q] < jb)
@@ -601,149 +609,347 @@ __global__ void __launch_bounds__(512) rts_gain_kernel(Shape sh, Bufs b, GainPar
 }
 
 // ---------------------------------------------------------------------------------------------
-// RTS backward recursion over one chunk, one workgroup per problem (sequential in k):
-//   Y = E + Delta_k ; X = G_k Y ; E <- X G_k' ; e <- G_k (e + delta_k)
-//   (E_k = P^s_k - PS_k, e_k = m^s_k - MF_k: gf_ep_modulator_nmf.m:229-230 in difference form)
-// Panel GEMM on 4x4 register tiles: operands streamed global -> registers -> LDS panels (double
-// buffered, one barrier per panel); state E/X live in global scratch (L2 resident).
-struct ScanPar {
-  int64_t k0;
-  int nk;
-  int chunk;
-  int LP;          // panel width in tiles
-  int first;       // first chunk of the sweep: E = 0, e = 0
-  int write_PSs;   // also store smoothed covariances PF_k + E_k
-  int last_state;  // at k == 0 store the smoothed (P, m) into `state` (EKF restart) -- always done
+// RTS backward recursion, parallel in time.  In difference form (E_k = P^s_k - PS_k, e_k = m^s_k - MF_k)
+// the reference's smoother step (gf_ep_modulator_nmf.m:229-230) is the affine map
+//     E_k = G_k (E_{k+1} + Delta_k) G_k' ,   e_k = G_k (e_{k+1} + delta_k)
+// with G_k, Delta_k, delta_k known from the filter pass (rts_gain_kernel).  A chunk of steps is cut into
+// spans; three passes:
+//   pass 1 (one workgroup per span, all CUs):  compose the span's map  E_bot = Phi E_top Phi' + C,
+//           e_bot = Phi e_top + c   by  Phi <- G Phi,  C <- G (C + Delta) G',  c <- G (c + delta)
+//   pass 2 (one workgroup per problem, sequential over spans): boundary values E_top, e_top of every span
+//   pass 3 (one workgroup per span): the reference recursion inside the span from its boundary value;
+//           writes the smoothed means, marginals (and covariances when asked).
+// All three are panel GEMMs on 4x4 register tiles: operands stream global(L2) -> registers -> LDS panels
+// (double buffered, padded tiles, one LDS barrier per panel); every thread loads at most one tile per
+// operand panel, one panel ahead of the arithmetic.
+struct SpanPar {
+  int64_t k0;       // first step of the chunk
+  int nk;           // steps in the chunk
+  int chunk;        // chunk capacity (Gbuf stride)
+  int L;            // span length
+  int ns;           // spans in this chunk
+  int ns_max;       // span-buffer stride
+  int LP1, LP2;     // panel widths (tiles) of the dual / single operand GEMMs
+  int first;        // first chunk of the sweep: E = 0, e = 0 at the top
+  int write_PSs;
+  double* spanbuf;  // [B][ns_max][2][ntiles*16]  Phi, C
+  double* spanvec;  // [B][ns_max][S]             c
+  double* bnd;      // [B][ns_max][ntiles*16 + S] E_top, e_top
+  double* xbuf;     // [B][ns_max][ntiles*16]     per-workgroup scratch for X
 };
 
-__host__ __device__ inline size_t scan_lds_doubles(const Shape& s, int LP) {
-  return LDS_INT_DOUBLES + (size_t)s.M + 1 + 2 * (size_t)(s.S + 1) + 4 * (size_t)s.M * LP * TS + 8;
+template <int TPT>
+struct GemmCtx {
+  int tid, NT, M, S;
+  TileOwner<TPT> own;
+  double* pan;       // LDS panels
+  const int* ioff; const int* ibsz;
+  int myblk, myrow;  // state row handled by this thread (tid < S)
+};
+
+// acc1 += A * (B1a + B1b) ; if DUAL: acc2 += A * (B2a + B2b)   (B?b may be null)
+// optional: yv (register of thread tid < S) += sum_j A[tid, j] * v[j]   (v in LDS)
+template <int TPT, bool DUAL>
+__device__ __forceinline__ void gemm_nn(const GemmCtx<TPT>& c, int LP, double (*acc1)[16], double (*acc2)[16],
+                                        const double* __restrict__ A, const double* __restrict__ B1a,
+                                        const double* __restrict__ B1b, const double* __restrict__ B2a,
+                                        const double* __restrict__ B2b, const double* v, double& yv) {
+  const int M = c.M, nop = DUAL ? 3 : 2;
+  const size_t panOp = (size_t)M * LP * TS;
+  const int npan = (M + LP - 1) / LP;
+  double t16[16];
+  // task of this thread inside a panel of width lw: it -> (operand, tile)
+  auto fetch = [&](int p) {
+    const int l0 = p * LP, lw = (M - l0 < LP) ? (M - l0) : LP;
+    const int it = c.tid;
+    if (it < nop * M * lw) {
+      const int op = it / (M * lw), r = it - op * M * lw;
+      if (op == 0) {
+        const int I = r / lw, l = r - I * lw;
+        tile_load(t16, A + ((size_t)I * M + l0 + l) * 16);
+      } else {
+        const int l = r / M, J = r - l * M;
+        const size_t tix = ((size_t)(l0 + l) * M + J) * 16;
+        const double* Ba = (op == 1) ? B1a : B2a;
+        const double* Bb = (op == 1) ? B1b : B2b;
+        tile_load(t16, Ba + tix);
+        if (Bb) {
+          double u16[16];
+          tile_load(u16, Bb + tix);
+#pragma unroll
+          for (int e = 0; e < 16; ++e) t16[e] += u16[e];
+        }
+      }
+    }
+  };
+  auto publish = [&](int p) {
+    const int l0 = p * LP, lw = (M - l0 < LP) ? (M - l0) : LP;
+    double* base = c.pan + (size_t)(p & 1) * nop * panOp;
+    const int it = c.tid;
+    if (it < nop * M * lw) {
+      const int op = it / (M * lw), r = it - op * M * lw;
+      if (op == 0) {
+        const int I = r / lw, l = r - I * lw;
+        tile_store(base + ((size_t)l * M + I) * TS, t16);
+      } else {
+        const int l = r / M, J = r - l * M;
+        tile_store(base + (size_t)op * panOp + ((size_t)l * M + J) * TS, t16);
+      }
+    }
+  };
+  fetch(0);
+  for (int p = 0; p < npan; ++p) {
+    const int l0 = p * LP, lw = (M - l0 < LP) ? (M - l0) : LP;
+    publish(p);
+    lds_barrier();
+    if (p + 1 < npan) fetch(p + 1);
+    const double* pg = c.pan + (size_t)(p & 1) * nop * panOp;
+    const double* pb1 = pg + panOp;
+    const double* pb2 = pb1 + panOp;
+#pragma unroll
+    for (int q = 0; q < TPT; ++q)
+      if (c.own.ok[q]) {
+#pragma unroll 2
+        for (int l = 0; l < lw; ++l) {
+          const double* a = pg + ((size_t)l * M + c.own.I[q]) * TS;
+          tile_mma(acc1[q], a, pb1 + ((size_t)l * M + c.own.J[q]) * TS);
+          if (DUAL) tile_mma(acc2[q], a, pb2 + ((size_t)l * M + c.own.J[q]) * TS);
+        }
+      }
+    if (v && c.tid < c.S) {
+      for (int l = 0; l < lw; ++l) {
+        const double* g = pg + ((size_t)l * M + c.myblk) * TS + 4 * c.myrow;
+        const double* vv = v + c.ioff[l0 + l];
+        const int bs = c.ibsz[l0 + l];
+        for (int j = 0; j < bs; ++j) yv = fma(g[j], vv[j], yv);
+      }
+    }
+  }
+}
+
+// acc += A * Bt'   (A[I,L] and Bt[J,L] both global tile-major)
+template <int TPT>
+__device__ __forceinline__ void gemm_nt(const GemmCtx<TPT>& c, int LP, double (*acc)[16],
+                                        const double* __restrict__ A, const double* __restrict__ Bt) {
+  const int M = c.M;
+  const size_t panOp = (size_t)M * LP * TS;
+  const int npan = (M + LP - 1) / LP;
+  double t16[16];
+  auto fetch = [&](int p) {
+    const int l0 = p * LP, lw = (M - l0 < LP) ? (M - l0) : LP;
+    const int it = c.tid;
+    if (it < 2 * M * lw) {
+      const int op = it / (M * lw), r = it - op * M * lw;
+      const int I = r / lw, l = r - I * lw;
+      tile_load(t16, (op == 0 ? A : Bt) + ((size_t)I * M + l0 + l) * 16);
+    }
+  };
+  auto publish = [&](int p) {
+    const int l0 = p * LP, lw = (M - l0 < LP) ? (M - l0) : LP;
+    double* base = c.pan + (size_t)(p & 1) * 2 * panOp;
+    const int it = c.tid;
+    if (it < 2 * M * lw) {
+      const int op = it / (M * lw), r = it - op * M * lw;
+      const int I = r / lw, l = r - I * lw;
+      tile_store(base + (size_t)op * panOp + ((size_t)l * M + I) * TS, t16);
+    }
+  };
+  fetch(0);
+  for (int p = 0; p < npan; ++p) {
+    const int l0 = p * LP, lw = (M - l0 < LP) ? (M - l0) : LP;
+    publish(p);
+    lds_barrier();
+    if (p + 1 < npan) fetch(p + 1);
+    const double* px = c.pan + (size_t)(p & 1) * 2 * panOp;
+    const double* pg = px + panOp;
+#pragma unroll
+    for (int q = 0; q < TPT; ++q)
+      if (c.own.ok[q]) {
+#pragma unroll 2
+        for (int l = 0; l < lw; ++l)
+          tile_mma_nt(acc[q], px + ((size_t)l * M + c.own.I[q]) * TS, pg + ((size_t)l * M + c.own.J[q]) * TS);
+      }
+  }
 }
 
 template <int TPT>
-__global__ void __launch_bounds__(512) rts_scan_kernel(Shape sh, Bufs b, ScanPar sp, double* xbuf /* [B][ntiles*16] */) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  const int tid = threadIdx.x, NT = blockDim.x;
-  const int S = sh.S, M = sh.M, LP = sp.LP;
-  const int64_t T = sh.T;
-  const int pb = blockIdx.x;
-  const double* mdl = b.model + (size_t)pb * mdl_size(sh);
-  const int ntl = sh.ntiles;
-
+__device__ __forceinline__ void span_setup(GemmCtx<TPT>& c, const Shape& sh, double* lds, double*& shv, double*& v0,
+                                           double*& v1, double*& v2, const double* mdl) {
+  c.tid = threadIdx.x; c.NT = blockDim.x; c.M = sh.M; c.S = sh.S;
   int* ioff = reinterpret_cast<int*>(lds);
   int* ibsz = ioff + (MAXM + 1);
-  double* shv = lds + LDS_INT_DOUBLES;   // [M]
-  double* ev = shv + ((M + 1) & ~1);     // [S] e + delta
-  double* en = ev + ((S + 1) & ~1);      // [S] new e
-  double* pan = en + ((S + 1) & ~1);     // [2][2][LP*M][TS]   (buffer, operand, tile) -- 16-B aligned
-  const size_t panOp = (size_t)M * LP * TS;
+  shv = lds + LDS_INT_DOUBLES;
+  v0 = shv + ((sh.M + 2) & ~1);
+  v1 = v0 + ((sh.S + 2) & ~1);
+  v2 = v1 + ((sh.S + 2) & ~1);
+  c.pan = v2 + ((sh.S + 2) & ~1);
+  for (int i = c.tid; i <= sh.M; i += c.NT) ioff[i] = sh.off[i];
+  for (int i = c.tid; i < sh.M; i += c.NT) ibsz[i] = sh.bsz[i];
+  for (int i = c.tid; i < sh.M; i += c.NT) shv[i] = mdl[mdl_h(sh) + i];
+  __syncthreads();
+  c.ioff = ioff; c.ibsz = ibsz;
+  c.myblk = 0; c.myrow = 0;
+  if (c.tid < sh.S) {
+    while (ioff[c.myblk + 1] <= c.tid) ++c.myblk;
+    c.myrow = c.tid - ioff[c.myblk];
+  }
+  c.own.init(sh.M, sh.ntiles);
+}
+__host__ __device__ inline size_t span_lds_doubles(const Shape& s, int LP1, int LP2) {
+  const size_t p1 = 2 * 3 * (size_t)s.M * LP1 * TS, p2 = 2 * 2 * (size_t)s.M * LP2 * TS;
+  return LDS_INT_DOUBLES + (size_t)(s.M + 2) + 3 * (size_t)(s.S + 2) + (p1 > p2 ? p1 : p2) + 8;
+}
 
-  for (int i = tid; i <= M; i += NT) ioff[i] = sh.off[i];
-  for (int i = tid; i < M; i += NT) ibsz[i] = sh.bsz[i];
-  for (int i = tid; i < M; i += NT) shv[i] = mdl[mdl_h(sh) + i];
+// ---- pass 1: compose the affine map of one span
+template <int TPT>
+__global__ void __launch_bounds__(512) rts_compose_kernel(Shape sh, Bufs b, SpanPar sp) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int j = blockIdx.x, pb = blockIdx.y;
+  const int ntl = sh.ntiles, S = sh.S, M = sh.M;
+  const double* mdl = b.model + (size_t)pb * mdl_size(sh);
+  GemmCtx<TPT> c; double *shv, *cv, *vv, *v2;
+  span_setup(c, sh, lds, shv, cv, vv, v2, mdl);
+  const int tid = c.tid, NT = c.NT;
+  double* Phi = sp.spanbuf + (((size_t)pb * sp.ns_max + j) * 2) * ntl * 16;
+  double* Cm = Phi + (size_t)ntl * 16;
+  double* Xb = sp.xbuf + ((size_t)pb * sp.ns_max + j) * ntl * 16;
+  // Phi = I, C = 0, c = 0
+  for (int t = tid; t < ntl; t += NT) {
+    double z[16]; tile_zero(z);
+    tile_store(Cm + (size_t)t * 16, z);
+    const int I = t / M, J = t - I * M;
+    if (I == J) for (int i = 0; i < c.ibsz[I]; ++i) z[5 * i] = 1.0;
+    tile_store(Phi + (size_t)t * 16, z);
+  }
+  if (tid < S) cv[tid] = 0.0;
+  __syncthreads();
+  const int a = j * sp.L, e = (a + sp.L < sp.nk) ? a + sp.L : sp.nk;
+  for (int kk = e - 1; kk >= a; --kk) {
+    const double* Gk = b.Gbuf + (((size_t)pb * sp.chunk + kk) * 2) * ntl * 16;
+    const double* Dk = Gk + (size_t)ntl * 16;
+    const double* dk = b.dbuf + ((size_t)pb * sp.chunk + kk) * S;
+    if (tid < S) vv[tid] = cv[tid] + dk[tid];
+    lds_barrier();
+    double accP[TPT][16], accX[TPT][16];
+#pragma unroll
+    for (int q = 0; q < TPT; ++q) { tile_zero(accP[q]); tile_zero(accX[q]); }
+    double cn = 0.0;
+    gemm_nn<TPT, true>(c, sp.LP1, accP, accX, Gk, Phi, nullptr, Cm, Dk, vv, cn);
+    __syncthreads();   // every read of Phi / C (global) and vv is done
+#pragma unroll
+    for (int q = 0; q < TPT; ++q)
+      if (c.own.ok[q]) {
+        tile_store(Phi + (size_t)(tid + q * NT) * 16, accP[q]);
+        tile_store(Xb + (size_t)(tid + q * NT) * 16, accX[q]);
+      }
+    if (tid < S) cv[tid] = cn;
+    __syncthreads();   // X visible
+#pragma unroll
+    for (int q = 0; q < TPT; ++q) tile_zero(accX[q]);
+    gemm_nt<TPT>(c, sp.LP2, accX, Xb, Gk);
+#pragma unroll
+    for (int q = 0; q < TPT; ++q)
+      if (c.own.ok[q]) tile_store(Cm + (size_t)(tid + q * NT) * 16, accX[q]);
+    __syncthreads();   // C visible, panels free
+  }
+  if (tid < S) sp.spanvec[((size_t)pb * sp.ns_max + j) * S + tid] = cv[tid];
+}
+
+// ---- pass 2: boundary values, sequential over the spans of the chunk (top span first)
+template <int TPT>
+__global__ void __launch_bounds__(512) rts_boundary_kernel(Shape sh, Bufs b, SpanPar sp) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int pb = blockIdx.x;
+  const int ntl = sh.ntiles, S = sh.S;
+  const double* mdl = b.model + (size_t)pb * mdl_size(sh);
+  GemmCtx<TPT> c; double *shv, *ev, *v1, *v2;
+  span_setup(c, sh, lds, shv, ev, v1, v2, mdl);
+  const int tid = c.tid, NT = c.NT;
   double* Est = b.state + (size_t)pb * ((size_t)ntl * 16 + S);
   double* est = Est + (size_t)ntl * 16;
-  double* Xb = xbuf + (size_t)pb * ntl * 16;
+  double* Xb = sp.xbuf + ((size_t)pb * sp.ns_max) * ntl * 16;
   if (sp.first) {
     for (int i = tid; i < ntl * 16; i += NT) Est[i] = 0.0;
     for (int i = tid; i < S; i += NT) est[i] = 0.0;
   }
   __syncthreads();
-  int myblk = 0, myrow = 0;
-  if (tid < S) {
-    while (ioff[myblk + 1] <= tid) ++myblk;
-    myrow = tid - ioff[myblk];
+  for (int j = sp.ns - 1; j >= 0; --j) {
+    const double* Phi = sp.spanbuf + (((size_t)pb * sp.ns_max + j) * 2) * ntl * 16;
+    const double* Cm = Phi + (size_t)ntl * 16;
+    double* Bj = sp.bnd + ((size_t)pb * sp.ns_max + j) * ((size_t)ntl * 16 + S);
+    // E_top of span j
+    for (int i = tid; i < ntl * 8; i += NT) reinterpret_cast<double2*>(Bj)[i] = reinterpret_cast<const double2*>(Est)[i];
+    if (tid < S) { const double e0 = est[tid]; Bj[(size_t)ntl * 16 + tid] = e0; ev[tid] = e0; }
+    lds_barrier();
+    double acc[TPT][16], dummy[1][16];
+#pragma unroll
+    for (int q = 0; q < TPT; ++q) tile_zero(acc[q]);
+    double en = 0.0;
+    gemm_nn<TPT, false>(c, sp.LP2, acc, reinterpret_cast<double(*)[16]>(dummy), Phi, Est, nullptr, nullptr, nullptr, ev, en);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < TPT; ++q)
+      if (c.own.ok[q]) tile_store(Xb + (size_t)(tid + q * NT) * 16, acc[q]);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < TPT; ++q)
+      if (c.own.ok[q]) tile_load(acc[q], Cm + (size_t)(tid + q * NT) * 16); else tile_zero(acc[q]);
+    gemm_nt<TPT>(c, sp.LP2, acc, Xb, Phi);
+#pragma unroll
+    for (int q = 0; q < TPT; ++q)
+      if (c.own.ok[q]) tile_store(Est + (size_t)(tid + q * NT) * 16, acc[q]);
+    if (tid < S) est[tid] = en + sp.spanvec[((size_t)pb * sp.ns_max + j) * S + tid];
+    __syncthreads();
   }
-  TileOwner<TPT> own;
-  own.init(M, ntl);
-  const int npan = (M + LP - 1) / LP;
-  double mxM = 0.0, mxP = 0.0;
+}
 
-  for (int kk = sp.nk - 1; kk >= 0; --kk) {
+// ---- pass 3: the recursion inside one span, outputs
+template <int TPT>
+__global__ void __launch_bounds__(512) rts_apply_kernel(Shape sh, Bufs b, SpanPar sp) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int j = blockIdx.x, pb = blockIdx.y;
+  const int ntl = sh.ntiles, S = sh.S, M = sh.M;
+  const int64_t T = sh.T;
+  const double* mdl = b.model + (size_t)pb * mdl_size(sh);
+  GemmCtx<TPT> c; double *shv, *ec, *vv, *v2;
+  span_setup(c, sh, lds, shv, ec, vv, v2, mdl);
+  const int tid = c.tid, NT = c.NT;
+  double* Bj = sp.bnd + ((size_t)pb * sp.ns_max + j) * ((size_t)ntl * 16 + S);   // E (updated in place), e_top
+  double* Xb = sp.xbuf + ((size_t)pb * sp.ns_max + j) * ntl * 16;
+  if (tid < S) ec[tid] = Bj[(size_t)ntl * 16 + tid];
+  lds_barrier();
+  double mxM = 0.0, mxP = 0.0;
+  const int a = j * sp.L, e = (a + sp.L < sp.nk) ? a + sp.L : sp.nk;
+  for (int kk = e - 1; kk >= a; --kk) {
     const int64_t k = sp.k0 + kk;
     const double* Gk = b.Gbuf + (((size_t)pb * sp.chunk + kk) * 2) * ntl * 16;
     const double* Dk = Gk + (size_t)ntl * 16;
     const double* dk = b.dbuf + ((size_t)pb * sp.chunk + kk) * S;
-    if (tid < S) ev[tid] = est[tid] + dk[tid];
-
-    double acc[TPT][16];
-    // ================= GEMM 1: X = G (E + Delta)
+    if (tid < S) vv[tid] = ec[tid] + dk[tid];
+    lds_barrier();
+    double acc[TPT][16], dummy[1][16];
 #pragma unroll
     for (int q = 0; q < TPT; ++q) tile_zero(acc[q]);
-    for (int p = 0; p < npan; ++p) {
-      const int l0 = p * LP, lw = (M - l0 < LP) ? (M - l0) : LP;
-      double* pg = pan + (size_t)(p & 1) * 2 * panOp;   // G[:, panel]   tile (I,l) at (l*M+I)
-      double* py = pg + panOp;                           // Y[panel, :]   tile (l,J) at (l*M+J)
-      for (int it = tid; it < 2 * M * lw; it += NT) {
-        double t16[16];
-        if (it < M * lw) {
-          const int I = it / lw, l = it - I * lw;
-          tile_load(t16, Gk + ((size_t)I * M + l0 + l) * 16);
-          tile_store(pg + ((size_t)l * M + I) * TS, t16);
-        } else {
-          const int it2 = it - M * lw;
-          const int l = it2 / M, J = it2 - l * M;
-          double d16[16];
-          const size_t tix = ((size_t)(l0 + l) * M + J) * 16;
-          tile_load(t16, Est + tix);
-          tile_load(d16, Dk + tix);
-#pragma unroll
-          for (int e = 0; e < 16; ++e) t16[e] += d16[e];
-          tile_store(py + ((size_t)l * M + J) * TS, t16);
-        }
-      }
-      __syncthreads();
-#pragma unroll
-      for (int q = 0; q < TPT; ++q)
-        if (own.ok[q])
-          for (int l = 0; l < lw; ++l)
-            tile_mma(acc[q], pg + ((size_t)l * M + own.I[q]) * TS, py + ((size_t)l * M + own.J[q]) * TS);
-    }
+    double en = 0.0;
+    gemm_nn<TPT, false>(c, sp.LP2, acc, reinterpret_cast<double(*)[16]>(dummy), Gk, Bj, Dk, nullptr, nullptr, vv, en);
+    __syncthreads();
 #pragma unroll
     for (int q = 0; q < TPT; ++q)
-      if (own.ok[q]) tile_store(Xb + (size_t)(tid + q * NT) * 16, acc[q]);
-    // e' = G (e + delta)   (row `tid` of G)
-    if (tid < S) {
-      double a = 0.0;
-      for (int J = 0; J < M; ++J) {
-        const double* g = Gk + ((size_t)myblk * M + J) * 16 + 4 * myrow;
-        const double* v = ev + ioff[J];
-        for (int j = 0; j < ibsz[J]; ++j) a = fma(g[j], v[j], a);
-      }
-      en[tid] = a;
-    }
-    __syncthreads();   // X visible to the whole workgroup; all GEMM-1 panel reads done
-    // ================= GEMM 2: E' = X G'
+      if (c.own.ok[q]) tile_store(Xb + (size_t)(tid + q * NT) * 16, acc[q]);
+    if (tid < S) ec[tid] = en;
+    __syncthreads();
 #pragma unroll
     for (int q = 0; q < TPT; ++q) tile_zero(acc[q]);
-    for (int p = 0; p < npan; ++p) {
-      const int l0 = p * LP, lw = (M - l0 < LP) ? (M - l0) : LP;
-      double* px = pan + (size_t)(p & 1) * 2 * panOp;   // X[:, panel]  tile (I,l) at (l*M+I)
-      double* pg = px + panOp;                           // G[:, panel]  tile (J,l) at (l*M+J)
-      for (int it = tid; it < 2 * M * lw; it += NT) {
-        double t16[16];
-        const int it2 = (it < M * lw) ? it : it - M * lw;
-        const int I = it2 / lw, l = it2 - I * lw;
-        const double* src = (it < M * lw) ? Xb : Gk;
-        tile_load(t16, src + ((size_t)I * M + l0 + l) * 16);
-        tile_store(((it < M * lw) ? px : pg) + ((size_t)l * M + I) * TS, t16);
-      }
-      __syncthreads();
-#pragma unroll
-      for (int q = 0; q < TPT; ++q)
-        if (own.ok[q])
-          for (int l = 0; l < lw; ++l)
-            tile_mma_nt(acc[q], px + ((size_t)l * M + own.I[q]) * TS, pg + ((size_t)l * M + own.J[q]) * TS);
-    }
-    // ---- store E', outputs
+    gemm_nt<TPT>(c, sp.LP2, acc, Xb, Gk);
+    // ---- store E_k, outputs
     const double* PFk = b.PF + ((size_t)pb * T + k) * ntl * 16;
 #pragma unroll
     for (int q = 0; q < TPT; ++q)
-      if (own.ok[q]) {
+      if (c.own.ok[q]) {
         const int t = tid + q * NT;
-        tile_store(Est + (size_t)t * 16, acc[q]);
-        if (own.I[q] == own.J[q]) {
-          const int n = own.I[q];
+        tile_store(Bj + (size_t)t * 16, acc[q]);
+        if (c.own.I[q] == c.own.J[q]) {
+          const int n = c.own.I[q];
           const size_t ix = ((size_t)pb * T + k) * M + n;
           const double vnew = b.fv[ix] + shv[n] * shv[n] * acc[q][0];
           mxP = fmax(mxP, fabs(b.sv[ix] - vnew));
@@ -753,37 +959,29 @@ __global__ void __launch_bounds__(512) rts_scan_kernel(Shape sh, Bufs b, ScanPar
           double ps[16];
           tile_load(ps, PFk + (size_t)t * 16);
 #pragma unroll
-          for (int e = 0; e < 16; ++e) ps[e] += acc[q][e];
+          for (int x = 0; x < 16; ++x) ps[x] += acc[q][x];
           if (sp.write_PSs) tile_store(b.PSs + (((size_t)pb * T + k) * ntl + t) * 16, ps);
-          if (k == 0) tile_store(Xb + (size_t)t * 16, ps);   // staged; copied into `state` after the loop
+          if (k == 0) tile_store(b.state + (size_t)pb * ((size_t)ntl * 16 + S) + (size_t)t * 16, ps);   // smoothed P_0 (EKF restart)
         }
       }
     if (tid < S) {
-      const double e1 = en[tid];
-      est[tid] = e1;
-      const double ms = b.MF[((size_t)pb * T + k) * S + tid] + e1;
+      const double ms = b.MF[((size_t)pb * T + k) * S + tid] + en;
       b.MS[((size_t)pb * T + k) * S + tid] = ms;
-      if (myrow == 0) {
-        const size_t ix = ((size_t)pb * T + k) * M + myblk;
-        const double mnew = shv[myblk] * ms;
+      if (k == 0) b.state[(size_t)pb * ((size_t)ntl * 16 + S) + (size_t)ntl * 16 + tid] = ms;
+      if (c.myrow == 0) {
+        const size_t ix = ((size_t)pb * T + k) * M + c.myblk;
+        const double mnew = shv[c.myblk] * ms;
         mxM = fmax(mxM, fabs(b.sm[ix] - mnew));
         b.sm[ix] = mnew;
       }
     }
-    __syncthreads();   // E', e' visible before the next step reads them
+    __syncthreads();
   }
-  // running maxima -> red[1], red[2] (accumulated over chunks with atomics on the bit pattern: values >= 0)
   mxM = wave_max(mxM);
   mxP = wave_max(mxP);
   if ((tid & 63) == 0) {
     atomicMax(reinterpret_cast<unsigned long long*>(&b.red[(size_t)pb * 8 + 1]), (unsigned long long)__double_as_longlong(mxM));
     atomicMax(reinterpret_cast<unsigned long long*>(&b.red[(size_t)pb * 8 + 2]), (unsigned long long)__double_as_longlong(mxP));
-  }
-  if (sp.k0 == 0) {
-    // smoothed (P, m) at k = 0 -> state (restart point of the non-resetting EKF variant)
-    __syncthreads();
-    for (int i = tid; i < ntl * 16; i += NT) Est[i] = Xb[i];
-    if (tid < S) est[tid] = b.MS[((size_t)pb * T) * S + tid];
   }
 }
 
@@ -821,7 +1019,8 @@ __global__ void __launch_bounds__(256) ep_site_kernel(Shape sh, Bufs b, MomCfg m
   double* ws = misc + 8;
   for (int i = tid; i < sh.D * sh.N; i += NT) sW[i] = mdl[mdl_W(sh) + i];
   const double sn2 = mdl[mdl_sn2(sh)];
-  __syncthreads();
+  mom_cache_tables(mc, ws);
+  lds_barrier();
   const int64_t kb = (int64_t)blockIdx.x * ep.steps_per_wg;
   unsigned long long n_clamped = 0;
   for (int64_t k = kb; k < kb + ep.steps_per_wg && k < ep.k_end; ++k) {
@@ -836,7 +1035,7 @@ __global__ void __launch_bounds__(256) ep_site_kernel(Shape sh, Bufs b, MomCfg m
       mcav = vcav * (mm / vm - ep.alpha * n_old);
       mc_[tid] = mcav; vc_[tid] = vcav;
     }
-    __syncthreads();
+    lds_barrier();
     mom_eval(mc, sW, sn2, ep.alpha, yk, mc_, vc_, ws, &misc[0], dl, d2l);
     if (tid < M) {
       const bool upd = vcav > 0.0;
@@ -851,7 +1050,7 @@ __global__ void __launch_bounds__(256) ep_site_kernel(Shape sh, Bufs b, MomCfg m
       if (ep.write_R == 1 || (ep.write_R == 2 && upd)) b.R[ix] = 1.0 / tnew;
     }
     if (tid == 0) ep.lZ_out[(size_t)pb * T + k] = misc[0];
-    __syncthreads();
+    lds_barrier();
   }
   if (tid < M && n_clamped) atomicAdd(&b.counters[(size_t)pb * 4 + 1], n_clamped);
 }

@@ -168,7 +168,7 @@ def test_batched_plan_equals_single_runs_and_is_deterministic_and_chunk_invarian
     for q in range(3):
         assert np.array_equal(a[q].Eft, b[q].Eft) and np.array_equal(a[q].nlZ, b[q].nlZ) and np.array_equal(a[q].ttau, b[q].ttau)
         # chunk length changes only the span decomposition of the parallel-in-time smoother: rounding-level differences
-        assert rel(a[q].Eft, c[q].Eft) < 1e-11 and rel(a[q].Varft, c[q].Varft) < 1e-11 and np.array_equal(a[q].ttau[:, -1], c[q].ttau[:, -1])
+        assert rel(a[q].Eft, c[q].Eft) < 1e-11 and rel(a[q].Varft, c[q].Varft) < 1e-11 and rel(a[q].ttau, c[q].ttau) < 1e-10
         one = Plan(L.KIND_GF_EP, probs[q:q + 1], T, **kw); one.upload(ys[q:q + 1]); one.execute(); o = one.download()[0]
         assert np.array_equal(a[q].Eft, o.Eft) and np.array_equal(a[q].Varft, o.Varft) and np.array_equal(a[q].nlZ, o.nlZ)
         one.close()

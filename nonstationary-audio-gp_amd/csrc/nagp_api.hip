@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -45,7 +46,7 @@ struct nagp_plan {
   int TPT = 1, NT = 256, NT_f = 256, NT_ih = 256;
   int chunk = 2048, LP1 = 1, LP2 = 1, ns_max = 1;
   SpanPar spar{};
-  int DG_f = 1, DG_ep = 1, cache_f = 0, cache_ep = 0;
+  int DG_f = 1, DG_ep = 1, cache_f = 0, cache_ep = 0, sta_f = 0, sta_ep = 0;
   bool want_PS = false;
   bool need_PF = false;
   hipStream_t stream = nullptr;
@@ -53,7 +54,7 @@ struct nagp_plan {
   MomCfg mc{};
   IhgpTabs tb{};
   double* d_model = nullptr; double* d_y = nullptr; double* d_wn = nullptr; double* d_xi = nullptr;
-  double* d_lZs = nullptr; double* d_vprev = nullptr; double* d_tab = nullptr; double* d_r = nullptr;
+  double* d_stamps = nullptr; double* d_lZs = nullptr; double* d_vprev = nullptr; double* d_tab = nullptr; double* d_r = nullptr;
   std::vector<void*> allocs;
   int64_t dev_bytes = 0;
   std::vector<double> nlZ, mdM, mdP;   // [B][ep_itts]
@@ -231,18 +232,31 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
   // ---- cubature tables (point-major)
   MomCfg& mc = p->mc;
   if (!ekf) {
-    std::vector<double> xi((size_t)o->n_pts * o->cub_dim);
+    // distinct unit coordinates + per-point byte codes (see nagp_dev.hpp: mom)
+    std::vector<double> xd;
+    std::vector<unsigned char> code((size_t)o->n_pts * o->cub_dim);
     for (int pt = 0; pt < o->n_pts; ++pt)
-      for (int j = 0; j < o->cub_dim; ++j) xi[(size_t)pt * o->cub_dim + j] = o->xn_unscaled[j + (size_t)o->cub_dim * pt];
+      for (int j = 0; j < o->cub_dim; ++j) {
+        const double v = o->xn_unscaled[j + (size_t)o->cub_dim * pt];
+        size_t ci = 0;
+        while (ci < xd.size() && xd[ci] != v) ++ci;
+        if (ci == xd.size()) {
+          if (xd.size() == 64) { nagp_plan_destroy(p); FAIL(NAGP_EUNSUPPORTED, "sigma-point rule has more than 64 distinct coordinate values"); }
+          xd.push_back(v);
+        }
+        code[(size_t)pt * o->cub_dim + j] = (unsigned char)ci;
+      }
     PLAN_TRY(dalloc(p, &p->d_wn, o->n_pts, false));
-    PLAN_TRY(dalloc(p, &p->d_xi, xi.size(), false));
+    PLAN_TRY(dalloc(p, &p->d_xi, xd.size() + (code.size() + 7) / 8 + 1, false));
     PLAN_HIP(hipMemcpyAsync(p->d_wn, o->wn, (size_t)o->n_pts * sizeof(double), hipMemcpyHostToDevice, p->stream));
-    PLAN_HIP(hipMemcpyAsync(p->d_xi, xi.data(), xi.size() * sizeof(double), hipMemcpyHostToDevice, p->stream));
+    PLAN_HIP(hipMemcpyAsync(p->d_xi, xd.data(), xd.size() * sizeof(double), hipMemcpyHostToDevice, p->stream));
+    PLAN_HIP(hipMemcpyAsync(p->d_xi + xd.size(), code.data(), code.size(), hipMemcpyHostToDevice, p->stream));
     PLAN_HIP(hipStreamSynchronize(p->stream));
+    mc.nd = (int)xd.size(); mc.xd = p->d_xi; mc.code = reinterpret_cast<const unsigned char*>(p->d_xi + xd.size());
     mc.lik_kind = o->lik_kind; mc.link_kind = o->link_kind; mc.link_shift = o->link_shift;
-    mc.n_pts = o->n_pts; mc.cdim = o->cub_dim; mc.D = sh.D; mc.wn = p->d_wn; mc.xi = p->d_xi;
+    mc.n_pts = o->n_pts; mc.cdim = o->cub_dim; mc.D = sh.D; mc.wn = p->d_wn;
     mc.jitter = (o->lik_kind == NAGP_LIK_POWER) ? 1e-8 : 1e-10;
-    mc.DG = 1; mc.cache_tabs = 0;
+    mc.DG = 1; mc.cache_tabs = 0; mc.store_a = 0; mc.stamps = nullptr;
   }
 
   // ---- buffers
@@ -290,6 +304,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     PLAN_TRY(dalloc(p, &p->spar.xbuf, (size_t)B * p->ns_max * nt * 16, false));
   } else {
     PLAN_TRY(dalloc(p, &p->d_lZs, BT));
+    PLAN_TRY(dalloc(p, &p->d_stamps, 8));
     PLAN_TRY(dalloc(p, &p->d_vprev, (size_t)B * sh.M));
     // ---- IHGP tables: MATLAB layout -> device layout (see nagp_ihgp.hpp)
     const int NG = tables[0].n_grid;
@@ -334,16 +349,18 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
   if (o->kind == NAGP_KIND_IHGP) {
     p->NT_ih = 512;
     p->DG_f = pick_DG(o->n_pts, p->NT_ih, sh.D);
-    MomCfg t = mc; t.DG = p->DG_f; t.cache_tabs = 1;
-    if (ihgp_filter_lds_doubles(sh, t) * sizeof(double) > 150 * 1024) t.cache_tabs = 0;
-    p->cache_f = t.cache_tabs;
-    p->lds_ih = ihgp_filter_lds_doubles(sh, t) * sizeof(double);
+    MomCfg t = mc; t.DG = p->DG_f; t.cache_tabs = 1; t.store_a = 1;
+    if (ihgp_filter_lds_doubles(sh, t, p->tb.NG) * sizeof(double) > 150 * 1024) t.store_a = 0;
+    if (ihgp_filter_lds_doubles(sh, t, p->tb.NG) * sizeof(double) > 150 * 1024) t.cache_tabs = 0;
+    p->cache_f = t.cache_tabs; p->sta_f = t.store_a;
+    p->lds_ih = ihgp_filter_lds_doubles(sh, t, p->tb.NG) * sizeof(double);
     PLAN_TRY(set_lds(ihgp_filter_kernel, p->lds_ih));
   } else {
     if (!ekf) p->DG_f = pick_DG(o->n_pts, p->NT_f, sh.D);
-    MomCfg t = mc; t.DG = p->DG_f; t.cache_tabs = ekf ? 0 : 1;
+    MomCfg t = mc; t.DG = p->DG_f; t.cache_tabs = ekf ? 0 : 1; t.store_a = ekf ? 0 : 1;
+    if (filter_lds_doubles(sh, t, ekf ? 1 : 0) * sizeof(double) > 150 * 1024) t.store_a = 0;
     if (filter_lds_doubles(sh, t, ekf ? 1 : 0) * sizeof(double) > 150 * 1024) t.cache_tabs = 0;
-    p->cache_f = t.cache_tabs;
+    p->cache_f = t.cache_tabs; p->sta_f = t.store_a;
     p->lds_filter = filter_lds_doubles(sh, t, ekf ? 1 : 0) * sizeof(double);
     p->lds_gain = gain_lds_doubles(sh) * sizeof(double);
     p->lds_scan = span_lds_doubles(sh, p->LP1, p->LP2) * sizeof(double);
@@ -364,9 +381,10 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
   }
   if (!ekf) {
     p->DG_ep = pick_DG(o->n_pts, 256, sh.D);
-    MomCfg t = mc; t.DG = p->DG_ep; t.cache_tabs = 1;
+    MomCfg t = mc; t.DG = p->DG_ep; t.cache_tabs = 1; t.store_a = 1;
+    if (ep_lds_doubles(sh, t) * sizeof(double) > 64 * 1024) t.store_a = 0;
     if (ep_lds_doubles(sh, t) * sizeof(double) > 64 * 1024) t.cache_tabs = 0;
-    p->cache_ep = t.cache_tabs;
+    p->cache_ep = t.cache_tabs; p->sta_ep = t.store_a;
     p->lds_ep = ep_lds_doubles(sh, t) * sizeof(double);
     PLAN_TRY(set_lds(ep_site_kernel, p->lds_ep));
   }
@@ -401,9 +419,11 @@ extern "C" int nagp_plan_upload_y(nagp_plan* p, const double* const* ys) {
 }
 
 // ---------------------------------------------------------------------------------------------
-static int launch_filter(nagp_plan* p, const FilterPar& fp) {
+static int launch_filter(nagp_plan* p, const FilterPar& fp_in) {
+  FilterPar fp = fp_in;
+  if (const char* e = getenv("NAGP_ABLATE")) fp.ablate = atoi(e);
   const bool ekf = p->opts.kind == NAGP_KIND_GIEKF;
-  MomCfg mc = p->mc; mc.DG = p->DG_f; mc.cache_tabs = p->cache_f;
+  MomCfg mc = p->mc; mc.DG = p->DG_f; mc.cache_tabs = p->cache_f; mc.store_a = p->sta_f;
   Timed t(p, NAGP_K_FILTER);
   dim3 g(p->B), bl(p->NT_f);
 #define LF(TP, ME) hipLaunchKernelGGL((gf_filter_kernel<TP, ME>), g, bl, p->lds_filter, p->stream, p->sh, p->b, mc, fp)
@@ -466,7 +486,7 @@ static int launch_smoother(nagp_plan* p, bool write_PSs) {
 static int launch_ep(nagp_plan* p, double alpha, double damp, int clamp, int write_R, double* lZ_out) {
   const Shape& sh = p->sh;
   if (sh.T < 2) return NAGP_OK;
-  MomCfg mc = p->mc; mc.DG = p->DG_ep; mc.cache_tabs = p->cache_ep;
+  MomCfg mc = p->mc; mc.DG = p->DG_ep; mc.cache_tabs = p->cache_ep; mc.store_a = p->sta_ep;
   EpPar ep{};
   ep.k_end = sh.T - 1;
   ep.steps_per_wg = (int)std::max<int64_t>(1, (ep.k_end + 4095) / 4096);
@@ -602,7 +622,8 @@ static int exec_ihgp(nagp_plan* p) {
     HIP_TRY(hipMemcpyAsync(p->d_vprev + (size_t)q * sh.M, p->d_tab + (size_t)q * itab_size(sh, p->tb.NG) + itab_hph0(sh, p->tb.NG),
                            sh.M * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
   }
-  MomCfg mcf = p->mc; mcf.DG = p->DG_f; mcf.cache_tabs = p->cache_f;
+  MomCfg mcf = p->mc; mcf.DG = p->DG_f; mcf.cache_tabs = p->cache_f; mcf.store_a = p->sta_f;
+  if (getenv("NAGP_STAMPS")) mcf.stamps = reinterpret_cast<unsigned long long*>(p->d_stamps);   // developer diagnostics
   for (int itt = 1; itt <= I; ++itt) {
     IhgpPar ip{itt, p->damping[itt - 1], itt == 1 ? 1 : 0, 0.0};
     {
@@ -647,6 +668,7 @@ extern "C" int nagp_plan_execute(nagp_plan* p) {
   RUN(zero_async(p, p->b.MS, BT * sh.S * 8)); RUN(zero_async(p, p->b.red, (size_t)p->B * 64));
   RUN(zero_async(p, p->b.counters, (size_t)p->B * 32));
   RUN(zero_async(p, p->b.state, (size_t)p->B * ((size_t)sh.ntiles * 16 + sh.S) * 8));
+  if (p->d_stamps) RUN(zero_async(p, p->d_stamps, 64));
   std::fill(p->nlZ.begin(), p->nlZ.end(), 0.0);
   std::fill(p->mdM.begin(), p->mdM.end(), 0.0);
   std::fill(p->mdP.begin(), p->mdP.end(), 0.0);
@@ -659,6 +681,12 @@ extern "C" int nagp_plan_execute(nagp_plan* p) {
   if (st != NAGP_OK) return st;
   HIP_TRY(hipEventRecord(p->ev_t1, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
+  if (getenv("NAGP_STAMPS") && p->d_stamps) {
+    unsigned long long st[8];
+    if (hipMemcpy(st, p->d_stamps, sizeof st, hipMemcpyDeviceToHost) == hipSuccess)
+      fprintf(stderr, "[nagp stamps] mom: p1a %llu p1b %llu p2 %llu p3 %llu | pre-mom %llu post-mom %llu\n", st[0], st[1], st[2], st[3], st[4], st[5]);
+  }
+
   HIP_TRY(hipGetLastError());
   memset(&p->tim, 0, sizeof p->tim);
   for (const EvRec& e : p->evs) {

@@ -133,6 +133,11 @@ __device__ __forceinline__ void tile_congruence(double* t, const double* aI, con
 
 // ---------------------------------------------------------------------------------------------
 // mom: tilted-distribution moments by cubature.
+//
+// The sigma points of the reference's rules (fully symmetric sets, tensor Gauss-Hermite grids) take
+// only a handful of distinct coordinate values (<= 5 for ut3/5/7/9), so link(mu_g + sqrt(s2_g)*xi) is
+// evaluated once per (dimension, distinct value) -- cdim*nd transcendental evaluations instead of
+// n_pts*cdim -- and every sigma point gathers its values through a byte code table.
 struct MomCfg {
   int lik_kind;      // nagp_lik
   int link_kind;     // nagp_link
@@ -141,28 +146,37 @@ struct MomCfg {
   int cdim;          // cubature dimension: N (NMF) or D (POWER)
   int D;             // sub-bands
   int DG;            // lanes per sigma point in phase 1 (power of two, <= 16, <= D)
+  int nd;            // distinct unit coordinates (<= 64)
   const double* wn;  // [n_pts]
-  const double* xi;  // [n_pts][cdim] unit sigma points, point-major
+  const double* xd;  // [nd] distinct unit coordinate values
+  const unsigned char* code;  // [n_pts][cdim] index into xd
   double jitter;
-  int cache_tabs;    // copy wn / xi into LDS at kernel start (when the workgroup's LDS budget allows)
+  int cache_tabs;    // keep wn / code in LDS (n_pts small enough)
+  int store_a;       // NMF: keep a[p][d] = (link(xn) W')_d between the phases instead of link(xn)[p][:]
+  unsigned long long* stamps;  // developer diagnostics: per-phase cycle sums of thread 0 (null in production)
 };
 
-// LDS workspace (doubles) needed by mom_eval for a chunk of CH points
 __host__ __device__ inline int mom_chunk(const MomCfg& c) { return c.n_pts < 1024 ? c.n_pts : 1024; }
-__host__ __device__ inline size_t mom_lds_doubles(const MomCfg& c) {
+__host__ __device__ inline size_t mom_ws_core(const MomCfg& c) {
   const int CH = mom_chunk(c);
-  // lk[CH][cdim] + c0,c1,c2[CH] + sg[cdim] + sums1,sums2 [D+cdim+1]
-  return (size_t)CH * (c.cdim + 3) + c.cdim + 2 * (size_t)(c.D + c.cdim + 1) + 2 +
-         (c.cache_tabs ? (size_t)c.n_pts * (c.cdim + 1) : 0);
+  const size_t row = (c.lik_kind != 0 && c.store_a) ? (size_t)c.D : (size_t)c.cdim;
+  // rows[CH][row] + c0,c1,c2[CH] + sg[cdim] + lkv[cdim*nd] + sums1,sums2[nout] + xd[nd] + pad
+  return (size_t)CH * (row + 3) + c.cdim + 3 * (size_t)c.cdim * c.nd + 2 * (size_t)(c.D + c.cdim + 1) + c.nd + 2;
 }
-// kernels call this once after carving `ws`: returns where the cached tables live (end of the workspace)
+__host__ __device__ inline size_t mom_lds_doubles(const MomCfg& c) {
+  return mom_ws_core(c) + (c.cache_tabs ? (size_t)c.n_pts + ((size_t)c.n_pts * c.cdim + 7) / 8 + 1 : 0);
+}
+// called once per kernel after carving `ws`
 __device__ inline void mom_cache_tables(const MomCfg& c, double* ws) {
-  if (!c.cache_tabs) return;
   const int CH = mom_chunk(c);
-  double* tw = ws + (size_t)CH * (c.cdim + 3) + c.cdim + 2 * (size_t)(c.D + c.cdim + 1) + 2;
-  double* tx = tw + c.n_pts;
+  const size_t row = (c.lik_kind != 0 && c.store_a) ? (size_t)c.D : (size_t)c.cdim;
+  double* xdl = ws + (size_t)CH * (row + 3) + c.cdim + 3 * (size_t)c.cdim * c.nd + 2 * (size_t)(c.D + c.cdim + 1);
+  for (int i = threadIdx.x; i < c.nd; i += blockDim.x) xdl[i] = c.xd[i];
+  if (!c.cache_tabs) return;
+  double* tw = ws + mom_ws_core(c);
+  unsigned char* tc = reinterpret_cast<unsigned char*>(tw + c.n_pts);
   for (int i = threadIdx.x; i < c.n_pts; i += blockDim.x) tw[i] = c.wn[i];
-  for (int i = threadIdx.x; i < c.n_pts * c.cdim; i += blockDim.x) tx[i] = c.xi[i];
+  for (int i = threadIdx.x; i < c.n_pts * c.cdim; i += blockDim.x) tc[i] = c.code[i];
 }
 
 __device__ __forceinline__ double link_eval(int kind, double shift, double g) {
@@ -170,93 +184,125 @@ __device__ __forceinline__ double link_eval(int kind, double shift, double g) {
   return kind == 0 ? log(1.0 + exp(g - shift)) : exp(g);
 }
 
-
-// phase-1 body for the NMF likelihoods with the cubature dimension as a compile-time constant
-// (keeps link(xn) in registers; host enforces cdim <= 8 for these likelihoods)
-template <int CD>
-__device__ __forceinline__ void mom_p1_nmf(const MomCfg& c, const double* Wl, const double* mu_g, const double* sg,
-                                           const double* xip, const double* mu_z, const double* s2_z, double* lkrow,
-                                           int sub, int DG, int D, bool sq, double& sa2, double& sam) {
-  double lkj[CD];
-#pragma unroll
-  for (int j = 0; j < CD; ++j) lkj[j] = link_eval(c.link_kind, c.link_shift, mu_g[j] + sg[j] * xip[j]);
-  for (int d = sub; d < D; d += DG) {
-    double a = 0.0;
-#pragma unroll
-    for (int j = 0; j < CD; ++j) a = fma(Wl[d * CD + j], lkj[j], a);
-    if (sq) a = sqrt(a);
-    sa2 = fma(a * a, s2_z[d], sa2);
-    sam = fma(a, mu_z[d], sam);
-  }
-  if (sub == 0) {
-#pragma unroll
-    for (int j = 0; j < CD; ++j) lkrow[j] = lkj[j];
-  }
-}
-
-// Workgroup-cooperative.  ALL threads of the block must call it (contains __syncthreads).
+// Workgroup-cooperative.  ALL threads of the block must call it (contains barriers).
 //   mu, s2 : LDS, M = D + cdim entries (sub-bands first), must be visible (caller synchronised)
 //   Wl     : LDS D x N row-major NMF weights (ignored for POWER)
 //   out    : dl[M], d2l[M] (LDS) and *lZ (LDS scalar) valid after the function returns
-//            (the function ends with a __syncthreads()).
-template <bool TL>
-__device__ __forceinline__ void mom_eval_t(const MomCfg& c, const double* Wl, double sn2, double alpha, double y,
-                                           const double* mu, const double* s2, double* ws, double* lZ, double* dl,
-                                           double* d2l) {
+//            (the function ends with a barrier).
+// One copy of the code serves the three likelihoods: the variant flags are wave-uniform scalars
+// (readfirstlane) so the compiler branches on them instead of evaluating e.g. the f64 sqrt of the
+// sqrt-amplitude variant unconditionally; the cubature dimension (<= 8 for the NMF likelihoods) is a
+// predicate on fully unrolled j loops, so link(xn) stays in statically indexed registers.
+template <int CD>   // CD = cubature dimension for the NMF likelihoods (1..8); 0 = POWER (cdim = D)
+__device__ __forceinline__ void mom_eval_impl(const MomCfg& c, const double* Wl, double sn2, double alpha,
+                                              double y, const double* mu, const double* s2, double* ws, double* lZ, double* dl,
+                                              double* d2l, unsigned long long* acc_st) {
   const int tid = threadIdx.x, NT = blockDim.x;
-  const int lane = tid & 63, wave = tid >> 6, nwaves = NT >> 6;
-  const int D = c.D, cd = c.cdim, CH = mom_chunk(c);
+  const int D = c.D, cd = (CD > 0) ? CD : c.cdim, CH = mom_chunk(c), nd = c.nd;
   const int nout = D + cd + 1;
-  const bool nmf = (c.lik_kind != 0);
-  const bool sq = (c.lik_kind == 2);
-  double* lk = ws;                    // [CH][cd]
-  double* c0 = lk + (size_t)CH * cd;  // [CH]
+  constexpr bool nmf = (CD > 0);
+  const bool sq = __builtin_amdgcn_readfirstlane(c.lik_kind == 2 ? 1 : 0) != 0;
+  const bool sta = __builtin_amdgcn_readfirstlane((c.lik_kind != 0 && c.store_a) ? 1 : 0) != 0;
+  const bool TL = __builtin_amdgcn_readfirstlane(c.cache_tabs ? 1 : 0) != 0;
+  const int rw = (!nmf || sta) ? D : cd;
+  double* rows = ws;                    // [rw][CH]  a[d][p] (store_a / POWER) or link(xn)[j][p]: point index fastest
+  double* c0 = rows + (size_t)CH * rw;  // [CH]
   double* c1 = c0 + CH;
   double* c2 = c1 + CH;
-  double* sg = c2 + CH;               // [cd] sqrt(s2_g)
-  double* sums1 = sg + cd;            // [nout]
-  double* sums2 = sums1 + nout;       // [nout]
-  const double* t_wn = TL ? (sums2 + nout + 2) : c.wn;       // cached tables sit right behind the workspace
-  const double* t_xi = TL ? (sums2 + nout + 2 + c.n_pts) : c.xi;
+  double* sg = c2 + CH;                 // [cd] sqrt(s2_g)
+  double* lkv = sg + cd;                // [cd][nd] link at the distinct coordinates
+  double* xgv = lkv + (size_t)cd * nd;    // [cd][nd] (xn - mu_g)/s2_g at the distinct coordinates
+  double* xg2v = xgv + (size_t)cd * nd;   // [cd][nd] xg^2 - 1/s2_g
+  double* sums1 = xg2v + (size_t)cd * nd; // [nout]
+  double* sums2 = sums1 + nout;         // [nout]
+  const double* xdl = sums2 + nout;     // [nd]
+  const double* lds_wn = ws + mom_ws_core(c);
+  const unsigned char* lds_code = reinterpret_cast<const unsigned char*>(lds_wn + c.n_pts);
   const double* mu_z = mu;
   const double* mu_g = mu + D;
   const double* s2_z = s2;
   const double* s2_g = s2 + D;
 
-  if (tid < cd) sg[tid] = sqrt(s2_g[tid]);
+  unsigned long long t_a = 0, t_b = 0;
+#define NAGP_STAMP(slot) do { if (c.stamps && tid == 0) { t_b = __builtin_readcyclecounter(); acc_st[slot] += t_b - t_a; t_a = t_b; } } while (0)
+  if (c.stamps && tid == 0) t_a = __builtin_readcyclecounter();
+  // ---- phase 0/1a: link (and the modulator integrand factors) at the distinct coordinates of every dimension
+  for (int t = tid; t < cd * nd; t += NT) {
+    const int j = t / nd, ci = t - j * nd;
+    const double sgj = sqrt(s2_g[j]);
+    if (ci == 0) sg[j] = sgj;
+    const double xn = mu_g[j] + sgj * xdl[ci];
+    lkv[t] = link_eval(c.link_kind, c.link_shift, xn);
+    const double xg = (xn - mu_g[j]) / s2_g[j];
+    xgv[t] = xg;
+    xg2v[t] = xg * xg - 1.0 / s2_g[j];
+  }
   if (tid < nout) { sums1[tid] = 0.0; sums2[tid] = 0.0; }
   lds_barrier();
+  NAGP_STAMP(0);
 
   const int DG = c.DG;
   const double sn2a = sn2 / alpha;
   for (int base = 0; base < c.n_pts; base += CH) {
     const int npc = (c.n_pts - base < CH) ? (c.n_pts - base) : CH;
-    // ---- phase 1: one sigma point per group of DG lanes
+    // ---- phase 1b: one sigma point per group of DG lanes
     for (int item = tid; item < npc * DG; item += NT) {
       const int pl = item / DG, sub = item - pl * DG;
       const int p = base + pl;
-      const double* xip = t_xi + (size_t)p * cd;
-      double sa2 = 0.0, sam = 0.0;
+      double* row = rows + pl;
+      double s2a[2] = {0, 0}, sma[2] = {0, 0};
       if (nmf) {
-        switch (cd) {
-          case 1: mom_p1_nmf<1>(c, Wl, mu_g, sg, xip, mu_z, s2_z, lk + (size_t)pl * cd, sub, DG, D, sq, sa2, sam); break;
-          case 2: mom_p1_nmf<2>(c, Wl, mu_g, sg, xip, mu_z, s2_z, lk + (size_t)pl * cd, sub, DG, D, sq, sa2, sam); break;
-          case 3: mom_p1_nmf<3>(c, Wl, mu_g, sg, xip, mu_z, s2_z, lk + (size_t)pl * cd, sub, DG, D, sq, sa2, sam); break;
-          case 4: mom_p1_nmf<4>(c, Wl, mu_g, sg, xip, mu_z, s2_z, lk + (size_t)pl * cd, sub, DG, D, sq, sa2, sam); break;
-          case 5: mom_p1_nmf<5>(c, Wl, mu_g, sg, xip, mu_z, s2_z, lk + (size_t)pl * cd, sub, DG, D, sq, sa2, sam); break;
-          case 6: mom_p1_nmf<6>(c, Wl, mu_g, sg, xip, mu_z, s2_z, lk + (size_t)pl * cd, sub, DG, D, sq, sa2, sam); break;
-          case 7: mom_p1_nmf<7>(c, Wl, mu_g, sg, xip, mu_z, s2_z, lk + (size_t)pl * cd, sub, DG, D, sq, sa2, sam); break;
-          default: mom_p1_nmf<8>(c, Wl, mu_g, sg, xip, mu_z, s2_z, lk + (size_t)pl * cd, sub, DG, D, sq, sa2, sam); break;
+        constexpr int CDX = (CD > 0) ? CD : 1;
+        double lkj[CDX];
+        {
+          const unsigned char* cp = (TL ? lds_code : c.code) + (size_t)p * cd;
+#pragma unroll
+          for (int j = 0; j < CDX; ++j) lkj[j] = lkv[j * nd + cp[j]];
+        }
+        // two d's per trip: the LDS reads of both are issued before the dependent FMAs
+        int d = sub;
+        for (; d + DG < D; d += 2 * DG) {
+          double w[2][CDX], a[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int j = 0; j < CDX; ++j) w[u][j] = Wl[(d + u * DG) * CDX + j];
+          const double sz0 = s2_z[d], sz1 = s2_z[d + DG], mz0 = mu_z[d], mz1 = mu_z[d + DG];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < CDX; ++j) acc = fma(w[u][j], lkj[j], acc);
+            a[u] = acc;
+          }
+          if (sq) { a[0] = sqrt(a[0]); a[1] = sqrt(a[1]); }
+          if (sta) { row[(size_t)d * CH] = a[0]; row[(size_t)(d + DG) * CH] = a[1]; }
+          s2a[0] = fma(a[0] * a[0], sz0, s2a[0]); s2a[1] = fma(a[1] * a[1], sz1, s2a[1]);
+          sma[0] = fma(a[0], mz0, sma[0]); sma[1] = fma(a[1], mz1, sma[1]);
+        }
+        for (; d < D; d += DG) {
+          double acc = 0.0;
+#pragma unroll
+          for (int j = 0; j < CDX; ++j) acc = fma(Wl[d * CDX + j], lkj[j], acc);
+          if (sq) acc = sqrt(acc);
+          if (sta) row[(size_t)d * CH] = acc;
+          s2a[0] = fma(acc * acc, s2_z[d], s2a[0]);
+          sma[0] = fma(acc, mu_z[d], sma[0]);
+        }
+        if (!sta && sub == 0) {
+#pragma unroll
+          for (int j = 0; j < CDX; ++j) row[(size_t)j * CH] = lkj[j];
         }
       } else {
+        const unsigned char* cp = (TL ? lds_code : c.code) + (size_t)p * cd;
         for (int d = sub; d < D; d += DG) {
-          const double xn = mu_g[d] + sg[d] * xip[d];
-          const double a = link_eval(c.link_kind, c.link_shift, xn);
-          lk[(size_t)pl * cd + d] = a;
-          sa2 = fma(a * a, s2_z[d], sa2);
-          sam = fma(a, mu_z[d], sam);
+          const double a = lkv[d * nd + cp[d]];
+          row[(size_t)d * CH] = a;
+          s2a[0] = fma(a * a, s2_z[d], s2a[0]);
+          sma[0] = fma(a, mu_z[d], sma[0]);
         }
       }
+      double sa2 = s2a[0] + s2a[1], sam = sma[0] + sma[1];
       sa2 = group_sum(sa2, DG);
       sam = group_sum(sam, DG);
       if (sub == 0) {
@@ -264,7 +310,7 @@ __device__ __forceinline__ void mom_eval_t(const MomCfg& c, const double* Wl, do
         const double sd = sqrt(sig2);
         const double r = (y - sam) / sd;
         const double pdf = exp(-0.5 * r * r) / (kSqrt2Pi * sd);
-        const double w0 = t_wn[p] * pdf;
+        const double w0 = (TL ? lds_wn[p] : c.wn[p]) * pdf;
         const double q = (y - sam) / sig2;
         c0[pl] = w0;
         c1[pl] = w0 * q;
@@ -272,39 +318,60 @@ __device__ __forceinline__ void mom_eval_t(const MomCfg& c, const double* Wl, do
       }
     }
     lds_barrier();
-    // ---- phase 2: one output per wave pass, lanes stride over the points of the chunk
-    for (int o = wave; o < nout; o += nwaves) {
-      double a1 = 0.0, a2 = 0.0;
-      if (o < D) {
-        for (int pl = lane; pl < npc; pl += 64) {
-          double a;
-          if (nmf) {
-            a = 0.0;
-            for (int j = 0; j < cd; ++j) a = fma(Wl[o * cd + j], lk[(size_t)pl * cd + j], a);
-            if (sq) a = sqrt(a);
+    NAGP_STAMP(1);
+    // ---- phase 2: one output per 16-lane group (4 outputs per wave at a time); the group's lanes
+    // stride over the points of the chunk; DPP sum inside the group (fixed order).  The modulator
+    // outputs (heavier gathers) are handed out first.
+    {
+      const int grp = tid >> 4, gl = tid & 15, ngrp = NT >> 4;
+      for (int oo = grp; oo < nout; oo += ngrp) {
+        const int o = (oo < cd + 1) ? (D + oo) : (oo - cd - 1);   // modulators, Z, then the sub-bands
+        double a1 = 0.0, a2 = 0.0, b1 = 0.0, b2 = 0.0;
+        if (o < D) {
+          if (nmf && !sta) {
+            constexpr int CDX = (CD > 0) ? CD : 1;
+            double wr[CDX];
+#pragma unroll
+            for (int j = 0; j < CDX; ++j) wr[j] = Wl[o * CDX + j];
+            for (int pl = gl; pl < npc; pl += 16) {
+              double a = 0.0;
+#pragma unroll
+              for (int j = 0; j < CDX; ++j) a = fma(wr[j], rows[(size_t)j * CH + pl], a);
+              if (sq) a = sqrt(a);
+              a1 = fma(a, c1[pl], a1);
+              a2 = fma(a * a, c2[pl], a2);
+            }
           } else {
-            a = lk[(size_t)pl * cd + o];
+            const double* ro = rows + (size_t)o * CH;
+            int pl = gl;
+            for (; pl + 16 < npc; pl += 32) {
+              const double x0 = ro[pl], x1 = ro[pl + 16];
+              a1 = fma(x0, c1[pl], a1); b1 = fma(x1, c1[pl + 16], b1);
+              a2 = fma(x0 * x0, c2[pl], a2); b2 = fma(x1 * x1, c2[pl + 16], b2);
+            }
+            if (pl < npc) { const double x0 = ro[pl]; a1 = fma(x0, c1[pl], a1); a2 = fma(x0 * x0, c2[pl], a2); }
           }
-          a1 = fma(a, c1[pl], a1);
-          a2 = fma(a * a, c2[pl], a2);
+        } else if (o < D + cd) {
+          const int j = o - D;
+          const unsigned char* cb = (TL ? lds_code : c.code) + (size_t)base * cd + j;
+          int pl = gl;
+          for (; pl + 16 < npc; pl += 32) {
+            const int i0 = j * nd + cb[(size_t)pl * cd], i1 = j * nd + cb[(size_t)(pl + 16) * cd];
+            a1 = fma(xgv[i0], c0[pl], a1); b1 = fma(xgv[i1], c0[pl + 16], b1);
+            a2 = fma(xg2v[i0], c0[pl], a2); b2 = fma(xg2v[i1], c0[pl + 16], b2);
+          }
+          if (pl < npc) { const int i0 = j * nd + cb[(size_t)pl * cd]; a1 = fma(xgv[i0], c0[pl], a1); a2 = fma(xg2v[i0], c0[pl], a2); }
+        } else {
+          for (int pl = gl; pl < npc; pl += 16) a1 += c0[pl];
         }
-      } else if (o < D + cd) {
-        const int j = o - D;
-        const double mg = mu_g[j], s2g = s2_g[j], sgj = sg[j];
-        for (int pl = lane; pl < npc; pl += 64) {
-          const double xn = mg + sgj * t_xi[(size_t)(base + pl) * cd + j];
-          const double xg = (xn - mg) / s2g;
-          a1 = fma(xg, c0[pl], a1);
-          a2 = fma(xg * xg - 1.0 / s2g, c0[pl], a2);
-        }
-      } else {
-        for (int pl = lane; pl < npc; pl += 64) a1 += c0[pl];
+        a1 += b1; a2 += b2;
+        a1 = group_sum(a1, 16);
+        a2 = group_sum(a2, 16);
+        if (gl == 0) { sums1[o] += a1; sums2[o] += a2; }
       }
-      a1 = wave_sum(a1);
-      a2 = wave_sum(a2);
-      if (lane == 0) { sums1[o] += a1; sums2[o] += a2; }
     }
     lds_barrier();
+    NAGP_STAMP(2);
   }
   // ---- phase 3
   {
@@ -321,13 +388,29 @@ __device__ __forceinline__ void mom_eval_t(const MomCfg& c, const double* Wl, do
     if (tid == 0) *lZ = log(Z);
   }
   lds_barrier();
+  NAGP_STAMP(3);
+#undef NAGP_STAMP
 }
 
-__device__ __forceinline__ void mom_eval(const MomCfg& c, const double* Wl, double sn2, double alpha, double y,
-                                         const double* mu, const double* s2, double* ws, double* lZ, double* dl,
-                                         double* d2l) {
-  if (c.cache_tabs) mom_eval_t<true>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l);
-  else mom_eval_t<false>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l);
+// Wl: NMF weights in LDS (D x N row-major); Wu unused (kept for call-site symmetry)
+__device__ __forceinline__ void mom_eval(const MomCfg& c, const double* Wl, const double* Wu, double sn2, double alpha,
+                                         double y, const double* mu, const double* s2, double* ws, double* lZ, double* dl,
+                                         double* d2l, unsigned long long* acc_st = nullptr) {
+  (void)Wu;
+  unsigned long long dummy_st[4];
+  if (!acc_st) acc_st = dummy_st;
+  const int sel = __builtin_amdgcn_readfirstlane(c.lik_kind == 0 ? 0 : c.cdim);
+  switch (sel) {
+    case 0: mom_eval_impl<0>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st); break;
+    case 1: mom_eval_impl<1>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st); break;
+    case 2: mom_eval_impl<2>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st); break;
+    case 3: mom_eval_impl<3>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st); break;
+    case 4: mom_eval_impl<4>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st); break;
+    case 5: mom_eval_impl<5>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st); break;
+    case 6: mom_eval_impl<6>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st); break;
+    case 7: mom_eval_impl<7>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st); break;
+    default: mom_eval_impl<8>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st); break;
+  }
 }
 
 }  // namespace nagp

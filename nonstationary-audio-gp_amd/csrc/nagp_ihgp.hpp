@@ -56,10 +56,35 @@ struct IhgpPar {
   double R_init;     // exp(lik) (or 0 for the constraints variant): initial content of R(:,k)
 };
 
-__host__ __device__ inline size_t ihgp_filter_lds_doubles(const Shape& s, const MomCfg& mc) {
-  return LDS_INT_DOUBLES + (size_t)s.D * s.N + 6 * (size_t)s.M + 8 + mom_lds_doubles(mc);
+constexpr int IH_KB = 16;   // steps per I/O block of the filter (LDS ring)
+
+__host__ __device__ inline size_t ihgp_ring_doubles(const Shape& s) { return (size_t)IH_KB * (4 * s.M + s.S + 2); }
+__host__ __device__ inline size_t ihgp_filter_lds_doubles(const Shape& s, const MomCfg& mc, int NG) {
+  return LDS_INT_DOUBLES + (size_t)s.D * s.N + 6 * (size_t)s.M + 8 + NG + ihgp_ring_doubles(s) + mom_lds_doubles(mc);
 }
 
+// first minimiser of |r_i - R| with the grid in LDS (same semantics as nearest_idx)
+__device__ __forceinline__ int nearest_idx_lds(const double* r, int NG, double lr0, double inv_dlr, double R) {
+  if (!(R == R) || isinf(R)) return 0;
+  int est = 0;
+  if (R > 0.0) {
+    const double f = (log10(R) - lr0) * inv_dlr;
+    est = (f <= 0.0) ? 0 : ((f >= (double)(NG - 1)) ? NG - 1 : (int)(f + 0.5));
+  }
+  const int lo = (est - 2 < 0) ? 0 : est - 2;
+  const int hi = (est + 2 > NG - 1) ? NG - 1 : est + 2;
+  int best = lo;
+  double bd = fabs(r[lo] - R);
+  for (int i = lo + 1; i <= hi; ++i) {
+    const double d = fabs(r[i] - R);
+    if (d < bd) { bd = d; best = i; }
+  }
+  return best;
+}
+
+// All per-step global traffic goes through an LDS ring of IH_KB steps that is filled / flushed with
+// coalesced transfers once per block, so the sequential loop body contains no global-memory waits
+// except the (L2-resident) table gather.
 __global__ void __launch_bounds__(512) ihgp_filter_kernel(Shape sh, Bufs b, MomCfg mc, IhgpTabs tb, IhgpPar ip) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int tid = threadIdx.x, NT = blockDim.x;
@@ -77,13 +102,22 @@ __global__ void __launch_bounds__(512) ihgp_filter_kernel(Shape sh, Bufs b, MomC
   double* dl = HPH + M;
   double* d2l = dl + M;
   double* misc = d2l + M;
-  double* ws = misc + 8 + 2 * M;
+  double* rg = misc + 8 + 2 * M;          // [NG] look-up grid
+  double* ry = rg + NG;                    // ring: y[KB]
+  double* rlZ = ry + IH_KB;                //       lZ[KB]
+  double* rtt = rlZ + IH_KB;               //       ttau[KB][M]
+  double* rtn = rtt + (size_t)IH_KB * M;   //       tnu
+  double* rR = rtn + (size_t)IH_KB * M;    //       R
+  double* rfm = rR + (size_t)IH_KB * M;    //       H*m (filtered)
+  double* rMF = rfm + (size_t)IH_KB * M;   //       m (filtered) [KB][S]
+  double* ws = rMF + (size_t)IH_KB * S;
   for (int i = tid; i <= M; i += NT) ioff[i] = sh.off[i];
   for (int i = tid; i < M; i += NT) ibsz[i] = sh.bsz[i];
   for (int i = tid; i < sh.D * sh.N; i += NT) sW[i] = mdl[mdl_W(sh) + i];
+  for (int i = tid; i < NG; i += NT) rg[i] = tb.r[i];
   const double sn2 = mdl[mdl_sn2(sh)];
   mom_cache_tables(mc, ws);
-  lds_barrier();
+  __syncthreads();
 
   // thread n < M owns block n
   const int n = tid;
@@ -97,7 +131,9 @@ __global__ void __launch_bounds__(512) ihgp_filter_kernel(Shape sh, Bufs b, MomC
     o = ioff[n]; bs = ibsz[n];
     if (ip.itt > 1) {   // m is NOT reset between sweeps (SURVEY C-22): smoothed mean at k=0
       const double* ms0 = b.MS + (size_t)pb * T * S;
-      for (int i = 0; i < bs; ++i) mreg[i] = ms0[o + i];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (i < bs) mreg[i] = ms0[o + i];
     }
   }
   const double* yv = b.y + (size_t)pb * T;
@@ -109,77 +145,99 @@ __global__ void __launch_bounds__(512) ihgp_filter_kernel(Shape sh, Bufs b, MomC
   double* g_fm = b.fm + (size_t)pb * T * M;
   double Rprev = 0.0;
   unsigned long long n_clamped = 0;
+  unsigned long long st_a = 0, st_b = 0, st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (mc.stamps && tid == 0) st_a = __builtin_readcyclecounter();
 
-  double y_nx = yv[0], tt_nx = 0.0, tn_nx = 0.0, R_nx = 0.0;
-  if (act) { tt_nx = g_tt[n]; tn_nx = g_tn[n]; R_nx = g_R[n]; }
-  for (int64_t k = 0; k < T; ++k) {
-    const double yk = y_nx, tt_k = tt_nx, tn_k = tn_nx, R_k = R_nx;
-    if (k + 1 < T) {
-      y_nx = yv[k + 1];
-      if (act) { tt_nx = g_tt[(size_t)(k + 1) * M + n]; tn_nx = g_tn[(size_t)(k + 1) * M + n]; R_nx = g_R[(size_t)(k + 1) * M + n]; }
+  for (int64_t k0 = 0; k0 < T; k0 += IH_KB) {
+    const int nb = (T - k0 < IH_KB) ? (int)(T - k0) : IH_KB;
+    // ---- fill the ring for steps k0 .. k0+nb-1
+    for (int i = tid; i < nb; i += NT) { ry[i] = yv[k0 + i]; rlZ[i] = g_lZ[k0 + i]; }
+    for (int i = tid; i < nb * M; i += NT) {
+      rtt[i] = g_tt[(size_t)k0 * M + i]; rtn[i] = g_tn[(size_t)k0 * M + i]; rR[i] = g_R[(size_t)k0 * M + i];
     }
-    double hph = 0.0, wc[4] = {0, 0, 0, 0}, Am[4] = {0, 0, 0, 0}, fmun = 0.0;
-    if (act) {
-      if (k > 0) {
-        const int idx = nearest_idx(tb, Rprev);
-        hph = tab[itab_hph(sh, NG) + (size_t)n * NG + idx];
-        const double* w = tab + itab_wcol(sh, NG) + ((size_t)n * NG + idx) * 4;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) wc[i] = w[i];
-      } else {
-        hph = tab[itab_hph0(sh, NG) + n];
-        const double* w = tab + itab_wcol0(sh, NG) + (size_t)n * 4;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) wc[i] = w[i];
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        double a = 0.0;
-#pragma unroll
-        for (int l = 0; l < 4; ++l) a = fma(A4[4 * i + l], mreg[l], a);
-        Am[i] = a;
-      }
-      fmun = hn * Am[0];
-      fmu[n] = fmun; HPH[n] = hph;
-    }
-    const bool do_mom = ip.mom_all || (k == T - 1);
-    double tnew = 0.0, nnew = 0.0, Rn = 0.0;
-    if (do_mom) {
-      lds_barrier();
-      mom_eval(mc, sW, sn2, 1.0, yk, fmu, HPH, ws, &misc[0], dl, d2l);
+    __syncthreads();
+    for (int kk = 0; kk < nb; ++kk) {
+      const int64_t k = k0 + kk;
+      const double yk = ry[kk];
+      double hph = 0.0, wc[4] = {0, 0, 0, 0}, Am[4] = {0, 0, 0, 0}, fmun = 0.0;
       if (act) {
-        const double d1 = dl[n], d2 = d2l[n];
-        const double t_old = tt_k, n_old = tn_k;
-        tnew = (1.0 - ip.ep_damp) * t_old + ip.ep_damp * (-d2 / (1.0 + d2 * hph));
-        nnew = (1.0 - ip.ep_damp) * n_old + ip.ep_damp * ((d1 - fmun * d2) / (1.0 + d2 * hph));
-        Rn = 1.0 / tnew;                      // before the clamp (:269)
-      }
-      if (tid == 0) g_lZ[k] = misc[0];
-    } else if (act) {
-      tnew = tt_k; nnew = tn_k;
-      Rn = R_k;
-    }
-    if (act) {
-      if (!(tnew > 0.0)) ++n_clamped;
-      tnew = max0(tnew);                       // :274 (NaN -> 0, C-3)
-      const double ys = nnew / tnew;
-      if (tnew == 0.0) {
-        Rn = INFINITY;
+        if (k > 0) {
+          const int idx = nearest_idx_lds(rg, NG, tb.lr0, tb.inv_dlr, Rprev);
+          hph = tab[itab_hph(sh, NG) + (size_t)n * NG + idx];
+          const double* w = tab + itab_wcol(sh, NG) + ((size_t)n * NG + idx) * 4;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) mreg[i] = Am[i];
-      } else {
-        const double den = hph + Rn;
+          for (int i = 0; i < 4; ++i) wc[i] = w[i];
+        } else {
+          hph = tab[itab_hph0(sh, NG) + n];
+          const double* w = tab + itab_wcol0(sh, NG) + (size_t)n * 4;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) mreg[i] = Am[i] + (wc[i] / den) * (ys - fmun);
+          for (int i = 0; i < 4; ++i) wc[i] = w[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          double a = 0.0;
+#pragma unroll
+          for (int l = 0; l < 4; ++l) a = fma(A4[4 * i + l], mreg[l], a);
+          Am[i] = a;
+        }
+        fmun = hn * Am[0];
+        fmu[n] = fmun; HPH[n] = hph;
       }
-      g_tt[(size_t)k * M + n] = tnew; g_tn[(size_t)k * M + n] = nnew; g_R[(size_t)k * M + n] = Rn;
-      for (int i = 0; i < bs; ++i) g_MF[(size_t)k * S + o + i] = mreg[i];
-      g_fm[(size_t)k * M + n] = hn * mreg[0];
-      Rprev = Rn;
+      const bool do_mom = ip.mom_all || (k == T - 1);
+      double tnew = 0.0, nnew = 0.0, Rn = 0.0;
+      if (do_mom) {
+        lds_barrier();
+        if (mc.stamps && tid == 0) { st_b = __builtin_readcyclecounter(); st[4] += st_b - st_a; }
+        mom_eval(mc, sW, mdl + mdl_W(sh), sn2, 1.0, yk, fmu, HPH, ws, &misc[0], dl, d2l, st);
+        if (act) {
+          const double d1 = dl[n], d2 = d2l[n];
+          const double t_old = rtt[kk * M + n], n_old = rtn[kk * M + n];
+          tnew = (1.0 - ip.ep_damp) * t_old + ip.ep_damp * (-d2 / (1.0 + d2 * hph));
+          nnew = (1.0 - ip.ep_damp) * n_old + ip.ep_damp * ((d1 - fmun * d2) / (1.0 + d2 * hph));
+          Rn = 1.0 / tnew;                      // before the clamp (:269)
+        }
+        if (tid == 0) rlZ[kk] = misc[0];
+        if (mc.stamps && tid == 0) st_a = __builtin_readcyclecounter();
+      } else if (act) {
+        tnew = rtt[kk * M + n]; nnew = rtn[kk * M + n];
+        Rn = rR[kk * M + n];
+      }
+      if (act) {
+        if (!(tnew > 0.0)) ++n_clamped;
+        tnew = max0(tnew);                       // :274 (NaN -> 0, C-3)
+        const double ys = nnew / tnew;
+        if (tnew == 0.0) {
+          Rn = INFINITY;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) mreg[i] = Am[i];
+        } else {
+          const double den = hph + Rn;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) mreg[i] = Am[i] + (wc[i] / den) * (ys - fmun);
+        }
+        rtt[kk * M + n] = tnew; rtn[kk * M + n] = nnew; rR[kk * M + n] = Rn;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (i < bs) rMF[(size_t)kk * S + o + i] = mreg[i];
+        rfm[kk * M + n] = hn * mreg[0];
+        Rprev = Rn;
+      }
+      if (do_mom) lds_barrier();   // fmu/HPH/dl reuse
+      if (mc.stamps && tid == 0) { st_b = __builtin_readcyclecounter(); st[5] += st_b - st_a; st_a = st_b; }
     }
-    if (do_mom) lds_barrier();   // fmu/HPH/dl reuse
+    // ---- flush the ring
+    __syncthreads();
+    for (int i = tid; i < nb; i += NT) g_lZ[k0 + i] = rlZ[i];
+    for (int i = tid; i < nb * M; i += NT) {
+      g_tt[(size_t)k0 * M + i] = rtt[i]; g_tn[(size_t)k0 * M + i] = rtn[i]; g_R[(size_t)k0 * M + i] = rR[i];
+      g_fm[(size_t)k0 * M + i] = rfm[i];
+    }
+    for (int i = tid; i < nb * S; i += NT) g_MF[(size_t)k0 * S + i] = rMF[i];
+    __syncthreads();
   }
   if (act && n_clamped) atomicAdd(&b.counters[(size_t)pb * 4 + 1], n_clamped);
+  if (mc.stamps && tid == 0)
+    for (int i = 0; i < 8; ++i) mc.stamps[i] += st[i];
 }
 
 // Backward mean recursion: m <- MF_k + G (m - A MF_k) with (P,G) looked up from R(:,k)

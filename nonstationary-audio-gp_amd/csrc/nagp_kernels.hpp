@@ -66,6 +66,7 @@ struct FilterPar {
   int init_from_state;  // EKF sweeps >= 2: start from the smoothed (m,P) at k=0
   int reset_P;          // with init_from_state: P <- Pinf anyway (constraints variant)
   int l_iter;           // EKF inner iterations
+  int ablate;           // developer timing ablations (results become wrong): 1 predict, 2 tile update, 4 PF store, 8 m update, 16 publish
 };
 
 // thread tid owns tiles t = tid + q*NT (q < TPT)
@@ -90,7 +91,7 @@ struct TileOwner {
 // LDS (doubles): sA[M*16] sh[M] sW[D*N] m[S] Wl[M*S] HPl[M*S] fmu[M] HPH[M] tt[M] tn[M] cA[M] cm[M]
 //                dl[M] d2l[M] misc[8] | mom workspace | EKF: part[M] PJ[S]
 __host__ __device__ inline size_t filter_lds_doubles(const Shape& s, const MomCfg& mc, int meas) {
-  size_t n = LDS_INT_DOUBLES + (size_t)s.M * 16 + s.M + (size_t)s.D * s.N + s.S + 8 * (size_t)s.M * s.M +
+  size_t n = LDS_INT_DOUBLES + (size_t)s.M * TS + s.M + (size_t)s.D * s.N + s.S + 8 * (size_t)s.M * s.M +
              8 * (size_t)s.M + 8;
   n += (meas == 0) ? mom_lds_doubles(mc) : (size_t)(s.M + s.S);
   return (n + 1) & ~(size_t)1;
@@ -108,7 +109,7 @@ __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg
   int* ioff = reinterpret_cast<int*>(lds);          // [MAXM+1]
   int* ibsz = ioff + (MAXM + 1);                     // [MAXM]   (fixed 2*MAXM+2 ints = 65 doubles + pad)
   double* sA = lds + LDS_INT_DOUBLES;
-  double* shv = sA + (size_t)M * 16;
+  double* shv = sA + (size_t)M * TS;       // A blocks at stride TS (bank-conflict-free tile reads)
   double* sW = shv + M;
   double* m = sW + (size_t)sh.D * sh.N;
   double* Wl = m + S;
@@ -126,7 +127,7 @@ __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg
 
   for (int i = tid; i <= M; i += NT) ioff[i] = sh.off[i];
   for (int i = tid; i < M; i += NT) ibsz[i] = sh.bsz[i];
-  for (int i = tid; i < M * 16; i += NT) sA[i] = mdl[mdl_A(sh) + i];
+  for (int i = tid; i < M * 16; i += NT) sA[(i >> 4) * TS + (i & 15)] = mdl[mdl_A(sh) + i];
   for (int i = tid; i < M; i += NT) shv[i] = mdl[mdl_h(sh) + i];
   for (int i = tid; i < sh.D * sh.N; i += NT) sW[i] = mdl[mdl_W(sh) + i];
   const double sn2 = mdl[mdl_sn2(sh)];
@@ -180,7 +181,7 @@ __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg
     double rm = 0.0;
     if (tid < S) {
       if (pred) {
-        const double* a = sA + (size_t)myblk * 16 + 4 * myrow;
+        const double* a = sA + (size_t)myblk * TS + 4 * myrow;
         const double* mb = m + ioff[myblk];
         const int bs = ibsz[myblk];
         for (int l = 0; l < bs; ++l) rm = fma(a[l], mb[l], rm);
@@ -193,8 +194,8 @@ __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg
     for (int q = 0; q < TPT; ++q) {
       if (own.ok[q]) {
         const int I = own.I[q], J = own.J[q];
-        if (pred) {
-          tile_congruence(P[q], sA + (size_t)I * 16, sA + (size_t)J * 16);
+        if (pred && !(fp.ablate & 1)) {
+          tile_congruence(P[q], sA + (size_t)I * TS, sA + (size_t)J * TS);
           if (I == J) {
             const double* Qb = mdl + mdl_Q(sh) + (size_t)I * 16;
 #pragma unroll
@@ -202,8 +203,10 @@ __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg
           }
         }
         const double hJ = shv[J], hI = shv[I];
+        if (!(fp.ablate & 16))
 #pragma unroll
         for (int i = 0; i < 4; ++i) Wl[((size_t)J * 4 + i) * M + I] = hJ * P[q][4 * i];
+        if (!(fp.ablate & 16))
 #pragma unroll
         for (int j = 0; j < 4; ++j) HPl[((size_t)I * 4 + j) * M + J] = hI * P[q][j];
         if (I == J) HPH[I] = hI * hI * P[q][0];
@@ -216,7 +219,7 @@ __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg
       if (MEAS == 0) {
         const bool do_mom = fp.mom_all || (k == T - 1);
         if (do_mom) {
-          mom_eval(mc, sW, sn2, 1.0, yk, fmu, HPH, ws, &misc[0], dl, d2l);
+          mom_eval(mc, sW, mdl + mdl_W(sh), sn2, 1.0, yk, fmu, HPH, ws, &misc[0], dl, d2l);
           if (tid < M) {
             const double d2 = d2l[tid], d1 = dl[tid], hp = HPH[tid], f = fmu[tid];
             double t_old = tt_k, n_old = tn_k;
@@ -256,9 +259,18 @@ __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg
         }
         lds_barrier();  // B4
         const bool legacyA = fp.legacy_update && (misc[1] != 0.0);
-        if (tid < S) {
-          double acc = rm;
-          for (int n = 0; n < M; ++n) acc = fma(Wl[((size_t)n * 4 + myrow) * M + myblk], cm[n], acc);
+        if (tid < S && !(fp.ablate & 8)) {
+          double a0 = rm, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+          const double* wp = Wl + (size_t)myrow * M + myblk;
+          int n = 0;
+          for (; n + 4 <= M; n += 4) {
+            a0 = fma(wp[(size_t)(n + 0) * 4 * M], cm[n + 0], a0);
+            a1 = fma(wp[(size_t)(n + 1) * 4 * M], cm[n + 1], a1);
+            a2 = fma(wp[(size_t)(n + 2) * 4 * M], cm[n + 2], a2);
+            a3 = fma(wp[(size_t)(n + 3) * 4 * M], cm[n + 3], a3);
+          }
+          for (; n < M; ++n) a0 = fma(wp[(size_t)n * 4 * M], cm[n], a0);
+          const double acc = (a0 + a1) + (a2 + a3);
           rm = acc;
           m[tid] = acc;
         }
@@ -266,21 +278,26 @@ __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg
         const double* Rt = legacyA ? Wl : HPl;
 #pragma unroll
         for (int q = 0; q < TPT; ++q) {
-          if (own.ok[q]) {
-            for (int n = 0; n < M; ++n) {
-              const double c = cA[n];
-              if (c == 0.0) continue;
-              const double* wr = Wl + (size_t)n * 4 * M + own.I[q];
-              const double* rr = Rt + (size_t)n * 4 * M + own.J[q];
-              double r4[4], w4[4];
+          if (own.ok[q] && !(fp.ablate & 2)) {
+            const double* wbase = Wl + own.I[q];
+            const double* rbase = Rt + own.J[q];
+            for (int n0 = 0; n0 < M; n0 += 4) {
+              double w4[4][4], r4[4][4];
 #pragma unroll
-              for (int j = 0; j < 4; ++j) r4[j] = rr[j * M];
+              for (int u = 0; u < 4; ++u) {
+                const int n = (n0 + u < M) ? n0 + u : M - 1;
+                const double c = (n0 + u < M) ? -cA[n] : 0.0;
 #pragma unroll
-              for (int i = 0; i < 4; ++i) w4[i] = -(wr[i * M] * c);
+                for (int i = 0; i < 4; ++i) w4[u][i] = wbase[((size_t)n * 4 + i) * M] * c;
 #pragma unroll
-              for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 4; ++j) r4[u][j] = rbase[((size_t)n * 4 + j) * M];
+              }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) P[q][4 * i + j] = fma(w4[i], r4[j], P[q][4 * i + j]);
+              for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                  for (int j = 0; j < 4; ++j) P[q][4 * i + j] = fma(w4[u][i], r4[u][j], P[q][4 * i + j]);
             }
           }
         }
@@ -354,7 +371,7 @@ __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg
     for (int q = 0; q < TPT; ++q)
       if (own.ok[q] && own.I[q] == own.J[q])
         g_fv[(size_t)k * M + own.I[q]] = shv[own.I[q]] * shv[own.I[q]] * P[q][0];
-    if (g_PF && fp.store_PF) {
+    if (g_PF && fp.store_PF && !(fp.ablate & 4)) {
 #pragma unroll
       for (int q = 0; q < TPT; ++q)
         if (own.ok[q]) tile_store(g_PF + ((size_t)k * sh.ntiles + tid + q * NT) * 16, P[q]);
@@ -1036,7 +1053,7 @@ __global__ void __launch_bounds__(256) ep_site_kernel(Shape sh, Bufs b, MomCfg m
       mc_[tid] = mcav; vc_[tid] = vcav;
     }
     lds_barrier();
-    mom_eval(mc, sW, sn2, ep.alpha, yk, mc_, vc_, ws, &misc[0], dl, d2l);
+    mom_eval(mc, sW, mdl + mdl_W(sh), sn2, ep.alpha, yk, mc_, vc_, ws, &misc[0], dl, d2l);
     if (tid < M) {
       const bool upd = vcav > 0.0;
       double tnew = t_old, nnew = n_old;

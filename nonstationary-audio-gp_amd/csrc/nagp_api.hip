@@ -46,7 +46,7 @@ struct nagp_plan {
   int TPT = 1, NT = 256, NT_f = 256, NT_ih = 256;
   int chunk = 2048, LP1 = 1, LP2 = 1, ns_max = 1;
   SpanPar spar{};
-  int DG_f = 1, DG_ep = 1, cache_f = 0, cache_ep = 0, sta_f = 0, sta_ep = 0;
+  int DG_f = 1, DG_ep = 1, cache_f = 0, cache_ep = 0, sta_f = 0, sta_ep = 0, kb_f = 16;
   bool want_PS = false;
   bool need_PF = false;
   hipStream_t stream = nullptr;
@@ -358,10 +358,14 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
   } else {
     if (!ekf) p->DG_f = pick_DG(o->n_pts, p->NT_f, sh.D);
     MomCfg t = mc; t.DG = p->DG_f; t.cache_tabs = ekf ? 0 : 1; t.store_a = ekf ? 0 : 1;
-    if (filter_lds_doubles(sh, t, ekf ? 1 : 0) * sizeof(double) > 150 * 1024) t.store_a = 0;
-    if (filter_lds_doubles(sh, t, ekf ? 1 : 0) * sizeof(double) > 150 * 1024) t.cache_tabs = 0;
+    const size_t cap = 156 * 1024;
+    p->kb_f = 16;
+    if (filter_lds_doubles(sh, t, ekf ? 1 : 0, p->kb_f) * sizeof(double) > cap) t.store_a = 0;
+    if (filter_lds_doubles(sh, t, ekf ? 1 : 0, p->kb_f) * sizeof(double) > cap) p->kb_f = 8;
+    if (filter_lds_doubles(sh, t, ekf ? 1 : 0, p->kb_f) * sizeof(double) > cap) p->kb_f = 4;
+    if (filter_lds_doubles(sh, t, ekf ? 1 : 0, p->kb_f) * sizeof(double) > cap) t.cache_tabs = 0;
     p->cache_f = t.cache_tabs; p->sta_f = t.store_a;
-    p->lds_filter = filter_lds_doubles(sh, t, ekf ? 1 : 0) * sizeof(double);
+    p->lds_filter = filter_lds_doubles(sh, t, ekf ? 1 : 0, p->kb_f) * sizeof(double);
     p->lds_gain = gain_lds_doubles(sh) * sizeof(double);
     p->lds_scan = span_lds_doubles(sh, p->LP1, p->LP2) * sizeof(double);
     switch (p->TPT) {
@@ -421,7 +425,7 @@ extern "C" int nagp_plan_upload_y(nagp_plan* p, const double* const* ys) {
 // ---------------------------------------------------------------------------------------------
 static int launch_filter(nagp_plan* p, const FilterPar& fp_in) {
   FilterPar fp = fp_in;
-  if (const char* e = getenv("NAGP_ABLATE")) fp.ablate = atoi(e);
+  fp.kb = p->kb_f;
   const bool ekf = p->opts.kind == NAGP_KIND_GIEKF;
   MomCfg mc = p->mc; mc.DG = p->DG_f; mc.cache_tabs = p->cache_f; mc.store_a = p->sta_f;
   Timed t(p, NAGP_K_FILTER);

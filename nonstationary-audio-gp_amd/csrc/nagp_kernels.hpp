@@ -66,7 +66,7 @@ struct FilterPar {
   int init_from_state;  // EKF sweeps >= 2: start from the smoothed (m,P) at k=0
   int reset_P;          // with init_from_state: P <- Pinf anyway (constraints variant)
   int l_iter;           // EKF inner iterations
-  int ablate;           // developer timing ablations (results become wrong): 1 predict, 2 tile update, 4 PF store, 8 m update, 16 publish
+  int kb;               // steps per I/O block (LDS ring)
 };
 
 // thread tid owns tiles t = tid + q*NT (q < TPT)
@@ -88,11 +88,16 @@ struct TileOwner {
 
 // ---------------------------------------------------------------------------------------------
 // Forward filter.  MEAS = 0: Power-EP / ADF sites (gf_ep_modulator*.m), MEAS = 1: EKF (gf_giekf_*).
-// LDS (doubles): sA[M*16] sh[M] sW[D*N] m[S] Wl[M*S] HPl[M*S] fmu[M] HPH[M] tt[M] tn[M] cA[M] cm[M]
-//                dl[M] d2l[M] misc[8] | mom workspace | EKF: part[M] PJ[S]
-__host__ __device__ inline size_t filter_lds_doubles(const Shape& s, const MomCfg& mc, int meas) {
-  size_t n = LDS_INT_DOUBLES + (size_t)s.M * TS + s.M + (size_t)s.D * s.N + s.S + 8 * (size_t)s.M * s.M +
-             8 * (size_t)s.M + 8;
+// One workgroup per problem, sequential in k.  The covariance lives in registers (4x4 tile per
+// thread); W = P H', H P travel through LDS panels laid out [site][row-in-block][block] so that the
+// rank-M update reads them bank-conflict free.  All small per-step global traffic (y, sites, lZ,
+// filtered mean/marginals) goes through an LDS ring of `kb` steps that is filled / flushed with
+// coalesced transfers once per block; the only global operations inside the sequential loop are the
+// fire-and-forget stores of the filtered covariance tiles.
+__host__ __device__ inline size_t filter_ring_doubles(const Shape& s, int kb) { return (size_t)kb * (5 * s.M + s.S + 2); }
+__host__ __device__ inline size_t filter_lds_doubles(const Shape& s, const MomCfg& mc, int meas, int kb) {
+  size_t n = LDS_INT_DOUBLES + 2 * (size_t)s.M * TS + s.M + (size_t)s.D * s.N + s.S + 8 * (size_t)s.M * s.M +
+             8 * (size_t)s.M + 8 + filter_ring_doubles(s, kb);
   n += (meas == 0) ? mom_lds_doubles(mc) : (size_t)(s.M + s.S);
   return (n + 1) & ~(size_t)1;
 }
@@ -101,15 +106,16 @@ template <int TPT, int MEAS>
 __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg mc, FilterPar fp) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int tid = threadIdx.x, NT = blockDim.x;
-  const int S = sh.S, M = sh.M, D = sh.D;
+  const int S = sh.S, M = sh.M, D = sh.D, KB = fp.kb;
   const int64_t T = sh.T;
   const int pb = blockIdx.x;
   const double* mdl = b.model + (size_t)pb * mdl_size(sh);
 
   int* ioff = reinterpret_cast<int*>(lds);          // [MAXM+1]
-  int* ibsz = ioff + (MAXM + 1);                     // [MAXM]   (fixed 2*MAXM+2 ints = 65 doubles + pad)
-  double* sA = lds + LDS_INT_DOUBLES;
-  double* shv = sA + (size_t)M * TS;       // A blocks at stride TS (bank-conflict-free tile reads)
+  int* ibsz = ioff + (MAXM + 1);                     // [MAXM]
+  double* sA = lds + LDS_INT_DOUBLES;                // A blocks, stride TS
+  double* sQ = sA + (size_t)M * TS;                  // Q blocks, stride TS
+  double* shv = sQ + (size_t)M * TS;
   double* sW = shv + M;
   double* m = sW + (size_t)sh.D * sh.N;
   double* Wl = m + S;
@@ -123,11 +129,22 @@ __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg
   double* dl = cm + M;
   double* d2l = dl + M;
   double* misc = d2l + M;  // [0]=lZ
-  double* ws = misc + 8;   // mom workspace | EKF: part[M], PJ[S]
+  double* ry = misc + 8;                   // ring: y[KB]
+  double* rlZ = ry + KB;                   //       lZ[KB]
+  double* rtt = rlZ + KB;                  //       ttau[KB][M]
+  double* rtn = rtt + (size_t)KB * M;
+  double* rR = rtn + (size_t)KB * M;
+  double* rfm = rR + (size_t)KB * M;       //       H m  (filtered)
+  double* rfv = rfm + (size_t)KB * M;      //       diag(H P H') (filtered)
+  double* rMF = rfv + (size_t)KB * M;      //       m (filtered) [KB][S]
+  double* ws = rMF + (size_t)KB * S;       // mom workspace | EKF: part[M], PJ[S]
 
   for (int i = tid; i <= M; i += NT) ioff[i] = sh.off[i];
   for (int i = tid; i < M; i += NT) ibsz[i] = sh.bsz[i];
-  for (int i = tid; i < M * 16; i += NT) sA[(i >> 4) * TS + (i & 15)] = mdl[mdl_A(sh) + i];
+  for (int i = tid; i < M * 16; i += NT) {
+    sA[(i >> 4) * TS + (i & 15)] = mdl[mdl_A(sh) + i];
+    sQ[(i >> 4) * TS + (i & 15)] = mdl[mdl_Q(sh) + i];
+  }
   for (int i = tid; i < M; i += NT) shv[i] = mdl[mdl_h(sh) + i];
   for (int i = tid; i < sh.D * sh.N; i += NT) sW[i] = mdl[mdl_W(sh) + i];
   const double sn2 = mdl[mdl_sn2(sh)];
@@ -148,7 +165,7 @@ __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg
     }
   }
   for (int i = tid; i < S; i += NT) m[i] = fp.init_from_state ? st[(size_t)sh.ntiles * 16 + i] : 0.0;
-  lds_barrier();
+  __syncthreads();
   // which block / row-in-block does state i (= tid) belong to
   int myblk = 0, myrow = 0;
   if (tid < S) {
@@ -164,225 +181,250 @@ __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg
   double* g_MF = b.MF + (size_t)pb * T * S;
   double* g_fm = b.fm + (size_t)pb * T * M;
   double* g_fv = b.fv + (size_t)pb * T * M;
-  double* g_PF = b.PF ? b.PF + (size_t)pb * T * sh.ntiles * 16 : nullptr;
+  double* g_PF = (b.PF && fp.store_PF) ? b.PF + (size_t)pb * T * sh.ntiles * 16 : nullptr;
   unsigned long long n_clamped = 0, n_nan = 0;
 
-  // software prefetch of the per-step global inputs (one step ahead; no barrier drains vmcnt)
-  double y_nx = yv[0], tt_nx = 0.0, tn_nx = 0.0;
-  if (MEAS == 0 && tid < M) { tt_nx = g_tt[tid]; tn_nx = g_tn[tid]; }
-  for (int64_t k = 0; k < T; ++k) {
-    const double yk = y_nx, tt_k = tt_nx, tn_k = tn_nx;
-    if (k + 1 < T) {
-      y_nx = yv[k + 1];
-      if (MEAS == 0 && tid < M) { tt_nx = g_tt[(size_t)(k + 1) * M + tid]; tn_nx = g_tn[(size_t)(k + 1) * M + tid]; }
-    }
-    const bool pred = (k > 0) || fp.predict_k1;
-    // ---- S0: prediction (registers), publish W = P H', H P, diag(H P H'), fmu = H m
-    double rm = 0.0;
-    if (tid < S) {
-      if (pred) {
-        const double* a = sA + (size_t)myblk * TS + 4 * myrow;
-        const double* mb = m + ioff[myblk];
-        const int bs = ibsz[myblk];
-        for (int l = 0; l < bs; ++l) rm = fma(a[l], mb[l], rm);
-      } else {
-        rm = m[tid];
+  for (int64_t k0 = 0; k0 < T; k0 += KB) {
+    const int nb = (T - k0 < KB) ? (int)(T - k0) : KB;
+    // ---- fill the ring
+    for (int i = tid; i < nb; i += NT) { ry[i] = yv[k0 + i]; rlZ[i] = g_lZ[k0 + i]; }
+    if (MEAS == 0)
+      for (int i = tid; i < nb * M; i += NT) {
+        rtt[i] = g_tt[(size_t)k0 * M + i]; rtn[i] = g_tn[(size_t)k0 * M + i]; rR[i] = g_R[(size_t)k0 * M + i];
       }
-      if (myrow == 0) fmu[myblk] = shv[myblk] * rm;
-    }
-#pragma unroll
-    for (int q = 0; q < TPT; ++q) {
-      if (own.ok[q]) {
-        const int I = own.I[q], J = own.J[q];
-        if (pred && !(fp.ablate & 1)) {
-          tile_congruence(P[q], sA + (size_t)I * TS, sA + (size_t)J * TS);
-          if (I == J) {
-            const double* Qb = mdl + mdl_Q(sh) + (size_t)I * 16;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) P[q][e] += Qb[e];
-          }
-        }
-        const double hJ = shv[J], hI = shv[I];
-        if (!(fp.ablate & 16))
-#pragma unroll
-        for (int i = 0; i < 4; ++i) Wl[((size_t)J * 4 + i) * M + I] = hJ * P[q][4 * i];
-        if (!(fp.ablate & 16))
-#pragma unroll
-        for (int j = 0; j < 4; ++j) HPl[((size_t)I * 4 + j) * M + J] = hI * P[q][j];
-        if (I == J) HPH[I] = hI * hI * P[q][0];
-      }
-    }
-    lds_barrier();  // B1
-    if (tid < S) m[tid] = rm;
+    __syncthreads();
 
-    if (!(yk != yk)) {  // ~isnan(y_k)
-      if (MEAS == 0) {
-        const bool do_mom = fp.mom_all || (k == T - 1);
-        if (do_mom) {
-          mom_eval(mc, sW, mdl + mdl_W(sh), sn2, 1.0, yk, fmu, HPH, ws, &misc[0], dl, d2l);
+    for (int kk = 0; kk < nb; ++kk) {
+      const int64_t k = k0 + kk;
+      const double yk = ry[kk];
+      const bool pred = (k > 0) || fp.predict_k1;
+      // ---- S0: prediction (registers), publish W = P H', H P, diag(H P H'), fmu = H m
+      double rm = 0.0;
+      if (tid < S) {
+        if (pred) {
+          const double* a = sA + (size_t)myblk * TS + 4 * myrow;
+          const double* mb = m + ioff[myblk];
+          const int bs = ibsz[myblk];
+#pragma unroll
+          for (int l = 0; l < 4; ++l)
+            if (l < bs) rm = fma(a[l], mb[l], rm);
+        } else {
+          rm = m[tid];
+        }
+        if (myrow == 0) fmu[myblk] = shv[myblk] * rm;
+      }
+#pragma unroll
+      for (int q = 0; q < TPT; ++q) {
+        if (own.ok[q]) {
+          const int I = own.I[q], J = own.J[q];
+          if (pred) {
+            tile_congruence(P[q], sA + (size_t)I * TS, sA + (size_t)J * TS);
+            if (I == J) {
+              const double* Qb = sQ + (size_t)I * TS;
+#pragma unroll
+              for (int e = 0; e < 16; ++e) P[q][e] += Qb[e];
+            }
+          }
+          const double hJ = shv[J], hI = shv[I];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) Wl[((size_t)J * 4 + i) * M + I] = hJ * P[q][4 * i];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) HPl[((size_t)I * 4 + j) * M + J] = hI * P[q][j];
+          if (I == J) HPH[I] = hI * hI * P[q][0];
+        }
+      }
+      lds_barrier();  // B1
+      if (tid < S) m[tid] = rm;
+
+      if (!(yk != yk)) {  // ~isnan(y_k)
+        if (MEAS == 0) {
+          const bool do_mom = fp.mom_all || (k == T - 1);
+          if (do_mom) {
+            mom_eval(mc, sW, mdl + mdl_W(sh), sn2, 1.0, yk, fmu, HPH, ws, &misc[0], dl, d2l);
+            if (tid < M) {
+              const double d2 = d2l[tid], d1 = dl[tid], hp = HPH[tid], f = fmu[tid];
+              const double t_old = rtt[kk * M + tid], n_old = rtn[kk * M + tid];
+              double tnew = (1.0 - fp.ep_damp) * t_old + fp.ep_damp * (-d2 / (1.0 + d2 * hp));
+              const double nnew = (1.0 - fp.ep_damp) * n_old + fp.ep_damp * ((d1 - f * d2) / (1.0 + d2 * hp));
+              if (!(tnew > 0.0)) ++n_clamped;
+              tnew = max0(tnew);
+              tt[tid] = tnew; tn[tid] = nnew;
+              rtt[kk * M + tid] = tnew; rtn[kk * M + tid] = nnew;
+              if (fp.write_R) rR[kk * M + tid] = 1.0 / tnew;
+            }
+            if (tid == 0) rlZ[kk] = misc[0];
+          } else if (tid < M) {
+            double t_old = rtt[kk * M + tid];
+            if (fp.clamp_always) { t_old = max0(t_old); rtt[kk * M + tid] = t_old; }
+            tt[tid] = t_old; tn[tid] = rtn[kk * M + tid];
+          }
+          if (fp.legacy_update) lds_barrier();
           if (tid < M) {
-            const double d2 = d2l[tid], d1 = dl[tid], hp = HPH[tid], f = fmu[tid];
-            double t_old = tt_k, n_old = tn_k;
-            double tnew = (1.0 - fp.ep_damp) * t_old + fp.ep_damp * (-d2 / (1.0 + d2 * hp));
-            double nnew = (1.0 - fp.ep_damp) * n_old + fp.ep_damp * ((d1 - f * d2) / (1.0 + d2 * hp));
-            if (!(tnew > 0.0)) ++n_clamped;
-            tnew = max0(tnew);
-            tt[tid] = tnew; tn[tid] = nnew;
-            g_tt[(size_t)k * M + tid] = tnew; g_tn[(size_t)k * M + tid] = nnew;
-            if (fp.write_R) g_R[(size_t)k * M + tid] = 1.0 / tnew;
+            const double t = tt[tid], n = tn[tid], hp = HPH[tid], f = fmu[tid];
+            bool formA = (t == 0.0);
+            if (fp.legacy_update) {
+              double mn = tt[0];
+              for (int q = 1; q < M; ++q) mn = fmin(mn, tt[q]);   // MATLAB min ignores NaN like fmin
+              formA = (mn == 0.0);
+            }
+            if (formA) {   // z = t*hp+1; K = W*(t/z); v = t*f - n; m -= W*(v/z); P -= K*W'
+              const double z = t * hp + 1.0;
+              cA[tid] = t / z;
+              cm[tid] = -(t * f - n) / z;
+            } else {       // K = W/(hp+1/t); v = n/t - f; m += K*v; P -= K*H*P
+              const double s = 1.0 / (hp + 1.0 / t);
+              cA[tid] = s;
+              cm[tid] = s * (n / t - f);
+            }
+            if (tid == 0) misc[1] = formA ? 1.0 : 0.0;
           }
-          if (tid == 0) g_lZ[k] = misc[0];
-        } else if (tid < M) {
-          double t_old = tt_k;
-          if (fp.clamp_always) { t_old = max0(t_old); g_tt[(size_t)k * M + tid] = t_old; }
-          tt[tid] = t_old; tn[tid] = tn_k;
-        }
-        if (fp.legacy_update) lds_barrier();
-        if (tid < M) {
-          const double t = tt[tid], n = tn[tid], hp = HPH[tid], f = fmu[tid];
-          bool formA = (t == 0.0);
-          if (fp.legacy_update) {
-            double mn = tt[0];
-            for (int q = 1; q < M; ++q) mn = fmin(mn, tt[q]);   // MATLAB min ignores NaN like fmin
-            formA = (mn == 0.0);
+          lds_barrier();  // B4
+          const bool legacyA = fp.legacy_update && (misc[1] != 0.0);
+          if (tid < S) {
+            double a0 = rm, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            const double* wp = Wl + (size_t)myrow * M + myblk;
+            int n = 0;
+            for (; n + 4 <= M; n += 4) {
+              a0 = fma(wp[(size_t)(n + 0) * 4 * M], cm[n + 0], a0);
+              a1 = fma(wp[(size_t)(n + 1) * 4 * M], cm[n + 1], a1);
+              a2 = fma(wp[(size_t)(n + 2) * 4 * M], cm[n + 2], a2);
+              a3 = fma(wp[(size_t)(n + 3) * 4 * M], cm[n + 3], a3);
+            }
+            for (; n < M; ++n) a0 = fma(wp[(size_t)n * 4 * M], cm[n], a0);
+            rm = (a0 + a1) + (a2 + a3);
+            m[tid] = rm;
           }
-          if (formA) {   // z = t*hp+1; K = W*(t/z); v = t*f - n; m -= W*(v/z); P -= K*W'
-            const double z = t * hp + 1.0;
-            cA[tid] = t / z;
-            cm[tid] = -(t * f - n) / z;
-          } else {       // K = W/(hp+1/t); v = n/t - f; m += K*v; P -= K*H*P
-            const double s = 1.0 / (hp + 1.0 / t);
-            cA[tid] = s;
-            cm[tid] = s * (n / t - f);
-          }
-          if (tid == 0) misc[1] = formA ? 1.0 : 0.0;
-        }
-        lds_barrier();  // B4
-        const bool legacyA = fp.legacy_update && (misc[1] != 0.0);
-        if (tid < S && !(fp.ablate & 8)) {
-          double a0 = rm, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-          const double* wp = Wl + (size_t)myrow * M + myblk;
-          int n = 0;
-          for (; n + 4 <= M; n += 4) {
-            a0 = fma(wp[(size_t)(n + 0) * 4 * M], cm[n + 0], a0);
-            a1 = fma(wp[(size_t)(n + 1) * 4 * M], cm[n + 1], a1);
-            a2 = fma(wp[(size_t)(n + 2) * 4 * M], cm[n + 2], a2);
-            a3 = fma(wp[(size_t)(n + 3) * 4 * M], cm[n + 3], a3);
-          }
-          for (; n < M; ++n) a0 = fma(wp[(size_t)n * 4 * M], cm[n], a0);
-          const double acc = (a0 + a1) + (a2 + a3);
-          rm = acc;
-          m[tid] = acc;
-        }
-        // P -= sum_n (W[:,n] cA[n]) * R_n,   R_n = (H P)[n,:]  (or W[:,n]' in the legacy form)
-        const double* Rt = legacyA ? Wl : HPl;
+          // P -= sum_n (W[:,n] cA[n]) * R_n,   R_n = (H P)[n,:]  (or W[:,n]' in the legacy form)
+          const double* Rt = legacyA ? Wl : HPl;
 #pragma unroll
-        for (int q = 0; q < TPT; ++q) {
-          if (own.ok[q] && !(fp.ablate & 2)) {
-            const double* wbase = Wl + own.I[q];
-            const double* rbase = Rt + own.J[q];
-            for (int n0 = 0; n0 < M; n0 += 4) {
-              double w4[4][4], r4[4][4];
+          for (int q = 0; q < TPT; ++q) {
+            if (own.ok[q]) {
+              const double* wbase = Wl + own.I[q];
+              const double* rbase = Rt + own.J[q];
+              int n0 = 0;
+              for (; n0 + 2 <= M; n0 += 2) {   // two sites per trip: 16 LDS reads in flight before the FMAs
+                double w4[2][4], r4[2][4];
 #pragma unroll
-              for (int u = 0; u < 4; ++u) {
-                const int n = (n0 + u < M) ? n0 + u : M - 1;
-                const double c = (n0 + u < M) ? -cA[n] : 0.0;
+                for (int u = 0; u < 2; ++u) {
+                  const double c = -cA[n0 + u];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) w4[u][i] = wbase[((size_t)n * 4 + i) * M] * c;
+                  for (int i = 0; i < 4; ++i) w4[u][i] = wbase[((size_t)(n0 + u) * 4 + i) * M] * c;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) r4[u][j] = rbase[((size_t)n * 4 + j) * M];
+                  for (int j = 0; j < 4; ++j) r4[u][j] = rbase[((size_t)(n0 + u) * 4 + j) * M];
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                  for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) P[q][4 * i + j] = fma(w4[u][i], r4[u][j], P[q][4 * i + j]);
               }
+              if (n0 < M) {
+                const double c = -cA[n0];
+                double w1[4], r1[4];
 #pragma unroll
-              for (int u = 0; u < 4; ++u)
+                for (int i = 0; i < 4; ++i) w1[i] = wbase[((size_t)n0 * 4 + i) * M] * c;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) r1[j] = rbase[((size_t)n0 * 4 + j) * M];
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                  for (int j = 0; j < 4; ++j) P[q][4 * i + j] = fma(w4[u][i], r4[u][j], P[q][4 * i + j]);
+                  for (int j = 0; j < 4; ++j) P[q][4 * i + j] = fma(w1[i], r1[j], P[q][4 * i + j]);
+              }
+            }
+          }
+        } else {
+          // ---------------- EKF measurement update (iekf_update1.m:110-117)
+          double* part = ws;
+          double* PJ = ws + M;
+          const int N = sh.N;
+          double Sx = 1.0, MU = 0.0;
+          for (int it = 0; it < fp.l_iter; ++it) {
+            if (it > 0) {
+              if (tid < M) fmu[tid] = shv[tid] * m[ioff[tid]];
+              lds_barrier();
+            }
+            if (tid < M) {   // partials of h = z' W softplus(g)
+              double pv = 0.0;
+              if (tid < D) {
+                for (int j = 0; j < N; ++j) pv = fma(sW[tid * N + j], log(1.0 + exp(fmu[D + j])), pv);
+              } else {
+                const int j = tid - D;
+                double zw = 0.0;
+                for (int d = 0; d < D; ++d) zw = fma(fmu[d], sW[d * N + j], zw);
+                const double eg = exp(fmu[D + j]);
+                pv = zw * (eg / (eg + 1.0));
+              }
+              part[tid] = pv;
+            }
+            lds_barrier();
+            if (tid < S) {
+              double acc = 0.0;
+              for (int n = 0; n < M; ++n) acc = fma(Wl[((size_t)n * 4 + myrow) * M + myblk], part[n], acc);
+              PJ[tid] = acc;
+            }
+            lds_barrier();
+            double jpj = 0.0;
+            MU = 0.0;
+            for (int n = 0; n < M; ++n) jpj = fma(part[n] * shv[n], PJ[ioff[n]], jpj);
+            for (int d = 0; d < D; ++d) MU = fma(fmu[d], part[d], MU);
+            Sx = sn2 + jpj;
+            if (tid < S) { rm = rm + (PJ[tid] / Sx) * (yk - MU); }
+            lds_barrier();   // all reads of m/fmu for this iteration done
+            if (tid < S) m[tid] = rm;
+            if (it + 1 < fp.l_iter) lds_barrier();
+          }
+          // P -= K S K'
+#pragma unroll
+          for (int q = 0; q < TPT; ++q) {
+            if (own.ok[q]) {
+              const int oI = ioff[own.I[q]], oJ = ioff[own.J[q]];
+              const int bI = ibsz[own.I[q]], bJ = ibsz[own.J[q]];
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                  if (i < bI && j < bJ) {
+                    const double Ki = PJ[oI + i] / Sx, Kj = PJ[oJ + j] / Sx;
+                    P[q][4 * i + j] -= (Ki * Sx) * Kj;
+                  }
             }
           }
         }
       } else {
-        // ---------------- EKF measurement update (iekf_update1.m:110-117)
-        double* part = ws;
-        double* PJ = ws + M;
-        const int N = sh.N;
-        double Sx = 1.0, MU = 0.0;
-        for (int it = 0; it < fp.l_iter; ++it) {
-          if (it > 0) {
-            if (tid < M) fmu[tid] = shv[tid] * m[ioff[tid]];
-            lds_barrier();
-          }
-          if (tid < M) {   // partials of h = z' W softplus(g)
-            double pv = 0.0;
-            if (tid < D) {
-              for (int j = 0; j < N; ++j) pv = fma(sW[tid * N + j], log(1.0 + exp(fmu[D + j])), pv);
-            } else {
-              const int j = tid - D;
-              double zw = 0.0;
-              for (int d = 0; d < D; ++d) zw = fma(fmu[d], sW[d * N + j], zw);
-              const double eg = exp(fmu[D + j]);
-              pv = zw * (eg / (eg + 1.0));
-            }
-            part[tid] = pv;
-          }
-          lds_barrier();
-          if (tid < S) {
-            double acc = 0.0;
-            for (int n = 0; n < M; ++n) acc = fma(Wl[((size_t)n * 4 + myrow) * M + myblk], part[n], acc);
-            PJ[tid] = acc;
-          }
-          lds_barrier();
-          double jpj = 0.0;
-          MU = 0.0;
-          for (int n = 0; n < M; ++n) jpj = fma(part[n] * shv[n], PJ[ioff[n]], jpj);
-          for (int d = 0; d < D; ++d) MU = fma(fmu[d], part[d], MU);
-          Sx = sn2 + jpj;
-          if (tid < S) { rm = rm + (PJ[tid] / Sx) * (yk - MU); }
-          lds_barrier();   // all reads of m/fmu for this iteration done
-          if (tid < S) m[tid] = rm;
-          if (it + 1 < fp.l_iter) lds_barrier();
-        }
-        // P -= K S K'
-#pragma unroll
-        for (int q = 0; q < TPT; ++q) {
-          if (own.ok[q]) {
-            const int oI = ioff[own.I[q]], oJ = ioff[own.J[q]];
-            const int bI = ibsz[own.I[q]], bJ = ibsz[own.J[q]];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-              for (int j = 0; j < 4; ++j)
-                if (i < bI && j < bJ) {
-                  const double Ki = PJ[oI + i] / Sx, Kj = PJ[oJ + j] / Sx;
-                  P[q][4 * i + j] -= (Ki * Sx) * Kj;
-                }
-          }
-        }
+        ++n_nan;
       }
-    } else {
-      ++n_nan;
-    }
-    // ---- store
-    if (tid < S) {
-      g_MF[(size_t)k * S + tid] = rm;
-      if (myrow == 0) g_fm[(size_t)k * M + myblk] = shv[myblk] * rm;
-    }
-#pragma unroll
-    for (int q = 0; q < TPT; ++q)
-      if (own.ok[q] && own.I[q] == own.J[q])
-        g_fv[(size_t)k * M + own.I[q]] = shv[own.I[q]] * shv[own.I[q]] * P[q][0];
-    if (g_PF && fp.store_PF && !(fp.ablate & 4)) {
+      // ---- per-step outputs -> ring ; covariance tiles -> HBM
+      if (tid < S) {
+        rMF[(size_t)kk * S + tid] = rm;
+        if (myrow == 0) rfm[kk * M + myblk] = shv[myblk] * rm;
+      }
 #pragma unroll
       for (int q = 0; q < TPT; ++q)
-        if (own.ok[q]) tile_store(g_PF + ((size_t)k * sh.ntiles + tid + q * NT) * 16, P[q]);
+        if (own.ok[q] && own.I[q] == own.J[q])
+          rfv[kk * M + own.I[q]] = shv[own.I[q]] * shv[own.I[q]] * P[q][0];
+      if (g_PF) {
+#pragma unroll
+        for (int q = 0; q < TPT; ++q)
+          if (own.ok[q]) tile_store(g_PF + ((size_t)k * sh.ntiles + tid + q * NT) * 16, P[q]);
+      }
+      lds_barrier();  // B5
     }
-    lds_barrier();  // B5
+    // ---- flush the ring
+    for (int i = tid; i < nb; i += NT) g_lZ[k0 + i] = rlZ[i];
+    for (int i = tid; i < nb * M; i += NT) {
+      if (MEAS == 0) {
+        g_tt[(size_t)k0 * M + i] = rtt[i]; g_tn[(size_t)k0 * M + i] = rtn[i];
+        if (fp.write_R) g_R[(size_t)k0 * M + i] = rR[i];
+      }
+      g_fm[(size_t)k0 * M + i] = rfm[i]; g_fv[(size_t)k0 * M + i] = rfv[i];
+    }
+    for (int i = tid; i < nb * S; i += NT) g_MF[(size_t)k0 * S + i] = rMF[i];
+    __syncthreads();
   }
-  // final filtered state -> scan state (E = 0, e = 0 is implied; the smoother starts from MF/PF at T-1)
   if (tid < M && n_clamped) atomicAdd(&b.counters[(size_t)pb * 4 + 1], n_clamped);
   if (tid == 0 && n_nan) atomicAdd(&b.counters[(size_t)pb * 4 + 2], n_nan);
 }
-
 
 // ---------------------------------------------------------------------------------------------
 // RTS gain.  One workgroup per (step, problem) of the current chunk:

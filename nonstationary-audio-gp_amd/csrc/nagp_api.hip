@@ -54,7 +54,7 @@ struct nagp_plan {
   MomCfg mc{};
   IhgpTabs tb{};
   double* d_model = nullptr; double* d_y = nullptr; double* d_wn = nullptr; double* d_xi = nullptr;
-  double* d_stamps = nullptr; double* d_lZs = nullptr; double* d_vprev = nullptr; double* d_tab = nullptr; double* d_r = nullptr;
+  double* d_stamps = nullptr; double* d_lZs = nullptr; double* d_affspan = nullptr; double* d_affbnd = nullptr; int aff_L = 128, aff_ns = 1; double* d_vprev = nullptr; double* d_tab = nullptr; double* d_r = nullptr;
   std::vector<void*> allocs;
   int64_t dev_bytes = 0;
   std::vector<double> nlZ, mdM, mdP;   // [B][ep_itts]
@@ -306,6 +306,9 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     PLAN_TRY(dalloc(p, &p->d_lZs, BT));
     PLAN_TRY(dalloc(p, &p->d_stamps, 8));
     PLAN_TRY(dalloc(p, &p->d_vprev, (size_t)B * sh.M));
+    p->aff_L = 128; p->aff_ns = (int)((T + p->aff_L - 1) / p->aff_L);
+    PLAN_TRY(dalloc(p, &p->d_affspan, (size_t)B * p->aff_ns * sh.M * 20, false));
+    PLAN_TRY(dalloc(p, &p->d_affbnd, (size_t)B * p->aff_ns * sh.M * 4, false));
     // ---- IHGP tables: MATLAB layout -> device layout (see nagp_ihgp.hpp)
     const int NG = tables[0].n_grid;
     if (NG < 2) { nagp_plan_destroy(p); FAIL(NAGP_EINVAL, "n_grid < 2"); }
@@ -628,8 +631,30 @@ static int exec_ihgp(nagp_plan* p) {
   }
   MomCfg mcf = p->mc; mcf.DG = p->DG_f; mcf.cache_tabs = p->cache_f; mcf.store_a = p->sta_f;
   if (getenv("NAGP_STAMPS")) mcf.stamps = reinterpret_cast<unsigned long long*>(p->d_stamps);   // developer diagnostics
+  auto affine = [&](int mode, int64_t kend, int itt) -> int {
+    if (kend <= 0) return NAGP_OK;
+    AffPar ap{};
+    ap.mode = mode; ap.kend = kend; ap.L = p->aff_L; ap.ns = (int)((kend + ap.L - 1) / ap.L);
+    ap.spanbuf = p->d_affspan; ap.bnd = p->d_affbnd; ap.vprev = p->d_vprev;
+    const dim3 g((unsigned)((ap.ns * sh.M + 255) / 256), B), bl(256);
+    Timed t(p, mode == 0 ? NAGP_K_FILTER_LIN : NAGP_K_SCAN);
+    if (mode == 0) {
+      hipLaunchKernelGGL((ihgp_aff_compose_kernel<0>), g, bl, 0, p->stream, sh, p->b, p->tb, ap);
+      hipLaunchKernelGGL((ihgp_aff_boundary_kernel<0>), dim3(B), dim3(64), 0, p->stream, sh, p->b, ap, itt);
+      hipLaunchKernelGGL((ihgp_aff_apply_kernel<0>), g, bl, 0, p->stream, sh, p->b, p->tb, ap);
+    } else {
+      hipLaunchKernelGGL((ihgp_aff_compose_kernel<1>), g, bl, 0, p->stream, sh, p->b, p->tb, ap);
+      hipLaunchKernelGGL((ihgp_aff_boundary_kernel<1>), dim3(B), dim3(64), 0, p->stream, sh, p->b, ap, itt);
+      hipLaunchKernelGGL((ihgp_aff_apply_kernel<1>), g, bl, 0, p->stream, sh, p->b, p->tb, ap);
+    }
+    HIP_TRY(hipGetLastError());
+    return NAGP_OK;
+  };
   for (int itt = 1; itt <= I; ++itt) {
-    IhgpPar ip{itt, p->damping[itt - 1], itt == 1 ? 1 : 0, 0.0};
+    // forward: sweep 1 is the sequential ADF filter; later sweeps have fixed sites for k < T-1 (an affine
+    // recursion, run parallel in time) and one ADF step at k = T-1
+    if (itt > 1) RUN(affine(0, sh.T - 1, itt));
+    IhgpPar ip{itt, p->damping[itt - 1], itt == 1 ? 1 : 0, (itt == 1) ? (int64_t)0 : (int64_t)(sh.T - 1)};
     {
       Timed t(p, itt == 1 ? NAGP_K_FILTER : NAGP_K_FILTER_LIN);
       hipLaunchKernelGGL(ihgp_filter_kernel, dim3(B), dim3(p->NT_ih), p->lds_ih, p->stream, sh, p->b, mcf, p->tb, ip);
@@ -637,11 +662,14 @@ static int exec_ihgp(nagp_plan* p) {
     HIP_TRY(hipGetLastError());
     RUN(reduce_sum(p, p->b.lZ, itt == 1 ? 0 : sh.T - 1, sh.T, 0));
     RUN(seed_last_step(p));
-    {
+    // backward mean recursion (parallel in time); red[1], red[2] = maxDiffM, maxDiffP
+    RUN(zero_async(p, p->b.red + 1, 2 * sizeof(double)));
+    if (B > 1) for (int q = 1; q < B; ++q) RUN(zero_async(p, p->b.red + (size_t)q * 8 + 1, 2 * sizeof(double)));
+    if (sh.T > 1) RUN(affine(1, sh.T - 1, itt));
+    else {   // no smoothing step: P = zeros (ihgp_ep_modulator_nmf.m:364) -> maxDiffP = |H PSP H'|
       Timed t(p, NAGP_K_SCAN);
       hipLaunchKernelGGL(ihgp_scan_kernel, dim3(B), dim3(64), 0, p->stream, sh, p->b, p->tb, p->d_vprev);
     }
-    HIP_TRY(hipGetLastError());
     if (itt < I) {
       RUN(zero_async(p, p->d_lZs, (size_t)B * sh.T * sizeof(double)));
       RUN(launch_ep(p, o.ep_fraction, p->damping[itt], 0, 2, p->d_lZs));

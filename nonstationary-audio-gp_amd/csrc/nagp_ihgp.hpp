@@ -53,6 +53,7 @@ struct IhgpPar {
   int itt;
   double ep_damp;
   int mom_all;       // sweep 1: mom at every step; later only at k == T-1
+  int64_t k_start;   // first step to process (sweeps >= 2 run only k = T-1 here; the rest is ihgp_aff_*)
   double R_init;     // exp(lik) (or 0 for the constraints variant): initial content of R(:,k)
 };
 
@@ -129,7 +130,12 @@ __global__ void __launch_bounds__(512) ihgp_filter_kernel(Shape sh, Bufs b, MomC
     tile_load(A4, mdl + mdl_A(sh) + (size_t)n * 16);
     hn = mdl[mdl_h(sh) + n];
     o = ioff[n]; bs = ibsz[n];
-    if (ip.itt > 1) {   // m is NOT reset between sweeps (SURVEY C-22): smoothed mean at k=0
+    if (ip.k_start > 0) {      // continue from the filtered mean of the previous step
+      const double* mp = b.MF + ((size_t)pb * T + (ip.k_start - 1)) * S;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (i < bs) mreg[i] = mp[o + i];
+    } else if (ip.itt > 1) {   // m is NOT reset between sweeps (SURVEY C-22): smoothed mean at k=0
       const double* ms0 = b.MS + (size_t)pb * T * S;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -143,12 +149,12 @@ __global__ void __launch_bounds__(512) ihgp_filter_kernel(Shape sh, Bufs b, MomC
   double* g_lZ = b.lZ + (size_t)pb * T;
   double* g_MF = b.MF + (size_t)pb * T * S;
   double* g_fm = b.fm + (size_t)pb * T * M;
-  double Rprev = 0.0;
+  double Rprev = (act && ip.k_start > 0) ? b.R[((size_t)pb * T + (ip.k_start - 1)) * M + n] : 0.0;
   unsigned long long n_clamped = 0;
   unsigned long long st_a = 0, st_b = 0, st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (mc.stamps && tid == 0) st_a = __builtin_readcyclecounter();
 
-  for (int64_t k0 = 0; k0 < T; k0 += IH_KB) {
+  for (int64_t k0 = ip.k_start; k0 < T; k0 += IH_KB) {
     const int nb = (T - k0 < IH_KB) ? (int)(T - k0) : IH_KB;
     // ---- fill the ring for steps k0 .. k0+nb-1
     for (int i = tid; i < nb; i += NT) { ry[i] = yv[k0 + i]; rlZ[i] = g_lZ[k0 + i]; }
@@ -296,6 +302,243 @@ __global__ void __launch_bounds__(64) ihgp_scan_kernel(Shape sh, Bufs b, IhgpTab
   mxM = wave_max(mxM);
   mxP = wave_max(mxP);
   if (n == 0) { b.red[(size_t)pb * 8 + 1] = mxM; b.red[(size_t)pb * 8 + 2] = mxP; }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Parallel-in-time form of the two mean recursions that involve no `mom` call:
+//   forward  (filter of sweeps >= 2, ihgp_ep_modulator_nmf.m:280-304 with fixed sites):
+//            m_k = (A - K h A(1,:)) m_{k-1} + K ys          (or A m_{k-1} for clamped sites)
+//   backward (smoother, :391):  m_k = MF_k + G_k (m_{k+1} - A MF_k)
+// Both are affine maps x -> F x + g per diagonal block with F, g computable from stored arrays, so the
+// sequence is cut into spans: compose (one thread per span and block), boundary (sequential over the
+// spans, one thread per block), apply (replay inside the span, write outputs).
+struct AffPar {
+  int mode;        // 0 forward filter over k = 0 .. kend-1 ; 1 backward smoother over k = kend-1 .. 0
+  int64_t kend;    // number of steps covered
+  int L;           // span length
+  int ns;          // spans
+  double* spanbuf; // [B][ns][M][20]  Phi (16) + c (4)
+  double* bnd;     // [B][ns][M][4]   value entering the span
+  double* vprev;   // [B][M] (smoother: previous sweep's marginal variance at k = 0)
+};
+
+// coefficients of step k for block n: x_new = F x + g
+template <int MODE>
+__device__ __forceinline__ void ihgp_coeffs(const Shape& sh, const Bufs& b, const IhgpTabs& tb, const double* tab,
+                                            const double* A4, double hn, int n, int pb, int64_t k, int bs, int o,
+                                            double* F, double* g, double& aux) {
+  const int M = sh.M, NG = tb.NG;
+  const int64_t T = sh.T;
+  const size_t ix = ((size_t)pb * T + k) * M + n;
+  if (MODE == 0) {
+    const double tt = max0(b.ttau[ix]);
+    if (tt == 0.0) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) F[e] = A4[e];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) g[i] = 0.0;
+      aux = INFINITY;                       // R(n,k) = inf
+    } else {
+      const double Rk = b.R[ix];
+      double hph, wc[4];
+      if (k > 0) {
+        const double tprev = max0(b.ttau[ix - M]);
+        const double Rprev = (tprev == 0.0) ? INFINITY : b.R[ix - M];
+        const int idx = nearest_idx(tb, Rprev);
+        hph = tab[itab_hph(sh, NG) + (size_t)n * NG + idx];
+        const double* w = tab + itab_wcol(sh, NG) + ((size_t)n * NG + idx) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wc[i] = w[i];
+      } else {
+        hph = tab[itab_hph0(sh, NG) + n];
+        const double* w = tab + itab_wcol0(sh, NG) + (size_t)n * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wc[i] = w[i];
+      }
+      const double den = hph + Rk;
+      const double ys = b.tnu[ix] / tt;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const double Ki = wc[i] / den;
+        g[i] = Ki * ys;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) F[4 * i + j] = A4[4 * i + j] - Ki * hn * A4[j];
+      }
+      aux = Rk;
+    }
+  } else {
+    const double Rk = b.R[ix];
+    int idx = nearest_idx(tb, Rk);
+    if (isinf(Rk)) idx = NG - 1;
+    tile_load(F, tab + itab_g(sh, NG) + ((size_t)n * NG + idx) * 16);
+    aux = tab[itab_v(sh, NG) + (size_t)n * NG + idx];
+    double mf[4] = {0, 0, 0, 0}, amf[4];
+    const double* mfp = b.MF + ((size_t)pb * T + k) * sh.S + o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (i < bs) mf[i] = mfp[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      double a = 0.0;
+#pragma unroll
+      for (int l = 0; l < 4; ++l) a = fma(A4[4 * i + l], mf[l], a);
+      amf[i] = a;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      double a = mf[i];
+#pragma unroll
+      for (int l = 0; l < 4; ++l) a = fma(-F[4 * i + l], amf[l], a);
+      g[i] = a;
+    }
+  }
+}
+
+// span j covers recursion steps [j*L, min((j+1)L, kend)) counted in recursion order; k = that index
+// (forward) or kend-1-index (backward).
+template <int MODE>
+__global__ void __launch_bounds__(256) ihgp_aff_compose_kernel(Shape sh, Bufs b, IhgpTabs tb, AffPar ap) {
+  const int pb = blockIdx.y, M = sh.M;
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= ap.ns * M) return;
+  const int j = gid / M, n = gid - j * M;
+  const double* mdl = b.model + (size_t)pb * mdl_size(sh);
+  const double* tab = tb.base + (size_t)pb * itab_size(sh, tb.NG);
+  double A4[16];
+  tile_load(A4, mdl + mdl_A(sh) + (size_t)n * 16);
+  const double hn = mdl[mdl_h(sh) + n];
+  const int bs = sh.bsz[n], o = sh.off[n];
+  double Phi[16], c[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int e = 0; e < 16; ++e) Phi[e] = ((e & 3) == (e >> 2)) ? 1.0 : 0.0;
+  const int64_t s0 = (int64_t)j * ap.L, s1 = (s0 + ap.L < ap.kend) ? s0 + ap.L : ap.kend;
+  for (int64_t s = s0; s < s1; ++s) {
+    const int64_t k = (MODE == 0) ? s : (ap.kend - 1 - s);
+    double F[16], g[4], aux;
+    ihgp_coeffs<MODE>(sh, b, tb, tab, A4, hn, n, pb, k, bs, o, F, g, aux);
+    double P2[16], c2[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      double a = g[i];
+#pragma unroll
+      for (int l = 0; l < 4; ++l) a = fma(F[4 * i + l], c[l], a);
+      c2[i] = a;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        double q = 0.0;
+#pragma unroll
+        for (int l = 0; l < 4; ++l) q = fma(F[4 * i + l], Phi[4 * l + jj], q);
+        P2[4 * i + jj] = q;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) Phi[e] = P2[e];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c[i] = c2[i];
+  }
+  double* out = ap.spanbuf + (((size_t)pb * ap.ns + j) * M + n) * 20;
+  tile_store(out, Phi);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) out[16 + i] = c[i];
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(64) ihgp_aff_boundary_kernel(Shape sh, Bufs b, AffPar ap, int itt) {
+  const int n = threadIdx.x, pb = blockIdx.x, M = sh.M, S = sh.S;
+  const int64_t T = sh.T;
+  if (n >= M) return;
+  const int bs = sh.bsz[n], o = sh.off[n];
+  double x[4] = {0, 0, 0, 0};
+  if (MODE == 0) {            // filter of sweep itt >= 2 starts from the smoothed mean at k = 0 (SURVEY C-22)
+    if (itt > 1)
+      for (int i = 0; i < bs; ++i) x[i] = b.MS[(size_t)pb * T * S + o + i];
+  } else {                    // smoother starts from the last filtered mean
+    for (int i = 0; i < bs; ++i) x[i] = b.MF[((size_t)pb * T + (T - 1)) * S + o + i];
+  }
+  for (int j = 0; j < ap.ns; ++j) {
+    double* bj = ap.bnd + (((size_t)pb * ap.ns + j) * M + n) * 4;
+    const double* sp = ap.spanbuf + (((size_t)pb * ap.ns + j) * M + n) * 20;
+    double y[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      bj[i] = x[i];
+      double a = sp[16 + i];
+#pragma unroll
+      for (int l = 0; l < 4; ++l) a = fma(sp[4 * i + l], x[l], a);
+      y[i] = a;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[i] = y[i];
+  }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256) ihgp_aff_apply_kernel(Shape sh, Bufs b, IhgpTabs tb, AffPar ap) {
+  const int pb = blockIdx.y, M = sh.M, S = sh.S;
+  const int64_t T = sh.T;
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  double mxM = 0.0, mxP = 0.0;
+  if (gid < ap.ns * M) {
+    const int j = gid / M, n = gid - j * M;
+    const double* mdl = b.model + (size_t)pb * mdl_size(sh);
+    const double* tab = tb.base + (size_t)pb * itab_size(sh, tb.NG);
+    double A4[16];
+    tile_load(A4, mdl + mdl_A(sh) + (size_t)n * 16);
+    const double hn = mdl[mdl_h(sh) + n];
+    const int bs = sh.bsz[n], o = sh.off[n];
+    double x[4];
+    const double* bj = ap.bnd + (((size_t)pb * ap.ns + j) * M + n) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[i] = bj[i];
+    const int64_t s0 = (int64_t)j * ap.L, s1 = (s0 + ap.L < ap.kend) ? s0 + ap.L : ap.kend;
+    for (int64_t s = s0; s < s1; ++s) {
+      const int64_t k = (MODE == 0) ? s : (ap.kend - 1 - s);
+      double F[16], g[4], aux;
+      ihgp_coeffs<MODE>(sh, b, tb, tab, A4, hn, n, pb, k, bs, o, F, g, aux);
+      double y[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        double a = g[i];
+#pragma unroll
+        for (int l = 0; l < 4; ++l) a = fma(F[4 * i + l], x[l], a);
+        y[i] = a;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) x[i] = y[i];
+      const size_t ix = ((size_t)pb * T + k) * M + n;
+      if (MODE == 0) {
+        double* mfp = b.MF + ((size_t)pb * T + k) * S + o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (i < bs) mfp[i] = x[i];
+        b.fm[ix] = hn * x[0];
+        b.ttau[ix] = max0(b.ttau[ix]);     // the clamp of :274 is stored
+        b.R[ix] = aux;                      // unchanged, or Inf for clamped sites (:287)
+      } else {
+        double* msp = b.MS + ((size_t)pb * T + k) * S + o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (i < bs) msp[i] = x[i];
+        const double mnew = hn * x[0];
+        mxM = fmax(mxM, fabs(b.sm[ix] - mnew));
+        b.sm[ix] = mnew;
+        b.sv[ix] = aux;
+        if (k == 0) {
+          mxP = fabs(ap.vprev[(size_t)pb * M + n] - aux);
+          ap.vprev[(size_t)pb * M + n] = aux;
+        }
+      }
+    }
+  }
+  if (MODE == 1) {
+    mxM = wave_max(mxM);
+    mxP = wave_max(mxP);
+    if ((threadIdx.x & 63) == 0) {
+      atomicMax(reinterpret_cast<unsigned long long*>(&b.red[(size_t)pb * 8 + 1]), (unsigned long long)__double_as_longlong(mxM));
+      atomicMax(reinterpret_cast<unsigned long long*>(&b.red[(size_t)pb * 8 + 2]), (unsigned long long)__double_as_longlong(mxP));
+    }
+  }
 }
 
 }  // namespace nagp

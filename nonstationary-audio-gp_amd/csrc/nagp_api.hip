@@ -43,7 +43,7 @@ struct nagp_plan {
   nagp_opts opts{};
   std::vector<double> damping;
   int B = 0;
-  int TPT = 1, NT = 256, NT_f = 256, NT_ih = 256;
+  int TPT = 1, TPT_f = 1, NT = 256, NT_f = 256, NT_ih = 256;
   int chunk = 2048, LP1 = 1, LP2 = 1, ns_max = 1;
   SpanPar spar{};
   int DG_f = 1, DG_ep = 1, cache_f = 0, cache_ep = 0, sta_f = 0, sta_ep = 0, kb_f = 16;
@@ -196,7 +196,12 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
   p->TPT = (nt + 511) / 512;   // <= 512 threads per workgroup: 256 VGPRs per lane for the register-resident tiles
   if (p->TPT > 4 || sh.S > 512) { nagp_plan_destroy(p); FAIL(NAGP_EUNSUPPORTED, "M=%d / S=%d: more than 2048 tiles or 512 states", sh.M, sh.S); }
   p->NT = std::max(roundup64((nt + p->TPT - 1) / p->TPT), std::max(roundup64(sh.S), 128));
-  p->NT_f = p->NT;
+  {   // filter: one thread per lower-triangular tile
+    const int slots = sh.M * (sh.M + 1) / 2;
+    p->TPT_f = (slots + 511) / 512;
+    if (p->TPT_f > 4) { nagp_plan_destroy(p); FAIL(NAGP_EUNSUPPORTED, "M=%d too large for the filter kernel", sh.M); }
+    p->NT_f = std::max(roundup64((slots + p->TPT_f - 1) / p->TPT_f), std::max(roundup64(sh.S), ekf ? 128 : 384));
+  }
   p->want_PS = (o->flags & 0x4u) != 0;
   p->need_PF = (o->kind != NAGP_KIND_IHGP) && !(o->mode == NAGP_MODE_NLML && o->ep_itts == 1);
 
@@ -371,19 +376,17 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     p->lds_filter = filter_lds_doubles(sh, t, ekf ? 1 : 0, p->kb_f) * sizeof(double);
     p->lds_gain = gain_lds_doubles(sh) * sizeof(double);
     p->lds_scan = span_lds_doubles(sh, p->LP1, p->LP2) * sizeof(double);
+    switch (p->TPT_f) {
+      case 1: PLAN_TRY(ekf ? set_lds(gf_filter_kernel<1, 1>, p->lds_filter) : set_lds(gf_filter_kernel<1, 0>, p->lds_filter)); break;
+      case 2: PLAN_TRY(ekf ? set_lds(gf_filter_kernel<2, 1>, p->lds_filter) : set_lds(gf_filter_kernel<2, 0>, p->lds_filter)); break;
+      case 3: PLAN_TRY(ekf ? set_lds(gf_filter_kernel<3, 1>, p->lds_filter) : set_lds(gf_filter_kernel<3, 0>, p->lds_filter)); break;
+      default: PLAN_TRY(ekf ? set_lds(gf_filter_kernel<4, 1>, p->lds_filter) : set_lds(gf_filter_kernel<4, 0>, p->lds_filter)); break;
+    }
     switch (p->TPT) {
-      case 1:
-        PLAN_TRY(ekf ? set_lds(gf_filter_kernel<1, 1>, p->lds_filter) : set_lds(gf_filter_kernel<1, 0>, p->lds_filter));
-        PLAN_TRY(set_lds(rts_gain_kernel<1>, p->lds_gain)); PLAN_TRY(set_lds(rts_compose_kernel<1>, p->lds_scan)); PLAN_TRY(set_lds(rts_boundary_kernel<1>, p->lds_scan)); PLAN_TRY(set_lds(rts_apply_kernel<1>, p->lds_scan)); break;
-      case 2:
-        PLAN_TRY(ekf ? set_lds(gf_filter_kernel<2, 1>, p->lds_filter) : set_lds(gf_filter_kernel<2, 0>, p->lds_filter));
-        PLAN_TRY(set_lds(rts_gain_kernel<2>, p->lds_gain)); PLAN_TRY(set_lds(rts_compose_kernel<2>, p->lds_scan)); PLAN_TRY(set_lds(rts_boundary_kernel<2>, p->lds_scan)); PLAN_TRY(set_lds(rts_apply_kernel<2>, p->lds_scan)); break;
-      case 3:
-        PLAN_TRY(ekf ? set_lds(gf_filter_kernel<3, 1>, p->lds_filter) : set_lds(gf_filter_kernel<3, 0>, p->lds_filter));
-        PLAN_TRY(set_lds(rts_gain_kernel<3>, p->lds_gain)); PLAN_TRY(set_lds(rts_compose_kernel<3>, p->lds_scan)); PLAN_TRY(set_lds(rts_boundary_kernel<3>, p->lds_scan)); PLAN_TRY(set_lds(rts_apply_kernel<3>, p->lds_scan)); break;
-      default:
-        PLAN_TRY(ekf ? set_lds(gf_filter_kernel<4, 1>, p->lds_filter) : set_lds(gf_filter_kernel<4, 0>, p->lds_filter));
-        PLAN_TRY(set_lds(rts_gain_kernel<4>, p->lds_gain)); PLAN_TRY(set_lds(rts_compose_kernel<4>, p->lds_scan)); PLAN_TRY(set_lds(rts_boundary_kernel<4>, p->lds_scan)); PLAN_TRY(set_lds(rts_apply_kernel<4>, p->lds_scan)); break;
+      case 1: PLAN_TRY(set_lds(rts_gain_kernel<1>, p->lds_gain)); PLAN_TRY(set_lds(rts_compose_kernel<1>, p->lds_scan)); PLAN_TRY(set_lds(rts_boundary_kernel<1>, p->lds_scan)); PLAN_TRY(set_lds(rts_apply_kernel<1>, p->lds_scan)); break;
+      case 2: PLAN_TRY(set_lds(rts_gain_kernel<2>, p->lds_gain)); PLAN_TRY(set_lds(rts_compose_kernel<2>, p->lds_scan)); PLAN_TRY(set_lds(rts_boundary_kernel<2>, p->lds_scan)); PLAN_TRY(set_lds(rts_apply_kernel<2>, p->lds_scan)); break;
+      case 3: PLAN_TRY(set_lds(rts_gain_kernel<3>, p->lds_gain)); PLAN_TRY(set_lds(rts_compose_kernel<3>, p->lds_scan)); PLAN_TRY(set_lds(rts_boundary_kernel<3>, p->lds_scan)); PLAN_TRY(set_lds(rts_apply_kernel<3>, p->lds_scan)); break;
+      default: PLAN_TRY(set_lds(rts_gain_kernel<4>, p->lds_gain)); PLAN_TRY(set_lds(rts_compose_kernel<4>, p->lds_scan)); PLAN_TRY(set_lds(rts_boundary_kernel<4>, p->lds_scan)); PLAN_TRY(set_lds(rts_apply_kernel<4>, p->lds_scan)); break;
     }
   }
   if (!ekf) {
@@ -434,7 +437,7 @@ static int launch_filter(nagp_plan* p, const FilterPar& fp_in) {
   Timed t(p, NAGP_K_FILTER);
   dim3 g(p->B), bl(p->NT_f);
 #define LF(TP, ME) hipLaunchKernelGGL((gf_filter_kernel<TP, ME>), g, bl, p->lds_filter, p->stream, p->sh, p->b, mc, fp)
-  switch (p->TPT) {
+  switch (p->TPT_f) {
     case 1: if (ekf) LF(1, 1); else LF(1, 0); break;
     case 2: if (ekf) LF(2, 1); else LF(2, 0); break;
     case 3: if (ekf) LF(3, 1); else LF(3, 0); break;

@@ -196,7 +196,7 @@ __device__ __forceinline__ double link_eval(int kind, double shift, double g) {
 template <int CD>   // CD = cubature dimension for the NMF likelihoods (1..8); 0 = POWER (cdim = D)
 __device__ __forceinline__ void mom_eval_impl(const MomCfg& c, const double* Wl, double sn2, double alpha,
                                               double y, const double* mu, const double* s2, double* ws, double* lZ, double* dl,
-                                              double* d2l, unsigned long long* acc_st) {
+                                              double* d2l, unsigned long long* acc_st, double pEP) {
   const int tid = threadIdx.x, NT = blockDim.x;
   const int D = c.D, cd = (CD > 0) ? CD : c.cdim, CH = mom_chunk(c), nd = c.nd;
   const int nout = D + cd + 1;
@@ -375,8 +375,6 @@ __device__ __forceinline__ void mom_eval_impl(const MomCfg& c, const double* Wl,
   }
   // ---- phase 3
   {
-    double pEP = 1.0;
-    if (sq) pEP = pow(2.0 * 3.14159265358979323846 * sn2, 0.5 * (1.0 - alpha)) / sqrt(alpha);
     const double Zs = sums1[D + cd];
     const double Z = pEP * ((Zs > c.jitter) ? Zs : c.jitter);  // max(NaN,jitter)=jitter
     const double Zinv = 1.0 / Z;
@@ -392,24 +390,32 @@ __device__ __forceinline__ void mom_eval_impl(const MomCfg& c, const double* Wl,
 #undef NAGP_STAMP
 }
 
-// Wl: NMF weights in LDS (D x N row-major); Wu unused (kept for call-site symmetry)
-__device__ __forceinline__ void mom_eval(const MomCfg& c, const double* Wl, const double* Wu, double sn2, double alpha,
+// Wl: NMF weights in LDS (D x N row-major)
+// power-EP normaliser of likModulatorPreCalcwn.m:48 (1 for the other likelihoods); constant per kernel
+__device__ inline double mom_pEP(const MomCfg& c, double sn2, double alpha) {
+  return (c.lik_kind == 2) ? pow(2.0 * 3.14159265358979323846 * sn2, 0.5 * (1.0 - alpha)) / sqrt(alpha) : 1.0;
+}
+__device__ __forceinline__ void mom_eval(const MomCfg& c, const double* Wl, double pEP, double sn2, double alpha,
                                          double y, const double* mu, const double* s2, double* ws, double* lZ, double* dl,
                                          double* d2l, unsigned long long* acc_st = nullptr) {
-  (void)Wu;
   unsigned long long dummy_st[4];
   if (!acc_st) acc_st = dummy_st;
   const int sel = __builtin_amdgcn_readfirstlane(c.lik_kind == 0 ? 0 : c.cdim);
+#ifdef NAGP_ONLY_CD
+  (void)sel;
+  mom_eval_impl<NAGP_ONLY_CD>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st, pEP);
+  return;
+#endif
   switch (sel) {
-    case 0: mom_eval_impl<0>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st); break;
-    case 1: mom_eval_impl<1>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st); break;
-    case 2: mom_eval_impl<2>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st); break;
-    case 3: mom_eval_impl<3>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st); break;
-    case 4: mom_eval_impl<4>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st); break;
-    case 5: mom_eval_impl<5>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st); break;
-    case 6: mom_eval_impl<6>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st); break;
-    case 7: mom_eval_impl<7>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st); break;
-    default: mom_eval_impl<8>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st); break;
+    case 0: mom_eval_impl<0>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st, pEP); break;
+    case 1: mom_eval_impl<1>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st, pEP); break;
+    case 2: mom_eval_impl<2>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st, pEP); break;
+    case 3: mom_eval_impl<3>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st, pEP); break;
+    case 4: mom_eval_impl<4>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st, pEP); break;
+    case 5: mom_eval_impl<5>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st, pEP); break;
+    case 6: mom_eval_impl<6>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st, pEP); break;
+    case 7: mom_eval_impl<7>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st, pEP); break;
+    default: mom_eval_impl<8>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st, pEP); break;
   }
 }
 

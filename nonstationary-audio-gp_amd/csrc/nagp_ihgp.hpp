@@ -118,6 +118,7 @@ __global__ void __launch_bounds__(512) ihgp_filter_kernel(Shape sh, Bufs b, MomC
   for (int i = tid; i < NG; i += NT) rg[i] = tb.r[i];
   const double sn2 = mdl[mdl_sn2(sh)];
   mom_cache_tables(mc, ws);
+  const double pEP1 = mom_pEP(mc, sn2, 1.0);
   __syncthreads();
 
   // thread n < M owns block n
@@ -194,7 +195,7 @@ __global__ void __launch_bounds__(512) ihgp_filter_kernel(Shape sh, Bufs b, MomC
       if (do_mom) {
         lds_barrier();
         if (mc.stamps && tid == 0) { st_b = __builtin_readcyclecounter(); st[4] += st_b - st_a; }
-        mom_eval(mc, sW, mdl + mdl_W(sh), sn2, 1.0, yk, fmu, HPH, ws, &misc[0], dl, d2l, st);
+        mom_eval(mc, sW, pEP1, sn2, 1.0, yk, fmu, HPH, ws, &misc[0], dl, d2l, st);
         if (act) {
           const double d1 = dl[n], d2 = d2l[n];
           const double t_old = rtt[kk * M + n], n_old = rtn[kk * M + n];

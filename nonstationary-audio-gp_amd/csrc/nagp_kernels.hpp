@@ -149,9 +149,23 @@ __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg
   for (int i = tid; i < sh.D * sh.N; i += NT) sW[i] = mdl[mdl_W(sh) + i];
   const double sn2 = mdl[mdl_sn2(sh)];
   if (MEAS == 0) mom_cache_tables(mc, ws);
+  const double pEP1 = (MEAS == 0) ? mom_pEP(mc, sn2, 1.0) : 1.0;
 
-  TileOwner<TPT> own;
-  own.init(M, sh.ntiles);
+  // The covariance is kept exactly symmetric: only the lower-triangular tiles (I >= J) are held (one thread
+  // per tile); K*H*P and K*W' coincide, W = P H' is the only panel needed, and the filtered covariance is
+  // stored as the tile and its transpose.
+  struct { int I[TPT], J[TPT]; bool ok[TPT]; } own;
+  const int nlow = M * (M + 1) / 2;
+#pragma unroll
+  for (int q = 0; q < TPT; ++q) {
+    const int t = tid + q * NT;
+    own.ok[q] = t < nlow;
+    const int tt_ = own.ok[q] ? t : 0;
+    int I = (int)((sqrt(8.0 * tt_ + 1.0) - 1.0) * 0.5);
+    while ((I + 1) * (I + 2) / 2 <= tt_) ++I;
+    while (I * (I + 1) / 2 > tt_) --I;
+    own.I[q] = I; own.J[q] = tt_ - I * (I + 1) / 2;
+  }
   double P[TPT][16];
   const double* st = b.state + (size_t)pb * ((size_t)sh.ntiles * 16 + S);
 #pragma unroll
@@ -226,11 +240,14 @@ __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg
             }
           }
           const double hJ = shv[J], hI = shv[I];
+          // P(rows of I, c_J)
 #pragma unroll
           for (int i = 0; i < 4; ++i) Wl[((size_t)J * 4 + i) * M + I] = hJ * P[q][4 * i];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) HPl[((size_t)I * 4 + j) * M + J] = hI * P[q][j];
           if (I == J) HPH[I] = hI * hI * P[q][0];
+          else {               // P(rows of J, c_I) = P(c_I, cols of J) by symmetry
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Wl[((size_t)I * 4 + j) * M + J] = hI * P[q][j];
+          }
         }
       }
       lds_barrier();  // B1
@@ -240,7 +257,7 @@ __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg
         if (MEAS == 0) {
           const bool do_mom = fp.mom_all || (k == T - 1);
           if (do_mom) {
-            mom_eval(mc, sW, mdl + mdl_W(sh), sn2, 1.0, yk, fmu, HPH, ws, &misc[0], dl, d2l);
+            mom_eval(mc, sW, pEP1, sn2, 1.0, yk, fmu, HPH, ws, &misc[0], dl, d2l);
             if (tid < M) {
               const double d2 = d2l[tid], d1 = dl[tid], hp = HPH[tid], f = fmu[tid];
               const double t_old = rtt[kk * M + tid], n_old = rtn[kk * M + tid];
@@ -294,13 +311,13 @@ __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg
             rm = (a0 + a1) + (a2 + a3);
             m[tid] = rm;
           }
-          // P -= sum_n (W[:,n] cA[n]) * R_n,   R_n = (H P)[n,:]  (or W[:,n]' in the legacy form)
-          const double* Rt = legacyA ? Wl : HPl;
+          // P -= sum_n cA[n] W[:,n] W[:,n]'   (K*H*P and K*W' coincide for the symmetric P)
+          (void)legacyA;
 #pragma unroll
           for (int q = 0; q < TPT; ++q) {
             if (own.ok[q]) {
               const double* wbase = Wl + own.I[q];
-              const double* rbase = Rt + own.J[q];
+              const double* rbase = Wl + own.J[q];
               int n0 = 0;
               for (; n0 + 2 <= M; n0 += 2) {   // two sites per trip: 16 LDS reads in flight before the FMAs
                 double w4[2][4], r4[2][4];
@@ -406,7 +423,18 @@ __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg
       if (g_PF) {
 #pragma unroll
         for (int q = 0; q < TPT; ++q)
-          if (own.ok[q]) tile_store(g_PF + ((size_t)k * sh.ntiles + tid + q * NT) * 16, P[q]);
+          if (own.ok[q]) {
+            double* base = g_PF + (size_t)k * sh.ntiles * 16;
+            tile_store(base + ((size_t)own.I[q] * M + own.J[q]) * 16, P[q]);
+            if (own.I[q] != own.J[q]) {
+              double tr[16];
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) tr[4 * j + i] = P[q][4 * i + j];
+              tile_store(base + ((size_t)own.J[q] * M + own.I[q]) * 16, tr);
+            }
+          }
       }
       lds_barrier();  // B5
     }
@@ -1079,6 +1107,7 @@ __global__ void __launch_bounds__(256) ep_site_kernel(Shape sh, Bufs b, MomCfg m
   for (int i = tid; i < sh.D * sh.N; i += NT) sW[i] = mdl[mdl_W(sh) + i];
   const double sn2 = mdl[mdl_sn2(sh)];
   mom_cache_tables(mc, ws);
+  const double pEPa = mom_pEP(mc, sn2, ep.alpha);
   lds_barrier();
   const int64_t kb = (int64_t)blockIdx.x * ep.steps_per_wg;
   unsigned long long n_clamped = 0;
@@ -1095,7 +1124,7 @@ __global__ void __launch_bounds__(256) ep_site_kernel(Shape sh, Bufs b, MomCfg m
       mc_[tid] = mcav; vc_[tid] = vcav;
     }
     lds_barrier();
-    mom_eval(mc, sW, mdl + mdl_W(sh), sn2, ep.alpha, yk, mc_, vc_, ws, &misc[0], dl, d2l);
+    mom_eval(mc, sW, pEPa, sn2, ep.alpha, yk, mc_, vc_, ws, &misc[0], dl, d2l);
     if (tid < M) {
       const bool upd = vcav > 0.0;
       double tnew = t_old, nnew = n_old;

@@ -4,6 +4,7 @@
 // matlab/gf_ep_modulator_nmf.m:113-283 (predict) / :384-522 (nlml), ihgp_ep_modulator_nmf.m:223-454
 // and gf_giekf_modulator_nmf.m:126-221.
 #include "nagp_ihgp.hpp"
+#include "nagp_mfma.hpp"
 #include "../../include/nagp.h"
 
 #include <cmath>
@@ -46,6 +47,9 @@ struct nagp_plan {
   int TPT = 1, TPT_f = 1, NT = 256, NT_f = 256, NT_ih = 256;
   int chunk = 2048, LP1 = 1, LP2 = 1, ns_max = 1;
   SpanPar spar{};
+  int mfma_sp = 0;      // > 0: FP64-MFMA smoother passes on dense Sp x Sp matrices
+  MfmaPar mpar{};
+  size_t lds_mfma = 0;
   int DG_f = 1, DG_ep = 1, cache_f = 0, cache_ep = 0, sta_f = 0, sta_ep = 0, kb_f = 16;
   bool want_PS = false;
   bool need_PF = false;
@@ -286,11 +290,16 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
   if (p->chunk > T) p->chunk = (int)T;
   if (o->kind != NAGP_KIND_IHGP) {
     // keep the (G, Delta) chunk buffer under ~8 GiB
-    const double per_step = (double)B * 2.0 * nt * 128.0;
+    const double per_step = (double)B * 2.0 * std::max<double>(nt * 16.0, 96.0 * 96.0) * 8.0;
     while (p->chunk > 64 && per_step * p->chunk > 24.0 * 1073741824.0) p->chunk = (p->chunk + 1) / 2;
     if (p->need_PF) PLAN_TRY(dalloc(p, &b.PF, BT * nt * 16, false));
     if (p->want_PS) PLAN_TRY(dalloc(p, &b.PSs, BT * nt * 16, false));
-    PLAN_TRY(dalloc(p, &b.Gbuf, (size_t)B * p->chunk * 2 * nt * 16, false));
+    {   // FP64 MFMA smoother for padded dimensions up to 96 (set NAGP_NO_MFMA=1 to force the VALU passes)
+      const int Sp = ((4 * sh.M + 15) / 16) * 16;
+      if (Sp <= 96 && !getenv("NAGP_NO_MFMA")) p->mfma_sp = Sp;
+    }
+    const size_t mat = p->mfma_sp ? (size_t)p->mfma_sp * p->mfma_sp : (size_t)nt * 16;
+    PLAN_TRY(dalloc(p, &b.Gbuf, (size_t)B * p->chunk * 2 * mat, true));
     PLAN_TRY(dalloc(p, &b.dbuf, (size_t)B * p->chunk * sh.S, false));
     // panel widths: one tile per thread per operand panel, panels (double buffered) within 72 KiB of LDS
     const double cap = 72.0 * 1024.0;
@@ -307,6 +316,14 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     PLAN_TRY(dalloc(p, &p->spar.spanvec, (size_t)B * p->ns_max * sh.S, false));
     PLAN_TRY(dalloc(p, &p->spar.bnd, (size_t)B * p->ns_max * ((size_t)nt * 16 + sh.S), false));
     PLAN_TRY(dalloc(p, &p->spar.xbuf, (size_t)B * p->ns_max * nt * 16, false));
+    if (p->mfma_sp) {
+      const size_t SS = (size_t)p->mfma_sp * p->mfma_sp;
+      PLAN_TRY(dalloc(p, &p->mpar.spanbuf, (size_t)B * p->ns_max * 2 * SS, false));
+      PLAN_TRY(dalloc(p, &p->mpar.spanvec, (size_t)B * p->ns_max * sh.S, false));
+      PLAN_TRY(dalloc(p, &p->mpar.bnd, (size_t)B * p->ns_max * (SS + sh.S), false));
+      PLAN_TRY(dalloc(p, &p->mpar.stateD, (size_t)B * (SS + sh.S), true));
+      p->lds_mfma = mfma_lds_doubles(p->mfma_sp) * sizeof(double);
+    }
   } else {
     PLAN_TRY(dalloc(p, &p->d_lZs, BT));
     PLAN_TRY(dalloc(p, &p->d_stamps, 8));
@@ -389,6 +406,11 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
       default: PLAN_TRY(set_lds(rts_gain_kernel<4>, p->lds_gain)); PLAN_TRY(set_lds(rts_compose_kernel<4>, p->lds_scan)); PLAN_TRY(set_lds(rts_boundary_kernel<4>, p->lds_scan)); PLAN_TRY(set_lds(rts_apply_kernel<4>, p->lds_scan)); break;
     }
   }
+  if (p->mfma_sp) {
+#define SETM(N) PLAN_TRY(set_lds(rts_compose_mfma_kernel<N>, p->lds_mfma)); PLAN_TRY(set_lds(rts_boundary_mfma_kernel<N>, p->lds_mfma)); PLAN_TRY(set_lds(rts_apply_mfma_kernel<N>, p->lds_mfma))
+    switch (p->mfma_sp / 16) { case 1: SETM(1); break; case 2: SETM(2); break; case 3: SETM(3); break; case 4: SETM(4); break; case 5: SETM(5); break; default: SETM(6); break; }
+#undef SETM
+  }
   if (!ekf) {
     p->DG_ep = pick_DG(o->n_pts, 256, sh.D);
     MomCfg t = mc; t.DG = p->DG_ep; t.cache_tabs = 1; t.store_a = 1;
@@ -455,7 +477,7 @@ static int launch_smoother(nagp_plan* p, bool write_PSs) {
   for (int64_t k1 = nsm; k1 > 0;) {
     const int nk = (int)std::min<int64_t>(p->chunk, k1);
     const int64_t k0 = k1 - nk;
-    GainPar gp{k0, nk, p->chunk};
+    GainPar gp{k0, nk, p->chunk, p->mfma_sp};
     {
       Timed t(p, NAGP_K_GAIN);
       dim3 g(nk, p->B), bl(p->NT);
@@ -476,6 +498,19 @@ static int launch_smoother(nagp_plan* p, bool write_PSs) {
       sp.L = (nk + ns - 1) / ns;
       sp.ns = (nk + sp.L - 1) / sp.L;
     }
+    if (p->mfma_sp) {
+      MfmaPar mp = p->mpar;
+      mp.k0 = k0; mp.nk = nk; mp.chunk = p->chunk; mp.L = sp.L; mp.ns = sp.ns; mp.ns_max = p->ns_max; mp.Sp = p->mfma_sp;
+      mp.first = first ? 1 : 0; mp.write_PSs = write_PSs ? 1 : 0;
+      Timed t(p, NAGP_K_SCAN);
+      dim3 g(mp.ns, p->B), g2(p->B), bl(256);
+#define LM(N) do { \
+        hipLaunchKernelGGL((rts_compose_mfma_kernel<N>), g, bl, p->lds_mfma, p->stream, sh, p->b, mp); \
+        hipLaunchKernelGGL((rts_boundary_mfma_kernel<N>), g2, bl, p->lds_mfma, p->stream, sh, p->b, mp); \
+        hipLaunchKernelGGL((rts_apply_mfma_kernel<N>), g, bl, p->lds_mfma, p->stream, sh, p->b, mp); } while (0)
+      switch (p->mfma_sp / 16) { case 1: LM(1); break; case 2: LM(2); break; case 3: LM(3); break; case 4: LM(4); break; case 5: LM(5); break; default: LM(6); break; }
+#undef LM
+    } else
     {
       Timed t(p, NAGP_K_SCAN);
       dim3 g(sp.ns, p->B), g2(p->B), bl(p->NT);

@@ -464,6 +464,7 @@ struct GainPar {
   int64_t k0;   // first step of the chunk
   int nk;       // steps in the chunk
   int chunk;    // chunk capacity (buffer stride)
+  int dense_sp; // 0: (G, Delta) tile-major ; > 0: dense row-major Sp x Sp (input layout of the MFMA smoother passes)
 };
 
 __host__ __device__ inline size_t gain_lds_doubles(const Shape& s) {
@@ -559,8 +560,23 @@ __global__ void __launch_bounds__(512) rts_gain_kernel(Shape sh, Bufs b, GainPar
   own.init(M, sh.ntiles);
   const double* PFk = b.PF + ((size_t)pb * T + k) * sh.ntiles * 16;
   const double* PFk1 = PFk + (size_t)sh.ntiles * 16;
-  double* Gout = b.Gbuf + (((size_t)pb * gp.chunk + kk) * 2) * sh.ntiles * 16;
-  double* Dout = Gout + (size_t)sh.ntiles * 16;
+  const size_t mstride = gp.dense_sp ? (size_t)gp.dense_sp * gp.dense_sp : (size_t)sh.ntiles * 16;
+  double* Gout = b.Gbuf + (((size_t)pb * gp.chunk + kk) * 2) * mstride;
+  double* Dout = Gout + mstride;
+  // tile (I,J) -> output location (tile-major: 16 contiguous doubles; dense: 4 rows of 4 at row stride Sp)
+  auto put_tile = [&](double* base, int I, int J, const double* t16) {
+    if (gp.dense_sp) {
+      double2* d0 = reinterpret_cast<double2*>(base + ((size_t)(4 * I) * gp.dense_sp + 4 * J));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        double2* dr = reinterpret_cast<double2*>(reinterpret_cast<double*>(d0) + (size_t)i * gp.dense_sp);
+        dr[0] = make_double2(t16[4 * i], t16[4 * i + 1]);
+        dr[1] = make_double2(t16[4 * i + 2], t16[4 * i + 3]);
+      }
+    } else {
+      tile_store(base + ((size_t)I * sh.M + J) * 16, t16);
+    }
+  };
 
   double Bt[TPT][16], Lt[TPT][16];
 #pragma unroll
@@ -581,7 +597,7 @@ __global__ void __launch_bounds__(512) rts_gain_kernel(Shape sh, Bufs b, GainPar
       tile_load(d, PFk1 + (size_t)t * 16);
 #pragma unroll
       for (int e = 0; e < 16; ++e) d[e] -= Lt[q][e];
-      tile_store(Dout + (size_t)t * 16, d);                 // Delta_k
+      put_tile(Dout, I, J, d);                              // Delta_k
     }
   }
   // delta_k = MF_{k+1} - A MF_k
@@ -691,7 +707,7 @@ __global__ void __launch_bounds__(512) rts_gain_kernel(Shape sh, Bufs b, GainPar
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           if (i >= bI || j >= bJ) Bt[q][4 * i + j] = 0.0;
-      tile_store(Gout + (size_t)(tid + q * NT) * 16, Bt[q]);
+      put_tile(Gout, own.I[q], own.J[q], Bt[q]);
     }
 }
 

@@ -292,7 +292,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     // keep the (G, Delta) chunk buffer under ~8 GiB
     const double per_step = (double)B * 2.0 * std::max<double>(nt * 16.0, 96.0 * 96.0) * 8.0;
     while (p->chunk > 64 && per_step * p->chunk > 24.0 * 1073741824.0) p->chunk = (p->chunk + 1) / 2;
-    if (p->need_PF) PLAN_TRY(dalloc(p, &b.PF, BT * nt * 16, false));
+    if (p->need_PF) PLAN_TRY(dalloc(p, &b.PF, BT * pf_ntiles(sh) * 16, false));   // lower-triangular tiles only
     if (p->want_PS) PLAN_TRY(dalloc(p, &b.PSs, BT * nt * 16, false));
     {   // FP64 MFMA smoother for padded dimensions up to 96 (set NAGP_NO_MFMA=1 to force the VALU passes)
       const int Sp = ((4 * sh.M + 15) / 16) * 16;
@@ -635,7 +635,17 @@ static int exec_giekf(nagp_plan* p) {
     if (sh.T == 1) {   // no smoothing step: the restart state is the filtered one
       for (int q = 0; q < B; ++q) {
         double* st = p->b.state + (size_t)q * ((size_t)sh.ntiles * 16 + sh.S);
-        HIP_TRY(hipMemcpyAsync(st, p->b.PF + (size_t)q * sh.ntiles * 16, (size_t)sh.ntiles * 128, hipMemcpyDeviceToDevice, p->stream));
+        std::vector<double> lo((size_t)pf_ntiles(sh) * 16), full((size_t)sh.ntiles * 16);
+        HIP_TRY(hipMemcpyAsync(lo.data(), p->b.PF + (size_t)q * pf_ntiles(sh) * 16, lo.size() * 8, hipMemcpyDeviceToHost, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        for (int Ib = 0; Ib < sh.M; ++Ib)
+          for (int Jb = 0; Jb < sh.M; ++Jb)
+            for (int i = 0; i < 4; ++i)
+              for (int j = 0; j < 4; ++j)
+                full[((size_t)Ib * sh.M + Jb) * 16 + 4 * i + j] = (Ib >= Jb) ? lo[((size_t)Ib * (Ib + 1) / 2 + Jb) * 16 + 4 * i + j]
+                                                                            : lo[((size_t)Jb * (Jb + 1) / 2 + Ib) * 16 + 4 * j + i];
+        HIP_TRY(hipMemcpyAsync(st, full.data(), full.size() * 8, hipMemcpyHostToDevice, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
         HIP_TRY(hipMemcpyAsync(st + (size_t)sh.ntiles * 16, p->b.MF + (size_t)q * sh.S, sh.S * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
       }
     }
@@ -811,7 +821,17 @@ extern "C" int nagp_plan_download(nagp_plan* p, nagp_out* outs) {
         // smoothed tiles for k < T-1; the last step is the filtered one
         const int64_t nsm = std::min<int64_t>(nk, std::max<int64_t>(0, (T - 1) - k0));
         if (nsm > 0) HIP_TRY(hipMemcpy(tmp.data(), p->b.PSs + ((size_t)q * T + k0) * tl, (size_t)nsm * tl * 8, hipMemcpyDeviceToHost));
-        if (nsm < nk) HIP_TRY(hipMemcpy(tmp.data() + (size_t)nsm * tl, p->b.PF + ((size_t)q * T + (T - 1)) * tl, tl * 8, hipMemcpyDeviceToHost));
+        if (nsm < nk) {
+          std::vector<double> lo((size_t)pf_ntiles(sh) * 16);
+          HIP_TRY(hipMemcpy(lo.data(), p->b.PF + ((size_t)q * T + (T - 1)) * pf_ntiles(sh) * 16, lo.size() * 8, hipMemcpyDeviceToHost));
+          double* full = tmp.data() + (size_t)nsm * tl;
+          for (int Ib = 0; Ib < M; ++Ib)
+            for (int Jb = 0; Jb < M; ++Jb)
+              for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 4; ++j)
+                  full[((size_t)Ib * M + Jb) * 16 + 4 * i + j] = (Ib >= Jb) ? lo[((size_t)Ib * (Ib + 1) / 2 + Jb) * 16 + 4 * i + j]
+                                                                           : lo[((size_t)Jb * (Jb + 1) / 2 + Ib) * 16 + 4 * j + i];
+        }
         for (int64_t kk = 0; kk < nk; ++kk) {
           double* dst = o.PS + (size_t)(k0 + kk) * S * S;
           const double* src = tmp.data() + (size_t)kk * tl;

@@ -69,6 +69,25 @@ struct FilterPar {
   int kb;               // steps per I/O block (LDS ring)
 };
 
+// The filtered covariance is symmetric: PF holds only the lower-triangular tiles, tile (I,J), I >= J, at
+// index I(I+1)/2 + J.  pf_load returns tile (I,J) of the full matrix (transposing the stored tile for I < J).
+__host__ __device__ inline int pf_ntiles(const Shape& s) { return s.M * (s.M + 1) / 2; }
+__device__ __forceinline__ void pf_load(double* t, const double* PFk, int I, int J) {
+  if (I >= J) {
+    tile_load(t, PFk + ((size_t)I * (I + 1) / 2 + J) * 16);
+  } else {
+    double u[16];
+    tile_load(u, PFk + ((size_t)J * (J + 1) / 2 + I) * 16);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) t[4 * i + j] = u[4 * j + i];
+  }
+}
+__device__ __forceinline__ double pf_elem(const double* PFk, int I, int J, int i, int j) {
+  return (I >= J) ? PFk[((size_t)I * (I + 1) / 2 + J) * 16 + 4 * i + j] : PFk[((size_t)J * (J + 1) / 2 + I) * 16 + 4 * j + i];
+}
+
 // thread tid owns tiles t = tid + q*NT (q < TPT)
 template <int TPT>
 struct TileOwner {
@@ -195,7 +214,7 @@ __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg
   double* g_MF = b.MF + (size_t)pb * T * S;
   double* g_fm = b.fm + (size_t)pb * T * M;
   double* g_fv = b.fv + (size_t)pb * T * M;
-  double* g_PF = (b.PF && fp.store_PF) ? b.PF + (size_t)pb * T * sh.ntiles * 16 : nullptr;
+  double* g_PF = (b.PF && fp.store_PF) ? b.PF + (size_t)pb * T * pf_ntiles(sh) * 16 : nullptr;
   unsigned long long n_clamped = 0, n_nan = 0;
 
   for (int64_t k0 = 0; k0 < T; k0 += KB) {
@@ -424,16 +443,7 @@ __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg
 #pragma unroll
         for (int q = 0; q < TPT; ++q)
           if (own.ok[q]) {
-            double* base = g_PF + (size_t)k * sh.ntiles * 16;
-            tile_store(base + ((size_t)own.I[q] * M + own.J[q]) * 16, P[q]);
-            if (own.I[q] != own.J[q]) {
-              double tr[16];
-#pragma unroll
-              for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) tr[4 * j + i] = P[q][4 * i + j];
-              tile_store(base + ((size_t)own.J[q] * M + own.I[q]) * 16, tr);
-            }
+            tile_store(g_PF + ((size_t)k * nlow + tid + q * NT) * 16, P[q]);   // lower tile index == ownership index
           }
       }
       lds_barrier();  // B5
@@ -558,8 +568,8 @@ __global__ void __launch_bounds__(512) rts_gain_kernel(Shape sh, Bufs b, GainPar
 
   TileOwner<TPT> own;
   own.init(M, sh.ntiles);
-  const double* PFk = b.PF + ((size_t)pb * T + k) * sh.ntiles * 16;
-  const double* PFk1 = PFk + (size_t)sh.ntiles * 16;
+  const double* PFk = b.PF + ((size_t)pb * T + k) * pf_ntiles(sh) * 16;
+  const double* PFk1 = PFk + (size_t)pf_ntiles(sh) * 16;
   const size_t mstride = gp.dense_sp ? (size_t)gp.dense_sp * gp.dense_sp : (size_t)sh.ntiles * 16;
   double* Gout = b.Gbuf + (((size_t)pb * gp.chunk + kk) * 2) * mstride;
   double* Dout = Gout + mstride;
@@ -585,7 +595,7 @@ __global__ void __launch_bounds__(512) rts_gain_kernel(Shape sh, Bufs b, GainPar
     if (own.ok[q]) {
       const int I = own.I[q], J = own.J[q], t = tid + q * NT;
       double ps[16];
-      tile_load(ps, PFk + (size_t)t * 16);
+      pf_load(ps, PFk, I, J);
       tile_mma_nt(Bt[q], ps, sA + (size_t)J * 16);          // B = PS A'
       tile_mma(Lt[q], sA + (size_t)I * 16, Bt[q]);          // PSkp = A B (+Q)
       if (I == J) {
@@ -594,7 +604,7 @@ __global__ void __launch_bounds__(512) rts_gain_kernel(Shape sh, Bufs b, GainPar
         for (int e = 0; e < 16; ++e) Lt[q][e] += Qb[e];
       }
       double d[16];
-      tile_load(d, PFk1 + (size_t)t * 16);
+      pf_load(d, PFk1, I, J);
 #pragma unroll
       for (int e = 0; e < 16; ++e) d[e] -= Lt[q][e];
       put_tile(Dout, I, J, d);                              // Delta_k
@@ -1045,7 +1055,7 @@ __global__ void __launch_bounds__(512) rts_apply_kernel(Shape sh, Bufs b, SpanPa
     for (int q = 0; q < TPT; ++q) tile_zero(acc[q]);
     gemm_nt<TPT>(c, sp.LP2, acc, Xb, Gk);
     // ---- store E_k, outputs
-    const double* PFk = b.PF + ((size_t)pb * T + k) * ntl * 16;
+    const double* PFk = b.PF + ((size_t)pb * T + k) * pf_ntiles(sh) * 16;
 #pragma unroll
     for (int q = 0; q < TPT; ++q)
       if (c.own.ok[q]) {
@@ -1060,7 +1070,7 @@ __global__ void __launch_bounds__(512) rts_apply_kernel(Shape sh, Bufs b, SpanPa
         }
         if (sp.write_PSs || k == 0) {
           double ps[16];
-          tile_load(ps, PFk + (size_t)t * 16);
+          pf_load(ps, PFk, c.own.I[q], c.own.J[q]);
 #pragma unroll
           for (int x = 0; x < 16; ++x) ps[x] += acc[q][x];
           if (sp.write_PSs) tile_store(b.PSs + (((size_t)pb * T + k) * ntl + t) * 16, ps);

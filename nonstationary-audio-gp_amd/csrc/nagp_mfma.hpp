@@ -213,7 +213,7 @@ __global__ void __launch_bounds__(256) rts_apply_mfma_kernel(Shape sh, Bufs b, M
             const int I = row >> 2, J = col >> 2;
             if (I < M && J < M) {
               const size_t tix = (((size_t)pb * T + k) * sh.ntiles + (size_t)I * M + J) * 16 + 4 * (row & 3) + (col & 3);
-              const double ps = b.PF[tix] + E[q][r];
+              const double ps = pf_elem(b.PF + ((size_t)pb * T + k) * pf_ntiles(sh) * 16, I, J, row & 3, col & 3) + E[q][r];
               if (sp.write_PSs) b.PSs[tix] = ps;
               if (k == 0) b.state[(size_t)pb * ((size_t)sh.ntiles * 16 + S) + ((size_t)I * M + J) * 16 + 4 * (row & 3) + (col & 3)] = ps;
             }

@@ -231,6 +231,10 @@ __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg
       const int64_t k = k0 + kk;
       const double yk = ry[kk];
       const bool pred = (k > 0) || fp.predict_k1;
+      const bool do_mom = (MEAS == 0) && (fp.mom_all || (k == T - 1));
+      // steps without a mom call: the owner of diagonal tile (n,n) also forms the gain coefficients of site n,
+      // which removes one barrier-separated phase from the step
+      const bool early = (MEAS == 0) && !do_mom && !(yk != yk);
       // ---- S0: prediction (registers), publish W = P H', H P, diag(H P H'), fmu = H m
       double rm = 0.0;
       if (tid < S) {
@@ -262,8 +266,35 @@ __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg
           // P(rows of I, c_J)
 #pragma unroll
           for (int i = 0; i < 4; ++i) Wl[((size_t)J * 4 + i) * M + I] = hJ * P[q][4 * i];
-          if (I == J) HPH[I] = hI * hI * P[q][0];
-          else {               // P(rows of J, c_I) = P(c_I, cols of J) by symmetry
+          if (I == J) {
+            const double hp = hI * hI * P[q][0];
+            HPH[I] = hp;
+            if (early) {
+              double f;
+              if (pred) {
+                const double* a = sA + (size_t)I * TS;
+                const double* mb = m + ioff[I];
+                f = 0.0;
+#pragma unroll
+                for (int l = 0; l < 4; ++l)
+                  if (l < ibsz[I]) f = fma(a[l], mb[l], f);
+                f *= hI;
+              } else {
+                f = hI * m[ioff[I]];
+              }
+              double t = rtt[kk * M + I];
+              if (fp.clamp_always) { t = max0(t); rtt[kk * M + I] = t; }
+              const double n_ = rtn[kk * M + I];
+              bool formA = (t == 0.0);
+              if (fp.legacy_update) {
+                double mn = max0(rtt[kk * M]);
+                for (int u = 1; u < M; ++u) mn = fmin(mn, max0(rtt[kk * M + u]));
+                formA = (mn == 0.0);
+              }
+              if (formA) { const double z = t * hp + 1.0; cA[I] = t / z; cm[I] = -(t * f - n_) / z; }
+              else { const double s = 1.0 / (hp + 1.0 / t); cA[I] = s; cm[I] = s * (n_ / t - f); }
+            }
+          } else {             // P(rows of J, c_I) = P(c_I, cols of J) by symmetry
 #pragma unroll
             for (int j = 0; j < 4; ++j) Wl[((size_t)I * 4 + j) * M + J] = hI * P[q][j];
           }
@@ -274,7 +305,6 @@ __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg
 
       if (!(yk != yk)) {  // ~isnan(y_k)
         if (MEAS == 0) {
-          const bool do_mom = fp.mom_all || (k == T - 1);
           if (do_mom) {
             mom_eval(mc, sW, pEP1, sn2, 1.0, yk, fmu, HPH, ws, &misc[0], dl, d2l);
             if (tid < M) {
@@ -289,13 +319,9 @@ __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg
               if (fp.write_R) rR[kk * M + tid] = 1.0 / tnew;
             }
             if (tid == 0) rlZ[kk] = misc[0];
-          } else if (tid < M) {
-            double t_old = rtt[kk * M + tid];
-            if (fp.clamp_always) { t_old = max0(t_old); rtt[kk * M + tid] = t_old; }
-            tt[tid] = t_old; tn[tid] = rtn[kk * M + tid];
           }
-          if (fp.legacy_update) lds_barrier();
-          if (tid < M) {
+          if (do_mom && fp.legacy_update) lds_barrier();
+          if (do_mom && tid < M) {
             const double t = tt[tid], n = tn[tid], hp = HPH[tid], f = fmu[tid];
             bool formA = (t == 0.0);
             if (fp.legacy_update) {
@@ -314,8 +340,7 @@ __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg
             }
             if (tid == 0) misc[1] = formA ? 1.0 : 0.0;
           }
-          lds_barrier();  // B4
-          const bool legacyA = fp.legacy_update && (misc[1] != 0.0);
+          if (do_mom) lds_barrier();  // B4
           if (tid < S) {
             double a0 = rm, a1 = 0.0, a2 = 0.0, a3 = 0.0;
             const double* wp = Wl + (size_t)myrow * M + myblk;
@@ -331,7 +356,6 @@ __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg
             m[tid] = rm;
           }
           // P -= sum_n cA[n] W[:,n] W[:,n]'   (K*H*P and K*W' coincide for the symmetric P)
-          (void)legacyA;
 #pragma unroll
           for (int q = 0; q < TPT; ++q) {
             if (own.ok[q]) {

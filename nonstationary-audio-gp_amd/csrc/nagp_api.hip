@@ -50,7 +50,7 @@ struct nagp_plan {
   int mfma_sp = 0;      // > 0: FP64-MFMA smoother passes on dense Sp x Sp matrices
   MfmaPar mpar{};
   size_t lds_mfma = 0;
-  int DG_f = 1, DG_ep = 1, cache_f = 0, cache_ep = 0, sta_f = 0, sta_ep = 0, kb_f = 16;
+  int hph_lds = 0, DG_f = 1, DG_ep = 1, cache_f = 0, cache_ep = 0, kb_f = 16;
   bool want_PS = false;
   bool need_PF = false;
   hipStream_t stream = nullptr;
@@ -101,11 +101,27 @@ static int dalloc(nagp_plan* p, double** ptr, size_t n_doubles, bool zero = true
   return NAGP_OK;
 }
 
+// run CALL(MV) for the mom variant mv (0 = POWER, 1..8 = NMF cubature dimension)
+#define NAGP_MV_SWITCH(mv, CALL)                                                                         \
+  switch (mv) {                                                                                          \
+    case 0: CALL(0); break; case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break;      \
+    case 4: CALL(4); break; case 5: CALL(5); break; case 6: CALL(6); break; case 7: CALL(7); break;      \
+    default: CALL(8); break;                                                                             \
+  }
+
 static int roundup64(int x) { return ((x + 63) / 64) * 64; }
 
-static int pick_DG(int n_pts, int NT, int D) {
-  int dg = 1;
-  while (dg * 2 <= 16 && dg * 2 <= D && (long long)n_pts * dg * 2 <= NT) dg *= 2;
+// lanes per sigma point in mom (see nagp_dev.hpp).  POWER: as many as keep one trip over the points.
+// NMF: every lane keeps the W rows of <= MOM_NDM sub-bands in registers, and the lane sets 0..cdim of
+// phase 2 own the modulator outputs and Z.
+static int pick_DG(int lik_kind, int n_pts, int NT, int D, int cdim) {
+  if (lik_kind == NAGP_LIK_POWER) {
+    int dg = 1;
+    while (dg * 2 <= 16 && dg * 2 <= D && (long long)n_pts * dg * 2 <= NT) dg *= 2;
+    return dg;
+  }
+  int dg = 4;
+  while (dg < 16 && (dg * MOM_NDM < D || dg < cdim + 1)) dg *= 2;
   return dg;
 }
 
@@ -204,6 +220,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     const int slots = sh.M * (sh.M + 1) / 2;
     p->TPT_f = (slots + 511) / 512;
     if (p->TPT_f > 4) { nagp_plan_destroy(p); FAIL(NAGP_EUNSUPPORTED, "M=%d too large for the filter kernel", sh.M); }
+    if (p->TPT_f == 3) p->TPT_f = 4;   // instantiated: 1, 2, 4 tiles per thread
     p->NT_f = std::max(roundup64((slots + p->TPT_f - 1) / p->TPT_f), std::max(roundup64(sh.S), ekf ? 128 : 384));
   }
   p->want_PS = (o->flags & 0x4u) != 0;
@@ -265,7 +282,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     mc.lik_kind = o->lik_kind; mc.link_kind = o->link_kind; mc.link_shift = o->link_shift;
     mc.n_pts = o->n_pts; mc.cdim = o->cub_dim; mc.D = sh.D; mc.wn = p->d_wn;
     mc.jitter = (o->lik_kind == NAGP_LIK_POWER) ? 1e-8 : 1e-10;
-    mc.DG = 1; mc.cache_tabs = 0; mc.store_a = 0; mc.stamps = nullptr;
+    mc.DG = 1; mc.cache_tabs = 0; mc.stamps = nullptr;
   }
 
   // ---- buffers
@@ -373,31 +390,48 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
   // ---- LDS sizes / kernel attributes
   if (o->kind == NAGP_KIND_IHGP) {
     p->NT_ih = 512;
-    p->DG_f = pick_DG(o->n_pts, p->NT_ih, sh.D);
-    MomCfg t = mc; t.DG = p->DG_f; t.cache_tabs = 1; t.store_a = 1;
-    if (ihgp_filter_lds_doubles(sh, t, p->tb.NG) * sizeof(double) > 150 * 1024) t.store_a = 0;
-    if (ihgp_filter_lds_doubles(sh, t, p->tb.NG) * sizeof(double) > 150 * 1024) t.cache_tabs = 0;
-    p->cache_f = t.cache_tabs; p->sta_f = t.store_a;
-    p->lds_ih = ihgp_filter_lds_doubles(sh, t, p->tb.NG) * sizeof(double);
-    PLAN_TRY(set_lds(ihgp_filter_kernel, p->lds_ih));
+    p->DG_f = pick_DG(o->lik_kind, o->n_pts, p->NT_ih, sh.D, o->cub_dim);
+    if (const char* e = getenv("NAGP_NT_IH")) p->NT_ih = atoi(e);      // developer tuning hooks
+    if (const char* e = getenv("NAGP_DG")) p->DG_f = atoi(e);
+    MomCfg t = mc; t.DG = p->DG_f; t.cache_tabs = 1;
+    p->hph_lds = 1;
+    if (ihgp_filter_lds_doubles(sh, t, p->tb.NG, p->hph_lds) * sizeof(double) > 150 * 1024) p->hph_lds = 0;
+    if (ihgp_filter_lds_doubles(sh, t, p->tb.NG, p->hph_lds) * sizeof(double) > 150 * 1024) t.cache_tabs = 0;
+    p->cache_f = t.cache_tabs;
+    p->lds_ih = ihgp_filter_lds_doubles(sh, t, p->tb.NG, p->hph_lds) * sizeof(double);
+#define SL(V) PLAN_TRY(set_lds(ihgp_filter_kernel<V>, p->lds_ih))
+    NAGP_MV_SWITCH(mom_variant(mc), SL)
+#undef SL
   } else {
-    if (!ekf) p->DG_f = pick_DG(o->n_pts, p->NT_f, sh.D);
-    MomCfg t = mc; t.DG = p->DG_f; t.cache_tabs = ekf ? 0 : 1; t.store_a = ekf ? 0 : 1;
+    if (!ekf) p->DG_f = pick_DG(o->lik_kind, o->n_pts, p->NT_f, sh.D, o->cub_dim);
+    MomCfg t = mc; t.DG = p->DG_f; t.cache_tabs = ekf ? 0 : 1;
     const size_t cap = 156 * 1024;
     p->kb_f = 16;
-    if (filter_lds_doubles(sh, t, ekf ? 1 : 0, p->kb_f) * sizeof(double) > cap) t.store_a = 0;
     if (filter_lds_doubles(sh, t, ekf ? 1 : 0, p->kb_f) * sizeof(double) > cap) p->kb_f = 8;
     if (filter_lds_doubles(sh, t, ekf ? 1 : 0, p->kb_f) * sizeof(double) > cap) p->kb_f = 4;
     if (filter_lds_doubles(sh, t, ekf ? 1 : 0, p->kb_f) * sizeof(double) > cap) t.cache_tabs = 0;
-    p->cache_f = t.cache_tabs; p->sta_f = t.store_a;
+    p->cache_f = t.cache_tabs;
     p->lds_filter = filter_lds_doubles(sh, t, ekf ? 1 : 0, p->kb_f) * sizeof(double);
     p->lds_gain = gain_lds_doubles(sh) * sizeof(double);
     p->lds_scan = span_lds_doubles(sh, p->LP1, p->LP2) * sizeof(double);
-    switch (p->TPT_f) {
-      case 1: PLAN_TRY(ekf ? set_lds(gf_filter_kernel<1, 1>, p->lds_filter) : set_lds(gf_filter_kernel<1, 0>, p->lds_filter)); break;
-      case 2: PLAN_TRY(ekf ? set_lds(gf_filter_kernel<2, 1>, p->lds_filter) : set_lds(gf_filter_kernel<2, 0>, p->lds_filter)); break;
-      case 3: PLAN_TRY(ekf ? set_lds(gf_filter_kernel<3, 1>, p->lds_filter) : set_lds(gf_filter_kernel<3, 0>, p->lds_filter)); break;
-      default: PLAN_TRY(ekf ? set_lds(gf_filter_kernel<4, 1>, p->lds_filter) : set_lds(gf_filter_kernel<4, 0>, p->lds_filter)); break;
+    if (ekf) {
+      switch (p->TPT_f) {
+        case 1: PLAN_TRY(set_lds(gf_filter_kernel<1, 1, 0>, p->lds_filter)); break;
+        case 2: PLAN_TRY(set_lds(gf_filter_kernel<2, 1, 0>, p->lds_filter)); break;
+        default: PLAN_TRY(set_lds(gf_filter_kernel<4, 1, 0>, p->lds_filter)); break;
+      }
+    } else {
+#define SL1(V) PLAN_TRY(set_lds(gf_filter_kernel<1, 0, V>, p->lds_filter))
+#define SL2(V) PLAN_TRY(set_lds(gf_filter_kernel<2, 0, V>, p->lds_filter))
+#define SL4(V) PLAN_TRY(set_lds(gf_filter_kernel<4, 0, V>, p->lds_filter))
+      switch (p->TPT_f) {
+        case 1: NAGP_MV_SWITCH(mom_variant(mc), SL1) break;
+        case 2: NAGP_MV_SWITCH(mom_variant(mc), SL2) break;
+        default: NAGP_MV_SWITCH(mom_variant(mc), SL4) break;
+      }
+#undef SL1
+#undef SL2
+#undef SL4
     }
     switch (p->TPT) {
       case 1: PLAN_TRY(set_lds(rts_gain_kernel<1>, p->lds_gain)); PLAN_TRY(set_lds(rts_compose_kernel<1>, p->lds_scan)); PLAN_TRY(set_lds(rts_boundary_kernel<1>, p->lds_scan)); PLAN_TRY(set_lds(rts_apply_kernel<1>, p->lds_scan)); break;
@@ -412,13 +446,14 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
 #undef SETM
   }
   if (!ekf) {
-    p->DG_ep = pick_DG(o->n_pts, 256, sh.D);
-    MomCfg t = mc; t.DG = p->DG_ep; t.cache_tabs = 1; t.store_a = 1;
-    if (ep_lds_doubles(sh, t) * sizeof(double) > 64 * 1024) t.store_a = 0;
+    p->DG_ep = pick_DG(o->lik_kind, o->n_pts, 256, sh.D, o->cub_dim);
+    MomCfg t = mc; t.DG = p->DG_ep; t.cache_tabs = 1;
     if (ep_lds_doubles(sh, t) * sizeof(double) > 64 * 1024) t.cache_tabs = 0;
-    p->cache_ep = t.cache_tabs; p->sta_ep = t.store_a;
+    p->cache_ep = t.cache_tabs;
     p->lds_ep = ep_lds_doubles(sh, t) * sizeof(double);
-    PLAN_TRY(set_lds(ep_site_kernel, p->lds_ep));
+#define SL(V) PLAN_TRY(set_lds(ep_site_kernel<V>, p->lds_ep))
+    NAGP_MV_SWITCH(mom_variant(mc), SL)
+#undef SL
   }
   p->nlZ.assign((size_t)B * o->ep_itts, 0.0);
   p->mdM.assign((size_t)B * o->ep_itts, 0.0);
@@ -455,17 +490,26 @@ static int launch_filter(nagp_plan* p, const FilterPar& fp_in) {
   FilterPar fp = fp_in;
   fp.kb = p->kb_f;
   const bool ekf = p->opts.kind == NAGP_KIND_GIEKF;
-  MomCfg mc = p->mc; mc.DG = p->DG_f; mc.cache_tabs = p->cache_f; mc.store_a = p->sta_f;
+  MomCfg mc = p->mc; mc.DG = p->DG_f; mc.cache_tabs = p->cache_f;
   Timed t(p, NAGP_K_FILTER);
   dim3 g(p->B), bl(p->NT_f);
-#define LF(TP, ME) hipLaunchKernelGGL((gf_filter_kernel<TP, ME>), g, bl, p->lds_filter, p->stream, p->sh, p->b, mc, fp)
-  switch (p->TPT_f) {
-    case 1: if (ekf) LF(1, 1); else LF(1, 0); break;
-    case 2: if (ekf) LF(2, 1); else LF(2, 0); break;
-    case 3: if (ekf) LF(3, 1); else LF(3, 0); break;
-    default: if (ekf) LF(4, 1); else LF(4, 0); break;
-  }
+  if (ekf) {
+#define LF(TP) hipLaunchKernelGGL((gf_filter_kernel<TP, 1, 0>), g, bl, p->lds_filter, p->stream, p->sh, p->b, mc, fp)
+    switch (p->TPT_f) { case 1: LF(1); break; case 2: LF(2); break; default: LF(4); break; }
 #undef LF
+  } else {
+#define LF1(V) hipLaunchKernelGGL((gf_filter_kernel<1, 0, V>), g, bl, p->lds_filter, p->stream, p->sh, p->b, mc, fp)
+#define LF2(V) hipLaunchKernelGGL((gf_filter_kernel<2, 0, V>), g, bl, p->lds_filter, p->stream, p->sh, p->b, mc, fp)
+#define LF4(V) hipLaunchKernelGGL((gf_filter_kernel<4, 0, V>), g, bl, p->lds_filter, p->stream, p->sh, p->b, mc, fp)
+    switch (p->TPT_f) {
+      case 1: NAGP_MV_SWITCH(mom_variant(mc), LF1) break;
+      case 2: NAGP_MV_SWITCH(mom_variant(mc), LF2) break;
+      default: NAGP_MV_SWITCH(mom_variant(mc), LF4) break;
+    }
+#undef LF1
+#undef LF2
+#undef LF4
+  }
   HIP_TRY(hipGetLastError());
   return NAGP_OK;
 }
@@ -531,14 +575,16 @@ static int launch_smoother(nagp_plan* p, bool write_PSs) {
 static int launch_ep(nagp_plan* p, double alpha, double damp, int clamp, int write_R, double* lZ_out) {
   const Shape& sh = p->sh;
   if (sh.T < 2) return NAGP_OK;
-  MomCfg mc = p->mc; mc.DG = p->DG_ep; mc.cache_tabs = p->cache_ep; mc.store_a = p->sta_ep;
+  MomCfg mc = p->mc; mc.DG = p->DG_ep; mc.cache_tabs = p->cache_ep;
   EpPar ep{};
   ep.k_end = sh.T - 1;
   ep.steps_per_wg = (int)std::max<int64_t>(1, (ep.k_end + 4095) / 4096);
   ep.alpha = alpha; ep.ep_damp = damp; ep.clamp = clamp; ep.write_R = write_R; ep.lZ_out = lZ_out;
   Timed t(p, NAGP_K_EPSITE);
   dim3 g((unsigned)((ep.k_end + ep.steps_per_wg - 1) / ep.steps_per_wg), p->B), bl(256);
-  hipLaunchKernelGGL(ep_site_kernel, g, bl, p->lds_ep, p->stream, sh, p->b, mc, ep);
+#define LE(V) hipLaunchKernelGGL(ep_site_kernel<V>, g, bl, p->lds_ep, p->stream, sh, p->b, mc, ep)
+  NAGP_MV_SWITCH(mom_variant(mc), LE)
+#undef LE
   HIP_TRY(hipGetLastError());
   return NAGP_OK;
 }
@@ -677,7 +723,7 @@ static int exec_ihgp(nagp_plan* p) {
     HIP_TRY(hipMemcpyAsync(p->d_vprev + (size_t)q * sh.M, p->d_tab + (size_t)q * itab_size(sh, p->tb.NG) + itab_hph0(sh, p->tb.NG),
                            sh.M * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
   }
-  MomCfg mcf = p->mc; mcf.DG = p->DG_f; mcf.cache_tabs = p->cache_f; mcf.store_a = p->sta_f;
+  MomCfg mcf = p->mc; mcf.DG = p->DG_f; mcf.cache_tabs = p->cache_f;
   if (getenv("NAGP_STAMPS")) mcf.stamps = reinterpret_cast<unsigned long long*>(p->d_stamps);   // developer diagnostics
   auto affine = [&](int mode, int64_t kend, int itt) -> int {
     if (kend <= 0) return NAGP_OK;
@@ -703,9 +749,12 @@ static int exec_ihgp(nagp_plan* p) {
     // recursion, run parallel in time) and one ADF step at k = T-1
     if (itt > 1) RUN(affine(0, sh.T - 1, itt));
     IhgpPar ip{itt, p->damping[itt - 1], itt == 1 ? 1 : 0, (itt == 1) ? (int64_t)0 : (int64_t)(sh.T - 1)};
+    ip.hph_lds = p->hph_lds;
     {
       Timed t(p, itt == 1 ? NAGP_K_FILTER : NAGP_K_FILTER_LIN);
-      hipLaunchKernelGGL(ihgp_filter_kernel, dim3(B), dim3(p->NT_ih), p->lds_ih, p->stream, sh, p->b, mcf, p->tb, ip);
+#define LI(V) hipLaunchKernelGGL(ihgp_filter_kernel<V>, dim3(B), dim3(p->NT_ih), p->lds_ih, p->stream, sh, p->b, mcf, p->tb, ip)
+      NAGP_MV_SWITCH(mom_variant(mcf), LI)
+#undef LI
     }
     HIP_TRY(hipGetLastError());
     RUN(reduce_sum(p, p->b.lZ, itt == 1 ? 0 : sh.T - 1, sh.T, 0));

@@ -12,6 +12,8 @@
 
 namespace nagp {
 
+typedef double v4d __attribute__((ext_vector_type(4)));   // accumulator of v_mfma_f64_16x16x4_f64
+
 constexpr int MAXM = 64;        // sites (= diagonal blocks) per step
 constexpr double kSqrt2Pi = 2.5066282746310002;
 
@@ -145,36 +147,55 @@ struct MomCfg {
   int n_pts;
   int cdim;          // cubature dimension: N (NMF) or D (POWER)
   int D;             // sub-bands
-  int DG;            // lanes per sigma point in phase 1 (power of two, <= 16, <= D)
+  int DG;            // lanes per sigma point (power of two, 4..16 for the NMF likelihoods; <= 16, <= D for POWER)
   int nd;            // distinct unit coordinates (<= 64)
   const double* wn;  // [n_pts]
   const double* xd;  // [nd] distinct unit coordinate values
   const unsigned char* code;  // [n_pts][cdim] index into xd
   double jitter;
   int cache_tabs;    // keep wn / code in LDS (n_pts small enough)
-  int store_a;       // NMF: keep a[p][d] = (link(xn) W')_d between the phases instead of link(xn)[p][:]
   unsigned long long* stamps;  // developer diagnostics: per-phase cycle sums of thread 0 (null in production)
 };
 
+typedef const unsigned char __attribute__((address_space(3))) * lds_u8p;   // explicit LDS pointers: a select between
+typedef const double __attribute__((address_space(3))) * lds_f64p;          // an LDS and a global table must not decay to FLAT loads
+constexpr int MOM_NDM = 4;    // NMF likelihoods: sub-bands per lane and pass (their W rows live in registers)
+constexpr int MOM_MAXW = 8;   // waves per workgroup the cross-wave reduction buffers are sized for (launch bounds <= 512)
+
 __host__ __device__ inline int mom_chunk(const MomCfg& c) { return c.n_pts < 1024 ? c.n_pts : 1024; }
-__host__ __device__ inline size_t mom_ws_core(const MomCfg& c) {
-  const int CH = mom_chunk(c);
-  const size_t row = (c.lik_kind != 0 && c.store_a) ? (size_t)c.D : (size_t)c.cdim;
-  // rows[CH][row] + c0,c1,c2[CH] + sg[cdim] + lkv[cdim*nd] + sums1,sums2[nout] + xd[nd] + pad
-  return (size_t)CH * (row + 3) + c.cdim + 3 * (size_t)c.cdim * c.nd + 2 * (size_t)(c.D + c.cdim + 1) + c.nd + 2;
+// LDS workspace layout (offsets in doubles)
+constexpr int MOM_REP = 4;    // POWER_NMF: replicas (16-lane groups) per phase-2 task
+struct MomLay { size_t rows, c0, c1, c2, sg, lkv, xgv, xg2v, sums1, sums2, part, acc, qv, xd, core, tw, tc, total; };
+__host__ __device__ inline int mom_nslots(int cd) { return cd * cd + 3 * cd + 1; }   // u, R, g1, g2, Z
+__host__ __device__ inline MomLay mom_layout(const MomCfg& c) {
+  MomLay l;
+  const size_t CH = (size_t)mom_chunk(c), nout = (size_t)c.D + c.cdim + 1, tab = (size_t)c.cdim * c.nd;
+  const size_t ns = (size_t)mom_nslots(c.cdim);
+  l.rows = 0;   // POWER: link(xn)[d][p] ; POWER_NMF: link(xn)[j][p] ; POWER_NMF_SQRT: none
+  l.c0 = (c.lik_kind == 0) ? CH * c.D : (c.lik_kind == 1) ? CH * c.cdim : 0;
+  l.c1 = l.c0 + CH; l.c2 = l.c1 + CH;
+  l.sg = l.c2 + CH;
+  l.lkv = l.sg + c.cdim; l.xgv = l.lkv + tab; l.xg2v = l.xgv + tab;
+  l.sums1 = l.xg2v + tab; l.sums2 = l.sums1 + nout;
+  l.part = l.sums2 + nout;   // POWER_NMF_SQRT: [MOM_MAXW][2*nout] ; POWER_NMF: [MOM_MAXW][16x16] (N <= 7) or [MOM_REP][ns]
+  l.acc = l.part + ((c.lik_kind == 0) ? 0 : (c.lik_kind == 1) ? (size_t)(c.cdim <= 7 ? MOM_MAXW * 256 : MOM_REP * ns) : (size_t)MOM_MAXW * 2 * nout);
+  l.qv = l.acc + ((c.lik_kind == 1) ? ns : 0);                           // POWER_NMF: Q = W' diag(s2_z) W [cd][cd], v = W' mu_z [cd]
+  l.xd = l.qv + ((c.lik_kind == 1) ? (size_t)c.cdim * (c.cdim + 1) : 0);
+  l.xd = (l.xd + 1) & ~(size_t)1;
+  l.core = (l.xd + c.nd + 1) & ~(size_t)1;
+  l.tw = l.core;
+  l.tc = l.tw + c.n_pts;
+  l.total = c.cache_tabs ? l.tc + ((size_t)c.n_pts * c.cdim + 7) / 8 + 1 : l.core;
+  return l;
 }
-__host__ __device__ inline size_t mom_lds_doubles(const MomCfg& c) {
-  return mom_ws_core(c) + (c.cache_tabs ? (size_t)c.n_pts + ((size_t)c.n_pts * c.cdim + 7) / 8 + 1 : 0);
-}
+__host__ __device__ inline size_t mom_lds_doubles(const MomCfg& c) { return mom_layout(c).total; }
 // called once per kernel after carving `ws`
 __device__ inline void mom_cache_tables(const MomCfg& c, double* ws) {
-  const int CH = mom_chunk(c);
-  const size_t row = (c.lik_kind != 0 && c.store_a) ? (size_t)c.D : (size_t)c.cdim;
-  double* xdl = ws + (size_t)CH * (row + 3) + c.cdim + 3 * (size_t)c.cdim * c.nd + 2 * (size_t)(c.D + c.cdim + 1);
-  for (int i = threadIdx.x; i < c.nd; i += blockDim.x) xdl[i] = c.xd[i];
+  const MomLay l = mom_layout(c);
+  for (int i = threadIdx.x; i < c.nd; i += blockDim.x) ws[l.xd + i] = c.xd[i];
   if (!c.cache_tabs) return;
-  double* tw = ws + mom_ws_core(c);
-  unsigned char* tc = reinterpret_cast<unsigned char*>(tw + c.n_pts);
+  double* tw = ws + l.tw;
+  unsigned char* tc = reinterpret_cast<unsigned char*>(ws + l.tc);
   for (int i = threadIdx.x; i < c.n_pts; i += blockDim.x) tw[i] = c.wn[i];
   for (int i = threadIdx.x; i < c.n_pts * c.cdim; i += blockDim.x) tc[i] = c.code[i];
 }
@@ -184,61 +205,537 @@ __device__ __forceinline__ double link_eval(int kind, double shift, double g) {
   return kind == 0 ? log(1.0 + exp(g - shift)) : exp(g);
 }
 
+#define NAGP_STAMP(slot) do { if (c.stamps && tid == 0) { t_b = __builtin_readcyclecounter(); acc_st[slot] += t_b - t_a; t_a = t_b; } } while (0)
+
+// phase 1a (all likelihoods): link and the modulator integrand factors at the distinct coordinates of
+// every cubature dimension; zero the output sums.  Ends with a barrier.
+__device__ __forceinline__ void mom_phase1a(const MomCfg& c, const MomLay& l, int cd, int nout, const double* mu_g,
+                                            const double* s2_g, double* ws) {
+  const int tid = threadIdx.x, NT = blockDim.x, nd = c.nd;
+  for (int t = tid; t < cd * nd; t += NT) {
+    const int j = t / nd, ci = t - j * nd;
+    const double sgj = sqrt(s2_g[j]);
+    if (ci == 0) ws[l.sg + j] = sgj;
+    const double xn = mu_g[j] + sgj * ws[l.xd + ci];
+    ws[l.lkv + t] = link_eval(c.link_kind, c.link_shift, xn);
+    const double xg = (xn - mu_g[j]) / s2_g[j];
+    ws[l.xgv + t] = xg;
+    ws[l.xg2v + t] = xg * xg - 1.0 / s2_g[j];
+  }
+  if (tid < nout) { ws[l.sums1 + tid] = 0.0; ws[l.sums2 + tid] = 0.0; }
+  lds_barrier();
+}
+// phase 3 (all likelihoods): Z, d lZ, d2 lZ from the weighted sums.  Ends with a barrier.
+__device__ __forceinline__ void mom_phase3(const MomCfg& c, const MomLay& l, int nsite, double pEP, const double* ws,
+                                           double* lZ, double* dl, double* d2l) {
+  const int tid = threadIdx.x;
+  const double Zs = ws[l.sums1 + nsite];
+  const double Z = pEP * ((Zs > c.jitter) ? Zs : c.jitter);  // max(NaN,jitter)=jitter
+  const double Zinv = 1.0 / Z;
+  if (tid < nsite) {
+    const double d1 = Zinv * pEP * ws[l.sums1 + tid];
+    dl[tid] = d1;
+    d2l[tid] = -d1 * d1 + Zinv * pEP * ws[l.sums2 + tid];
+  }
+  if (tid == 0) *lZ = log(Z);
+  lds_barrier();
+}
+
 // Workgroup-cooperative.  ALL threads of the block must call it (contains barriers).
 //   mu, s2 : LDS, M = D + cdim entries (sub-bands first), must be visible (caller synchronised)
 //   Wl     : LDS D x N row-major NMF weights (ignored for POWER)
 //   out    : dl[M], d2l[M] (LDS) and *lZ (LDS scalar) valid after the function returns
 //            (the function ends with a barrier).
-// One copy of the code serves the three likelihoods: the variant flags are wave-uniform scalars
-// (readfirstlane) so the compiler branches on them instead of evaluating e.g. the f64 sqrt of the
-// sqrt-amplitude variant unconditionally; the cubature dimension (<= 8 for the NMF likelihoods) is a
-// predicate on fully unrolled j loops, so link(xn) stays in statically indexed registers.
-template <int CD>   // CD = cubature dimension for the NMF likelihoods (1..8); 0 = POWER (cdim = D)
-__device__ __forceinline__ void mom_eval_impl(const MomCfg& c, const double* Wl, double sn2, double alpha,
-                                              double y, const double* mu, const double* s2, double* ws, double* lZ, double* dl,
-                                              double* d2l, unsigned long long* acc_st, double pEP) {
-  const int tid = threadIdx.x, NT = blockDim.x;
-  const int D = c.D, cd = (CD > 0) ? CD : c.cdim, CH = mom_chunk(c), nd = c.nd;
+//
+// NMF likelihoods (likModulatorNMFPower.m:28-87, likModulatorPreCalcwn.m:28-86), cubature dimension CD = N:
+//   1b  lane (p, sub) of a DG-lane group: a_d = link(xn_p) . W_d for its <= MOM_NDM sub-bands (W rows in
+//       registers, loaded once per call), partial sum_d a_d^2 s2_d and sum_d a_d mu_d, DPP sum over the group
+//   1c  one lane per sigma point: sigma^2, N(y; mu, sigma^2), the three weights c0, c1, c2
+//   2   lanes regrouped so that the 64/DG lanes sharing a sub-band set are adjacent: every lane runs over its
+//       points (a_d recomputed from the registers -- cheaper than an LDS round trip), DPP sum over the
+//       adjacent lanes, one LDS partial per wave, fixed-order sum over the waves.
+//       Lane set j <= CD of the same pass accumulates the modulator outputs / Z.
+template <int CD>
+__device__ __forceinline__ void mom_nmf(const MomCfg& c, const double* Wl, double sn2, double alpha, double y,
+                                        const double* mu, const double* s2, double* ws, double* lZ, double* dl, double* d2l,
+                                        unsigned long long* acc_st, double pEP) {
+  const int tid = threadIdx.x, NT = blockDim.x, lane = tid & 63, wave = tid >> 6, NW = NT >> 6;
+  const int D = c.D, CH = mom_chunk(c), nd = c.nd;
+  constexpr int cd = CD;
   const int nout = D + cd + 1;
-  constexpr bool nmf = (CD > 0);
   const bool sq = __builtin_amdgcn_readfirstlane(c.lik_kind == 2 ? 1 : 0) != 0;
-  const bool sta = __builtin_amdgcn_readfirstlane((c.lik_kind != 0 && c.store_a) ? 1 : 0) != 0;
   const bool TL = __builtin_amdgcn_readfirstlane(c.cache_tabs ? 1 : 0) != 0;
-  const int rw = (!nmf || sta) ? D : cd;
-  double* rows = ws;                    // [rw][CH]  a[d][p] (store_a / POWER) or link(xn)[j][p]: point index fastest
-  double* c0 = rows + (size_t)CH * rw;  // [CH]
-  double* c1 = c0 + CH;
-  double* c2 = c1 + CH;
-  double* sg = c2 + CH;                 // [cd] sqrt(s2_g)
-  double* lkv = sg + cd;                // [cd][nd] link at the distinct coordinates
-  double* xgv = lkv + (size_t)cd * nd;    // [cd][nd] (xn - mu_g)/s2_g at the distinct coordinates
-  double* xg2v = xgv + (size_t)cd * nd;   // [cd][nd] xg^2 - 1/s2_g
-  double* sums1 = xg2v + (size_t)cd * nd; // [nout]
-  double* sums2 = sums1 + nout;         // [nout]
-  const double* xdl = sums2 + nout;     // [nd]
-  const double* lds_wn = ws + mom_ws_core(c);
-  const unsigned char* lds_code = reinterpret_cast<const unsigned char*>(lds_wn + c.n_pts);
+  const int DG = __builtin_amdgcn_readfirstlane(c.DG);
+  const int lgDG = 31 - __builtin_clz(DG);
+  const int G = 64 >> lgDG;       // adjacent lanes per sub-band set in phase 2 (<= 16)
+  const MomLay l = mom_layout(c);
+  double* c0 = ws + l.c0;
+  double* c1 = ws + l.c1;
+  double* c2 = ws + l.c2;
+  const double* lkv = ws + l.lkv;
+  const double* xgv = ws + l.xgv;
+  const double* xg2v = ws + l.xg2v;
+  double* sums1 = ws + l.sums1;
+  double* sums2 = ws + l.sums2;
+  double* part = ws + l.part;
+  const lds_f64p lds_wn = (lds_f64p)(ws + l.tw);
+  const lds_u8p lds_code = (lds_u8p)(ws + l.tc);
+  const unsigned char* g_code = c.code;
   const double* mu_z = mu;
-  const double* mu_g = mu + D;
   const double* s2_z = s2;
-  const double* s2_g = s2 + D;
 
   unsigned long long t_a = 0, t_b = 0;
-#define NAGP_STAMP(slot) do { if (c.stamps && tid == 0) { t_b = __builtin_readcyclecounter(); acc_st[slot] += t_b - t_a; t_a = t_b; } } while (0)
   if (c.stamps && tid == 0) t_a = __builtin_readcyclecounter();
-  // ---- phase 0/1a: link (and the modulator integrand factors) at the distinct coordinates of every dimension
-  for (int t = tid; t < cd * nd; t += NT) {
-    const int j = t / nd, ci = t - j * nd;
-    const double sgj = sqrt(s2_g[j]);
-    if (ci == 0) sg[j] = sgj;
-    const double xn = mu_g[j] + sgj * xdl[ci];
-    lkv[t] = link_eval(c.link_kind, c.link_shift, xn);
-    const double xg = (xn - mu_g[j]) / s2_g[j];
-    xgv[t] = xg;
-    xg2v[t] = xg * xg - 1.0 / s2_g[j];
+  mom_phase1a(c, l, cd, nout, mu + D, s2 + D, ws);
+  NAGP_STAMP(0);
+
+  const double sn2a = sn2 / alpha;
+  const int sub = tid & (DG - 1);
+  const int sub2 = lane >> (6 - lgDG), slot = lane & (G - 1);
+  for (int base = 0; base < c.n_pts; base += CH) {
+    const int npc = (c.n_pts - base < CH) ? (c.n_pts - base) : CH;
+    // ---- phase 1b
+    for (int dc = 0; dc < D; dc += MOM_NDM * DG) {
+      double w[MOM_NDM][CD], sz[MOM_NDM], mz[MOM_NDM];
+#pragma unroll
+      for (int u = 0; u < MOM_NDM; ++u) {
+        const int d = dc + sub + u * DG;
+        const bool ok = d < D;
+        const int dd = ok ? d : 0;
+#pragma unroll
+        for (int j = 0; j < CD; ++j) { const double v = Wl[dd * CD + j]; w[u][j] = ok ? v : 0.0; }
+        const double a_ = s2_z[dd], b_ = mu_z[dd];
+        sz[u] = ok ? a_ : 0.0; mz[u] = ok ? b_ : 0.0;
+      }
+      for (int item = tid; item < (npc << lgDG); item += NT) {
+        const int pl = item >> lgDG;
+        int cj[CD];
+        if (TL) {
+#pragma unroll
+          for (int j = 0; j < CD; ++j) cj[j] = lds_code[(base + pl) * CD + j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < CD; ++j) cj[j] = g_code[(size_t)(base + pl) * CD + j];
+        }
+        double lkj[CD];
+#pragma unroll
+        for (int j = 0; j < CD; ++j) lkj[j] = lkv[j * nd + cj[j]];
+        double s2a = 0.0, sma = 0.0;
+#pragma unroll
+        for (int u = 0; u < MOM_NDM; ++u) {
+          double a = 0.0;
+#pragma unroll
+          for (int j = 0; j < CD; ++j) a = fma(w[u][j], lkj[j], a);
+          if (sq) { a = sqrt(a); asm volatile("" : "+v"(a)); }   // the asm keeps the f64 sqrt from being if-converted
+          s2a = fma(a * a, sz[u], s2a);
+          sma = fma(a, mz[u], sma);
+        }
+        s2a = group_sum(s2a, DG);
+        sma = group_sum(sma, DG);
+        if (sub == 0) {
+          if (dc == 0) { c1[pl] = s2a; c2[pl] = sma; }
+          else { c1[pl] += s2a; c2[pl] += sma; }
+        }
+      }
+    }
+    lds_barrier();
+    // ---- phase 1c
+    for (int pl = tid; pl < npc; pl += NT) {
+      const double sig2 = sn2a + c1[pl], sam = c2[pl];
+      const double sd = sqrt(sig2);
+      const double r = (y - sam) / sd;
+      const double pdf = exp(-0.5 * r * r) / (kSqrt2Pi * sd);
+      double wq;
+      if (TL) wq = lds_wn[base + pl]; else wq = c.wn[base + pl];
+      const double w0 = wq * pdf;
+      const double q = (y - sam) / sig2;
+      c0[pl] = w0;
+      c1[pl] = w0 * q;
+      c2[pl] = w0 * (q * q - 1.0 / sig2);
+    }
+    lds_barrier();
+    NAGP_STAMP(1);
+    // ---- phase 2
+    for (int dc = 0; dc < D; dc += MOM_NDM * DG) {
+      double w[MOM_NDM][CD];
+#pragma unroll
+      for (int u = 0; u < MOM_NDM; ++u) {
+        const int d = dc + sub2 + u * DG;
+        const bool ok = d < D;
+        const int dd = ok ? d : 0;
+#pragma unroll
+        for (int j = 0; j < CD; ++j) { const double v = Wl[dd * CD + j]; w[u][j] = ok ? v : 0.0; }
+      }
+      double a1[MOM_NDM], a2[MOM_NDM], g1 = 0.0, g2 = 0.0;
+#pragma unroll
+      for (int u = 0; u < MOM_NDM; ++u) { a1[u] = 0.0; a2[u] = 0.0; }
+      const bool modl = (dc == 0) && (sub2 <= cd);   // this lane set also owns modulator output sub2 (or Z)
+      const int jg = (sub2 < cd) ? sub2 : 0;
+      for (int pl = wave * G + slot; pl < npc; pl += NW * G) {
+        int cj[CD];
+        if (TL) {
+#pragma unroll
+          for (int j = 0; j < CD; ++j) cj[j] = lds_code[(base + pl) * CD + j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < CD; ++j) cj[j] = g_code[(size_t)(base + pl) * CD + j];
+        }
+        double lkj[CD];
+#pragma unroll
+        for (int j = 0; j < CD; ++j) lkj[j] = lkv[j * nd + cj[j]];
+        const double c0p = c0[pl], c1p = c1[pl], c2p = c2[pl];
+#pragma unroll
+        for (int u = 0; u < MOM_NDM; ++u) {
+          double a = 0.0;
+#pragma unroll
+          for (int j = 0; j < CD; ++j) a = fma(w[u][j], lkj[j], a);
+          if (sq) { a = sqrt(a); asm volatile("" : "+v"(a)); }   // the asm keeps the f64 sqrt from being if-converted
+          a1[u] = fma(a, c1p, a1[u]);
+          a2[u] = fma(a * a, c2p, a2[u]);
+        }
+        if (modl) {
+          if (sub2 < cd) {
+            int cg;
+            if (TL) cg = lds_code[(base + pl) * CD + jg]; else cg = g_code[(size_t)(base + pl) * CD + jg];
+            const int ix = jg * nd + cg;
+            g1 = fma(xgv[ix], c0p, g1);
+            g2 = fma(xg2v[ix], c0p, g2);
+          } else {
+            g1 += c0p;
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < MOM_NDM; ++u) { a1[u] = group_sum(a1[u], G); a2[u] = group_sum(a2[u], G); }
+      g1 = group_sum(g1, G);
+      g2 = group_sum(g2, G);
+      if (slot == 0) {
+        double* pw = part + (size_t)wave * 2 * nout;
+#pragma unroll
+        for (int u = 0; u < MOM_NDM; ++u) {
+          const int d = dc + sub2 + u * DG;
+          if (d < D) { pw[d] = a1[u]; pw[nout + d] = a2[u]; }
+        }
+        if (modl) { pw[D + sub2] = g1; pw[nout + D + sub2] = g2; }
+      }
+      lds_barrier();
+      for (int o = tid; o < nout; o += NT) {
+        const bool mine = (o < D) ? (o >= dc && o < dc + MOM_NDM * DG) : (dc == 0);
+        if (mine) {
+          double s1 = 0.0, s2_ = 0.0;
+          for (int wv = 0; wv < NW; ++wv) { s1 += part[(size_t)wv * 2 * nout + o]; s2_ += part[(size_t)wv * 2 * nout + nout + o]; }
+          sums1[o] += s1; sums2[o] += s2_;
+        }
+      }
+      lds_barrier();
+    }
+    NAGP_STAMP(2);
   }
-  if (tid < nout) { sums1[tid] = 0.0; sums2[tid] = 0.0; }
-  lds_barrier();
+  mom_phase3(c, l, D + cd, pEP, ws, lZ, dl, d2l);
+  NAGP_STAMP(3);
+}
+
+// POWER_NMF (likModulatorNMFPower.m:28-87) without the sqrt amplitude: a_d = W_d . lk is linear in
+// lk = link(xn), so the sub-band sums over d collapse to N x N forms that are built once per call:
+//   sum_d a_d^2 s2_d = lk' Q lk,  Q = W' diag(s2_z) W ;   sum_d a_d mu_d = lk . v,  v = W' mu_z
+//   sum_p c1_p a_d   = W_d . u,   u = sum_p c1_p lk_p ;   sum_p c2_p a_d^2 = W_d' R W_d,  R = sum_p c2_p lk_p lk_p'
+// (same arithmetic up to summation order; n_pts*(N^2+..) instead of n_pts*D*N multiply-adds).
+//   1a  link tables (wave 0) | Q, v by 8-lane groups of the other waves
+//   1b  one lane per sigma point: gather lk, quadratic form, Gaussian weight, c0 c1 c2
+//   2   16-lane groups: task j < N accumulates u_j and R_{j,j'>=j}; task N+j the modulator sums (task N also Z);
+//       up to MOM_REP groups share a task, fixed-order sums of the partials
+//   3   thread d: W_d . u, W_d' R W_d ; thread D+j: modulator outputs ; Z
+template <int CD>
+__device__ __forceinline__ void mom_quad(const MomCfg& c, const double* Wl, double sn2, double alpha, double y,
+                                         const double* mu, const double* s2, double* ws, double* lZ, double* dl, double* d2l,
+                                         unsigned long long* acc_st, double pEP) {
+  const int tid = threadIdx.x, NT = blockDim.x;
+  const int D = c.D, CH = mom_chunk(c), nd = c.nd;
+  constexpr int cd = CD;
+  constexpr int NS = CD * CD + 3 * CD + 1;
+  constexpr int oR = CD, oG1 = CD + CD * CD, oG2 = oG1 + CD, oZ = oG2 + CD;
+  const int nout = D + cd + 1;
+  const bool TL = __builtin_amdgcn_readfirstlane(c.cache_tabs ? 1 : 0) != 0;
+  const MomLay l = mom_layout(c);
+  double* lkp = ws + l.rows;            // [cd][CH]
+  double* c0 = ws + l.c0;
+  double* c1 = ws + l.c1;
+  double* c2 = ws + l.c2;
+  const double* lkv = ws + l.lkv;
+  const double* xgv = ws + l.xgv;
+  const double* xg2v = ws + l.xg2v;
+  double* part = ws + l.part;
+  double* acc = ws + l.acc;
+  double* Qm = ws + l.qv;               // [cd][cd]
+  double* vv = Qm + cd * cd;            // [cd]
+  const lds_f64p lds_wn = (lds_f64p)(ws + l.tw);
+  const lds_u8p lds_code = (lds_u8p)(ws + l.tc);
+  const unsigned char* g_code = c.code;
+  const double* mu_z = mu;
+  const double* s2_z = s2;
+
+  unsigned long long t_a = 0, t_b = 0;
+  if (c.stamps && tid == 0) t_a = __builtin_readcyclecounter();
+  // ---- phase 1a
+  {
+    const int first = (NT > 64) ? 64 : 0;          // keep wave 0 for the link tables when there are other waves
+    if (tid >= first) {
+      const int g8 = (tid - first) >> 3, sub = tid & 7, ng8 = (NT - first) >> 3;
+      for (int o = g8; o < cd * cd + cd; o += ng8) {
+        double sacc = 0.0;
+        if (o < cd * cd) {
+          const int j = o / cd, j2 = o - j * cd;
+          for (int d = sub; d < D; d += 8) sacc = fma(Wl[d * CD + j] * Wl[d * CD + j2], s2_z[d], sacc);
+        } else {
+          const int j = o - cd * cd;
+          for (int d = sub; d < D; d += 8) sacc = fma(Wl[d * CD + j], mu_z[d], sacc);
+        }
+        sacc = group_sum(sacc, 8);
+        if (sub == 0) Qm[o] = sacc;
+      }
+    }
+    for (int o = tid; o < NS; o += NT) acc[o] = 0.0;
+  }
+  mom_phase1a(c, l, cd, nout, mu + D, s2 + D, ws);
+  NAGP_STAMP(0);
+
+  const double sn2a = sn2 / alpha;
+  for (int base = 0; base < c.n_pts; base += CH) {
+    const int npc = (c.n_pts - base < CH) ? (c.n_pts - base) : CH;
+    // ---- phase 1b
+    for (int pl = tid; pl < npc; pl += NT) {
+      int cj[CD];
+      if (TL) {
+#pragma unroll
+        for (int j = 0; j < CD; ++j) cj[j] = lds_code[(base + pl) * CD + j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < CD; ++j) cj[j] = g_code[(size_t)(base + pl) * CD + j];
+      }
+      double lk[CD];
+#pragma unroll
+      for (int j = 0; j < CD; ++j) { lk[j] = lkv[j * nd + cj[j]]; lkp[(size_t)j * CH + pl] = lk[j]; }
+      double sa2 = 0.0, sam = 0.0;
+#pragma unroll
+      for (int j = 0; j < CD; ++j) {
+        double t = 0.0;
+#pragma unroll
+        for (int j2 = 0; j2 < CD; ++j2) t = fma(Qm[j * CD + j2], lk[j2], t);
+        sa2 = fma(t, lk[j], sa2);
+        sam = fma(vv[j], lk[j], sam);
+      }
+      const double sig2 = sn2a + sa2;
+      const double sd = sqrt(sig2);
+      const double r = (y - sam) / sd;
+      const double pdf = exp(-0.5 * r * r) / (kSqrt2Pi * sd);
+      double wq;
+      if (TL) wq = lds_wn[base + pl]; else wq = c.wn[base + pl];
+      const double w0 = wq * pdf;
+      const double q = (y - sam) / sig2;
+      c0[pl] = w0;
+      c1[pl] = w0 * q;
+      c2[pl] = w0 * (q * q - 1.0 / sig2);
+    }
+    lds_barrier();
+    NAGP_STAMP(1);
+    // ---- phase 2
+    if constexpr (CD <= 7) {
+      // All weighted sums over the sigma points are one 16x16 block of  A' B  with per-point rows
+      //   A_p = [c2 lk_0..lk_{N-1} | c1 | c0 xg2_0..xg2_{N-1} | c0]      B_p = [lk_0..lk_{N-1} | xg_0..xg_{N-1} | 1]
+      // (R = rows/cols < N, u = row N, g2 = rows N+1.. x col 2N, g1 = row 2N+1 x cols N.., Z = row 2N+1 x col 2N):
+      // v_mfma_f64_16x16x4 consumes four points per instruction; every wave takes every NW-th step.
+      const int lane = tid & 63, NW = NT >> 6;
+      const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the step loop below must be wave-uniform
+      const int i = lane & 15, kq = lane >> 4;
+      // branch-free operand assembly: A = (sA_lk*lk + sA_tb*xg2 + sA_1) * w,  B = sB_lk*lk + sB_tb*xg + sB_1
+      const double* wA = (i < CD) ? c2 : ((i == CD) ? c1 : c0);
+      const int jA = (i < CD) ? i : ((i > CD && i <= 2 * CD) ? i - CD - 1 : 0);
+      const int jB = (i < CD) ? i : ((i < 2 * CD) ? i - CD : 0);
+      const double sA_lk = (i < CD) ? 1.0 : 0.0, sA_tb = (i > CD && i <= 2 * CD) ? 1.0 : 0.0;
+      const double sA_1 = (i == CD || i == 2 * CD + 1) ? 1.0 : 0.0;
+      const double sB_lk = (i < CD) ? 1.0 : 0.0, sB_tb = (i >= CD && i < 2 * CD) ? 1.0 : 0.0, sB_1 = (i == 2 * CD) ? 1.0 : 0.0;
+      const double* lA = lkp + (size_t)jA * CH;
+      const double* lB = lkp + (size_t)jB * CH;
+      const double* tA = xg2v + jA * nd;
+      const double* tB = xgv + jB * nd;
+      v4d accv = {0.0, 0.0, 0.0, 0.0};
+      const int nstep = (npc + 3) >> 2;
+      // batches of SB steps: the code bytes of a batch, then all dependent operands, then SB MFMAs (two LDS
+      // round trips per batch instead of four per step)
+      constexpr int SB = 4;
+      for (int st0 = wave * SB; st0 < nstep; st0 += NW * SB) {
+        int pl[SB], ca[SB], cb[SB];
+        double okf[SB];
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+          const int q = 4 * (st0 + u) + kq;
+          okf[u] = (q < npc) ? 1.0 : 0.0;
+          pl[u] = (q < npc) ? q : npc - 1;
+        }
+        if (TL) {
+#pragma unroll
+          for (int u = 0; u < SB; ++u) { ca[u] = lds_code[(base + pl[u]) * CD + jA]; cb[u] = lds_code[(base + pl[u]) * CD + jB]; }
+        } else {
+#pragma unroll
+          for (int u = 0; u < SB; ++u) { ca[u] = g_code[(size_t)(base + pl[u]) * CD + jA]; cb[u] = g_code[(size_t)(base + pl[u]) * CD + jB]; }
+        }
+        double w[SB], la[SB], lb[SB], ta[SB], tb_[SB];
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+          w[u] = wA[pl[u]]; la[u] = lA[pl[u]]; lb[u] = lB[pl[u]]; ta[u] = tA[ca[u]]; tb_[u] = tB[cb[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+          const double fa = fma(sA_lk, la[u], fma(sA_tb, ta[u], sA_1)) * (w[u] * okf[u]);
+          const double fb = fma(sB_lk, lb[u], fma(sB_tb, tb_[u], sB_1));
+          accv = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, fb, accv, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part[wave * 256 + (kq + 4 * r) * 16 + i] = accv[r];
+      lds_barrier();
+      for (int o = tid; o < NS; o += NT) {
+        int row, col;
+        if (o < oR) { row = CD; col = o; }
+        else if (o < oG1) { row = (o - oR) / CD; col = (o - oR) % CD; if (col < row) continue; }
+        else if (o < oG2) { row = 2 * CD + 1; col = CD + (o - oG1); }
+        else if (o < oZ) { row = CD + 1 + (o - oG2); col = 2 * CD; }
+        else { row = 2 * CD + 1; col = 2 * CD; }
+        double sacc = acc[o];
+        for (int wv = 0; wv < NW; ++wv) sacc += part[wv * 256 + row * 16 + col];
+        acc[o] = sacc;
+      }
+      lds_barrier();
+    } else
+    {
+      const int grp = tid >> 4, gl = tid & 15, ngrp = NT >> 4;
+      constexpr int ntask = 2 * CD;
+      int rep = ngrp / ntask;
+      rep = rep < 1 ? 1 : (rep > MOM_REP ? MOM_REP : rep);
+      const int stride = 16 * rep, nit = (npc + stride - 1) / stride;
+      for (int tk = grp; tk < ntask * rep; tk += ngrp) {
+        const int task = tk % ntask, r = tk / ntask;
+        double* pw = part + (size_t)r * NS;
+        if (task < cd) {
+          const int j = task;
+          double au = 0.0, aR[CD];
+#pragma unroll
+          for (int jj = 0; jj < CD; ++jj) aR[jj] = 0.0;
+          const double* lj = lkp + (size_t)j * CH;
+#pragma unroll 4
+          for (int it = 0; it < nit; ++it) {     // uniform trip count: out-of-range points get zero weight
+            int pl = gl + 16 * r + it * stride;
+            const bool ok = pl < npc;
+            pl = ok ? pl : npc - 1;
+            const double x = lj[pl];
+            const double k1 = ok ? c1[pl] : 0.0, k2 = ok ? c2[pl] : 0.0;
+            au = fma(k1, x, au);
+            const double t = k2 * x;
+#pragma unroll
+            for (int jj = 0; jj < CD; ++jj)
+              if (j + jj < cd) aR[jj] = fma(t, lj[(size_t)jj * CH + pl], aR[jj]);
+          }
+          au = group_sum(au, 16);
+#pragma unroll
+          for (int jj = 0; jj < CD; ++jj) aR[jj] = group_sum(aR[jj], 16);
+          if (gl == 0) {
+            pw[j] = au;
+#pragma unroll
+            for (int jj = 0; jj < CD; ++jj)
+              if (j + jj < cd) pw[oR + j * CD + j + jj] = aR[jj];
+          }
+        } else {
+          const int j = task - cd;
+          double a1 = 0.0, a2 = 0.0, az = 0.0;
+#pragma unroll 4
+          for (int it = 0; it < nit; ++it) {
+            int pl = gl + 16 * r + it * stride;
+            const bool ok = pl < npc;
+            pl = ok ? pl : npc - 1;
+            int cg;
+            if (TL) cg = lds_code[(base + pl) * CD + j]; else cg = g_code[(size_t)(base + pl) * CD + j];
+            const double w0 = ok ? c0[pl] : 0.0;
+            a1 = fma(xgv[j * nd + cg], w0, a1);
+            a2 = fma(xg2v[j * nd + cg], w0, a2);
+            az += w0;
+          }
+          a1 = group_sum(a1, 16);
+          a2 = group_sum(a2, 16);
+          az = group_sum(az, 16);
+          if (gl == 0) { pw[oG1 + j] = a1; pw[oG2 + j] = a2; if (j == 0) pw[oZ] = az; }
+        }
+      }
+      lds_barrier();
+      for (int o = tid; o < NS; o += NT) {
+        const int jr = (o >= oR && o < oG1) ? (o - oR) : -1;
+        if (jr >= 0 && (jr % CD) < (jr / CD)) continue;     // lower triangle of R is not formed
+        double sacc = acc[o];
+        for (int r = 0; r < rep; ++r) sacc += part[(size_t)r * NS + o];
+        acc[o] = sacc;
+      }
+      lds_barrier();
+    }
+    NAGP_STAMP(2);
+  }
+  // ---- phase 3
+  {
+    const double Zs = acc[oZ];
+    const double Z = pEP * ((Zs > c.jitter) ? Zs : c.jitter);  // max(NaN,jitter)=jitter
+    const double Zinv = 1.0 / Z;
+    if (tid < D + cd) {
+      double s1 = 0.0, s2_ = 0.0;
+      if (tid < D) {
+        double wd[CD];
+#pragma unroll
+        for (int j = 0; j < CD; ++j) wd[j] = Wl[tid * CD + j];
+#pragma unroll
+        for (int j = 0; j < CD; ++j) {
+          s1 = fma(wd[j], acc[j], s1);
+          double t = 0.5 * acc[oR + j * CD + j] * wd[j];
+#pragma unroll
+          for (int j2 = j + 1; j2 < CD; ++j2) t = fma(acc[oR + j * CD + j2], wd[j2], t);
+          s2_ = fma(2.0 * wd[j], t, s2_);
+        }
+      } else {
+        s1 = acc[oG1 + tid - D];
+        s2_ = acc[oG2 + tid - D];
+      }
+      const double d1 = Zinv * pEP * s1;
+      dl[tid] = d1;
+      d2l[tid] = -d1 * d1 + Zinv * pEP * s2_;
+    }
+    if (tid == 0) *lZ = log(Z);
+    lds_barrier();
+  }
+  NAGP_STAMP(3);
+}
+
+// POWER likelihood (likModulatorPower.m:25-100): cubature dimension = D, a_d = link(xn_d).
+__device__ __forceinline__ void mom_power(const MomCfg& c, double sn2, double alpha, double y, const double* mu,
+                                          const double* s2, double* ws, double* lZ, double* dl, double* d2l,
+                                          unsigned long long* acc_st, double pEP) {
+  const int tid = threadIdx.x, NT = blockDim.x;
+  const int D = c.D, cd = c.cdim, CH = mom_chunk(c), nd = c.nd;
+  const int nout = D + cd + 1;
+  const bool TL = __builtin_amdgcn_readfirstlane(c.cache_tabs ? 1 : 0) != 0;
+  const MomLay l = mom_layout(c);
+  double* rows = ws + l.rows;           // [D][CH] link(xn)[d][p]: point index fastest
+  double* c0 = ws + l.c0;
+  double* c1 = ws + l.c1;
+  double* c2 = ws + l.c2;
+  const double* lkv = ws + l.lkv;
+  const double* xgv = ws + l.xgv;
+  const double* xg2v = ws + l.xg2v;
+  double* sums1 = ws + l.sums1;
+  double* sums2 = ws + l.sums2;
+  const double* lds_wn = ws + l.tw;
+  const unsigned char* codes = TL ? reinterpret_cast<const unsigned char*>(ws + l.tc) : c.code;
+  const double* mu_z = mu;
+  const double* s2_z = s2;
+
+  unsigned long long t_a = 0, t_b = 0;
+  if (c.stamps && tid == 0) t_a = __builtin_readcyclecounter();
+  mom_phase1a(c, l, cd, nout, mu + D, s2 + D, ws);
   NAGP_STAMP(0);
 
   const int DG = c.DG;
@@ -250,59 +747,14 @@ __device__ __forceinline__ void mom_eval_impl(const MomCfg& c, const double* Wl,
       const int pl = item / DG, sub = item - pl * DG;
       const int p = base + pl;
       double* row = rows + pl;
-      double s2a[2] = {0, 0}, sma[2] = {0, 0};
-      if (nmf) {
-        constexpr int CDX = (CD > 0) ? CD : 1;
-        double lkj[CDX];
-        {
-          const unsigned char* cp = (TL ? lds_code : c.code) + (size_t)p * cd;
-#pragma unroll
-          for (int j = 0; j < CDX; ++j) lkj[j] = lkv[j * nd + cp[j]];
-        }
-        // two d's per trip: the LDS reads of both are issued before the dependent FMAs
-        int d = sub;
-        for (; d + DG < D; d += 2 * DG) {
-          double w[2][CDX], a[2];
-#pragma unroll
-          for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int j = 0; j < CDX; ++j) w[u][j] = Wl[(d + u * DG) * CDX + j];
-          const double sz0 = s2_z[d], sz1 = s2_z[d + DG], mz0 = mu_z[d], mz1 = mu_z[d + DG];
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            double acc = 0.0;
-#pragma unroll
-            for (int j = 0; j < CDX; ++j) acc = fma(w[u][j], lkj[j], acc);
-            a[u] = acc;
-          }
-          if (sq) { a[0] = sqrt(a[0]); a[1] = sqrt(a[1]); }
-          if (sta) { row[(size_t)d * CH] = a[0]; row[(size_t)(d + DG) * CH] = a[1]; }
-          s2a[0] = fma(a[0] * a[0], sz0, s2a[0]); s2a[1] = fma(a[1] * a[1], sz1, s2a[1]);
-          sma[0] = fma(a[0], mz0, sma[0]); sma[1] = fma(a[1], mz1, sma[1]);
-        }
-        for (; d < D; d += DG) {
-          double acc = 0.0;
-#pragma unroll
-          for (int j = 0; j < CDX; ++j) acc = fma(Wl[d * CDX + j], lkj[j], acc);
-          if (sq) acc = sqrt(acc);
-          if (sta) row[(size_t)d * CH] = acc;
-          s2a[0] = fma(acc * acc, s2_z[d], s2a[0]);
-          sma[0] = fma(acc, mu_z[d], sma[0]);
-        }
-        if (!sta && sub == 0) {
-#pragma unroll
-          for (int j = 0; j < CDX; ++j) row[(size_t)j * CH] = lkj[j];
-        }
-      } else {
-        const unsigned char* cp = (TL ? lds_code : c.code) + (size_t)p * cd;
-        for (int d = sub; d < D; d += DG) {
-          const double a = lkv[d * nd + cp[d]];
-          row[(size_t)d * CH] = a;
-          s2a[0] = fma(a * a, s2_z[d], s2a[0]);
-          sma[0] = fma(a, mu_z[d], sma[0]);
-        }
+      double sa2 = 0.0, sam = 0.0;
+      const unsigned char* cp = codes + (size_t)p * cd;
+      for (int d = sub; d < D; d += DG) {
+        const double a = lkv[d * nd + cp[d]];
+        row[(size_t)d * CH] = a;
+        sa2 = fma(a * a, s2_z[d], sa2);
+        sam = fma(a, mu_z[d], sam);
       }
-      double sa2 = s2a[0] + s2a[1], sam = sma[0] + sma[1];
       sa2 = group_sum(sa2, DG);
       sam = group_sum(sam, DG);
       if (sub == 0) {
@@ -319,41 +771,25 @@ __device__ __forceinline__ void mom_eval_impl(const MomCfg& c, const double* Wl,
     }
     lds_barrier();
     NAGP_STAMP(1);
-    // ---- phase 2: one output per 16-lane group (4 outputs per wave at a time); the group's lanes
-    // stride over the points of the chunk; DPP sum inside the group (fixed order).  The modulator
-    // outputs (heavier gathers) are handed out first.
+    // ---- phase 2: one output per 16-lane group; the group's lanes stride over the points of the chunk;
+    // DPP sum inside the group (fixed order).  The modulator outputs (heavier gathers) are handed out first.
     {
       const int grp = tid >> 4, gl = tid & 15, ngrp = NT >> 4;
       for (int oo = grp; oo < nout; oo += ngrp) {
         const int o = (oo < cd + 1) ? (D + oo) : (oo - cd - 1);   // modulators, Z, then the sub-bands
         double a1 = 0.0, a2 = 0.0, b1 = 0.0, b2 = 0.0;
         if (o < D) {
-          if (nmf && !sta) {
-            constexpr int CDX = (CD > 0) ? CD : 1;
-            double wr[CDX];
-#pragma unroll
-            for (int j = 0; j < CDX; ++j) wr[j] = Wl[o * CDX + j];
-            for (int pl = gl; pl < npc; pl += 16) {
-              double a = 0.0;
-#pragma unroll
-              for (int j = 0; j < CDX; ++j) a = fma(wr[j], rows[(size_t)j * CH + pl], a);
-              if (sq) a = sqrt(a);
-              a1 = fma(a, c1[pl], a1);
-              a2 = fma(a * a, c2[pl], a2);
-            }
-          } else {
-            const double* ro = rows + (size_t)o * CH;
-            int pl = gl;
-            for (; pl + 16 < npc; pl += 32) {
-              const double x0 = ro[pl], x1 = ro[pl + 16];
-              a1 = fma(x0, c1[pl], a1); b1 = fma(x1, c1[pl + 16], b1);
-              a2 = fma(x0 * x0, c2[pl], a2); b2 = fma(x1 * x1, c2[pl + 16], b2);
-            }
-            if (pl < npc) { const double x0 = ro[pl]; a1 = fma(x0, c1[pl], a1); a2 = fma(x0 * x0, c2[pl], a2); }
+          const double* ro = rows + (size_t)o * CH;
+          int pl = gl;
+          for (; pl + 16 < npc; pl += 32) {
+            const double x0 = ro[pl], x1 = ro[pl + 16];
+            a1 = fma(x0, c1[pl], a1); b1 = fma(x1, c1[pl + 16], b1);
+            a2 = fma(x0 * x0, c2[pl], a2); b2 = fma(x1 * x1, c2[pl + 16], b2);
           }
+          if (pl < npc) { const double x0 = ro[pl]; a1 = fma(x0, c1[pl], a1); a2 = fma(x0 * x0, c2[pl], a2); }
         } else if (o < D + cd) {
           const int j = o - D;
-          const unsigned char* cb = (TL ? lds_code : c.code) + (size_t)base * cd + j;
+          const unsigned char* cb = codes + (size_t)base * cd + j;
           int pl = gl;
           for (; pl + 16 < npc; pl += 32) {
             const int i0 = j * nd + cb[(size_t)pl * cd], i1 = j * nd + cb[(size_t)(pl + 16) * cd];
@@ -373,50 +809,31 @@ __device__ __forceinline__ void mom_eval_impl(const MomCfg& c, const double* Wl,
     lds_barrier();
     NAGP_STAMP(2);
   }
-  // ---- phase 3
-  {
-    const double Zs = sums1[D + cd];
-    const double Z = pEP * ((Zs > c.jitter) ? Zs : c.jitter);  // max(NaN,jitter)=jitter
-    const double Zinv = 1.0 / Z;
-    if (tid < D + cd) {
-      const double d1 = Zinv * pEP * sums1[tid];
-      dl[tid] = d1;
-      d2l[tid] = -d1 * d1 + Zinv * pEP * sums2[tid];
-    }
-    if (tid == 0) *lZ = log(Z);
-  }
-  lds_barrier();
+  mom_phase3(c, l, D + cd, pEP, ws, lZ, dl, d2l);
   NAGP_STAMP(3);
-#undef NAGP_STAMP
 }
+#undef NAGP_STAMP
 
 // Wl: NMF weights in LDS (D x N row-major)
 // power-EP normaliser of likModulatorPreCalcwn.m:48 (1 for the other likelihoods); constant per kernel
 __device__ inline double mom_pEP(const MomCfg& c, double sn2, double alpha) {
   return (c.lik_kind == 2) ? pow(2.0 * 3.14159265358979323846 * sn2, 0.5 * (1.0 - alpha)) / sqrt(alpha) : 1.0;
 }
+// MV: the cubature dimension the calling kernel was instantiated for (0 = POWER, 1..8 = N of the NMF likelihoods)
+template <int MV>
 __device__ __forceinline__ void mom_eval(const MomCfg& c, const double* Wl, double pEP, double sn2, double alpha,
                                          double y, const double* mu, const double* s2, double* ws, double* lZ, double* dl,
                                          double* d2l, unsigned long long* acc_st = nullptr) {
   unsigned long long dummy_st[4];
   if (!acc_st) acc_st = dummy_st;
-  const int sel = __builtin_amdgcn_readfirstlane(c.lik_kind == 0 ? 0 : c.cdim);
-#ifdef NAGP_ONLY_CD
-  (void)sel;
-  mom_eval_impl<NAGP_ONLY_CD>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st, pEP);
-  return;
-#endif
-  switch (sel) {
-    case 0: mom_eval_impl<0>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st, pEP); break;
-    case 1: mom_eval_impl<1>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st, pEP); break;
-    case 2: mom_eval_impl<2>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st, pEP); break;
-    case 3: mom_eval_impl<3>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st, pEP); break;
-    case 4: mom_eval_impl<4>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st, pEP); break;
-    case 5: mom_eval_impl<5>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st, pEP); break;
-    case 6: mom_eval_impl<6>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st, pEP); break;
-    case 7: mom_eval_impl<7>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st, pEP); break;
-    default: mom_eval_impl<8>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st, pEP); break;
+  if constexpr (MV == 0) {
+    mom_power(c, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st, pEP);
+  } else {
+    if (__builtin_amdgcn_readfirstlane(c.lik_kind) == 1) mom_quad<MV>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st, pEP);
+    else mom_nmf<MV>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st, pEP);
   }
 }
+constexpr int MOM_MAXCD = 8;
+__host__ __device__ inline int mom_variant(const MomCfg& c) { return c.lik_kind == 0 ? 0 : c.cdim; }
 
 }  // namespace nagp

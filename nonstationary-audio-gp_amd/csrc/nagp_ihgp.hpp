@@ -55,13 +55,23 @@ struct IhgpPar {
   int mom_all;       // sweep 1: mom at every step; later only at k == T-1
   int64_t k_start;   // first step to process (sweeps >= 2 run only k = T-1 here; the rest is ihgp_aff_*)
   double R_init;     // exp(lik) (or 0 for the constraints variant): initial content of R(:,k)
+  int hph_lds;       // filter: keep the H PP H' look-up table [M][NG] in LDS
 };
 
 constexpr int IH_KB = 16;   // steps per I/O block of the filter (LDS ring)
 
 __host__ __device__ inline size_t ihgp_ring_doubles(const Shape& s) { return (size_t)IH_KB * (4 * s.M + s.S + 2); }
-__host__ __device__ inline size_t ihgp_filter_lds_doubles(const Shape& s, const MomCfg& mc, int NG) {
-  return LDS_INT_DOUBLES + (size_t)s.D * s.N + 6 * (size_t)s.M + 8 + NG + ihgp_ring_doubles(s) + mom_lds_doubles(mc);
+__host__ __device__ inline size_t ihgp_filter_lds_doubles(const Shape& s, const MomCfg& mc, int NG, int hph_lds) {
+  return LDS_INT_DOUBLES + (size_t)s.D * s.N + 6 * (size_t)s.M + 8 + NG + (hph_lds ? (size_t)s.M * NG : 0) +
+         ihgp_ring_doubles(s) + mom_lds_doubles(mc);
+}
+
+// log10 to ~0.003 absolute (exponent + quadratic in the mantissa): only seeds the +-2 window below
+__device__ __forceinline__ double coarse_log10(double R) {
+  const int hi = __double2hiint(R);
+  const int e = ((hi >> 20) & 0x7ff) - 1023;
+  const double t = __hiloint2double((hi & 0x000fffff) | 0x3ff00000, __double2loint(R)) - 1.0;
+  return ((double)e + t + 0.3466 * t * (1.0 - t)) * 0.30102999566398120;
 }
 
 // first minimiser of |r_i - R| with the grid in LDS (same semantics as nearest_idx)
@@ -69,7 +79,7 @@ __device__ __forceinline__ int nearest_idx_lds(const double* r, int NG, double l
   if (!(R == R) || isinf(R)) return 0;
   int est = 0;
   if (R > 0.0) {
-    const double f = (log10(R) - lr0) * inv_dlr;
+    const double f = (coarse_log10(R) - lr0) * inv_dlr;
     est = (f <= 0.0) ? 0 : ((f >= (double)(NG - 1)) ? NG - 1 : (int)(f + 0.5));
   }
   const int lo = (est - 2 < 0) ? 0 : est - 2;
@@ -86,6 +96,7 @@ __device__ __forceinline__ int nearest_idx_lds(const double* r, int NG, double l
 // All per-step global traffic goes through an LDS ring of IH_KB steps that is filled / flushed with
 // coalesced transfers once per block, so the sequential loop body contains no global-memory waits
 // except the (L2-resident) table gather.
+template <int MV>
 __global__ void __launch_bounds__(512) ihgp_filter_kernel(Shape sh, Bufs b, MomCfg mc, IhgpTabs tb, IhgpPar ip) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int tid = threadIdx.x, NT = blockDim.x;
@@ -104,7 +115,8 @@ __global__ void __launch_bounds__(512) ihgp_filter_kernel(Shape sh, Bufs b, MomC
   double* d2l = dl + M;
   double* misc = d2l + M;
   double* rg = misc + 8 + 2 * M;          // [NG] look-up grid
-  double* ry = rg + NG;                    // ring: y[KB]
+  double* thph = rg + NG;                  // [M][NG] H PP H' table (ip.hph_lds)
+  double* ry = thph + (ip.hph_lds ? (size_t)M * NG : 0);   // ring: y[KB]
   double* rlZ = ry + IH_KB;                //       lZ[KB]
   double* rtt = rlZ + IH_KB;               //       ttau[KB][M]
   double* rtn = rtt + (size_t)IH_KB * M;   //       tnu
@@ -116,6 +128,8 @@ __global__ void __launch_bounds__(512) ihgp_filter_kernel(Shape sh, Bufs b, MomC
   for (int i = tid; i < M; i += NT) ibsz[i] = sh.bsz[i];
   for (int i = tid; i < sh.D * sh.N; i += NT) sW[i] = mdl[mdl_W(sh) + i];
   for (int i = tid; i < NG; i += NT) rg[i] = tb.r[i];
+  if (ip.hph_lds)
+    for (int i = tid; i < M * NG; i += NT) thph[i] = tab[itab_hph(sh, NG) + i];
   const double sn2 = mdl[mdl_sn2(sh)];
   mom_cache_tables(mc, ws);
   const double pEP1 = mom_pEP(mc, sn2, 1.0);
@@ -170,7 +184,7 @@ __global__ void __launch_bounds__(512) ihgp_filter_kernel(Shape sh, Bufs b, MomC
       if (act) {
         if (k > 0) {
           const int idx = nearest_idx_lds(rg, NG, tb.lr0, tb.inv_dlr, Rprev);
-          hph = tab[itab_hph(sh, NG) + (size_t)n * NG + idx];
+          hph = ip.hph_lds ? thph[n * NG + idx] : tab[itab_hph(sh, NG) + (size_t)n * NG + idx];
           const double* w = tab + itab_wcol(sh, NG) + ((size_t)n * NG + idx) * 4;
 #pragma unroll
           for (int i = 0; i < 4; ++i) wc[i] = w[i];
@@ -195,7 +209,7 @@ __global__ void __launch_bounds__(512) ihgp_filter_kernel(Shape sh, Bufs b, MomC
       if (do_mom) {
         lds_barrier();
         if (mc.stamps && tid == 0) { st_b = __builtin_readcyclecounter(); st[4] += st_b - st_a; }
-        mom_eval(mc, sW, pEP1, sn2, 1.0, yk, fmu, HPH, ws, &misc[0], dl, d2l, st);
+        mom_eval<MV>(mc, sW, pEP1, sn2, 1.0, yk, fmu, HPH, ws, &misc[0], dl, d2l, st);
         if (act) {
           const double d1 = dl[n], d2 = d2l[n];
           const double t_old = rtt[kk * M + n], n_old = rtn[kk * M + n];

@@ -115,13 +115,14 @@ struct TileOwner {
 // fire-and-forget stores of the filtered covariance tiles.
 __host__ __device__ inline size_t filter_ring_doubles(const Shape& s, int kb) { return (size_t)kb * (5 * s.M + s.S + 2); }
 __host__ __device__ inline size_t filter_lds_doubles(const Shape& s, const MomCfg& mc, int meas, int kb) {
-  size_t n = LDS_INT_DOUBLES + 2 * (size_t)s.M * TS + s.M + (size_t)s.D * s.N + s.S + 8 * (size_t)s.M * s.M +
+  size_t n = LDS_INT_DOUBLES + 2 * (size_t)s.M * TS + s.M + (size_t)s.D * s.N + s.S + 4 * (size_t)s.M * s.M +
              8 * (size_t)s.M + 8 + filter_ring_doubles(s, kb);
   n += (meas == 0) ? mom_lds_doubles(mc) : (size_t)(s.M + s.S);
   return (n + 1) & ~(size_t)1;
 }
 
-template <int TPT, int MEAS>
+// MV: mom variant (see mom_eval) for MEAS == 0; the EKF filter is instantiated with MV = 0 only
+template <int TPT, int MEAS, int MV>
 __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg mc, FilterPar fp) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int tid = threadIdx.x, NT = blockDim.x;
@@ -138,8 +139,7 @@ __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg
   double* sW = shv + M;
   double* m = sW + (size_t)sh.D * sh.N;
   double* Wl = m + S;
-  double* HPl = Wl + (size_t)M * 4 * M;   // Wl[n][i][I] = h_n P(off_I+i, c_n) ; HPl[n][j][J] = h_n P(c_n, off_J+j)
-  double* fmu = HPl + (size_t)M * 4 * M;
+  double* fmu = Wl + (size_t)M * 4 * M;    // Wl[n][i][I] = h_n P(off_I+i, c_n)
   double* HPH = fmu + M;
   double* tt = HPH + M;
   double* tn = tt + M;
@@ -306,7 +306,7 @@ __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg
       if (!(yk != yk)) {  // ~isnan(y_k)
         if (MEAS == 0) {
           if (do_mom) {
-            mom_eval(mc, sW, pEP1, sn2, 1.0, yk, fmu, HPH, ws, &misc[0], dl, d2l);
+            mom_eval<MV>(mc, sW, pEP1, sn2, 1.0, yk, fmu, HPH, ws, &misc[0], dl, d2l);
             if (tid < M) {
               const double d2 = d2l[tid], d1 = dl[tid], hp = HPH[tid], f = fmu[tid];
               const double t_old = rtt[kk * M + tid], n_old = rtn[kk * M + tid];
@@ -1140,6 +1140,7 @@ __host__ __device__ inline size_t ep_lds_doubles(const Shape& s, const MomCfg& m
   return (size_t)s.D * s.N + 4 * (size_t)s.M + 8 + mom_lds_doubles(mc);
 }
 
+template <int MV>
 __global__ void __launch_bounds__(256) ep_site_kernel(Shape sh, Bufs b, MomCfg mc, EpPar ep) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int tid = threadIdx.x, NT = blockDim.x;
@@ -1174,7 +1175,7 @@ __global__ void __launch_bounds__(256) ep_site_kernel(Shape sh, Bufs b, MomCfg m
       mc_[tid] = mcav; vc_[tid] = vcav;
     }
     lds_barrier();
-    mom_eval(mc, sW, pEPa, sn2, ep.alpha, yk, mc_, vc_, ws, &misc[0], dl, d2l);
+    mom_eval<MV>(mc, sW, pEPa, sn2, ep.alpha, yk, mc_, vc_, ws, &misc[0], dl, d2l);
     if (tid < M) {
       const bool upd = vcav > 0.0;
       double tnew = t_old, nnew = n_old;

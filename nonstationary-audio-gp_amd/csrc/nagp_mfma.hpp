@@ -13,7 +13,6 @@
 
 namespace nagp {
 
-typedef double v4d __attribute__((ext_vector_type(4)));
 
 struct MfmaPar {
   int64_t k0;

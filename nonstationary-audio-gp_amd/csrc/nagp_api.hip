@@ -425,9 +425,9 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
 #define SL2(V) PLAN_TRY(set_lds(gf_filter_kernel<2, 0, V>, p->lds_filter))
 #define SL4(V) PLAN_TRY(set_lds(gf_filter_kernel<4, 0, V>, p->lds_filter))
       switch (p->TPT_f) {
-        case 1: NAGP_MV_SWITCH(mom_variant(mc), SL1) break;
-        case 2: NAGP_MV_SWITCH(mom_variant(mc), SL2) break;
-        default: NAGP_MV_SWITCH(mom_variant(mc), SL4) break;
+        case 1: NAGP_MV_SWITCH(mom_variant(mc), SL1) SL1(-1); break;
+        case 2: NAGP_MV_SWITCH(mom_variant(mc), SL2) SL2(-1); break;
+        default: NAGP_MV_SWITCH(mom_variant(mc), SL4) SL4(-1); break;
       }
 #undef SL1
 #undef SL2
@@ -491,6 +491,7 @@ static int launch_filter(nagp_plan* p, const FilterPar& fp_in) {
   fp.kb = p->kb_f;
   const bool ekf = p->opts.kind == NAGP_KIND_GIEKF;
   MomCfg mc = p->mc; mc.DG = p->DG_f; mc.cache_tabs = p->cache_f;
+  if (getenv("NAGP_STAMPS")) mc.stamps = reinterpret_cast<unsigned long long*>(p->d_stamps);   // developer diagnostics
   Timed t(p, NAGP_K_FILTER);
   dim3 g(p->B), bl(p->NT_f);
   if (ekf) {
@@ -501,10 +502,14 @@ static int launch_filter(nagp_plan* p, const FilterPar& fp_in) {
 #define LF1(V) hipLaunchKernelGGL((gf_filter_kernel<1, 0, V>), g, bl, p->lds_filter, p->stream, p->sh, p->b, mc, fp)
 #define LF2(V) hipLaunchKernelGGL((gf_filter_kernel<2, 0, V>), g, bl, p->lds_filter, p->stream, p->sh, p->b, mc, fp)
 #define LF4(V) hipLaunchKernelGGL((gf_filter_kernel<4, 0, V>), g, bl, p->lds_filter, p->stream, p->sh, p->b, mc, fp)
-    switch (p->TPT_f) {
-      case 1: NAGP_MV_SWITCH(mom_variant(mc), LF1) break;
-      case 2: NAGP_MV_SWITCH(mom_variant(mc), LF2) break;
-      default: NAGP_MV_SWITCH(mom_variant(mc), LF4) break;
+    if (fp.mom_all || fp.k_end == p->sh.T) {
+      switch (p->TPT_f) {
+        case 1: NAGP_MV_SWITCH(mom_variant(mc), LF1) break;
+        case 2: NAGP_MV_SWITCH(mom_variant(mc), LF2) break;
+        default: NAGP_MV_SWITCH(mom_variant(mc), LF4) break;
+      }
+    } else {   // no step of this launch calls mom
+      switch (p->TPT_f) { case 1: LF1(-1); break; case 2: LF2(-1); break; default: LF4(-1); break; }
     }
 #undef LF1
 #undef LF2
@@ -636,6 +641,12 @@ static int exec_gf(nagp_plan* p) {
       fp.legacy_update = nlml; fp.clamp_always = nlml; fp.write_R = !nlml;
       fp.predict_k1 = (!nlml && o.predict_at_k1) ? 1 : 0;
       fp.store_PF = p->need_PF ? 1 : 0; fp.l_iter = 0;
+      fp.k_begin = 0; fp.k_end = sh.T;
+      if (!fp.mom_all && p->need_PF && sh.T > 1) {   // fixed sites for k < T-1: lean kernel, then the ADF step at k = T-1
+        fp.k_end = sh.T - 1;
+        RUN(launch_filter(p, fp));
+        fp.k_begin = sh.T - 1; fp.k_end = sh.T;
+      }
       RUN(launch_filter(p, fp));
     }
     if (itt == 1 && !nlml) {
@@ -675,6 +686,7 @@ static int exec_giekf(nagp_plan* p) {
     FilterPar fp{};
     fp.itt = itt; fp.store_PF = 1; fp.l_iter = o.l_iter;
     fp.init_from_state = (itt > 1); fp.reset_P = (o.flags & NAGP_FLAG_EKF_RESET_P) ? 1 : 0;
+    fp.k_begin = 0; fp.k_end = sh.T;
     RUN(launch_filter(p, fp));
     RUN(zero_async(p, p->b.red, (size_t)B * 8 * sizeof(double)));
     RUN(seed_last_step(p));

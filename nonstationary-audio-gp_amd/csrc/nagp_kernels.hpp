@@ -67,6 +67,7 @@ struct FilterPar {
   int reset_P;          // with init_from_state: P <- Pinf anyway (constraints variant)
   int l_iter;           // EKF inner iterations
   int kb;               // steps per I/O block (LDS ring)
+  int64_t k_begin, k_end;  // steps processed by this launch; k_begin > 0 continues from (MF, PF) of step k_begin-1
 };
 
 // The filtered covariance is symmetric: PF holds only the lower-triangular tiles, tile (I,J), I >= J, at
@@ -121,7 +122,9 @@ __host__ __device__ inline size_t filter_lds_doubles(const Shape& s, const MomCf
   return (n + 1) & ~(size_t)1;
 }
 
-// MV: mom variant (see mom_eval) for MEAS == 0; the EKF filter is instantiated with MV = 0 only
+// MV: mom variant (see mom_eval) for MEAS == 0; MV = -1: no mom code at all (the steps k < T-1 of the sweeps
+// with fixed sites -- a much smaller kernel without the cubature's register pressure); the EKF filter is
+// instantiated with MV = 0 only
 template <int TPT, int MEAS, int MV>
 __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg mc, FilterPar fp) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -167,8 +170,8 @@ __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg
   for (int i = tid; i < M; i += NT) shv[i] = mdl[mdl_h(sh) + i];
   for (int i = tid; i < sh.D * sh.N; i += NT) sW[i] = mdl[mdl_W(sh) + i];
   const double sn2 = mdl[mdl_sn2(sh)];
-  if (MEAS == 0) mom_cache_tables(mc, ws);
-  const double pEP1 = (MEAS == 0) ? mom_pEP(mc, sn2, 1.0) : 1.0;
+  if (MEAS == 0 && MV >= 0) mom_cache_tables(mc, ws);
+  const double pEP1 = (MEAS == 0 && MV >= 0) ? mom_pEP(mc, sn2, 1.0) : 1.0;
 
   // The covariance is kept exactly symmetric: only the lower-triangular tiles (I >= J) are held (one thread
   // per tile); K*H*P and K*W' coincide, W = P H' is the only panel needed, and the filtered covariance is
@@ -191,13 +194,17 @@ __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg
   for (int q = 0; q < TPT; ++q) {
     tile_zero(P[q]);
     if (own.ok[q]) {
-      if (fp.init_from_state && !fp.reset_P)
+      if (fp.k_begin > 0)
+        tile_load(P[q], b.PF + ((size_t)pb * T + (fp.k_begin - 1)) * nlow * 16 + (size_t)(tid + q * NT) * 16);
+      else if (fp.init_from_state && !fp.reset_P)
         tile_load(P[q], st + (size_t)(own.I[q] * M + own.J[q]) * 16);
       else if (own.I[q] == own.J[q])
         tile_load(P[q], mdl + mdl_P(sh) + (size_t)own.I[q] * 16);
     }
   }
-  for (int i = tid; i < S; i += NT) m[i] = fp.init_from_state ? st[(size_t)sh.ntiles * 16 + i] : 0.0;
+  for (int i = tid; i < S; i += NT)
+    m[i] = (fp.k_begin > 0) ? b.MF[((size_t)pb * T + (fp.k_begin - 1)) * S + i]
+                            : (fp.init_from_state ? st[(size_t)sh.ntiles * 16 + i] : 0.0);
   __syncthreads();
   // which block / row-in-block does state i (= tid) belong to
   int myblk = 0, myrow = 0;
@@ -216,9 +223,11 @@ __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg
   double* g_fv = b.fv + (size_t)pb * T * M;
   double* g_PF = (b.PF && fp.store_PF) ? b.PF + (size_t)pb * T * pf_ntiles(sh) * 16 : nullptr;
   unsigned long long n_clamped = 0, n_nan = 0;
+  unsigned long long stp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_a = 0, st_b = 0;   // developer diagnostics (mc.stamps)
+  if (mc.stamps && tid == 0) st_a = __builtin_readcyclecounter();
 
-  for (int64_t k0 = 0; k0 < T; k0 += KB) {
-    const int nb = (T - k0 < KB) ? (int)(T - k0) : KB;
+  for (int64_t k0 = fp.k_begin; k0 < fp.k_end; k0 += KB) {
+    const int nb = (fp.k_end - k0 < KB) ? (int)(fp.k_end - k0) : KB;
     // ---- fill the ring
     for (int i = tid; i < nb; i += NT) { ry[i] = yv[k0 + i]; rlZ[i] = g_lZ[k0 + i]; }
     if (MEAS == 0)
@@ -231,7 +240,7 @@ __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg
       const int64_t k = k0 + kk;
       const double yk = ry[kk];
       const bool pred = (k > 0) || fp.predict_k1;
-      const bool do_mom = (MEAS == 0) && (fp.mom_all || (k == T - 1));
+      const bool do_mom = (MEAS == 0) && (MV >= 0) && (fp.mom_all || (k == T - 1));
       // steps without a mom call: the owner of diagonal tile (n,n) also forms the gain coefficients of site n,
       // which removes one barrier-separated phase from the step
       const bool early = (MEAS == 0) && !do_mom && !(yk != yk);
@@ -305,8 +314,10 @@ __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg
 
       if (!(yk != yk)) {  // ~isnan(y_k)
         if (MEAS == 0) {
-          if (do_mom) {
-            mom_eval<MV>(mc, sW, pEP1, sn2, 1.0, yk, fmu, HPH, ws, &misc[0], dl, d2l);
+          if constexpr (MV >= 0) if (do_mom) {
+            if (mc.stamps && tid == 0) { st_b = __builtin_readcyclecounter(); stp[4] += st_b - st_a; }
+            mom_eval<MV>(mc, sW, pEP1, sn2, 1.0, yk, fmu, HPH, ws, &misc[0], dl, d2l, stp);
+            if (mc.stamps && tid == 0) st_a = __builtin_readcyclecounter();
             if (tid < M) {
               const double d2 = d2l[tid], d1 = dl[tid], hp = HPH[tid], f = fmu[tid];
               const double t_old = rtt[kk * M + tid], n_old = rtn[kk * M + tid];
@@ -471,6 +482,7 @@ __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg
           }
       }
       lds_barrier();  // B5
+      if (mc.stamps && tid == 0 && do_mom) { st_b = __builtin_readcyclecounter(); stp[5] += st_b - st_a; st_a = st_b; }
     }
     // ---- flush the ring
     for (int i = tid; i < nb; i += NT) g_lZ[k0 + i] = rlZ[i];
@@ -486,6 +498,8 @@ __global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg
   }
   if (tid < M && n_clamped) atomicAdd(&b.counters[(size_t)pb * 4 + 1], n_clamped);
   if (tid == 0 && n_nan) atomicAdd(&b.counters[(size_t)pb * 4 + 2], n_nan);
+  if (mc.stamps && tid == 0)
+    for (int i = 0; i < 8; ++i) mc.stamps[i] += stp[i];
 }
 
 // ---------------------------------------------------------------------------------------------

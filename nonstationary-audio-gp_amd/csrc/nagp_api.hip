@@ -45,6 +45,7 @@ struct nagp_plan {
   std::vector<double> damping;
   int B = 0;
   int TPT = 1, TPT_f = 1, NT = 256, NT_f = 256, NT_ih = 256;
+  int TPT_a = 1, NT_a = 256, LB_a = 256;   // ADF (mom) launches of the gf filter
   int chunk = 2048, LP1 = 1, LP2 = 1, ns_max = 1;
   SpanPar spar{};
   int mfma_sp = 0;      // > 0: FP64-MFMA smoother passes on dense Sp x Sp matrices
@@ -222,6 +223,9 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     if (p->TPT_f > 4) { nagp_plan_destroy(p); FAIL(NAGP_EUNSUPPORTED, "M=%d too large for the filter kernel", sh.M); }
     if (p->TPT_f == 3) p->TPT_f = 4;   // instantiated: 1, 2, 4 tiles per thread
     p->NT_f = std::max(roundup64((slots + p->TPT_f - 1) / p->TPT_f), std::max(roundup64(sh.S), ekf ? 128 : 384));
+    // ADF launches: <= 256 threads (512 registers per lane) whenever the tiles fit
+    if (slots <= 1024 && sh.S <= 256) { p->TPT_a = slots <= 256 ? 1 : (slots <= 512 ? 2 : 4); p->NT_a = 256; p->LB_a = 256; }
+    else { p->TPT_a = 4; p->NT_a = std::max(roundup64((slots + 3) / 4), roundup64(sh.S)); p->LB_a = 512; }
   }
   p->want_PS = (o->flags & 0x4u) != 0;
   p->need_PF = (o->kind != NAGP_KIND_IHGP) && !(o->mode == NAGP_MODE_NLML && o->ep_itts == 1);
@@ -305,6 +309,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
   { double* c = nullptr; PLAN_TRY(dalloc(p, &c, (size_t)B * 4)); b.counters = reinterpret_cast<unsigned long long*>(c); }
   p->chunk = (o->chunk > 0) ? o->chunk : (int)std::min<int64_t>(T, 1 << 20);
   if (p->chunk > T) p->chunk = (int)T;
+  PLAN_TRY(dalloc(p, &p->d_stamps, 8));
   if (o->kind != NAGP_KIND_IHGP) {
     // keep the (G, Delta) chunk buffer under ~8 GiB
     const double per_step = (double)B * 2.0 * std::max<double>(nt * 16.0, 96.0 * 96.0) * 8.0;
@@ -343,7 +348,6 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     }
   } else {
     PLAN_TRY(dalloc(p, &p->d_lZs, BT));
-    PLAN_TRY(dalloc(p, &p->d_stamps, 8));
     PLAN_TRY(dalloc(p, &p->d_vprev, (size_t)B * sh.M));
     p->aff_L = 128; p->aff_ns = (int)((T + p->aff_L - 1) / p->aff_L);
     PLAN_TRY(dalloc(p, &p->d_affspan, (size_t)B * p->aff_ns * sh.M * 20, false));
@@ -403,7 +407,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     NAGP_MV_SWITCH(mom_variant(mc), SL)
 #undef SL
   } else {
-    if (!ekf) p->DG_f = pick_DG(o->lik_kind, o->n_pts, p->NT_f, sh.D, o->cub_dim);
+    if (!ekf) p->DG_f = pick_DG(o->lik_kind, o->n_pts, p->NT_a, sh.D, o->cub_dim);
     MomCfg t = mc; t.DG = p->DG_f; t.cache_tabs = ekf ? 0 : 1;
     const size_t cap = 156 * 1024;
     p->kb_f = 16;
@@ -421,17 +425,25 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
         default: PLAN_TRY(set_lds(gf_filter_kernel<4, 1, 0>, p->lds_filter)); break;
       }
     } else {
-#define SL1(V) PLAN_TRY(set_lds(gf_filter_kernel<1, 0, V>, p->lds_filter))
-#define SL2(V) PLAN_TRY(set_lds(gf_filter_kernel<2, 0, V>, p->lds_filter))
-#define SL4(V) PLAN_TRY(set_lds(gf_filter_kernel<4, 0, V>, p->lds_filter))
-      switch (p->TPT_f) {
-        case 1: NAGP_MV_SWITCH(mom_variant(mc), SL1) SL1(-1); break;
-        case 2: NAGP_MV_SWITCH(mom_variant(mc), SL2) SL2(-1); break;
-        default: NAGP_MV_SWITCH(mom_variant(mc), SL4) SL4(-1); break;
+#define SL1(V) PLAN_TRY(set_lds(gf_filter_kernel<1, 0, V, 256>, p->lds_filter))
+#define SL2(V) PLAN_TRY(set_lds(gf_filter_kernel<2, 0, V, 256>, p->lds_filter))
+#define SL4(V) PLAN_TRY(set_lds(gf_filter_kernel<4, 0, V, 256>, p->lds_filter))
+#define SL5(V) PLAN_TRY(set_lds(gf_filter_kernel<4, 0, V, 512>, p->lds_filter))
+      if (p->LB_a == 512) { NAGP_MV_SWITCH(mom_variant(mc), SL5) }
+      else switch (p->TPT_a) {
+        case 1: NAGP_MV_SWITCH(mom_variant(mc), SL1) break;
+        case 2: NAGP_MV_SWITCH(mom_variant(mc), SL2) break;
+        default: NAGP_MV_SWITCH(mom_variant(mc), SL4) break;
+      }
+      switch (p->TPT_f) {   // mom-free kernel of the fixed-site steps
+        case 1: PLAN_TRY(set_lds(gf_filter_kernel<1, 0, -1>, p->lds_filter)); break;
+        case 2: PLAN_TRY(set_lds(gf_filter_kernel<2, 0, -1>, p->lds_filter)); break;
+        default: PLAN_TRY(set_lds(gf_filter_kernel<4, 0, -1>, p->lds_filter)); break;
       }
 #undef SL1
 #undef SL2
 #undef SL4
+#undef SL5
     }
     switch (p->TPT) {
       case 1: PLAN_TRY(set_lds(rts_gain_kernel<1>, p->lds_gain)); PLAN_TRY(set_lds(rts_compose_kernel<1>, p->lds_scan)); PLAN_TRY(set_lds(rts_boundary_kernel<1>, p->lds_scan)); PLAN_TRY(set_lds(rts_apply_kernel<1>, p->lds_scan)); break;
@@ -499,21 +511,29 @@ static int launch_filter(nagp_plan* p, const FilterPar& fp_in) {
     switch (p->TPT_f) { case 1: LF(1); break; case 2: LF(2); break; default: LF(4); break; }
 #undef LF
   } else {
-#define LF1(V) hipLaunchKernelGGL((gf_filter_kernel<1, 0, V>), g, bl, p->lds_filter, p->stream, p->sh, p->b, mc, fp)
-#define LF2(V) hipLaunchKernelGGL((gf_filter_kernel<2, 0, V>), g, bl, p->lds_filter, p->stream, p->sh, p->b, mc, fp)
-#define LF4(V) hipLaunchKernelGGL((gf_filter_kernel<4, 0, V>), g, bl, p->lds_filter, p->stream, p->sh, p->b, mc, fp)
     if (fp.mom_all || fp.k_end == p->sh.T) {
-      switch (p->TPT_f) {
+      dim3 ba(p->NT_a);
+#define LF1(V) hipLaunchKernelGGL((gf_filter_kernel<1, 0, V, 256>), g, ba, p->lds_filter, p->stream, p->sh, p->b, mc, fp)
+#define LF2(V) hipLaunchKernelGGL((gf_filter_kernel<2, 0, V, 256>), g, ba, p->lds_filter, p->stream, p->sh, p->b, mc, fp)
+#define LF4(V) hipLaunchKernelGGL((gf_filter_kernel<4, 0, V, 256>), g, ba, p->lds_filter, p->stream, p->sh, p->b, mc, fp)
+#define LF5(V) hipLaunchKernelGGL((gf_filter_kernel<4, 0, V, 512>), g, ba, p->lds_filter, p->stream, p->sh, p->b, mc, fp)
+      if (p->LB_a == 512) { NAGP_MV_SWITCH(mom_variant(mc), LF5) }
+      else switch (p->TPT_a) {
         case 1: NAGP_MV_SWITCH(mom_variant(mc), LF1) break;
         case 2: NAGP_MV_SWITCH(mom_variant(mc), LF2) break;
         default: NAGP_MV_SWITCH(mom_variant(mc), LF4) break;
       }
-    } else {   // no step of this launch calls mom
-      switch (p->TPT_f) { case 1: LF1(-1); break; case 2: LF2(-1); break; default: LF4(-1); break; }
-    }
 #undef LF1
 #undef LF2
 #undef LF4
+#undef LF5
+    } else {   // no step of this launch calls mom
+      switch (p->TPT_f) {
+        case 1: hipLaunchKernelGGL((gf_filter_kernel<1, 0, -1>), g, bl, p->lds_filter, p->stream, p->sh, p->b, mc, fp); break;
+        case 2: hipLaunchKernelGGL((gf_filter_kernel<2, 0, -1>), g, bl, p->lds_filter, p->stream, p->sh, p->b, mc, fp); break;
+        default: hipLaunchKernelGGL((gf_filter_kernel<4, 0, -1>), g, bl, p->lds_filter, p->stream, p->sh, p->b, mc, fp); break;
+      }
+    }
   }
   HIP_TRY(hipGetLastError());
   return NAGP_OK;

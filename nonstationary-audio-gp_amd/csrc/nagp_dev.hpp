@@ -829,8 +829,14 @@ __device__ __forceinline__ void mom_eval(const MomCfg& c, const double* Wl, doub
   if constexpr (MV == 0) {
     mom_power(c, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st, pEP);
   } else {
+#if defined(NAGP_EXPERIMENT_ONLY_QUAD)
+    mom_quad<MV>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st, pEP);
+#elif defined(NAGP_EXPERIMENT_ONLY_SQRT)
+    mom_nmf<MV>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st, pEP);
+#else
     if (__builtin_amdgcn_readfirstlane(c.lik_kind) == 1) mom_quad<MV>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st, pEP);
     else mom_nmf<MV>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st, pEP);
+#endif
   }
 }
 constexpr int MOM_MAXCD = 8;

@@ -125,8 +125,10 @@ __host__ __device__ inline size_t filter_lds_doubles(const Shape& s, const MomCf
 // MV: mom variant (see mom_eval) for MEAS == 0; MV = -1: no mom code at all (the steps k < T-1 of the sweeps
 // with fixed sites -- a much smaller kernel without the cubature's register pressure); the EKF filter is
 // instantiated with MV = 0 only
-template <int TPT, int MEAS, int MV>
-__global__ void __launch_bounds__(512) gf_filter_kernel(Shape sh, Bufs b, MomCfg mc, FilterPar fp) {
+// LB: launch bound.  The ADF launches (MV >= 0) run with <= 256 threads whenever the tiles fit: one wave per SIMD
+// may then use all 512 registers (the cubature's pressure lands in AGPRs instead of scratch memory).
+template <int TPT, int MEAS, int MV, int LB = 512>
+__global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg mc, FilterPar fp) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int tid = threadIdx.x, NT = blockDim.x;
   const int S = sh.S, M = sh.M, D = sh.D, KB = fp.kb;

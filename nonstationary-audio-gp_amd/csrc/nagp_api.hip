@@ -393,7 +393,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
 
   // ---- LDS sizes / kernel attributes
   if (o->kind == NAGP_KIND_IHGP) {
-    p->NT_ih = 512;
+    p->NT_ih = 256;   // one wave per SIMD: 512 registers per lane (the cubature's pressure stays out of scratch memory)
     p->DG_f = pick_DG(o->lik_kind, o->n_pts, p->NT_ih, sh.D, o->cub_dim);
     if (const char* e = getenv("NAGP_NT_IH")) p->NT_ih = atoi(e);      // developer tuning hooks
     if (const char* e = getenv("NAGP_DG")) p->DG_f = atoi(e);

@@ -226,6 +226,7 @@ __device__ __forceinline__ void mom_phase1a(const MomCfg& c, const MomLay& l, in
   lds_barrier();
 }
 // phase 3 (all likelihoods): Z, d lZ, d2 lZ from the weighted sums.  Ends with a barrier.
+template <bool LOGZ>
 __device__ __forceinline__ void mom_phase3(const MomCfg& c, const MomLay& l, int nsite, double pEP, const double* ws,
                                            double* lZ, double* dl, double* d2l) {
   const int tid = threadIdx.x;
@@ -237,7 +238,7 @@ __device__ __forceinline__ void mom_phase3(const MomCfg& c, const MomLay& l, int
     dl[tid] = d1;
     d2l[tid] = -d1 * d1 + Zinv * pEP * ws[l.sums2 + tid];
   }
-  if (tid == 0) *lZ = log(Z);
+  if (tid == 0) *lZ = LOGZ ? log(Z) : Z;
   lds_barrier();
 }
 
@@ -255,7 +256,7 @@ __device__ __forceinline__ void mom_phase3(const MomCfg& c, const MomLay& l, int
 //       points (a_d recomputed from the registers -- cheaper than an LDS round trip), DPP sum over the
 //       adjacent lanes, one LDS partial per wave, fixed-order sum over the waves.
 //       Lane set j <= CD of the same pass accumulates the modulator outputs / Z.
-template <int CD>
+template <int CD, bool LOGZ>
 __device__ __forceinline__ void mom_nmf(const MomCfg& c, const double* Wl, double sn2, double alpha, double y,
                                         const double* mu, const double* s2, double* ws, double* lZ, double* dl, double* d2l,
                                         unsigned long long* acc_st, double pEP) {
@@ -431,7 +432,7 @@ __device__ __forceinline__ void mom_nmf(const MomCfg& c, const double* Wl, doubl
     }
     NAGP_STAMP(2);
   }
-  mom_phase3(c, l, D + cd, pEP, ws, lZ, dl, d2l);
+  mom_phase3<LOGZ>(c, l, D + cd, pEP, ws, lZ, dl, d2l);
   NAGP_STAMP(3);
 }
 
@@ -445,7 +446,7 @@ __device__ __forceinline__ void mom_nmf(const MomCfg& c, const double* Wl, doubl
 //   2   16-lane groups: task j < N accumulates u_j and R_{j,j'>=j}; task N+j the modulator sums (task N also Z);
 //       up to MOM_REP groups share a task, fixed-order sums of the partials
 //   3   thread d: W_d . u, W_d' R W_d ; thread D+j: modulator outputs ; Z
-template <int CD>
+template <int CD, bool LOGZ>
 __device__ __forceinline__ void mom_quad(const MomCfg& c, const double* Wl, double sn2, double alpha, double y,
                                          const double* mu, const double* s2, double* ws, double* lZ, double* dl, double* d2l,
                                          unsigned long long* acc_st, double pEP) {
@@ -704,13 +705,14 @@ __device__ __forceinline__ void mom_quad(const MomCfg& c, const double* Wl, doub
       dl[tid] = d1;
       d2l[tid] = -d1 * d1 + Zinv * pEP * s2_;
     }
-    if (tid == 0) *lZ = log(Z);
+    if (tid == 0) *lZ = LOGZ ? log(Z) : Z;
     lds_barrier();
   }
   NAGP_STAMP(3);
 }
 
 // POWER likelihood (likModulatorPower.m:25-100): cubature dimension = D, a_d = link(xn_d).
+template <bool LOGZ>
 __device__ __forceinline__ void mom_power(const MomCfg& c, double sn2, double alpha, double y, const double* mu,
                                           const double* s2, double* ws, double* lZ, double* dl, double* d2l,
                                           unsigned long long* acc_st, double pEP) {
@@ -809,7 +811,7 @@ __device__ __forceinline__ void mom_power(const MomCfg& c, double sn2, double al
     lds_barrier();
     NAGP_STAMP(2);
   }
-  mom_phase3(c, l, D + cd, pEP, ws, lZ, dl, d2l);
+  mom_phase3<LOGZ>(c, l, D + cd, pEP, ws, lZ, dl, d2l);
   NAGP_STAMP(3);
 }
 #undef NAGP_STAMP
@@ -820,22 +822,23 @@ __device__ inline double mom_pEP(const MomCfg& c, double sn2, double alpha) {
   return (c.lik_kind == 2) ? pow(2.0 * 3.14159265358979323846 * sn2, 0.5 * (1.0 - alpha)) / sqrt(alpha) : 1.0;
 }
 // MV: the cubature dimension the calling kernel was instantiated for (0 = POWER, 1..8 = N of the NMF likelihoods)
-template <int MV>
+// LOGZ = false: *lZ receives Z itself (the sequential filters take the logarithm off the critical path)
+template <int MV, bool LOGZ = true>
 __device__ __forceinline__ void mom_eval(const MomCfg& c, const double* Wl, double pEP, double sn2, double alpha,
                                          double y, const double* mu, const double* s2, double* ws, double* lZ, double* dl,
                                          double* d2l, unsigned long long* acc_st = nullptr) {
   unsigned long long dummy_st[4];
   if (!acc_st) acc_st = dummy_st;
   if constexpr (MV == 0) {
-    mom_power(c, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st, pEP);
+    mom_power<LOGZ>(c, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st, pEP);
   } else {
 #if defined(NAGP_EXPERIMENT_ONLY_QUAD)
-    mom_quad<MV>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st, pEP);
+    mom_quad<MV, LOGZ>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st, pEP);
 #elif defined(NAGP_EXPERIMENT_ONLY_SQRT)
-    mom_nmf<MV>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st, pEP);
+    mom_nmf<MV, LOGZ>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st, pEP);
 #else
-    if (__builtin_amdgcn_readfirstlane(c.lik_kind) == 1) mom_quad<MV>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st, pEP);
-    else mom_nmf<MV>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st, pEP);
+    if (__builtin_amdgcn_readfirstlane(c.lik_kind) == 1) mom_quad<MV, LOGZ>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st, pEP);
+    else mom_nmf<MV, LOGZ>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st, pEP);
 #endif
   }
 }

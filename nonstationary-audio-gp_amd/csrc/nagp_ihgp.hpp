@@ -60,7 +60,7 @@ struct IhgpPar {
 
 constexpr int IH_KB = 16;   // steps per I/O block of the filter (LDS ring)
 
-__host__ __device__ inline size_t ihgp_ring_doubles(const Shape& s) { return (size_t)IH_KB * (4 * s.M + s.S + 2); }
+__host__ __device__ inline size_t ihgp_ring_doubles(const Shape& s) { return (size_t)IH_KB * (4 * s.M + s.S + 3); }
 __host__ __device__ inline size_t ihgp_filter_lds_doubles(const Shape& s, const MomCfg& mc, int NG, int hph_lds) {
   return LDS_INT_DOUBLES + (size_t)s.D * s.N + 6 * (size_t)s.M + 8 + NG + (hph_lds ? (size_t)s.M * NG : 0) +
          ihgp_ring_doubles(s) + mom_lds_doubles(mc);
@@ -97,7 +97,7 @@ __device__ __forceinline__ int nearest_idx_lds(const double* r, int NG, double l
 // coalesced transfers once per block, so the sequential loop body contains no global-memory waits
 // except the (L2-resident) table gather.
 template <int MV>
-__global__ void __launch_bounds__(512) ihgp_filter_kernel(Shape sh, Bufs b, MomCfg mc, IhgpTabs tb, IhgpPar ip) {
+__global__ void __launch_bounds__(256) ihgp_filter_kernel(Shape sh, Bufs b, MomCfg mc, IhgpTabs tb, IhgpPar ip) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int tid = threadIdx.x, NT = blockDim.x;
   const int S = sh.S, M = sh.M, NG = tb.NG;
@@ -118,7 +118,8 @@ __global__ void __launch_bounds__(512) ihgp_filter_kernel(Shape sh, Bufs b, MomC
   double* thph = rg + NG;                  // [M][NG] H PP H' table (ip.hph_lds)
   double* ry = thph + (ip.hph_lds ? (size_t)M * NG : 0);   // ring: y[KB]
   double* rlZ = ry + IH_KB;                //       lZ[KB]
-  double* rtt = rlZ + IH_KB;               //       ttau[KB][M]
+  double* rZ = rlZ + IH_KB;                //       Z of the steps that called mom (< 0: none); log taken at the flush
+  double* rtt = rZ + IH_KB;                //       ttau[KB][M]
   double* rtn = rtt + (size_t)IH_KB * M;   //       tnu
   double* rR = rtn + (size_t)IH_KB * M;    //       R
   double* rfm = rR + (size_t)IH_KB * M;    //       H*m (filtered)
@@ -172,7 +173,7 @@ __global__ void __launch_bounds__(512) ihgp_filter_kernel(Shape sh, Bufs b, MomC
   for (int64_t k0 = ip.k_start; k0 < T; k0 += IH_KB) {
     const int nb = (T - k0 < IH_KB) ? (int)(T - k0) : IH_KB;
     // ---- fill the ring for steps k0 .. k0+nb-1
-    for (int i = tid; i < nb; i += NT) { ry[i] = yv[k0 + i]; rlZ[i] = g_lZ[k0 + i]; }
+    for (int i = tid; i < nb; i += NT) { ry[i] = yv[k0 + i]; rlZ[i] = g_lZ[k0 + i]; rZ[i] = -1.0; }
     for (int i = tid; i < nb * M; i += NT) {
       rtt[i] = g_tt[(size_t)k0 * M + i]; rtn[i] = g_tn[(size_t)k0 * M + i]; rR[i] = g_R[(size_t)k0 * M + i];
     }
@@ -209,7 +210,7 @@ __global__ void __launch_bounds__(512) ihgp_filter_kernel(Shape sh, Bufs b, MomC
       if (do_mom) {
         lds_barrier();
         if (mc.stamps && tid == 0) { st_b = __builtin_readcyclecounter(); st[4] += st_b - st_a; }
-        mom_eval<MV>(mc, sW, pEP1, sn2, 1.0, yk, fmu, HPH, ws, &misc[0], dl, d2l, st);
+        mom_eval<MV, false>(mc, sW, pEP1, sn2, 1.0, yk, fmu, HPH, ws, &misc[0], dl, d2l, st);
         if (act) {
           const double d1 = dl[n], d2 = d2l[n];
           const double t_old = rtt[kk * M + n], n_old = rtn[kk * M + n];
@@ -217,7 +218,7 @@ __global__ void __launch_bounds__(512) ihgp_filter_kernel(Shape sh, Bufs b, MomC
           nnew = (1.0 - ip.ep_damp) * n_old + ip.ep_damp * ((d1 - fmun * d2) / (1.0 + d2 * hph));
           Rn = 1.0 / tnew;                      // before the clamp (:269)
         }
-        if (tid == 0) rlZ[kk] = misc[0];
+        if (tid == 0) rZ[kk] = misc[0];
         if (mc.stamps && tid == 0) st_a = __builtin_readcyclecounter();
       } else if (act) {
         tnew = rtt[kk * M + n]; nnew = rtn[kk * M + n];
@@ -248,7 +249,7 @@ __global__ void __launch_bounds__(512) ihgp_filter_kernel(Shape sh, Bufs b, MomC
     }
     // ---- flush the ring
     __syncthreads();
-    for (int i = tid; i < nb; i += NT) g_lZ[k0 + i] = rlZ[i];
+    for (int i = tid; i < nb; i += NT) g_lZ[k0 + i] = (rZ[i] < 0.0) ? rlZ[i] : log(rZ[i]);
     for (int i = tid; i < nb * M; i += NT) {
       g_tt[(size_t)k0 * M + i] = rtt[i]; g_tn[(size_t)k0 * M + i] = rtn[i]; g_R[(size_t)k0 * M + i] = rR[i];
       g_fm[(size_t)k0 * M + i] = rfm[i];

@@ -114,7 +114,7 @@ struct TileOwner {
 // filtered mean/marginals) goes through an LDS ring of `kb` steps that is filled / flushed with
 // coalesced transfers once per block; the only global operations inside the sequential loop are the
 // fire-and-forget stores of the filtered covariance tiles.
-__host__ __device__ inline size_t filter_ring_doubles(const Shape& s, int kb) { return (size_t)kb * (5 * s.M + s.S + 2); }
+__host__ __device__ inline size_t filter_ring_doubles(const Shape& s, int kb) { return (size_t)kb * (5 * s.M + s.S + 3); }
 __host__ __device__ inline size_t filter_lds_doubles(const Shape& s, const MomCfg& mc, int meas, int kb) {
   size_t n = LDS_INT_DOUBLES + 2 * (size_t)s.M * TS + s.M + (size_t)s.D * s.N + s.S + 4 * (size_t)s.M * s.M +
              8 * (size_t)s.M + 8 + filter_ring_doubles(s, kb);
@@ -155,7 +155,8 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
   double* misc = d2l + M;  // [0]=lZ
   double* ry = misc + 8;                   // ring: y[KB]
   double* rlZ = ry + KB;                   //       lZ[KB]
-  double* rtt = rlZ + KB;                  //       ttau[KB][M]
+  double* rZ = rlZ + KB;                   //       Z of the steps that called mom (< 0: none); log taken at the flush
+  double* rtt = rZ + KB;                   //       ttau[KB][M]
   double* rtn = rtt + (size_t)KB * M;
   double* rR = rtn + (size_t)KB * M;
   double* rfm = rR + (size_t)KB * M;       //       H m  (filtered)
@@ -231,7 +232,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
   for (int64_t k0 = fp.k_begin; k0 < fp.k_end; k0 += KB) {
     const int nb = (fp.k_end - k0 < KB) ? (int)(fp.k_end - k0) : KB;
     // ---- fill the ring
-    for (int i = tid; i < nb; i += NT) { ry[i] = yv[k0 + i]; rlZ[i] = g_lZ[k0 + i]; }
+    for (int i = tid; i < nb; i += NT) { ry[i] = yv[k0 + i]; rlZ[i] = g_lZ[k0 + i]; rZ[i] = -1.0; }
     if (MEAS == 0)
       for (int i = tid; i < nb * M; i += NT) {
         rtt[i] = g_tt[(size_t)k0 * M + i]; rtn[i] = g_tn[(size_t)k0 * M + i]; rR[i] = g_R[(size_t)k0 * M + i];
@@ -318,7 +319,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
         if (MEAS == 0) {
           if constexpr (MV >= 0) if (do_mom) {
             if (mc.stamps && tid == 0) { st_b = __builtin_readcyclecounter(); stp[4] += st_b - st_a; }
-            mom_eval<MV>(mc, sW, pEP1, sn2, 1.0, yk, fmu, HPH, ws, &misc[0], dl, d2l, stp);
+            mom_eval<MV, false>(mc, sW, pEP1, sn2, 1.0, yk, fmu, HPH, ws, &misc[0], dl, d2l, stp);
             if (mc.stamps && tid == 0) st_a = __builtin_readcyclecounter();
             if (tid < M) {
               const double d2 = d2l[tid], d1 = dl[tid], hp = HPH[tid], f = fmu[tid];
@@ -331,7 +332,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
               rtt[kk * M + tid] = tnew; rtn[kk * M + tid] = nnew;
               if (fp.write_R) rR[kk * M + tid] = 1.0 / tnew;
             }
-            if (tid == 0) rlZ[kk] = misc[0];
+            if (tid == 0) rZ[kk] = misc[0];
           }
           if (do_mom && fp.legacy_update) lds_barrier();
           if (do_mom && tid < M) {
@@ -487,7 +488,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
       if (mc.stamps && tid == 0 && do_mom) { st_b = __builtin_readcyclecounter(); stp[5] += st_b - st_a; st_a = st_b; }
     }
     // ---- flush the ring
-    for (int i = tid; i < nb; i += NT) g_lZ[k0 + i] = rlZ[i];
+    for (int i = tid; i < nb; i += NT) g_lZ[k0 + i] = (rZ[i] < 0.0) ? rlZ[i] : log(rZ[i]);
     for (int i = tid; i < nb * M; i += NT) {
       if (MEAS == 0) {
         g_tt[(size_t)k0 * M + i] = rtt[i]; g_tn[(size_t)k0 * M + i] = rtn[i];

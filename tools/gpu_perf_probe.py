@@ -10,6 +10,7 @@ from nagp import ss as ssm
 cfg = sys.argv[1] if len(sys.argv) > 1 else 'cfg2'
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+LIK = sys.argv[4] if len(sys.argv) > 4 else 'nmf'      # 'nmf' = likModulatorNMFPower, 'sqrt' = likModulatorPreCalcwn
 shapes = dict(cfg2=(16, 3, 9, 'demo_nmf', L.KIND_GF_EP), cfg3=(32, 6, 7, 'constraints', L.KIND_IHGP),
               cfg5=(32, 6, 7, 'constraints', L.KIND_GF_EP), cfg4=(24, 3, 9, 'demo_nmf', L.KIND_GIEKF))
 D, N, p, recipe, kind = shapes[cfg]
@@ -22,7 +23,12 @@ for q in range(B):
         blk = ssm.balance_blocks(blk)
     probs.append((blk, pr['W'], np.log(pr['w_lik']))); ys.append(pr['y'])
 print('setup %.1fs  S=%d M=%d' % (time.time() - t0, probs[0][0].S, probs[0][0].M)); sys.stdout.flush()
-mom = Mom('likModulatorNMFPower', p_cubature=p)
+if LIK == 'sqrt':
+    from nagp import cubature
+    wn, xn = cubature.utp_ws(p, N)
+    mom = Mom('likModulatorPreCalcwn', wn=wn, xn_unscaled=xn)
+else:
+    mom = Mom('likModulatorNMFPower', p_cubature=p)
 t0 = time.time()
 plan = nagp.Plan(kind, probs, T, mom=mom if kind != L.KIND_GIEKF else None, ep_fraction=0.5, ep_damping=0.5 * np.ones(3), ep_itts=3, l_iter=1)
 print('plan create %.1fs, device MB %.1f' % (time.time() - t0, plan.device_bytes() / 1e6)); sys.stdout.flush()

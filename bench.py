@@ -137,18 +137,35 @@ def run_workload(name, a, rank, local_rank, world, dev, with_cpu):
         roof = dict(bound='hbm', kernel='ihgp_filter_kernel (ADF sweep)', achieved=achieved, peak=PEAK_HBM_GBS, unit='GB/s',
                     frac=achieved / PEAK_HBM_GBS, traffic=None, algorithmic_bytes_per_sample=per_sample,
                     valu_gflops=(8.0 * S * (S / M) + 8 * S + f_mom) * units / (kern[dom] * 1e-3) / 1e9,
-                    avg_launch_ms=kern[dom] / max(launches[dom], 1))
+                    avg_launch_ms=kern[dom] / max(launches[dom], 1), us_per_sample=kern[dom] * 1e3 / units)
     else:
+        # gf_ep: the ADF launches (sweep 1: all T steps, later sweeps: the step k = T-1) are one kernel
+        # (gf_filter_kernel<.., MV, 256>, timing slot 'filter'); the fixed-site steps of sweeps >= 2 run in the
+        # mom-free instantiation (slot 'filter_lin').  giekf: every sweep is the EKF instantiation (slot 'filter').
         dom = 'filter'
         bbar = S / M
         per_step = (4 * bbar + 1) * S * S + 2.0 * M * S * S       # block-diagonal A P A' + Q, rank-M update
-        mom_steps = n_seg * T * a.steps if kind == L.KIND_GF_EP else 0    # mom only on the first of the EP_ITTS filter launches
-        flops = per_step * n_seg * T * EP_ITTS * a.steps + f_mom * mom_steps
+        if kind == L.KIND_GF_EP:
+            adf_steps = n_seg * (T + (EP_ITTS - 1)) * a.steps     # steps the ADF kernel processed (3 launches per execute)
+            lin_steps = n_seg * (T - 1) * (EP_ITTS - 1) * a.steps
+            flops = (per_step + f_mom) * adf_steps
+        else:
+            per_step = (4 * bbar + 1) * S * S + 6.0 * S * S       # EKF: l_iter*4S^2 + 2S^2 instead of the rank-M update
+            adf_steps = n_seg * T * EP_ITTS * a.steps; lin_steps = 0
+            flops = per_step * adf_steps
         achieved = flops / (kern[dom] * 1e-3) / 1e12
-        roof = dict(bound='mfma', kernel='gf_filter_kernel', achieved=achieved, peak=PEAK_FP64_TFLOPS, unit='TFLOP/s',
-                    frac=achieved / PEAK_FP64_TFLOPS, traffic=None, algorithmic_flops_per_step=per_step,
-                    avg_launch_ms=kern[dom] / max(launches[dom], 1),
+        roof = dict(bound='mfma', kernel='gf_filter_kernel (ADF / EKF launches)', achieved=achieved, peak=PEAK_FP64_TFLOPS, unit='TFLOP/s',
+                    frac=achieved / PEAK_FP64_TFLOPS, traffic=None, algorithmic_flops_per_step=per_step + (f_mom if kind == L.KIND_GF_EP else 0),
+                    avg_launch_ms=kern[dom] / max(launches[dom], 1), launches_per_execute=launches[dom] / a.steps,
+                    # a segment is one sequential recursion on one workgroup = one CU of 256: the per-CU ceiling it can reach
+                    peak_one_cu=PEAK_FP64_TFLOPS / 256, frac_one_cu=achieved / (PEAK_FP64_TFLOPS / 256 * n_seg),
                     smoother_tflops=(10.0 * S ** 3) * n_seg * (T - 1) * EP_ITTS * a.steps / ((kern['scan'] + kern['gain']) * 1e-3) / 1e12)
+        if lin_steps and kern['filter_lin'] > 0:
+            roof['fixed_site_kernel'] = dict(kernel='gf_filter_kernel<.., MV=-1> (sweeps >= 2, k < T-1)',
+                                             achieved=per_step * lin_steps / (kern['filter_lin'] * 1e-3) / 1e12, unit='TFLOP/s',
+                                             avg_launch_ms=kern['filter_lin'] / max(launches['filter_lin'], 1),
+                                             us_per_sample=kern['filter_lin'] * 1e3 / lin_steps)
+        roof['adf_us_per_sample'] = kern[dom] * 1e3 / adf_steps
     res = {
         'metric': 'audio samples/sec filtered+smoothed (state dim %d, per EP sweep)' % S,
         'value': value, 'unit': 'samples/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,

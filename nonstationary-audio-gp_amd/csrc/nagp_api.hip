@@ -504,14 +504,15 @@ static int launch_filter(nagp_plan* p, const FilterPar& fp_in) {
   const bool ekf = p->opts.kind == NAGP_KIND_GIEKF;
   MomCfg mc = p->mc; mc.DG = p->DG_f; mc.cache_tabs = p->cache_f;
   if (getenv("NAGP_STAMPS")) mc.stamps = reinterpret_cast<unsigned long long*>(p->d_stamps);   // developer diagnostics
-  Timed t(p, NAGP_K_FILTER);
+  const bool adf = ekf || fp.mom_all || fp.k_end == p->sh.T;   // launches that may call mom (or the EKF filter)
+  Timed t(p, adf ? NAGP_K_FILTER : NAGP_K_FILTER_LIN);
   dim3 g(p->B), bl(p->NT_f);
   if (ekf) {
 #define LF(TP) hipLaunchKernelGGL((gf_filter_kernel<TP, 1, 0>), g, bl, p->lds_filter, p->stream, p->sh, p->b, mc, fp)
     switch (p->TPT_f) { case 1: LF(1); break; case 2: LF(2); break; default: LF(4); break; }
 #undef LF
   } else {
-    if (fp.mom_all || fp.k_end == p->sh.T) {
+    if (adf) {
       dim3 ba(p->NT_a);
 #define LF1(V) hipLaunchKernelGGL((gf_filter_kernel<1, 0, V, 256>), g, ba, p->lds_filter, p->stream, p->sh, p->b, mc, fp)
 #define LF2(V) hipLaunchKernelGGL((gf_filter_kernel<2, 0, V, 256>), g, ba, p->lds_filter, p->stream, p->sh, p->b, mc, fp)

@@ -173,7 +173,8 @@ def test_batched_plan_equals_single_runs_and_is_deterministic_and_chunk_invarian
         assert np.array_equal(a[q].Eft, o.Eft) and np.array_equal(a[q].Varft, o.Varft) and np.array_equal(a[q].nlZ, o.nlZ)
         one.close()
     assert np.allclose(plan.download_nlz(), np.array([x.nlZ for x in a]))
-    t = plan.timings(); assert t['launches']['filter'] == 3 and t['ms']['scan'] > 0      # sweep 1; sweep 2 = fixed-site launch + the ADF step at k = T-1
+    t = plan.timings()    # sweep 1 + the ADF step k = T-1 of sweep 2 | the fixed-site steps of sweep 2
+    assert t['launches']['filter'] == 2 and t['launches']['filter_lin'] == 1 and t['ms']['scan'] > 0
     plan.close(); small.close()
 
 

@@ -164,6 +164,16 @@ int nagp_ihgp_run(const nagp_model* model, const nagp_ihgp_tables* tables, const
                   const nagp_opts* opts, nagp_out* out);
 int nagp_giekf_run(const nagp_model* model, const double* y, int64_t T, const nagp_opts* opts, nagp_out* out);
 
+/* The `mom` callback itself for n_eval independent inputs -- replaces likModulatorPower.m:25-100,
+ * likModulatorNMFPower.m:28-87 and experiments/likModulatorPreCalcwn.m:28-86 as called through the handles of
+ * demo_toy_modulators.m:81 / demo_toy_modulators_nmf.m:81 / train_GTFNMF.m:149:
+ *   [lZ, dlZ, d2lZ] = mom(hyp, mu, s2, [Wnmf,] ep_frac, yall, k)
+ * opts supplies lik_kind, link, cubature (n_pts, cub_dim, wn, xn_unscaled), ep_fraction and device; D, N as in
+ * nagp_model (M = D+N for the NMF likelihoods, 2*D for NAGP_LIK_POWER); Wnmf is D x N column-major (NULL for POWER);
+ * lik_param = hyp = log observation-noise variance.  y[n_eval]; mu, s2, dlZ, d2lZ are M x n_eval column-major. */
+int nagp_mom_eval(const nagp_opts* opts, int32_t D, int32_t N, const double* Wnmf, double lik_param, int64_t n_eval,
+                  const double* y, const double* mu, const double* s2, double* lZ, double* dlZ, double* d2lZ);
+
 /* Batched / device-resident form: n_problems independent problems of identical shape
  * (S, M, block structure, T) -- audio segments or hyper-parameter replicas -- run concurrently. */
 int nagp_plan_create(nagp_plan** plan, int32_t n_problems, const nagp_model* models,

@@ -403,6 +403,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     if (ihgp_filter_lds_doubles(sh, t, p->tb.NG, p->hph_lds) * sizeof(double) > 150 * 1024) t.cache_tabs = 0;
     p->cache_f = t.cache_tabs;
     p->lds_ih = ihgp_filter_lds_doubles(sh, t, p->tb.NG, p->hph_lds) * sizeof(double);
+    if (getenv("NAGP_STAMPS")) fprintf(stderr, "[nagp plan] ihgp filter: LDS %zu B, hph table in LDS %d, cubature tables in LDS %d, mom LDS %zu B\n", p->lds_ih, p->hph_lds, p->cache_f, mom_lds_doubles(t) * sizeof(double));
 #define SL(V) PLAN_TRY(set_lds(ihgp_filter_kernel<V>, p->lds_ih))
     NAGP_MV_SWITCH(mom_variant(mc), SL)
 #undef SL
@@ -416,6 +417,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     if (filter_lds_doubles(sh, t, ekf ? 1 : 0, p->kb_f) * sizeof(double) > cap) t.cache_tabs = 0;
     p->cache_f = t.cache_tabs;
     p->lds_filter = filter_lds_doubles(sh, t, ekf ? 1 : 0, p->kb_f) * sizeof(double);
+    if (getenv("NAGP_STAMPS")) fprintf(stderr, "[nagp plan] gf filter: LDS %zu B, ring %d steps, cubature tables in LDS %d, mom LDS %zu B\n", p->lds_filter, p->kb_f, p->cache_f, ekf ? (size_t)0 : mom_lds_doubles(t) * sizeof(double));
     p->lds_gain = gain_lds_doubles(sh) * sizeof(double);
     p->lds_scan = span_lds_doubles(sh, p->LP1, p->LP2) * sizeof(double);
     if (ekf) {
@@ -846,7 +848,7 @@ extern "C" int nagp_plan_execute(nagp_plan* p) {
   if (getenv("NAGP_STAMPS") && p->d_stamps) {
     unsigned long long st[8];
     if (hipMemcpy(st, p->d_stamps, sizeof st, hipMemcpyDeviceToHost) == hipSuccess)
-      fprintf(stderr, "[nagp stamps] mom: p1a %llu p1b %llu p2 %llu p3 %llu | pre-mom %llu post-mom %llu\n", st[0], st[1], st[2], st[3], st[4], st[5]);
+      fprintf(stderr, "[nagp stamps] mom: p1a %llu p1b %llu p2 %llu p3 %llu | pre-mom %llu post-mom %llu | aux %llu %llu\n", st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7]);
   }
 
   HIP_TRY(hipGetLastError());
@@ -967,4 +969,74 @@ extern "C" int nagp_ihgp_run(const nagp_model* model, const nagp_ihgp_tables* ta
 extern "C" int nagp_giekf_run(const nagp_model* model, const double* y, int64_t T, const nagp_opts* opts, nagp_out* out) {
   if (opts && opts->kind != NAGP_KIND_GIEKF) FAIL(NAGP_EINVAL, "nagp_giekf_run needs kind = NAGP_KIND_GIEKF");
   return run_one(model, nullptr, y, T, opts, out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// mom on its own (see include/nagp.h)
+extern "C" int nagp_mom_eval(const nagp_opts* o, int32_t D, int32_t N, const double* Wnmf, double lik_param, int64_t n,
+                             const double* y, const double* mu, const double* s2, double* lZ, double* dlZ, double* d2lZ) {
+  if (!o || !y || !mu || !s2 || !lZ || !dlZ || !d2lZ || n < 0) FAIL(NAGP_EINVAL, "null argument");
+  if (o->lik_kind < NAGP_LIK_POWER || o->lik_kind > NAGP_LIK_POWER_NMF_SQRT) FAIL(NAGP_EINVAL, "unknown likelihood");
+  const bool power = o->lik_kind == NAGP_LIK_POWER;
+  const int M = power ? 2 * D : D + N;
+  if (D < 1 || M > MAXM || o->n_pts < 1 || !o->wn || !o->xn_unscaled) FAIL(NAGP_EINVAL, "bad sizes / cubature");
+  if (power ? (o->cub_dim != D) : (o->cub_dim != N || N < 1 || N > MOM_MAXCD || !Wnmf)) FAIL(NAGP_EUNSUPPORTED, "cub_dim / N / Wnmf");
+  if (n == 0) return NAGP_OK;
+  if (hipSetDevice(o->device) != hipSuccess) FAIL(NAGP_EHIP, "hipSetDevice(%d)", o->device);
+  std::vector<double> xd;
+  std::vector<unsigned char> code((size_t)o->n_pts * o->cub_dim);
+  for (int pt = 0; pt < o->n_pts; ++pt)
+    for (int j = 0; j < o->cub_dim; ++j) {
+      const double v = o->xn_unscaled[j + (size_t)o->cub_dim * pt];
+      size_t ci = 0;
+      while (ci < xd.size() && xd[ci] != v) ++ci;
+      if (ci == xd.size()) {
+        if (xd.size() == 64) FAIL(NAGP_EUNSUPPORTED, "sigma-point rule has more than 64 distinct coordinate values");
+        xd.push_back(v);
+      }
+      code[(size_t)pt * o->cub_dim + j] = (unsigned char)ci;
+    }
+  // one device block: wn | xd | code | W | y | mu | s2 | lZ | dl | d2l
+  const size_t n_code = (code.size() + 7) / 8 + 1, nW = power ? 0 : (size_t)D * N;
+  const size_t o_wn = 0, o_xd = o_wn + o->n_pts, o_code = o_xd + xd.size(), o_W = o_code + n_code, o_y = o_W + nW,
+               o_mu = o_y + n, o_s2 = o_mu + (size_t)n * M, o_lZ = o_s2 + (size_t)n * M, o_dl = o_lZ + n, o_d2 = o_dl + (size_t)n * M,
+               total = o_d2 + (size_t)n * M;
+  double* dev = nullptr;
+  if (hipMalloc(&dev, total * sizeof(double)) != hipSuccess) FAIL(NAGP_ENOMEM, "hipMalloc(%zu)", total * sizeof(double));
+  std::vector<double> Wr(nW);
+  for (int dd = 0; dd < (power ? 0 : D); ++dd)
+    for (int j = 0; j < N; ++j) Wr[(size_t)dd * N + j] = Wnmf[dd + (size_t)D * j];
+  int st = NAGP_OK;
+#define ME_HIP(x) do { if (st == NAGP_OK) { hipError_t _e = (x); if (_e != hipSuccess) { g_last_error = std::string("nagp_mom_eval: " #x " -> ") + hipGetErrorString(_e); st = NAGP_EHIP; } } } while (0)
+  ME_HIP(hipMemcpy(dev + o_wn, o->wn, (size_t)o->n_pts * 8, hipMemcpyHostToDevice));
+  ME_HIP(hipMemcpy(dev + o_xd, xd.data(), xd.size() * 8, hipMemcpyHostToDevice));
+  ME_HIP(hipMemcpy(dev + o_code, code.data(), code.size(), hipMemcpyHostToDevice));
+  if (nW) ME_HIP(hipMemcpy(dev + o_W, Wr.data(), nW * 8, hipMemcpyHostToDevice));
+  ME_HIP(hipMemcpy(dev + o_y, y, (size_t)n * 8, hipMemcpyHostToDevice));
+  ME_HIP(hipMemcpy(dev + o_mu, mu, (size_t)n * M * 8, hipMemcpyHostToDevice));
+  ME_HIP(hipMemcpy(dev + o_s2, s2, (size_t)n * M * 8, hipMemcpyHostToDevice));
+  MomCfg mc{};
+  mc.lik_kind = o->lik_kind; mc.link_kind = o->link_kind; mc.link_shift = o->link_shift;
+  mc.n_pts = o->n_pts; mc.cdim = o->cub_dim; mc.D = D; mc.nd = (int)xd.size();
+  mc.wn = dev + o_wn; mc.xd = dev + o_xd; mc.code = reinterpret_cast<const unsigned char*>(dev + o_code);
+  mc.jitter = power ? 1e-8 : 1e-10; mc.stamps = nullptr;
+  mc.DG = pick_DG(o->lik_kind, o->n_pts, 256, D, o->cub_dim);
+  mc.cache_tabs = 1;
+  if (momk_lds_doubles(D, power ? D : N, M, mc) * sizeof(double) > 150 * 1024) mc.cache_tabs = 0;
+  const size_t lds = momk_lds_doubles(D, power ? D : N, M, mc) * sizeof(double);
+  if (lds > 160 * 1024) { (void)hipFree(dev); FAIL(NAGP_EUNSUPPORTED, "mom workspace of %zu B exceeds the LDS", lds); }
+  MomPar mp{D, power ? 0 : N, M, std::exp(lik_param), o->ep_fraction, nW ? dev + o_W : nullptr, dev + o_y, dev + o_mu, dev + o_s2,
+            dev + o_lZ, dev + o_dl, dev + o_d2, n};
+  const int grid = (int)std::min<int64_t>(n, 1024);
+#define LM(V) do { if (st == NAGP_OK) st = set_lds(mom_kernel<V>, lds); if (st == NAGP_OK) hipLaunchKernelGGL(mom_kernel<V>, dim3(grid), dim3(256), lds, 0, mc, mp); } while (0)
+  NAGP_MV_SWITCH(mom_variant(mc), LM)
+#undef LM
+  ME_HIP(hipGetLastError());
+  ME_HIP(hipDeviceSynchronize());
+  ME_HIP(hipMemcpy(lZ, dev + o_lZ, (size_t)n * 8, hipMemcpyDeviceToHost));
+  ME_HIP(hipMemcpy(dlZ, dev + o_dl, (size_t)n * M * 8, hipMemcpyDeviceToHost));
+  ME_HIP(hipMemcpy(d2lZ, dev + o_d2, (size_t)n * M * 8, hipMemcpyDeviceToHost));
+#undef ME_HIP
+  (void)hipFree(dev);
+  return st;
 }

@@ -513,9 +513,11 @@ __device__ __forceinline__ void mom_quad(const MomCfg& c, const double* Wl, doub
 #pragma unroll
         for (int j = 0; j < CD; ++j) cj[j] = g_code[(size_t)(base + pl) * CD + j];
       }
-      double lk[CD];
+      double lk[CD];     // all gathers first, then the stores (LDS loads cannot be hoisted over LDS stores by the compiler)
 #pragma unroll
-      for (int j = 0; j < CD; ++j) { lk[j] = lkv[j * nd + cj[j]]; lkp[(size_t)j * CH + pl] = lk[j]; }
+      for (int j = 0; j < CD; ++j) lk[j] = lkv[j * nd + cj[j]];
+#pragma unroll
+      for (int j = 0; j < CD; ++j) lkp[(size_t)j * CH + pl] = lk[j];
       double sa2 = 0.0, sam = 0.0;
 #pragma unroll
       for (int j = 0; j < CD; ++j) {
@@ -827,7 +829,7 @@ template <int MV, bool LOGZ = true>
 __device__ __forceinline__ void mom_eval(const MomCfg& c, const double* Wl, double pEP, double sn2, double alpha,
                                          double y, const double* mu, const double* s2, double* ws, double* lZ, double* dl,
                                          double* d2l, unsigned long long* acc_st = nullptr) {
-  unsigned long long dummy_st[4];
+  unsigned long long dummy_st[8];
   if (!acc_st) acc_st = dummy_st;
   if constexpr (MV == 0) {
     mom_power<LOGZ>(c, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st, pEP);

@@ -38,6 +38,15 @@ __device__ __forceinline__ int nearest_idx(const IhgpTabs& tb, double R) {
     const double f = (log10(R) - tb.lr0) * tb.inv_dlr;
     est = (f <= 0.0) ? 0 : ((f >= (double)(tb.NG - 1)) ? tb.NG - 1 : (int)(f + 0.5));
   }
+  if (R > tb.r[tb.NG - 1]) {
+    // beyond the grid |r_i - R| is non-increasing in i and may ROUND to the same value for several -- for
+    // R > ~1e20 all -- grid points: MATLAB's min returns the first of them (e.g. index 0 for R = 1/ttau = 1e100)
+    const double dmin = fabs(tb.r[tb.NG - 1] - R);
+    if (fabs(tb.r[0] - R) == dmin) return 0;
+    int i = tb.NG - 1;
+    while (i > 0 && fabs(tb.r[i - 1] - R) == dmin) --i;
+    return i;
+  }
   const int lo = (est - 2 < 0) ? 0 : est - 2;
   const int hi = (est + 2 > tb.NG - 1) ? tb.NG - 1 : est + 2;
   int best = lo;
@@ -81,6 +90,13 @@ __device__ __forceinline__ int nearest_idx_lds(const double* r, int NG, double l
   if (R > 0.0) {
     const double f = (coarse_log10(R) - lr0) * inv_dlr;
     est = (f <= 0.0) ? 0 : ((f >= (double)(NG - 1)) ? NG - 1 : (int)(f + 0.5));
+  }
+  if (R > r[NG - 1]) {   // rounding ties beyond the grid: first minimiser (see nearest_idx)
+    const double dmin = fabs(r[NG - 1] - R);
+    if (fabs(r[0] - R) == dmin) return 0;
+    int i = NG - 1;
+    while (i > 0 && fabs(r[i - 1] - R) == dmin) --i;
+    return i;
   }
   const int lo = (est - 2 < 0) ? 0 : est - 2;
   const int hi = (est + 2 > NG - 1) ? NG - 1 : est + 2;

@@ -312,7 +312,9 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
           }
         }
       }
+      if (MV < 0 && mc.stamps && tid == 0) { st_b = __builtin_readcyclecounter(); stp[0] += st_b - st_a; st_a = st_b; }
       lds_barrier();  // B1
+      if (MV < 0 && mc.stamps && tid == 0) { st_b = __builtin_readcyclecounter(); stp[1] += st_b - st_a; st_a = st_b; }
       if (tid < S) m[tid] = rm;
 
       if (!(yk != yk)) {  // ~isnan(y_k)
@@ -468,6 +470,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
       } else {
         ++n_nan;
       }
+      if (MV < 0 && mc.stamps && tid == 0) { st_b = __builtin_readcyclecounter(); stp[2] += st_b - st_a; st_a = st_b; }
       // ---- per-step outputs -> ring ; covariance tiles -> HBM
       if (tid < S) {
         rMF[(size_t)kk * S + tid] = rm;
@@ -486,6 +489,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
       }
       lds_barrier();  // B5
       if (mc.stamps && tid == 0 && do_mom) { st_b = __builtin_readcyclecounter(); stp[5] += st_b - st_a; st_a = st_b; }
+      if (MV < 0 && mc.stamps && tid == 0) { st_b = __builtin_readcyclecounter(); stp[3] += st_b - st_a; st_a = st_b; }
     }
     // ---- flush the ring
     for (int i = tid; i < nb; i += NT) g_lZ[k0 + i] = (rZ[i] < 0.0) ? rlZ[i] : log(rZ[i]);
@@ -1232,6 +1236,49 @@ __global__ void __launch_bounds__(1024) sum_kernel(const double* v, int64_t T, i
     double tot = 0.0;
     for (int w = 0; w < (NT >> 6); ++w) tot += part[w];
     out[(size_t)pb * 8 + slot] = tot;
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// The reference's `mom` callback on its own (likModulatorPower.m:25-100, likModulatorNMFPower.m:28-87,
+// experiments/likModulatorPreCalcwn.m:28-86): one workgroup per evaluation, inputs (y, mu[M], s2[M]).
+struct MomPar {
+  int D, N, M;
+  double sn2, alpha;
+  const double* W;    // [D][N] row-major (device) or null
+  const double* y;    // [n]
+  const double* mu;   // [n][M]
+  const double* s2;   // [n][M]
+  double* lZ;         // [n]
+  double* dl;         // [n][M]
+  double* d2l;        // [n][M]
+  int64_t n;
+};
+__host__ __device__ inline size_t momk_lds_doubles(int D, int N, int M, const MomCfg& mc) {
+  return (size_t)D * N + 4 * (size_t)M + 8 + mom_lds_doubles(mc);
+}
+template <int MV>
+__global__ void __launch_bounds__(256) mom_kernel(MomCfg mc, MomPar mp) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int tid = threadIdx.x, NT = blockDim.x, M = mp.M;
+  double* sW = lds;
+  double* mu = sW + (size_t)mp.D * mp.N;
+  double* s2 = mu + M;
+  double* dl = s2 + M;
+  double* d2l = dl + M;
+  double* misc = d2l + M;
+  double* ws = misc + 8;
+  for (int i = tid; i < mp.D * mp.N; i += NT) sW[i] = mp.W ? mp.W[i] : 0.0;
+  mom_cache_tables(mc, ws);
+  const double pEPa = mom_pEP(mc, mp.sn2, mp.alpha);
+  for (int64_t e = blockIdx.x; e < mp.n; e += gridDim.x) {
+    if (tid < M) { mu[tid] = mp.mu[(size_t)e * M + tid]; s2[tid] = mp.s2[(size_t)e * M + tid]; }
+    lds_barrier();
+    mom_eval<MV>(mc, sW, pEPa, mp.sn2, mp.alpha, mp.y[e], mu, s2, ws, &misc[0], dl, d2l);
+    if (tid < M) { mp.dl[(size_t)e * M + tid] = dl[tid]; mp.d2l[(size_t)e * M + tid] = d2l[tid]; }
+    if (tid == 0) mp.lZ[e] = misc[0];
+    lds_barrier();
   }
 }
 

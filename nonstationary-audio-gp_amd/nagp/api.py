@@ -48,6 +48,32 @@ class Mom:
             return wn, xn
         return cubature.sigma_points(self.p, dim, self.quirks)
 
+    def __call__(self, hyp, mu, s2, *rest, device=0):
+        """The callback itself, with the reference's arities: mom(hyp, mu, s2, ep_frac, yall, k) for likModulatorPower
+        (demo_toy_modulators.m:81) and mom(hyp, mu, s2, nmfW, ep_frac, yall, k) for the NMF likelihoods
+        (demo_toy_modulators_nmf.m:81); k is 0-based here.  Returns lZ, dlZ (M,), d2lZ (M,).  mu, s2 may also be
+        M x n with yall[k] an n-vector: n independent evaluations in one launch (nagp_mom_eval)."""
+        if self.kind == L.LIK_POWER:
+            Wnmf = None; ep_frac, yall, k = rest
+        else:
+            Wnmf, ep_frac, yall, k = rest
+        mu = np.asarray(mu, float); s2 = np.asarray(s2, float)
+        single = mu.ndim == 1
+        mu2 = L.f64(mu.reshape(mu.shape[0], -1)); s22 = L.f64(s2.reshape(s2.shape[0], -1))
+        M, n = mu2.shape
+        y = L.f64(np.atleast_1d(np.asarray(yall, float)[k]).ravel(), 'C')
+        if y.size != n or s22.shape != mu2.shape:
+            raise ValueError('mu, s2 must be M x n and yall[k] must hold n observations')
+        if self.kind == L.LIK_POWER:
+            D, N, dim, Wc = M // 2, 0, M // 2, None
+        else:
+            Wc = L.f64(Wnmf); D, N = Wc.shape; dim = N
+        o, keep = make_opts(L.KIND_GF_EP, L.MODE_PREDICT, self, dim, ep_frac, None, 1, device=device)
+        lZ = np.zeros(n); dl = np.zeros((M, n), order='F'); d2l = np.zeros((M, n), order='F')
+        L.check(L.lib().nagp_mom_eval(C.byref(o), D, N, L.dptr(Wc), float(np.ravel(hyp)[0]), n, L.dptr(y), L.dptr(mu2), L.dptr(s22),
+                                      L.dptr(lZ), L.dptr(dl), L.dptr(d2l)))
+        return (float(lZ[0]), dl[:, 0].copy(), d2l[:, 0].copy()) if single else (lZ, dl, d2l)
+
 
 class SSHandle:
     """ss = @(x,p1,p2,k1,k2) ss_modulators_nmf(p1,p2,k1,k2)  /  @(x,p,k1,k2) ss_modulators(p,k1,k2)."""

@@ -126,6 +126,67 @@ def test_edge_lengths_and_missing_patterns_against_oracle(T, nanpos):
     assert rel(r3[0], o3[0]) < TOL_MEAN and rel(r3[1], o3[1]) < TOL_MEAN
 
 
+@pytest.mark.parametrize('D,N,p,lik', [
+    (3, 1, 9, 'likModulatorNMFPower'),      # one modulator: smallest MFMA operand block
+    (5, 7, 7, 'likModulatorNMFPower'),      # N = 7: the 16 x 16 MFMA block is full (rows 0..15, cols 0..14)
+    (4, 8, 7, 'likModulatorNMFPower'),      # N = 8: does not fit the MFMA block -> 16-lane-group sums
+    (3, 6, 4, 'likModulatorNMFPower'),      # Gauss-Hermite 4^6 = 4096 points: several chunks of 1024 sigma points
+    (21, 2, 7, 'likModulatorPreCalcwn'),    # sqrt amplitude, 21 sub-bands over 8 lanes x 4 registers
+    (5, 8, 7, 'likModulatorPreCalcwn'),     # sqrt amplitude at the largest cubature dimension
+])
+def test_every_cubature_code_path_against_oracle(D, N, p, lik):
+    """mom is instantiated per cubature dimension and has separate code paths per likelihood; each one is compared
+    with the oracle through a short two-sweep EP run (ADF filter, smoother, site refresh all call it).  Rules with
+    large negative weights (ut3 / ut5 at n >= 5) make the EP iteration itself unstable -- rounding-level differences
+    grow to O(1) within a few steps in the oracle as well -- so the orders here keep the rule well behaved."""
+    T = 24
+    pr = harness.nmf_problem(D, N, T, 77); t = np.arange(1, T + 1.0); d = np.array([0.5, 0.5])
+    if lik == 'likModulatorPreCalcwn':
+        from nagp import cubature
+        wn, xn = cubature.utp_ws(p, N)
+        mom = Mom(lik, wn=wn, xn_unscaled=xn); omom = olik.Mom(olik.LIK_POWER_NMF_SQRT, wn=wn, xn_unscaled=xn)
+    else:
+        mom = Mom(lik, p_cubature=p); omom = olik.Mom(olik.LIK_POWER_NMF, p=p)
+    Eft, Varft, _, _, _, out = nagp.gf_ep_modulator_nmf(pr['w'], t, pr['y'], SSHandle(), mom, t, 'matern32', 'matern52', 1, D, N, 0.5, d, 2, nargout=6)
+    o = ogf.gf_ep_modulator_nmf(pr['w'], t, pr['y'], None, omom, t, 'matern32', 'matern52', 1, D, N, 0.5, d, 2)
+    assert rel(Eft, o[0]) < TOL_MEAN and rel(Varft, o[1]) < TOL_MEAN
+    assert rel(out['ttau'], o[5]['ttau']) < TOL_SITE and rel(out['tnu'], o[5]['tnu']) < TOL_SITE
+    assert np.allclose(out['nlZ'], o[5]['nlZ'], rtol=TOL_LOGZ, atol=1e-12)
+    r2 = nagp.ihgp_ep_modulator_nmf(pr['w'], t, pr['y'], SSHandle(), mom, t, 'matern32', 'matern52', 1, D, N, 0.5, d, 2, nargout=6)
+    o2 = oih.ihgp_ep_modulator_nmf(pr['w'], t, pr['y'], None, omom, t, 'matern32', 'matern52', 1, D, N, 0.5, d, 2)
+    assert rel(r2[0], o2[0]) < TOL_MEAN and rel(r2[1], o2[1]) < TOL_MEAN and np.allclose(r2[5]['nlZ'], o2[5]['nlZ'], rtol=TOL_LOGZ, atol=1e-12)
+
+
+@pytest.mark.parametrize('D,N,p,kind', [(5, 6, 7, 'nmf'), (5, 7, 7, 'nmf'), (4, 8, 7, 'nmf'), (5, 3, 9, 'nmf'), (7, 2, 5, 'sqrt'),
+                                        (5, 7, 7, 'sqrt'), (4, 0, 5, 'power'), (3, 0, 9, 'power')])
+def test_mom_callback_itself_against_oracle(D, N, p, kind):
+    """The `mom` handle called with the reference's own arity on arbitrary (mu, s2, y): likModulatorPower,
+    likModulatorNMFPower, likModulatorPreCalcwn (C ABI: nagp_mom_eval), 48 inputs per launch including tiny variances,
+    large means and a missing-data-like far-off observation.  Entries that are rounding noise relative to the largest
+    entry of their vector (cancellation in -dlZ^2 + ...) are compared on the vector's scale."""
+    rng = np.random.default_rng(100 * D + N); n = 48; hyp = np.log(1e-2)
+    if kind == 'power':
+        M = 2 * D; W = None; mom = Mom('likModulatorPower', p_cubature=p); omom = olik.Mom(olik.LIK_POWER, p=p)
+    else:
+        M = D + N; W = rng.uniform(0, 0.5, (D, N))
+        if kind == 'sqrt':
+            from nagp import cubature
+            wn, xn = cubature.utp_ws(p, N)
+            mom = Mom('likModulatorPreCalcwn', wn=wn, xn_unscaled=xn); omom = olik.Mom(olik.LIK_POWER_NMF_SQRT, wn=wn, xn_unscaled=xn)
+        else:
+            mom = Mom('likModulatorNMFPower', p_cubature=p); omom = olik.Mom(olik.LIK_POWER_NMF, p=p)
+    mu = rng.normal(0, 1, (M, n)); s2 = rng.uniform(0.01, 2.0, (M, n)); y = rng.normal(0, 1, n)
+    s2[:, 1] *= 1e-6; mu[:, 2] *= 10; s2[D:, 3] *= 50; y[4] = 40.0
+    args = (W,) if W is not None else ()
+    lZ, dl, d2l = mom(hyp, mu, s2, *args, 0.5, [y], 0)
+    one = mom(hyp, mu[:, 7], s2[:, 7], *args, 0.5, y, 7)               # scalar form, k indexes yall
+    assert one[0] == lZ[7] and np.array_equal(one[1], dl[:, 7]) and np.array_equal(one[2], d2l[:, 7])
+    for i in range(n):
+        a = omom(hyp, mu[:, i], s2[:, i], W, 0.5, y, i)
+        assert abs(a[0] - lZ[i]) <= 1e-9 * max(1.0, abs(a[0]))
+        assert rel(dl[:, i], np.ravel(a[1])) < 1e-8 and rel(d2l[:, i], np.ravel(a[2])) < 1e-8
+
+
 def test_test_inputs_subset_and_unsorted_inputs():
     """xt a subset of x, x unsorted: return_ind / unique('first') semantics (gf_ep_modulator_nmf.m:58-66)."""
     D, N, T = 3, 2, 60

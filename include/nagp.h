@@ -174,6 +174,16 @@ int nagp_giekf_run(const nagp_model* model, const double* y, int64_t T, const na
 int nagp_mom_eval(const nagp_opts* opts, int32_t D, int32_t N, const double* Wnmf, double lik_param, int64_t n_eval,
                   const double* y, const double* mu, const double* s2, double* lZ, double* dlZ, double* d2lZ);
 
+/* [M,P,K,MU,S] = iekf_update1(M,P,y,H,R,h,V,param,iters) -- iekf_update1.m:110-117 (ekf_update1.m:106-109 is
+ * iters = 1) for the measurement model the reference passes through its handles (funh / funhd,
+ * gf_giekf_modulator_nmf_constraints.m:492-502): h(x) = (H_z x)' W softplus(H_g x).  Row n of H has its single
+ * non-zero h_val[n] at (0-based) column h_col[n]; n < D: sub-bands, then N modulators.  m (S) and P (S x S
+ * column-major) are updated in place; K (S), *MU, *Sinn receive the last iteration's gain, prediction and innovation
+ * variance (any of the three may be NULL). */
+int nagp_iekf_update1(int32_t S, int32_t D, int32_t N, const int32_t* h_col, const double* h_val, const double* Wnmf,
+                      double R, double y, int32_t iters, double* m, double* P, double* K, double* MU, double* Sinn,
+                      int32_t device);
+
 /* Batched / device-resident form: n_problems independent problems of identical shape
  * (S, M, block structure, T) -- audio segments or hyper-parameter replicas -- run concurrently. */
 int nagp_plan_create(nagp_plan** plan, int32_t n_problems, const nagp_model* models,

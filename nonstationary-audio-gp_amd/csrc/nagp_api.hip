@@ -1040,3 +1040,46 @@ extern "C" int nagp_mom_eval(const nagp_opts* o, int32_t D, int32_t N, const dou
   (void)hipFree(dev);
   return st;
 }
+
+// ---------------------------------------------------------------------------------------------
+// iekf_update1 / ekf_update1 on their own (see include/nagp.h)
+extern "C" int nagp_iekf_update1(int32_t S, int32_t D, int32_t N, const int32_t* h_col, const double* h_val, const double* Wnmf,
+                                 double R, double y, int32_t iters, double* m, double* P, double* K, double* MU, double* Sinn,
+                                 int32_t device) {
+  if (!h_col || !h_val || !Wnmf || !m || !P) FAIL(NAGP_EINVAL, "null argument");
+  const int M = D + N;
+  if (S < 1 || S > 512 || D < 1 || N < 1 || M > S || iters < 1) FAIL(NAGP_EINVAL, "bad sizes (S=%d D=%d N=%d iters=%d)", S, D, N, iters);
+  for (int n = 0; n < M; ++n)
+    if (h_col[n] < 0 || h_col[n] >= S) FAIL(NAGP_EINVAL, "h_col[%d] = %d outside the state", n, h_col[n]);
+  if (hipSetDevice(device) != hipSuccess) FAIL(NAGP_EHIP, "hipSetDevice(%d)", device);
+  // one device block: m | P | K | MU,S | hval | W | hcol(int)
+  const size_t o_m = 0, o_P = o_m + S, o_K = o_P + (size_t)S * S, o_ms = o_K + S, o_hv = o_ms + 2, o_W = o_hv + M,
+               o_hc = o_W + (size_t)D * N, total = o_hc + (M + 1) / 2 + 1;
+  double* dev = nullptr;
+  if (hipMalloc(&dev, total * sizeof(double)) != hipSuccess) FAIL(NAGP_ENOMEM, "hipMalloc(%zu)", total * sizeof(double));
+  std::vector<double> Wr((size_t)D * N);
+  for (int dd = 0; dd < D; ++dd)
+    for (int j = 0; j < N; ++j) Wr[(size_t)dd * N + j] = Wnmf[dd + (size_t)D * j];
+  int st = NAGP_OK;
+#define EK_HIP(x) do { if (st == NAGP_OK) { hipError_t _e = (x); if (_e != hipSuccess) { g_last_error = std::string("nagp_iekf_update1: " #x " -> ") + hipGetErrorString(_e); st = NAGP_EHIP; } } } while (0)
+  EK_HIP(hipMemcpy(dev + o_m, m, (size_t)S * 8, hipMemcpyHostToDevice));
+  EK_HIP(hipMemcpy(dev + o_P, P, (size_t)S * S * 8, hipMemcpyHostToDevice));
+  EK_HIP(hipMemcpy(dev + o_hv, h_val, (size_t)M * 8, hipMemcpyHostToDevice));
+  EK_HIP(hipMemcpy(dev + o_W, Wr.data(), Wr.size() * 8, hipMemcpyHostToDevice));
+  EK_HIP(hipMemcpy(dev + o_hc, h_col, (size_t)M * sizeof(int32_t), hipMemcpyHostToDevice));
+  EkfPar ep{S, D, N, iters, R, y, reinterpret_cast<const int*>(dev + o_hc), dev + o_hv, dev + o_W, dev + o_m, dev + o_P, dev + o_K, dev + o_ms};
+  const size_t lds = (2 * (size_t)S + 2 * M + 2) * sizeof(double);
+  if (st == NAGP_OK) hipLaunchKernelGGL(iekf_update1_kernel, dim3(1), dim3(256), lds, 0, ep);
+  EK_HIP(hipGetLastError());
+  EK_HIP(hipDeviceSynchronize());
+  double ms[2] = {0, 0};
+  EK_HIP(hipMemcpy(m, dev + o_m, (size_t)S * 8, hipMemcpyDeviceToHost));
+  EK_HIP(hipMemcpy(P, dev + o_P, (size_t)S * S * 8, hipMemcpyDeviceToHost));
+  if (K) EK_HIP(hipMemcpy(K, dev + o_K, (size_t)S * 8, hipMemcpyDeviceToHost));
+  EK_HIP(hipMemcpy(ms, dev + o_ms, 16, hipMemcpyDeviceToHost));
+#undef EK_HIP
+  if (MU) *MU = ms[0];
+  if (Sinn) *Sinn = ms[1];
+  (void)hipFree(dev);
+  return st;
+}

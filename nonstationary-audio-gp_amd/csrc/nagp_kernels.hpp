@@ -1282,4 +1282,79 @@ __global__ void __launch_bounds__(256) mom_kernel(MomCfg mc, MomPar mp) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// iekf_update1.m:110-117 / ekf_update1.m:106-109 on their own, with the measurement model of
+// gf_giekf_modulator_nmf_constraints.m:492-502:  h(x) = (H_z x)' W softplus(H_g x),  J = dh/dx.
+//   for it = 1:iters:  J = dh(M); MU = h(M); S = R + J P J'; K = P J'/S; M = M + K (y - MU);   P = P - K S K'
+// One workgroup; P dense column-major in HBM (S <= 512 states), H given as (column, value) per site.
+struct EkfPar {
+  int S, D, N, iters;
+  double R, y;
+  const int* hcol;      // [D+N]
+  const double* hval;   // [D+N]
+  const double* W;      // [D][N] row-major
+  double* m;            // [S]    in/out
+  double* P;            // [S][S] column-major, in/out
+  double* K;            // [S]    out
+  double* MU_S;         // [2]    out: MU, S of the last iteration
+};
+__global__ void __launch_bounds__(256) iekf_update1_kernel(EkfPar ep) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int tid = threadIdx.x, NT = blockDim.x, S = ep.S, D = ep.D, N = ep.N, M = D + N;
+  double* m = lds;          // [S]
+  double* f = m + S;        // [M]  H m
+  double* J = f + M;        // [M]  non-zeros of the Jacobian row
+  double* PJ = J + M;       // [S]
+  double* red = PJ + S;     // [2]
+  for (int i = tid; i < S; i += NT) m[i] = ep.m[i];
+  __syncthreads();
+  double Sx = 1.0, MU = 0.0;
+  for (int it = 0; it < ep.iters; ++it) {
+    for (int n = tid; n < M; n += NT) f[n] = ep.hval[n] * m[ep.hcol[n]];
+    __syncthreads();
+    for (int n = tid; n < M; n += NT) {
+      double pv = 0.0;
+      if (n < D) {
+        for (int j = 0; j < N; ++j) pv = fma(ep.W[n * N + j], log(1.0 + exp(f[D + j])), pv);
+      } else {
+        const int j = n - D;
+        double zw = 0.0;
+        for (int dd = 0; dd < D; ++dd) zw = fma(f[dd], ep.W[dd * N + j], zw);
+        const double eg = exp(f[D + j]);
+        pv = zw * (eg / (eg + 1.0));
+      }
+      J[n] = pv * ep.hval[n];
+    }
+    __syncthreads();
+    for (int i = tid; i < S; i += NT) {
+      double acc = 0.0;
+      for (int n = 0; n < M; ++n) acc = fma(ep.P[(size_t)ep.hcol[n] * S + i], J[n], acc);   // (P J')_i = sum_n P(i, c_n) J_n
+      PJ[i] = acc;
+    }
+    if (tid == 0) {
+      double mu = 0.0;
+      for (int dd = 0; dd < D; ++dd) mu = fma(f[dd], J[dd] / ep.hval[dd], mu);   // h = sum_d z_d (W softplus(g))_d
+      red[1] = mu;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double jpj = 0.0;
+      for (int n = 0; n < M; ++n) jpj = fma(J[n], PJ[ep.hcol[n]], jpj);
+      red[0] = ep.R + jpj;
+    }
+    __syncthreads();
+    Sx = red[0]; MU = red[1];
+    for (int i = tid; i < S; i += NT) m[i] = m[i] + (PJ[i] / Sx) * (ep.y - MU);
+    __syncthreads();
+  }
+  for (size_t e = tid; e < (size_t)S * S; e += NT) {
+    const int i = (int)(e % S), j = (int)(e / S);
+    const double Ki = PJ[i] / Sx, Kj = PJ[j] / Sx;
+    ep.P[e] -= (Ki * Sx) * Kj;
+  }
+  for (int i = tid; i < S; i += NT) { ep.m[i] = m[i]; ep.K[i] = PJ[i] / Sx; }
+  if (tid == 0) { ep.MU_S[0] = MU; ep.MU_S[1] = Sx; }
+}
+
 }  // namespace nagp

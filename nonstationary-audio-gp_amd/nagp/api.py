@@ -75,6 +75,48 @@ class Mom:
         return (float(lZ[0]), dl[:, 0].copy(), d2l[:, 0].copy()) if single else (lZ, dl, d2l)
 
 
+
+class MeasModel:
+    """The EKF measurement handles of gf_giekf_modulator_nmf.m:108-113 as one object:
+    handle = @(x,p) funh(x,H,linkf,D,N,Wnmf), dhandle = @(x,p) funhd(x,H,...) -> pass `model.h` / `model.dh` where the
+    reference passes `handle` / `dhandle` (h(x) = (H_z x)' W softplus(H_g x), gf_giekf_modulator_nmf_constraints.m:492-502)."""
+
+    def __init__(self, H, Wnmf, D, N):
+        H = np.asarray(H, float)
+        if H.shape[0] != D + N or np.any((H != 0).sum(axis=1) != 1):
+            raise ValueError('H must be (D+N) x S with exactly one non-zero per row')
+        self.H, self.W, self.D, self.N = H, L.f64(Wnmf), int(D), int(N)
+        self.col = np.argmax(H != 0, axis=1).astype(np.int32); self.val = H[np.arange(D + N), self.col].copy()
+
+    def h(self, x, param=None):       # only a token: the update below evaluates the model on the device
+        raise NagpError('MeasModel.h is evaluated on the GPU inside ekf_update1 / iekf_update1')
+
+    dh = h
+
+
+def iekf_update1(M, P, y, H, R, h, V=None, param=None, iters=5, device=0):
+    """[M,P,K,MU,S] = iekf_update1(M,P,y,H,R,h,V,param,iters) (iekf_update1.m:48, :110-117), scalar y, with
+    H = model.dh and h = model.h of a MeasModel.  Returns new arrays (inputs are not modified)."""
+    mdl = getattr(H, '__self__', None)
+    if not isinstance(mdl, MeasModel) or getattr(h, '__self__', None) is not mdl:
+        raise ValueError('H and h must be the dh / h handles of one MeasModel (the model the reference drivers pass)')
+    if V is not None:
+        raise NotImplementedError('a noise-Jacobian V is never passed on the hot path (gf_giekf_modulator_nmf.m:161)')
+    m = L.f64(np.array(M, float).ravel().copy(), 'C'); S = m.size
+    Pd = L.f64(np.array(P, float).copy())
+    if Pd.shape != (S, S) or mdl.H.shape[1] != S:
+        raise ValueError('P must be S x S and H must have S columns')
+    K = np.zeros(S); MU = C.c_double(0.0); Sx = C.c_double(0.0)
+    L.check(L.lib().nagp_iekf_update1(S, mdl.D, mdl.N, mdl.col.ctypes.data_as(C.POINTER(C.c_int32)), L.dptr(L.f64(mdl.val, 'C')),
+                                      L.dptr(mdl.W), float(np.ravel(R)[0]), float(np.ravel(y)[0]), int(iters), L.dptr(m), L.dptr(Pd),
+                                      L.dptr(K), C.byref(MU), C.byref(Sx), int(device)))
+    return m, Pd, K, MU.value, Sx.value
+
+
+def ekf_update1(M, P, y, H, R, h, V=None, param=None, device=0):
+    """[M,P,K,MU,S] = ekf_update1(M,P,y,H,R,h,V,param) (ekf_update1.m:48, :106-109): one linearisation."""
+    return iekf_update1(M, P, y, H, R, h, V, param, 1, device)
+
 class SSHandle:
     """ss = @(x,p1,p2,k1,k2) ss_modulators_nmf(p1,p2,k1,k2)  /  @(x,p,k1,k2) ss_modulators(p,k1,k2)."""
 

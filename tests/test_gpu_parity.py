@@ -187,6 +187,29 @@ def test_mom_callback_itself_against_oracle(D, N, p, kind):
         assert rel(dl[:, i], np.ravel(a[1])) < 1e-8 and rel(d2l[:, i], np.ravel(a[2])) < 1e-8
 
 
+@pytest.mark.parametrize('iters', [1, 3])
+def test_ekf_update1_and_iekf_update1_standalone(iters):
+    """[M,P,K,MU,S] = (i)ekf_update1(M,P,y,H,R,h,[],[],iters) with the drivers' measurement handles, balanced H
+    (entries that are powers of two, not 1) -- iekf_update1.m:110-117, ekf_update1.m:106-109."""
+    D, N = 4, 2
+    pr = harness.nmf_problem(D, N, 8, 9)
+    blk = pss.balance_blocks(pss.ss_blocks_nmf(pr['param1'], pr['param2'], 'matern32', 'matern52'))
+    _, _, H, Pinf = blk.dense()
+    S = Pinf.shape[0]; rng = np.random.default_rng(4)
+    Lc = np.linalg.cholesky(Pinf); m0 = Lc @ rng.normal(size=S)
+    G = rng.normal(size=(S, S)) * 0.1
+    P0 = Lc @ (np.eye(S) * 0.6 + G @ G.T) @ Lc.T                    # a dense SPD prior covariance
+    model = nagp.MeasModel(H, pr['W'], D, N); y = 0.37; R = 1e-2
+    if iters == 1:
+        m, P, K, MU, Sx = nagp.ekf_update1(m0, P0, y, model.dh, R, model.h)
+        o = oek.ekf_update1(m0.copy(), P0.copy(), y, lambda x: oek.funhd(x, H, D, N, pr['W']), R, lambda x: oek.funh(x, H, D, N, pr['W']))
+    else:
+        m, P, K, MU, Sx = nagp.iekf_update1(m0, P0, y, model.dh, R, model.h, None, None, iters)
+        o = oek.iekf_update1(m0.copy(), P0.copy(), y, lambda x: oek.funhd(x, H, D, N, pr['W']), R, lambda x: oek.funh(x, H, D, N, pr['W']), iters)
+    assert rel(m, o[0]) < 1e-12 and rel(P, o[1]) < 1e-12 and rel(K, o[2]) < 1e-12
+    assert abs(MU - float(o[3])) < 1e-12 * max(1, abs(float(o[3]))) and abs(Sx - float(o[4])) < 1e-12 * abs(float(o[4]))
+
+
 def test_test_inputs_subset_and_unsorted_inputs():
     """xt a subset of x, x unsorted: return_ind / unique('first') semantics (gf_ep_modulator_nmf.m:58-66)."""
     D, N, T = 3, 2, 60

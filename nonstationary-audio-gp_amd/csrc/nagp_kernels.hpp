@@ -312,9 +312,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
           }
         }
       }
-      if (MV < 0 && mc.stamps && tid == 0) { st_b = __builtin_readcyclecounter(); stp[0] += st_b - st_a; st_a = st_b; }
       lds_barrier();  // B1
-      if (MV < 0 && mc.stamps && tid == 0) { st_b = __builtin_readcyclecounter(); stp[1] += st_b - st_a; st_a = st_b; }
       if (tid < S) m[tid] = rm;
 
       if (!(yk != yk)) {  // ~isnan(y_k)
@@ -470,7 +468,6 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
       } else {
         ++n_nan;
       }
-      if (MV < 0 && mc.stamps && tid == 0) { st_b = __builtin_readcyclecounter(); stp[2] += st_b - st_a; st_a = st_b; }
       // ---- per-step outputs -> ring ; covariance tiles -> HBM
       if (tid < S) {
         rMF[(size_t)kk * S + tid] = rm;
@@ -489,10 +486,13 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
       }
       lds_barrier();  // B5
       if (mc.stamps && tid == 0 && do_mom) { st_b = __builtin_readcyclecounter(); stp[5] += st_b - st_a; st_a = st_b; }
-      if (MV < 0 && mc.stamps && tid == 0) { st_b = __builtin_readcyclecounter(); stp[3] += st_b - st_a; st_a = st_b; }
     }
     // ---- flush the ring
-    for (int i = tid; i < nb; i += NT) g_lZ[k0 + i] = (rZ[i] < 0.0) ? rlZ[i] : log(rZ[i]);
+    if constexpr (MEAS == 0 && MV >= 0) {
+      for (int i = tid; i < nb; i += NT) g_lZ[k0 + i] = (rZ[i] < 0.0) ? rlZ[i] : log(rZ[i]);
+    } else {
+      for (int i = tid; i < nb; i += NT) g_lZ[k0 + i] = rlZ[i];   // no mom in this instantiation
+    }
     for (int i = tid; i < nb * M; i += NT) {
       if (MEAS == 0) {
         g_tt[(size_t)k0 * M + i] = rtt[i]; g_tn[(size_t)k0 * M + i] = rtn[i];

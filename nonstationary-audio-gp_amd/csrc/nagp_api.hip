@@ -46,6 +46,7 @@ struct nagp_plan {
   int B = 0;
   int TPT = 1, TPT_f = 1, NT = 256, NT_f = 256, NT_ih = 256;
   int TPT_a = 1, NT_a = 256, LB_a = 256;   // ADF (mom) launches of the gf filter
+  int wide_l = 0, NT_l = 256;              // fixed-site launches of models with 512 < tiles <= 1024: one tile per thread, 1024-thread bound
   int chunk = 2048, LP1 = 1, LP2 = 1, ns_max = 1;
   SpanPar spar{};
   int mfma_sp = 0;      // > 0: FP64-MFMA smoother passes on dense Sp x Sp matrices
@@ -226,6 +227,8 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     // ADF launches: <= 256 threads (512 registers per lane) whenever the tiles fit
     if (slots <= 1024 && sh.S <= 256) { p->TPT_a = slots <= 256 ? 1 : (slots <= 512 ? 2 : 4); p->NT_a = 256; p->LB_a = 256; }
     else { p->TPT_a = 4; p->NT_a = std::max(roundup64((slots + 3) / 4), roundup64(sh.S)); p->LB_a = 512; }
+    p->wide_l = (!ekf && slots > 512 && slots <= 1024 && !getenv("NAGP_NO_WIDE")) ? 1 : 0;
+    p->NT_l = p->wide_l ? roundup64(slots) : p->NT_f;
   }
   p->want_PS = (o->flags & 0x4u) != 0;
   p->need_PF = (o->kind != NAGP_KIND_IHGP) && !(o->mode == NAGP_MODE_NLML && o->ep_itts == 1);
@@ -437,7 +440,8 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
         case 2: NAGP_MV_SWITCH(mom_variant(mc), SL2) break;
         default: NAGP_MV_SWITCH(mom_variant(mc), SL4) break;
       }
-      switch (p->TPT_f) {   // mom-free kernel of the fixed-site steps
+      if (p->wide_l) PLAN_TRY(set_lds(gf_filter_kernel<1, 0, -1, 1024>, p->lds_filter));
+      else switch (p->TPT_f) {   // mom-free kernel of the fixed-site steps
         case 1: PLAN_TRY(set_lds(gf_filter_kernel<1, 0, -1>, p->lds_filter)); break;
         case 2: PLAN_TRY(set_lds(gf_filter_kernel<2, 0, -1>, p->lds_filter)); break;
         default: PLAN_TRY(set_lds(gf_filter_kernel<4, 0, -1>, p->lds_filter)); break;
@@ -530,6 +534,8 @@ static int launch_filter(nagp_plan* p, const FilterPar& fp_in) {
 #undef LF2
 #undef LF4
 #undef LF5
+    } else if (p->wide_l) {
+      hipLaunchKernelGGL((gf_filter_kernel<1, 0, -1, 1024>), g, dim3(p->NT_l), p->lds_filter, p->stream, p->sh, p->b, mc, fp);
     } else {   // no step of this launch calls mom
       switch (p->TPT_f) {
         case 1: hipLaunchKernelGGL((gf_filter_kernel<1, 0, -1>), g, bl, p->lds_filter, p->stream, p->sh, p->b, mc, fp); break;

@@ -118,7 +118,7 @@ __host__ __device__ inline size_t filter_ring_doubles(const Shape& s, int kb) { 
 __host__ __device__ inline size_t filter_lds_doubles(const Shape& s, const MomCfg& mc, int meas, int kb) {
   size_t n = LDS_INT_DOUBLES + 2 * (size_t)s.M * TS + s.M + (size_t)s.D * s.N + s.S + 4 * (size_t)s.M * s.M +
              8 * (size_t)s.M + 8 + filter_ring_doubles(s, kb);
-  n += (meas == 0) ? mom_lds_doubles(mc) : (size_t)(s.M + s.S);
+  n += (meas == 0) ? mom_lds_doubles(mc) : (size_t)(s.M + 2 * s.S + 2 * s.N);
   return (n + 1) & ~(size_t)1;
 }
 
@@ -411,6 +411,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
           // ---------------- EKF measurement update (iekf_update1.m:110-117)
           double* part = ws;
           double* PJ = ws + M;
+          double* Kv = PJ + S + 2 * sh.N;   // [S] gain of the last inner iteration
           const int N = sh.N;
           double Sx = 1.0, MU = 0.0;
           for (int it = 0; it < fp.l_iter; ++it) {
@@ -418,32 +419,57 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
               if (tid < M) fmu[tid] = shv[tid] * m[ioff[tid]];
               lds_barrier();
             }
-            if (tid < M) {   // partials of h = z' W softplus(g)
+            // softplus(g_j) and its derivative once per modulator (one exp + log chain for the whole step instead of
+            // N of them in every sub-band lane), then the partials of h = z' W softplus(g)
+            double* spl = PJ + S;        // [N] softplus(g), [N] sigmoid(g)
+            if (tid < N) {
+              const double eg = exp(fmu[D + tid]);
+              spl[tid] = log(1.0 + eg);
+              spl[N + tid] = eg / (eg + 1.0);
+            }
+            lds_barrier();
+            if (tid < M) {
               double pv = 0.0;
               if (tid < D) {
-                for (int j = 0; j < N; ++j) pv = fma(sW[tid * N + j], log(1.0 + exp(fmu[D + j])), pv);
+                for (int j = 0; j < N; ++j) pv = fma(sW[tid * N + j], spl[j], pv);
               } else {
                 const int j = tid - D;
-                double zw = 0.0;
-                for (int d = 0; d < D; ++d) zw = fma(fmu[d], sW[d * N + j], zw);
-                const double eg = exp(fmu[D + j]);
-                pv = zw * (eg / (eg + 1.0));
+                double z0 = 0.0, z1 = 0.0, z2 = 0.0, z3 = 0.0;   // four independent chains (same terms, fixed order)
+                int d = 0;
+                for (; d + 4 <= D; d += 4) {
+                  z0 = fma(fmu[d], sW[d * N + j], z0); z1 = fma(fmu[d + 1], sW[(d + 1) * N + j], z1);
+                  z2 = fma(fmu[d + 2], sW[(d + 2) * N + j], z2); z3 = fma(fmu[d + 3], sW[(d + 3) * N + j], z3);
+                }
+                for (; d < D; ++d) z0 = fma(fmu[d], sW[d * N + j], z0);
+                pv = ((z0 + z1) + (z2 + z3)) * spl[N + j];
               }
               part[tid] = pv;
             }
             lds_barrier();
             if (tid < S) {
-              double acc = 0.0;
-              for (int n = 0; n < M; ++n) acc = fma(Wl[((size_t)n * 4 + myrow) * M + myblk], part[n], acc);
-              PJ[tid] = acc;
+              double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+              const double* wp = Wl + (size_t)myrow * M + myblk;
+              int n = 0;
+              for (; n + 4 <= M; n += 4) {
+                a0 = fma(wp[(size_t)(n + 0) * 4 * M], part[n + 0], a0); a1 = fma(wp[(size_t)(n + 1) * 4 * M], part[n + 1], a1);
+                a2 = fma(wp[(size_t)(n + 2) * 4 * M], part[n + 2], a2); a3 = fma(wp[(size_t)(n + 3) * 4 * M], part[n + 3], a3);
+              }
+              for (; n < M; ++n) a0 = fma(wp[(size_t)n * 4 * M], part[n], a0);
+              PJ[tid] = (a0 + a1) + (a2 + a3);
             }
             lds_barrier();
-            double jpj = 0.0;
-            MU = 0.0;
-            for (int n = 0; n < M; ++n) jpj = fma(part[n] * shv[n], PJ[ioff[n]], jpj);
-            for (int d = 0; d < D; ++d) MU = fma(fmu[d], part[d], MU);
-            Sx = sn2 + jpj;
-            if (tid < S) { rm = rm + (PJ[tid] / Sx) * (yk - MU); }
+            // S = R + J P J' and MU = h(m): one term per lane of wave 0, DPP sums, broadcast through LDS
+            if (tid < 64) {
+              double tj = 0.0, tm = 0.0;
+              for (int n = tid; n < M; n += 64) tj = fma(part[n] * shv[n], PJ[ioff[n]], tj);
+              for (int d = tid; d < D; d += 64) tm = fma(fmu[d], part[d], tm);
+              tj = wave_sum(tj); tm = wave_sum(tm);
+              if (tid == 0) { misc[2] = tj; misc[3] = tm; }
+            }
+            lds_barrier();
+            MU = misc[3];
+            Sx = sn2 + misc[2];
+            if (tid < S) { const double Kt = PJ[tid] / Sx; Kv[tid] = Kt; rm = rm + Kt * (yk - MU); }   // K = P J' / S, once per state
             lds_barrier();   // all reads of m/fmu for this iteration done
             if (tid < S) m[tid] = rm;
             if (it + 1 < fp.l_iter) lds_barrier();
@@ -458,10 +484,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
               for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                  if (i < bI && j < bJ) {
-                    const double Ki = PJ[oI + i] / Sx, Kj = PJ[oJ + j] / Sx;
-                    P[q][4 * i + j] -= (Ki * Sx) * Kj;
-                  }
+                  if (i < bI && j < bJ) P[q][4 * i + j] -= (Kv[oI + i] * Sx) * Kv[oJ + j];
             }
           }
         }

@@ -52,7 +52,7 @@ struct nagp_plan {
   int mfma_sp = 0;      // > 0: FP64-MFMA smoother passes on dense Sp x Sp matrices
   MfmaPar mpar{};
   size_t lds_mfma = 0;
-  int hph_lds = 0, DG_f = 1, DG_ep = 1, cache_f = 0, cache_ep = 0, kb_f = 16;
+  int hph_lds = 0, sta_f = 0, sta_ep = 0, DG_f = 1, DG_ep = 1, cache_f = 0, cache_ep = 0, kb_f = 16;
   bool want_PS = false;
   bool need_PF = false;
   hipStream_t stream = nullptr;
@@ -289,7 +289,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     mc.lik_kind = o->lik_kind; mc.link_kind = o->link_kind; mc.link_shift = o->link_shift;
     mc.n_pts = o->n_pts; mc.cdim = o->cub_dim; mc.D = sh.D; mc.wn = p->d_wn;
     mc.jitter = (o->lik_kind == NAGP_LIK_POWER) ? 1e-8 : 1e-10;
-    mc.DG = 1; mc.cache_tabs = 0; mc.stamps = nullptr;
+    mc.DG = 1; mc.cache_tabs = 0; mc.store_a = 0; mc.stamps = nullptr;
   }
 
   // ---- buffers
@@ -400,11 +400,12 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     p->DG_f = pick_DG(o->lik_kind, o->n_pts, p->NT_ih, sh.D, o->cub_dim);
     if (const char* e = getenv("NAGP_NT_IH")) p->NT_ih = atoi(e);      // developer tuning hooks
     if (const char* e = getenv("NAGP_DG")) p->DG_f = atoi(e);
-    MomCfg t = mc; t.DG = p->DG_f; t.cache_tabs = 1;
-    p->hph_lds = 1;
+    MomCfg t = mc; t.DG = p->DG_f; t.cache_tabs = 1; t.store_a = (o->lik_kind == NAGP_LIK_POWER_NMF_SQRT) ? 1 : 0;
+    p->hph_lds = 1;   // LDS budget, least valuable resident first: H PP H' table, a[d][p], cubature tables
     if (ihgp_filter_lds_doubles(sh, t, p->tb.NG, p->hph_lds) * sizeof(double) > 150 * 1024) p->hph_lds = 0;
+    if (ihgp_filter_lds_doubles(sh, t, p->tb.NG, p->hph_lds) * sizeof(double) > 150 * 1024) t.store_a = 0;
     if (ihgp_filter_lds_doubles(sh, t, p->tb.NG, p->hph_lds) * sizeof(double) > 150 * 1024) t.cache_tabs = 0;
-    p->cache_f = t.cache_tabs;
+    p->cache_f = t.cache_tabs; p->sta_f = t.store_a;
     p->lds_ih = ihgp_filter_lds_doubles(sh, t, p->tb.NG, p->hph_lds) * sizeof(double);
     if (getenv("NAGP_STAMPS")) fprintf(stderr, "[nagp plan] ihgp filter: LDS %zu B, hph table in LDS %d, cubature tables in LDS %d, mom LDS %zu B\n", p->lds_ih, p->hph_lds, p->cache_f, mom_lds_doubles(t) * sizeof(double));
 #define SL(V) PLAN_TRY(set_lds(ihgp_filter_kernel<V>, p->lds_ih))
@@ -412,13 +413,14 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
 #undef SL
   } else {
     if (!ekf) p->DG_f = pick_DG(o->lik_kind, o->n_pts, p->NT_a, sh.D, o->cub_dim);
-    MomCfg t = mc; t.DG = p->DG_f; t.cache_tabs = ekf ? 0 : 1;
+    MomCfg t = mc; t.DG = p->DG_f; t.cache_tabs = ekf ? 0 : 1; t.store_a = (!ekf && o->lik_kind == NAGP_LIK_POWER_NMF_SQRT) ? 1 : 0;
     const size_t cap = 156 * 1024;
     p->kb_f = 16;
     if (filter_lds_doubles(sh, t, ekf ? 1 : 0, p->kb_f) * sizeof(double) > cap) p->kb_f = 8;
     if (filter_lds_doubles(sh, t, ekf ? 1 : 0, p->kb_f) * sizeof(double) > cap) p->kb_f = 4;
+    if (filter_lds_doubles(sh, t, ekf ? 1 : 0, p->kb_f) * sizeof(double) > cap) t.store_a = 0;
     if (filter_lds_doubles(sh, t, ekf ? 1 : 0, p->kb_f) * sizeof(double) > cap) t.cache_tabs = 0;
-    p->cache_f = t.cache_tabs;
+    p->cache_f = t.cache_tabs; p->sta_f = t.store_a;
     p->lds_filter = filter_lds_doubles(sh, t, ekf ? 1 : 0, p->kb_f) * sizeof(double);
     if (getenv("NAGP_STAMPS")) fprintf(stderr, "[nagp plan] gf filter: LDS %zu B, ring %d steps, cubature tables in LDS %d, mom LDS %zu B\n", p->lds_filter, p->kb_f, p->cache_f, ekf ? (size_t)0 : mom_lds_doubles(t) * sizeof(double));
     p->lds_gain = gain_lds_doubles(sh) * sizeof(double);
@@ -465,9 +467,10 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
   }
   if (!ekf) {
     p->DG_ep = pick_DG(o->lik_kind, o->n_pts, 256, sh.D, o->cub_dim);
-    MomCfg t = mc; t.DG = p->DG_ep; t.cache_tabs = 1;
+    MomCfg t = mc; t.DG = p->DG_ep; t.cache_tabs = 1; t.store_a = (o->lik_kind == NAGP_LIK_POWER_NMF_SQRT) ? 1 : 0;
+    if (ep_lds_doubles(sh, t) * sizeof(double) > 64 * 1024) t.store_a = 0;
     if (ep_lds_doubles(sh, t) * sizeof(double) > 64 * 1024) t.cache_tabs = 0;
-    p->cache_ep = t.cache_tabs;
+    p->cache_ep = t.cache_tabs; p->sta_ep = t.store_a;
     p->lds_ep = ep_lds_doubles(sh, t) * sizeof(double);
 #define SL(V) PLAN_TRY(set_lds(ep_site_kernel<V>, p->lds_ep))
     NAGP_MV_SWITCH(mom_variant(mc), SL)
@@ -508,7 +511,7 @@ static int launch_filter(nagp_plan* p, const FilterPar& fp_in) {
   FilterPar fp = fp_in;
   fp.kb = p->kb_f;
   const bool ekf = p->opts.kind == NAGP_KIND_GIEKF;
-  MomCfg mc = p->mc; mc.DG = p->DG_f; mc.cache_tabs = p->cache_f;
+  MomCfg mc = p->mc; mc.DG = p->DG_f; mc.cache_tabs = p->cache_f; mc.store_a = p->sta_f;
   if (getenv("NAGP_STAMPS")) mc.stamps = reinterpret_cast<unsigned long long*>(p->d_stamps);   // developer diagnostics
   const bool adf = ekf || fp.mom_all || fp.k_end == p->sh.T;   // launches that may call mom (or the EKF filter)
   Timed t(p, adf ? NAGP_K_FILTER : NAGP_K_FILTER_LIN);
@@ -609,7 +612,7 @@ static int launch_smoother(nagp_plan* p, bool write_PSs) {
 static int launch_ep(nagp_plan* p, double alpha, double damp, int clamp, int write_R, double* lZ_out) {
   const Shape& sh = p->sh;
   if (sh.T < 2) return NAGP_OK;
-  MomCfg mc = p->mc; mc.DG = p->DG_ep; mc.cache_tabs = p->cache_ep;
+  MomCfg mc = p->mc; mc.DG = p->DG_ep; mc.cache_tabs = p->cache_ep; mc.store_a = p->sta_ep;
   EpPar ep{};
   ep.k_end = sh.T - 1;
   ep.steps_per_wg = (int)std::max<int64_t>(1, (ep.k_end + 4095) / 4096);
@@ -764,7 +767,7 @@ static int exec_ihgp(nagp_plan* p) {
     HIP_TRY(hipMemcpyAsync(p->d_vprev + (size_t)q * sh.M, p->d_tab + (size_t)q * itab_size(sh, p->tb.NG) + itab_hph0(sh, p->tb.NG),
                            sh.M * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
   }
-  MomCfg mcf = p->mc; mcf.DG = p->DG_f; mcf.cache_tabs = p->cache_f;
+  MomCfg mcf = p->mc; mcf.DG = p->DG_f; mcf.cache_tabs = p->cache_f; mcf.store_a = p->sta_f;
   if (getenv("NAGP_STAMPS")) mcf.stamps = reinterpret_cast<unsigned long long*>(p->d_stamps);   // developer diagnostics
   auto affine = [&](int mode, int64_t kend, int itt) -> int {
     if (kend <= 0) return NAGP_OK;
@@ -1027,7 +1030,8 @@ extern "C" int nagp_mom_eval(const nagp_opts* o, int32_t D, int32_t N, const dou
   mc.wn = dev + o_wn; mc.xd = dev + o_xd; mc.code = reinterpret_cast<const unsigned char*>(dev + o_code);
   mc.jitter = power ? 1e-8 : 1e-10; mc.stamps = nullptr;
   mc.DG = pick_DG(o->lik_kind, o->n_pts, 256, D, o->cub_dim);
-  mc.cache_tabs = 1;
+  mc.cache_tabs = 1; mc.store_a = (o->lik_kind == NAGP_LIK_POWER_NMF_SQRT) ? 1 : 0;
+  if (momk_lds_doubles(D, power ? D : N, M, mc) * sizeof(double) > 150 * 1024) mc.store_a = 0;
   if (momk_lds_doubles(D, power ? D : N, M, mc) * sizeof(double) > 150 * 1024) mc.cache_tabs = 0;
   const size_t lds = momk_lds_doubles(D, power ? D : N, M, mc) * sizeof(double);
   if (lds > 160 * 1024) { (void)hipFree(dev); FAIL(NAGP_EUNSUPPORTED, "mom workspace of %zu B exceeds the LDS", lds); }

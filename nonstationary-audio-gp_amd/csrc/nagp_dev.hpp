@@ -154,6 +154,7 @@ struct MomCfg {
   const unsigned char* code;  // [n_pts][cdim] index into xd
   double jitter;
   int cache_tabs;    // keep wn / code in LDS (n_pts small enough)
+  int store_a;       // POWER_NMF_SQRT: keep a[d][p] = sqrt(W_d . link(xn_p)) in LDS between the phases (one sqrt per (p, d))
   unsigned long long* stamps;  // developer diagnostics: per-phase cycle sums of thread 0 (null in production)
 };
 
@@ -171,8 +172,8 @@ __host__ __device__ inline MomLay mom_layout(const MomCfg& c) {
   MomLay l;
   const size_t CH = (size_t)mom_chunk(c), nout = (size_t)c.D + c.cdim + 1, tab = (size_t)c.cdim * c.nd;
   const size_t ns = (size_t)mom_nslots(c.cdim);
-  l.rows = 0;   // POWER: link(xn)[d][p] ; POWER_NMF: link(xn)[j][p] ; POWER_NMF_SQRT: none
-  l.c0 = (c.lik_kind == 0) ? CH * c.D : (c.lik_kind == 1) ? CH * c.cdim : 0;
+  l.rows = 0;   // POWER: link(xn)[d][p] ; POWER_NMF: link(xn)[j][p] ; POWER_NMF_SQRT: a[d][p] (store_a) or none
+  l.c0 = (c.lik_kind == 0) ? CH * c.D : (c.lik_kind == 1) ? CH * c.cdim : (c.store_a ? CH * c.D : 0);
   l.c1 = l.c0 + CH; l.c2 = l.c1 + CH;
   l.sg = l.c2 + CH;
   l.lkv = l.sg + c.cdim; l.xgv = l.lkv + tab; l.xg2v = l.xgv + tab;
@@ -266,10 +267,12 @@ __device__ __forceinline__ void mom_nmf(const MomCfg& c, const double* Wl, doubl
   const int nout = D + cd + 1;
   const bool sq = __builtin_amdgcn_readfirstlane(c.lik_kind == 2 ? 1 : 0) != 0;
   const bool TL = __builtin_amdgcn_readfirstlane(c.cache_tabs ? 1 : 0) != 0;
+  const bool sta = __builtin_amdgcn_readfirstlane(c.store_a ? 1 : 0) != 0;
   const int DG = __builtin_amdgcn_readfirstlane(c.DG);
   const int lgDG = 31 - __builtin_clz(DG);
   const int G = 64 >> lgDG;       // adjacent lanes per sub-band set in phase 2 (<= 16)
   const MomLay l = mom_layout(c);
+  double* rows = ws + l.rows;           // [D][CH] a[d][p] (store_a)
   double* c0 = ws + l.c0;
   double* c1 = ws + l.c1;
   double* c2 = ws + l.c2;
@@ -328,6 +331,7 @@ __device__ __forceinline__ void mom_nmf(const MomCfg& c, const double* Wl, doubl
 #pragma unroll
           for (int j = 0; j < CD; ++j) a = fma(w[u][j], lkj[j], a);
           if (sq) { a = sqrt(a); asm volatile("" : "+v"(a)); }   // the asm keeps the f64 sqrt from being if-converted
+          if (sta) { const int d = dc + sub + u * DG; if (d < D) rows[(size_t)d * CH + pl] = a; }
           s2a = fma(a * a, sz[u], s2a);
           sma = fma(a, mz[u], sma);
         }
@@ -372,27 +376,40 @@ __device__ __forceinline__ void mom_nmf(const MomCfg& c, const double* Wl, doubl
       for (int u = 0; u < MOM_NDM; ++u) { a1[u] = 0.0; a2[u] = 0.0; }
       const bool modl = (dc == 0) && (sub2 <= cd);   // this lane set also owns modulator output sub2 (or Z)
       const int jg = (sub2 < cd) ? sub2 : 0;
+      int dsel[MOM_NDM];      // rows of the stored a (clamped; the W = 0 padding of phase 1b left a = 0 unwritten)
+      double dok[MOM_NDM];
+#pragma unroll
+      for (int u = 0; u < MOM_NDM; ++u) { const int d = dc + sub2 + u * DG; dsel[u] = (d < D) ? d : 0; dok[u] = (d < D) ? 1.0 : 0.0; }
       for (int pl = wave * G + slot; pl < npc; pl += NW * G) {
-        int cj[CD];
-        if (TL) {
-#pragma unroll
-          for (int j = 0; j < CD; ++j) cj[j] = lds_code[(base + pl) * CD + j];
-        } else {
-#pragma unroll
-          for (int j = 0; j < CD; ++j) cj[j] = g_code[(size_t)(base + pl) * CD + j];
-        }
-        double lkj[CD];
-#pragma unroll
-        for (int j = 0; j < CD; ++j) lkj[j] = lkv[j * nd + cj[j]];
         const double c0p = c0[pl], c1p = c1[pl], c2p = c2[pl];
+        if (sta) {
 #pragma unroll
-        for (int u = 0; u < MOM_NDM; ++u) {
-          double a = 0.0;
+          for (int u = 0; u < MOM_NDM; ++u) {
+            const double a = rows[(size_t)dsel[u] * CH + pl] * dok[u];
+            a1[u] = fma(a, c1p, a1[u]);
+            a2[u] = fma(a * a, c2p, a2[u]);
+          }
+        } else {
+          int cj[CD];
+          if (TL) {
 #pragma unroll
-          for (int j = 0; j < CD; ++j) a = fma(w[u][j], lkj[j], a);
-          if (sq) { a = sqrt(a); asm volatile("" : "+v"(a)); }   // the asm keeps the f64 sqrt from being if-converted
-          a1[u] = fma(a, c1p, a1[u]);
-          a2[u] = fma(a * a, c2p, a2[u]);
+            for (int j = 0; j < CD; ++j) cj[j] = lds_code[(base + pl) * CD + j];
+          } else {
+#pragma unroll
+            for (int j = 0; j < CD; ++j) cj[j] = g_code[(size_t)(base + pl) * CD + j];
+          }
+          double lkj[CD];
+#pragma unroll
+          for (int j = 0; j < CD; ++j) lkj[j] = lkv[j * nd + cj[j]];
+#pragma unroll
+          for (int u = 0; u < MOM_NDM; ++u) {
+            double a = 0.0;
+#pragma unroll
+            for (int j = 0; j < CD; ++j) a = fma(w[u][j], lkj[j], a);
+            if (sq) { a = sqrt(a); asm volatile("" : "+v"(a)); }   // the asm keeps the f64 sqrt from being if-converted
+            a1[u] = fma(a, c1p, a1[u]);
+            a2[u] = fma(a * a, c2p, a2[u]);
+          }
         }
         if (modl) {
           if (sub2 < cd) {

@@ -184,6 +184,17 @@ int nagp_iekf_update1(int32_t S, int32_t D, int32_t N, const int32_t* h_col, con
                       double R, double y, int32_t iters, double* m, double* P, double* K, double* MU, double* Sinn,
                       int32_t device);
 
+/* Stationary filterbank (the step before the hot path in every real-audio script, e.g. train_GTFNMF.m:56-65):
+ * the two loops of unifying_prob_tf/kernel_ss_kalmanFastFB.m -- infinite-horizon Kalman filter (:83-110)
+ *     if ~isnan(y_k): v = y_k - HA*m; m = AKHA*m + K*y_k; else m = A*m;   MS(:,k) = m
+ * and steady-state RTS smoother (:134-151)   m = MS(:,k) + G*(m - A*MS(:,k)),  k = T-1 .. 1.
+ * The caller keeps the set-up lines of the .m (dare, K, AKHA = A-K*H*A, HA = H*A, G = PF2*A'/PP) and passes the constant
+ * matrices: A, AKHA, G are S x S column-major (G = NULL: filter only, the KF = 1 option); HA, K have S entries.
+ * MS (S x T, column-major) receives the filtered / smoothed means, *sum_v2 the sum of squared innovations of the observed
+ * steps (lik = -( T/2 log(2 pi S_inn) + sum_v2 / (2 S_inn) ), :80,:101,:158).  S <= 96 (both matrices live in LDS). */
+int nagp_fastfb_run(int32_t S, const double* A, const double* AKHA, const double* HA, const double* K, const double* G,
+                    const double* y, int64_t T, double* MS, double* sum_v2, int32_t device);
+
 /* Batched / device-resident form: n_problems independent problems of identical shape
  * (S, M, block structure, T) -- audio segments or hyper-parameter replicas -- run concurrently. */
 int nagp_plan_create(nagp_plan** plan, int32_t n_problems, const nagp_model* models,

@@ -1093,3 +1093,71 @@ extern "C" int nagp_iekf_update1(int32_t S, int32_t D, int32_t N, const int32_t*
   (void)hipFree(dev);
   return st;
 }
+
+// ---------------------------------------------------------------------------------------------
+// stationary filterbank: kernel_ss_kalmanFastFB (see include/nagp.h)
+extern "C" int nagp_fastfb_run(int32_t S, const double* A, const double* AKHA, const double* HA, const double* K, const double* G,
+                               const double* y, int64_t T, double* MS, double* sum_v2, int32_t device) {
+  if (!A || !AKHA || !HA || !K || !y || !MS) FAIL(NAGP_EINVAL, "null argument");
+  if (S < 1 || T < 1) FAIL(NAGP_EINVAL, "bad sizes (S=%d T=%lld)", S, (long long)T);
+  const size_t lds = fb_lds_doubles(S) * sizeof(double);
+  if (S > 256 || lds > 160 * 1024) FAIL(NAGP_EUNSUPPORTED, "S=%d: the two constant S x S matrices do not fit the LDS (S <= 96)", S);
+  if (hipSetDevice(device) != hipSuccess) FAIL(NAGP_EHIP, "hipSetDevice(%d)", device);
+  // spans of the parallel-in-time form (needs two more S x S work matrices in LDS: S <= 64); short series run as one span
+  const size_t lds_c = fb_compose_lds_doubles(S) * sizeof(double);
+  int ns = 1;
+  if (lds_c <= 160 * 1024 && T >= 2048 && !getenv("NAGP_FB_SEQUENTIAL")) ns = (int)std::min<int64_t>(512, T / 128);
+  const int64_t L = (T + ns - 1) / ns;
+  ns = (int)((T + L - 1) / L);
+  const size_t SS = (size_t)S * S, SP = (size_t)S + 4;
+  const size_t o_A = 0, o_B = o_A + SS, o_G = o_B + SS, o_ha = o_G + SS, o_k = o_ha + S, o_y = o_k + S, o_ms = o_y + T,
+               o_sv = o_ms + (size_t)T * S, o_phi = o_sv + ns + 1, o_st = o_phi + (size_t)ns * S * SP, total = o_st + (size_t)ns * S + 2;
+  double* dev = nullptr;
+  if (hipMalloc(&dev, total * sizeof(double)) != hipSuccess) FAIL(NAGP_ENOMEM, "hipMalloc(%zu)", total * sizeof(double));
+  int st = NAGP_OK;
+#define FB_HIP(x) do { if (st == NAGP_OK) { hipError_t _e = (x); if (_e != hipSuccess) { g_last_error = std::string("nagp_fastfb_run: " #x " -> ") + hipGetErrorString(_e); st = NAGP_EHIP; } } } while (0)
+  FB_HIP(hipMemcpy(dev + o_A, A, SS * 8, hipMemcpyHostToDevice));
+  FB_HIP(hipMemcpy(dev + o_B, AKHA, SS * 8, hipMemcpyHostToDevice));
+  if (G) FB_HIP(hipMemcpy(dev + o_G, G, SS * 8, hipMemcpyHostToDevice));
+  FB_HIP(hipMemcpy(dev + o_ha, HA, (size_t)S * 8, hipMemcpyHostToDevice));
+  FB_HIP(hipMemcpy(dev + o_k, K, (size_t)S * 8, hipMemcpyHostToDevice));
+  FB_HIP(hipMemcpy(dev + o_y, y, (size_t)T * 8, hipMemcpyHostToDevice));
+  const int NT = std::max(64, roundup64(S));
+  if (st == NAGP_OK) st = set_lds(fastfb_filter_kernel, lds);
+  if (st == NAGP_OK) st = set_lds(fastfb_smoother_kernel, lds);
+  if (st == NAGP_OK && ns > 1) st = set_lds(fastfb_compose_kernel<false>, lds_c);
+  if (st == NAGP_OK && ns > 1) st = set_lds(fastfb_compose_kernel<true>, lds_c);
+  if (st == NAGP_OK) {
+    FbPar fp{S, T, dev + o_A, dev + o_B, dev + o_ha, dev + o_k, dev + o_y, dev + o_ms, dev + o_sv, L, ns, dev + o_phi,
+             ns > 1 ? dev + o_st : nullptr};
+    if (ns > 1) {
+      hipLaunchKernelGGL(fastfb_compose_kernel<false>, dim3(ns), dim3(256), lds_c, 0, fp);
+      hipLaunchKernelGGL(fastfb_boundary_kernel<false>, dim3(1), dim3(256), 0, 0, fp);
+    }
+    hipLaunchKernelGGL(fastfb_filter_kernel, dim3(ns), dim3(NT), lds, 0, fp);
+    if (G && T > 1) {
+      fp.B = dev + o_G;
+      // the T-1 smoothing steps are partitioned with the same span length
+      const int nss = (int)((T - 1 + L - 1) / L);
+      fp.ns = nss;
+      if (ns > 1) {
+        hipLaunchKernelGGL(fastfb_compose_kernel<true>, dim3(nss), dim3(256), lds_c, 0, fp);
+        hipLaunchKernelGGL(fastfb_boundary_kernel<true>, dim3(1), dim3(256), 0, 0, fp);
+      }
+      hipLaunchKernelGGL(fastfb_smoother_kernel, dim3(nss), dim3(NT), lds, 0, fp);
+    }
+  }
+  FB_HIP(hipGetLastError());
+  FB_HIP(hipDeviceSynchronize());
+  FB_HIP(hipMemcpy(MS, dev + o_ms, (size_t)T * S * 8, hipMemcpyDeviceToHost));
+  if (sum_v2) {
+    std::vector<double> part((size_t)ns);
+    FB_HIP(hipMemcpy(part.data(), dev + o_sv, (size_t)ns * 8, hipMemcpyDeviceToHost));
+    double acc = 0.0;
+    for (int j = 0; j < ns; ++j) acc += part[j];      // fixed order
+    *sum_v2 = acc;
+  }
+#undef FB_HIP
+  (void)hipFree(dev);
+  return st;
+}

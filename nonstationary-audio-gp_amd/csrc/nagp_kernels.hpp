@@ -1380,4 +1380,235 @@ __global__ void __launch_bounds__(256) iekf_update1_kernel(EkfPar ep) {
   if (tid == 0) { ep.MU_S[0] = MU; ep.MU_S[1] = Sx; }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Stationary filterbank: infinite-horizon Kalman filter and steady-state RTS smoother of
+// unifying_prob_tf/kernel_ss_kalmanFastFB.m.  Both recursions are affine with time-constant matrices
+//   filter   (:83-110)   m_k = M_k m_{k-1} + u_k,   M_k = AKHA, u_k = K y_k   (y_k observed)  |  M_k = A, u_k = 0  (NaN)
+//   smoother (:134-151)  m_k = G m_{k+1} + (MS_k - G A MS_k)
+// so they run PARALLEL IN TIME over spans of L steps: pass 1 composes every span to (Phi_j, c_j) with the span's own
+// matrices, pass 2 walks the span boundaries, pass 3 replays the reference recursion inside every span from its exact
+// boundary value.  All matrices live in LDS, transposed (thread i walks along row i with conflict-free reads).
+constexpr int FB_CHK = 16;
+struct FbPar {
+  int S;
+  int64_t T;
+  const double* A;      // [S][S] column-major  (predict-only steps / smoother)
+  const double* B;      // filter: AKHA = A - K H A ; smoother: G      [S][S] column-major
+  const double* HA;     // [S]  H*A        (filter)
+  const double* K;      // [S]  gain       (filter)
+  const double* y;      // [T]             (filter)
+  double* MS;           // [T][S] filtered (filter: out) / smoothed (smoother: in-out)
+  double* sum_v2;       // [ns] per span: sum over observed steps of (y - HA m)^2   (filter)
+  int64_t L;            // span length; span j = steps [j L, min((j+1) L, n)) of n = T (filter) or T-1 (smoother) steps
+  int ns;               // spans
+  double* Phi;          // [ns][S][SP]  pass 1 out (row-major, SP = S + 4; column S = c_j)
+  double* starts;       // [ns][S]      pass 2 out: value entering span j
+};
+__host__ __device__ inline size_t fb_lds_doubles(int S) { return 2 * (size_t)S * S + 5 * (size_t)S + (size_t)FB_CHK * (S + 1) + 8; }
+__host__ __device__ inline size_t fb_compose_lds_doubles(int S) { return 2 * (size_t)S * S + 2 * (size_t)(S + 4) * (S + 4) + 3 * (size_t)S + 8; }
+
+// pass 3 (and the whole job when ns == 1):  if ~isnan(y): v = y - HA*m; m = AKHA*m + K*y; else m = A*m
+__global__ void __launch_bounds__(256) fastfb_filter_kernel(FbPar fp) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int tid = threadIdx.x, NT = blockDim.x, S = fp.S;
+  double* At = lds;                       // At[j*S + i] = A(i,j): the column-major input is already this layout
+  double* Bt = At + (size_t)S * S;
+  double* ha = Bt + (size_t)S * S;
+  double* kg = ha + S;
+  double* m0 = kg + S;
+  double* m1 = m0 + S;
+  double* yc = m1 + S + S;                // [FB_CHK]
+  double* msc = yc + FB_CHK;              // [FB_CHK][S] staged output
+  const int64_t ka = (int64_t)blockIdx.x * fp.L, kb = (ka + fp.L < fp.T) ? ka + fp.L : fp.T;
+  for (int e = tid; e < S * S; e += NT) { At[e] = fp.A[e]; Bt[e] = fp.B[e]; }
+  for (int i = tid; i < S; i += NT) { ha[i] = fp.HA[i]; kg[i] = fp.K[i]; m0[i] = fp.starts ? fp.starts[(size_t)blockIdx.x * S + i] : 0.0; }
+  double sv2 = 0.0;
+  __syncthreads();
+  double* mc = m0;
+  double* mn = m1;
+  for (int64_t k0 = ka; k0 < kb; k0 += FB_CHK) {
+    const int nb = (kb - k0 < FB_CHK) ? (int)(kb - k0) : FB_CHK;
+    for (int i = tid; i < nb; i += NT) yc[i] = fp.y[k0 + i];
+    __syncthreads();
+    for (int kk = 0; kk < nb; ++kk) {
+      const double yk = yc[kk];
+      const bool obs = !(yk != yk);
+      if (tid < S) {
+        const double* Mt = obs ? Bt : At;
+        double a0 = 0.0, a1 = 0.0, h0 = 0.0, h1 = 0.0;
+        int j = 0;
+        for (; j + 2 <= S; j += 2) {
+          const double x0 = mc[j], x1 = mc[j + 1];
+          a0 = fma(Mt[(size_t)j * S + tid], x0, a0); a1 = fma(Mt[(size_t)(j + 1) * S + tid], x1, a1);
+          h0 = fma(ha[j], x0, h0); h1 = fma(ha[j + 1], x1, h1);
+        }
+        if (j < S) { a0 = fma(Mt[(size_t)j * S + tid], mc[j], a0); h0 = fma(ha[j], mc[j], h0); }
+        double mi = a0 + a1;
+        if (obs) {
+          const double v = yk - (h0 + h1);
+          mi = mi + kg[tid] * yk;
+          if (tid == 0) sv2 = fma(v, v, sv2);
+        }
+        mn[tid] = mi;
+        msc[(size_t)kk * S + tid] = mi;
+      }
+      lds_barrier();
+      double* t_ = mc; mc = mn; mn = t_;
+    }
+    for (int e = tid; e < nb * S; e += NT) fp.MS[(size_t)k0 * S + e] = msc[e];
+    __syncthreads();
+  }
+  if (tid == 0) fp.sum_v2[blockIdx.x] = sv2;
+}
+
+// pass 3:  m = MS_k + G*(m - A*MS_k), k descending inside span j of the n = T-1 smoothing steps
+__global__ void __launch_bounds__(256) fastfb_smoother_kernel(FbPar fp) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int tid = threadIdx.x, NT = blockDim.x, S = fp.S;
+  double* At = lds;
+  double* Gt = At + (size_t)S * S;
+  double* m = Gt + (size_t)S * S + 2 * (size_t)S;   // [S] current smoothed mean
+  double* dv = m + S;                                // [S] m - A*MS_k
+  double* msc = dv + 2 * (size_t)S + FB_CHK;         // [FB_CHK][S]
+  const int64_t n = fp.T - 1;
+  const int64_t ka = (int64_t)blockIdx.x * fp.L, kb = (ka + fp.L < n) ? ka + fp.L : n;   // steps ka .. kb-1
+  for (int e = tid; e < S * S; e += NT) { At[e] = fp.A[e]; Gt[e] = fp.B[e]; }
+  for (int i = tid; i < S; i += NT) m[i] = fp.starts ? fp.starts[(size_t)blockIdx.x * S + i] : fp.MS[(size_t)(fp.T - 1) * S + i];
+  __syncthreads();
+  for (int64_t k1 = kb; k1 > ka; k1 -= FB_CHK) {            // steps k1-1 ... k1-nb, descending
+    const int nb = (k1 - ka < FB_CHK) ? (int)(k1 - ka) : FB_CHK;
+    const int64_t kl = k1 - nb;
+    for (int e = tid; e < nb * S; e += NT) msc[e] = fp.MS[(size_t)kl * S + e];
+    __syncthreads();
+    for (int kk = nb - 1; kk >= 0; --kk) {
+      const double* mk = msc + (size_t)kk * S;
+      if (tid < S) {
+        double a0 = 0.0, a1 = 0.0;
+        int j = 0;
+        for (; j + 2 <= S; j += 2) { a0 = fma(At[(size_t)j * S + tid], mk[j], a0); a1 = fma(At[(size_t)(j + 1) * S + tid], mk[j + 1], a1); }
+        if (j < S) a0 = fma(At[(size_t)j * S + tid], mk[j], a0);
+        dv[tid] = m[tid] - (a0 + a1);
+      }
+      lds_barrier();
+      double mi = 0.0;
+      if (tid < S) {
+        double g0 = 0.0, g1 = 0.0;
+        int j = 0;
+        for (; j + 2 <= S; j += 2) { g0 = fma(Gt[(size_t)j * S + tid], dv[j], g0); g1 = fma(Gt[(size_t)(j + 1) * S + tid], dv[j + 1], g1); }
+        if (j < S) g0 = fma(Gt[(size_t)j * S + tid], dv[j], g0);
+        mi = mk[tid] + (g0 + g1);
+      }
+      lds_barrier();     // all reads of m / mk of this step are done
+      if (tid < S) { m[tid] = mi; msc[(size_t)kk * S + tid] = mi; }
+      lds_barrier();
+    }
+    for (int e = tid; e < nb * S; e += NT) fp.MS[(size_t)kl * S + e] = msc[e];
+    __syncthreads();
+  }
+}
+
+// pass 1: span j -> Phi_j (product of the span's step matrices) and c_j (the span run from a zero entry value), as the
+// S x (S+1) matrix recursion  X <- M_k X (+ input in column S)  on 4 x 4 register tiles.
+template <bool SMOOTH>
+__global__ void __launch_bounds__(256) fastfb_compose_kernel(FbPar fp) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int tid = threadIdx.x, NT = blockDim.x, S = fp.S, SP = S + 4;
+  double* At = lds;
+  double* Bt = At + (size_t)S * S;
+  double* Xa = Bt + (size_t)S * S;          // [SP rows][SP]: X[j][c], rows >= S are zero padding
+  double* Xb = Xa + (size_t)SP * SP;
+  double* kg = Xb + (size_t)SP * SP;        // filter: K ; smoother: MS_k
+  double* dv = kg + S;                      // smoother: X[:,S] - A MS_k
+  const int64_t n = SMOOTH ? fp.T - 1 : fp.T;
+  const int j = blockIdx.x;
+  const int64_t ka = (int64_t)j * fp.L, kb = (ka + fp.L < n) ? ka + fp.L : n;
+  for (int e = tid; e < S * S; e += NT) { At[e] = fp.A[e]; Bt[e] = fp.B[e]; }
+  for (int e = tid; e < SP * SP; e += NT) { const int r = e / SP, c = e - r * SP; Xa[e] = (r == c && r < S) ? 1.0 : 0.0; Xb[e] = 0.0; }
+  if (!SMOOTH) for (int i = tid; i < S; i += NT) kg[i] = fp.K[i];
+  __syncthreads();
+  double* Xc = Xa;
+  double* Xn = Xb;
+  const int RT = (S + 3) >> 2, CT = (S + 1 + 3) >> 2;       // row / column tiles (column S is the affine part)
+  const int64_t nsteps = kb - ka;
+  for (int64_t q = 0; q < nsteps; ++q) {
+    const int64_t k = SMOOTH ? (kb - 1 - q) : (ka + q);
+    const double* Mt = Bt;
+    double yk = 0.0;
+    bool obs = true;
+    if (SMOOTH) {
+      // d = X[:,S] - A MS_k replaces column S of the input; MS_k is added to column S of the output
+      for (int i = tid; i < S; i += NT) kg[i] = fp.MS[(size_t)k * S + i];
+      __syncthreads();
+      if (tid < S) {
+        double a0 = 0.0;
+        for (int l = 0; l < S; ++l) a0 = fma(At[(size_t)l * S + tid], kg[l], a0);
+        dv[tid] = Xc[(size_t)tid * SP + S] - a0;
+      }
+      __syncthreads();
+      if (tid < S) Xc[(size_t)tid * SP + S] = dv[tid];
+      __syncthreads();
+    } else {
+      yk = fp.y[k];
+      obs = !(yk != yk);
+      Mt = obs ? Bt : At;
+    }
+    for (int t = tid; t < RT * CT; t += NT) {
+      const int ti = t / CT, tc = t - ti * CT, i0 = 4 * ti, c0 = 4 * tc;
+      double acc[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.0;
+      for (int l = 0; l < S; ++l) {
+        double mr[4], xr[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { mr[u] = (i0 + u < S) ? Mt[(size_t)l * S + i0 + u] : 0.0; xr[u] = Xc[(size_t)l * SP + c0 + u]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int w = 0; w < 4; ++w) acc[4 * u + w] = fma(mr[u], xr[w], acc[4 * u + w]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const int i = i0 + u, c = c0 + w;
+          if (i < S && c <= S) {
+            double v = acc[4 * u + w];
+            if (c == S) v += SMOOTH ? kg[i] : (obs ? kg[i] * yk : 0.0);
+            Xn[(size_t)i * SP + c] = v;
+          }
+        }
+    }
+    __syncthreads();
+    double* t_ = Xc; Xc = Xn; Xn = t_;
+  }
+  double* out = fp.Phi + (size_t)j * S * SP;
+  for (int e = tid; e < S * SP; e += NT) out[e] = Xc[e];
+}
+
+// pass 2: boundary values.  Filter: s_0 = 0, s_{j+1} = Phi_j s_j + c_j.  Smoother: s_{ns-1} = MS_{T-1}, s_{j-1} = Phi_j s_j + c_j.
+template <bool SMOOTH>
+__global__ void __launch_bounds__(256) fastfb_boundary_kernel(FbPar fp) {
+  __shared__ double sv[256];
+  const int tid = threadIdx.x, S = fp.S, SP = S + 4;
+  if (tid < S) sv[tid] = SMOOTH ? fp.MS[(size_t)(fp.T - 1) * S + tid] : 0.0;
+  __syncthreads();
+  for (int q = 0; q < fp.ns; ++q) {
+    const int j = SMOOTH ? (fp.ns - 1 - q) : q;
+    if (tid < S) fp.starts[(size_t)j * S + tid] = sv[tid];
+    double nv = 0.0;
+    if (tid < S) {
+      const double* ph = fp.Phi + ((size_t)j * S + tid) * SP;
+      double a0 = 0.0, a1 = 0.0;
+      int l = 0;
+      for (; l + 2 <= S; l += 2) { a0 = fma(ph[l], sv[l], a0); a1 = fma(ph[l + 1], sv[l + 1], a1); }
+      if (l < S) a0 = fma(ph[l], sv[l], a0);
+      nv = (a0 + a1) + ph[S];
+    }
+    __syncthreads();
+    if (tid < S) sv[tid] = nv;
+    __syncthreads();
+  }
+}
+
 }  // namespace nagp

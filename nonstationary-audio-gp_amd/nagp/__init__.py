@@ -9,3 +9,4 @@ from .api import (Mom, SSHandle, gf_ep_modulator, gf_ep_modulator_nmf, gf_ep_mod
 from .ss import ss_modulators, ss_modulators_nmf, lti_disc, sigmoid, inv_sigmoid  # noqa: F401
 from .cubature import utp_ws, gauher, mvhermgauss_unit  # noqa: F401
 from .plan import Plan  # noqa: F401
+from .fastfb import get_disc_model, kernel_ss_kalmanFastFB  # noqa: F401

@@ -106,13 +106,14 @@ def lib():
     L.nagp_mom_eval.argtypes = [C.POINTER(Opts), C.c_int32, C.c_int32, c_dp, C.c_double, C.c_int64, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp]
     L.nagp_iekf_update1.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), c_dp, c_dp, C.c_double, C.c_double, C.c_int32,
                                     c_dp, c_dp, c_dp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32]
+    L.nagp_fastfb_run.argtypes = [C.c_int32, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, C.c_int64, c_dp, C.POINTER(C.c_double), C.c_int32]
     L.nagp_plan_upload_y.argtypes = [C.c_void_p, C.POINTER(c_dp)]
     L.nagp_plan_execute.argtypes = [C.c_void_p]
     L.nagp_plan_timings.argtypes = [C.c_void_p, C.POINTER(Timings)]
     L.nagp_plan_download.argtypes = [C.c_void_p, C.POINTER(Out)]
     L.nagp_plan_device_bytes.argtypes = [C.c_void_p]; L.nagp_plan_device_bytes.restype = C.c_int64
     L.nagp_plan_destroy.argtypes = [C.c_void_p]; L.nagp_plan_destroy.restype = None
-    for f in ('nagp_ep_run', 'nagp_ihgp_run', 'nagp_giekf_run', 'nagp_mom_eval', 'nagp_iekf_update1', 'nagp_plan_create', 'nagp_plan_upload_y',
+    for f in ('nagp_ep_run', 'nagp_ihgp_run', 'nagp_giekf_run', 'nagp_mom_eval', 'nagp_iekf_update1', 'nagp_fastfb_run', 'nagp_plan_create', 'nagp_plan_upload_y',
               'nagp_plan_execute', 'nagp_plan_timings', 'nagp_plan_download'):
         getattr(L, f).restype = C.c_int
     _lib = L

@@ -12,7 +12,7 @@ import pytest
 import nagp
 from nagp import harness, Mom, SSHandle, Plan, _lib as L
 from nagp import ss as pss
-from oracle import gf_ep as ogf, ihgp as oih, giekf as oek, lik as olik
+from oracle import gf_ep as ogf, ihgp as oih, giekf as oek, lik as olik, fastfb as offb
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), 'golden')
@@ -208,6 +208,35 @@ def test_ekf_update1_and_iekf_update1_standalone(iters):
         o = oek.iekf_update1(m0.copy(), P0.copy(), y, lambda x: oek.funhd(x, H, D, N, pr['W']), R, lambda x: oek.funh(x, H, D, N, pr['W']), iters)
     assert rel(m, o[0]) < 1e-12 and rel(P, o[1]) < 1e-12 and rel(K, o[2]) < 1e-12
     assert abs(MU - float(o[3])) < 1e-12 * max(1, abs(float(o[3]))) and abs(Sx - float(o[4])) < 1e-12 * abs(float(o[4]))
+
+
+@pytest.mark.parametrize('kernel,D,T,KF', [('exp', 16, 3000, 0), ('matern32', 8, 1000, 0), ('matern52', 5, 700, 1), ('exp', 3, 1, 0),
+                                           ('exp', 48, 400, 0)])
+def test_stationary_filterbank_kalmanFastFB(kernel, D, T, KF):
+    """[lik,Xfin,Pfin] = kernel_ss_kalmanFastFB(A,Q,C,P0,K,vary,y,verbose,KF) with the model of get_disc_model
+    (SURVEY 8f row f-2): missing samples, filter-only option, T = 1, S = 96 (the LDS limit)."""
+    rng = np.random.default_rng(D + T)
+    lam = 1.0 / rng.uniform(20, 400, D); var = rng.uniform(0.1, 1.0, D); om = np.linspace(np.pi / 3, np.pi / 50, D)
+    A, Q, H, Pinf, K, tau1 = nagp.get_disc_model(lam, var, om, D, kernel, 6)
+    Ao, Qo, Ho, Po, Ko, to = offb.get_disc_model(lam, var, om, D, kernel, 6)
+    assert rel(A, Ao) < 1e-13 and rel(Q, Qo) < 1e-12 and np.array_equal(H, Ho) and rel(Pinf, Po) < 1e-14 and (K, tau1) == (Ko, to)
+    S = A.shape[0]; Lc = np.linalg.cholesky(Pinf); Lq = np.linalg.cholesky(Q + 1e-14 * np.eye(S))
+    z = Lc @ rng.normal(size=S); y = np.zeros(T)
+    for k in range(T):
+        z = A @ z + Lq @ rng.normal(size=S); y[k] = (H @ z)[0] + 0.1 * rng.normal()
+    if T > 100:
+        y[40:75] = np.nan; y[T - 3] = np.nan
+    lik, Xfin, Pfin = nagp.kernel_ss_kalmanFastFB(A, Q, H, Pinf, K, 0.01, y, 0, KF)
+    lo, MSo, PF2o, Pso = offb.kernel_ss_kalmanFastFB(Ao, Qo, Ho, Po, Ko, 0.01, y, 0, KF)
+    assert Xfin.shape == (1, S, T) and Pfin.shape == (S, S, T)
+    assert rel(Xfin[0], MSo) < TOL_MEAN and abs(lik - lo) < TOL_LOGZ * abs(lo)
+    assert rel(Pfin[:, :, T - 1], PF2o) < 1e-10 and (T == 1 or rel(Pfin[:, :, 0], PF2o if KF == 1 else Pso) < 1e-10)
+
+
+def test_stationary_filterbank_refuses_what_does_not_fit():
+    A, Q, H, Pinf, K, _ = nagp.get_disc_model(np.full(50, 0.01), np.ones(50), np.linspace(1, 0.1, 50), 50, 'exp')   # S = 100
+    with pytest.raises(nagp.NagpError):
+        nagp.kernel_ss_kalmanFastFB(A, Q, H, Pinf, K, 0.01, np.zeros(10))
 
 
 def test_test_inputs_subset_and_unsorted_inputs():

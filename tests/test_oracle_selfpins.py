@@ -203,3 +203,33 @@ def test_oracle_reproduces_committed_golden_vectors():
     o = ogf.gf_ep_modulator(g['w'], t, g['y'][:300], None, olik.Mom(olik.LIK_POWER, p=9), t, 'matern32', 'matern52', 1, 0.5,
                             g['ep_damping'][:1], 1)
     assert np.allclose(o[5]['ttau'][:, :299], g['ttau'][:, :299] * 0 + o[5]['ttau'][:, :299])   # runs; prefix property checked on GPU
+
+
+def test_fastfb_steady_state_filter_equals_the_full_kalman_filter_after_burn_in():
+    """kernel_ss_kalmanFastFB.m replaces the Riccati recursion by its fixed point: after the transient the stationary
+    filter must coincide with the ordinary Kalman filter on the same model (and lik with the exact one up to the
+    transient), and the DARE fixed point must satisfy its equation."""
+    from oracle import fastfb
+    rng = np.random.default_rng(2)
+    D = 4; lam = 1 / np.array([30., 60, 90, 150]); var = np.array([1., .6, .8, .4]); om = np.array([.9, .6, .35, .12])
+    A, Q, H, Pinf, K, tau1 = fastfb.get_disc_model(lam, var, om, D, 'matern32')
+    assert np.allclose(Q, Pinf - A @ Pinf @ A.T, atol=1e-12) and (K, tau1) == (8, 2)
+    S = A.shape[0]; T = 600; R = 0.05
+    Lc = np.linalg.cholesky(Pinf); Lq = np.linalg.cholesky(Q + 1e-14 * np.eye(S))
+    z = Lc @ rng.normal(size=S); y = np.zeros(T)
+    for k in range(T):
+        z = A @ z + Lq @ rng.normal(size=S); y[k] = (H @ z)[0] + np.sqrt(R) * rng.normal()
+    lik, MS, PF2, Ps = fastfb.kernel_ss_kalmanFastFB(A, Q, H, Pinf, K, R, y, 0, 1)
+    st = fastfb.steady_state(A, Q, H, R)
+    PP = st['PP']; res = A @ (PP - np.outer(PP @ H.T.ravel(), H @ PP) / st['S']) @ A.T + Q - PP
+    assert np.max(np.abs(res)) < 1e-10 * np.max(np.abs(PP))
+    m = np.zeros(S); P = PP.copy(); MF = np.zeros((S, T))                 # ordinary KF started at the fixed point
+    for k in range(T):
+        if k > 0:
+            m = A @ m; P = A @ P @ A.T + Q
+        else:
+            m = A @ m
+        Sx = float((H @ P @ H.T)[0, 0]) + R; Kk = (P @ H.T / Sx).ravel()
+        m = m + Kk * (y[k] - float((H @ m)[0])); P = P - np.outer(Kk, Kk) * Sx
+        MF[:, k] = m
+    assert np.max(np.abs(MF - MS)) < 1e-9 * np.max(np.abs(MS)) and np.max(np.abs(P - PF2)) < 1e-9 * np.max(np.abs(PF2))

@@ -10,3 +10,4 @@ from .ss import ss_modulators, ss_modulators_nmf, lti_disc, sigmoid, inv_sigmoid
 from .cubature import utp_ws, gauher, mvhermgauss_unit  # noqa: F401
 from .plan import Plan  # noqa: F401
 from .fastfb import get_disc_model, kernel_ss_kalmanFastFB  # noqa: F401
+from .train import nlml_batch, fd_value_and_gradient  # noqa: F401

@@ -239,6 +239,31 @@ def test_stationary_filterbank_refuses_what_does_not_fit():
         nagp.kernel_ss_kalmanFastFB(A, Q, H, Pinf, K, 0.01, np.zeros(10))
 
 
+def test_batched_nlml_driver_equals_serial_calls_and_finite_differences():
+    """Row f-3: the numel(w)+1 objective evaluations of one fminunc iteration (GradObj off, train_GTFNMF.m:186-201) as one
+    batched plan: bitwise equal to the serial calls of gf_ep_modulator_nmf_constraints, and the forward-difference
+    gradient agrees with differences of the oracle's objective."""
+    D, N, T = 3, 2, 120
+    pr = harness.nmf_problem(D, N, T, 31, 'constraints'); t = np.arange(1, T + 1.0)
+    cons = harness.CONSTRAINTS_DEMO(D); w, wf = harness.constrained_vectors(pr, cons, harness.TUNE_DEMO)
+    mom = Mom('likModulatorNMFPower', p_cubature=5); d = np.array([0.5, 0.5])
+    args = (t, pr['y'], SSHandle(), mom, 'matern32', 'matern52', 1, D, N, 0.5, d, 2)
+    f0, g = nagp.fd_value_and_gradient(w, *args, constraints=cons, w_fixed=wf, tune_hypers=harness.TUNE_DEMO)
+    serial = nagp.gf_ep_modulator_nmf_constraints(w, t, pr['y'], SSHandle(), mom, None, 'matern32', 'matern52', 1, D, N, 0.5, d, 2,
+                                                  cons, wf, harness.TUNE_DEMO)[0]
+    assert f0 == serial and g.shape == w.shape and np.all(np.isfinite(g))
+    omom = olik.Mom(olik.LIK_POWER_NMF, p=5)
+    def obj(wv):
+        return ogf.gf_ep_modulator_nmf_constraints(wv, t, pr['y'], None, omom, None, 'matern32', 'matern52', 1, D, N, 0.5, d, 2,
+                                                   cons, wf, harness.TUNE_DEMO)[0]
+    fo = obj(w)
+    assert abs(f0 - fo) < TOL_LOGZ * abs(fo)
+    i = int(np.argmax(np.abs(g))); h = 1e-6 * max(abs(w[i]), 1.0)
+    e = np.zeros(w.size); e[i] = h
+    go = (obj(w + e) - obj(w - e)) / (2 * h)
+    assert abs(g[i] - go) < 1e-3 * abs(go)
+
+
 def test_test_inputs_subset_and_unsorted_inputs():
     """xt a subset of x, x unsorted: return_ind / unique('first') semantics (gf_ep_modulator_nmf.m:58-66)."""
     D, N, T = 3, 2, 60

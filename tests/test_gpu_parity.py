@@ -264,6 +264,22 @@ def test_batched_nlml_driver_equals_serial_calls_and_finite_differences():
     assert abs(g[i] - go) < 1e-3 * abs(go)
 
 
+def test_randomised_configurations_against_oracle():
+    """tools/gpu_fuzz.py with a fixed seed: 30 random draws of shape, kernels, likelihood, link, cubature order, power,
+    damping, sweeps and missing data through all three function families.  Instances the reference itself cannot
+    reproduce (site updates divided by 1 + d2*v ~ 1e-14, arg-min ties of the IHGP grid: detected by re-running the ORACLE
+    on y*(1+1e-13)) are excused and must stay rare."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('gpu_fuzz', os.path.join(os.path.dirname(__file__), '..', 'tools', 'gpu_fuzz.py'))
+    fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
+    rng = np.random.default_rng(2024); excused = 0
+    for _ in range(30):
+        desc, res, _cfg = fz.one(rng)
+        excused += desc.count('unstable instance')
+        assert max(res.values()) < TOL_MEAN, (desc, res)
+    assert excused <= 4
+
+
 def test_test_inputs_subset_and_unsorted_inputs():
     """xt a subset of x, x unsorted: return_ind / unique('first') semantics (gf_ep_modulator_nmf.m:58-66)."""
     D, N, T = 3, 2, 60

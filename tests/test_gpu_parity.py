@@ -280,6 +280,40 @@ def test_randomised_configurations_against_oracle():
     assert excused <= 4
 
 
+@pytest.mark.parametrize('link', ['exp', 'softplus'])
+@pytest.mark.parametrize('kind', ['nmf', 'sqrt'])
+def test_mom_exceptional_inputs_same_nan_patterns_and_floors(link, kind):
+    """Overflowing link values, huge / negative cavity variances and NaN means: the device returns NaN exactly where the
+    reference formulas do, and the same floored log Z (max(Z, 1e-10), SURVEY C-3/C-4)."""
+    from nagp import cubature
+    rng = np.random.default_rng(5); D, N, p = 4, 3, 7
+    W = rng.uniform(0, 0.5, (D, N)); hyp = np.log(1e-2)
+    ol = olik.exp_link() if link == 'exp' else olik.softplus_link(0.0)
+    if kind == 'sqrt':
+        wn, xn = cubature.utp_ws(p, N)
+        mom = Mom('likModulatorPreCalcwn', link=link, wn=wn, xn_unscaled=xn); omom = olik.Mom(olik.LIK_POWER_NMF_SQRT, link=ol, wn=wn, xn_unscaled=xn)
+    else:
+        mom = Mom('likModulatorNMFPower', link=link, p_cubature=p); omom = olik.Mom(olik.LIK_POWER_NMF, link=ol, p=p)
+    mu = rng.normal(0, 1, D + N); s2 = rng.uniform(0.1, 1, D + N)
+    cases = []
+    m1 = mu.copy(); m1[D] = 800.0; cases.append((m1, s2))
+    s3 = s2.copy(); s3[D + 1] = 1e6; cases.append((mu, s3))
+    s4 = s2.copy(); s4[0] = -0.1; cases.append((mu, s4))
+    s5 = s2.copy(); s5[D] = -0.1; cases.append((mu, s5))
+    m6 = mu.copy(); m6[1] = np.nan; cases.append((m6, s2))
+    for m_, s_ in cases:
+        y = np.array([0.3])
+        with np.errstate(all='ignore'):
+            o = omom(hyp, m_, s_, W, 0.5, y, 0)
+        g = mom(hyp, m_, s_, W, 0.5, y, 0)
+        o1 = np.real(np.ravel(o[1])); o2 = np.real(np.ravel(o[2]))
+        assert np.array_equal(np.isnan(g[1]), np.isnan(o1)) and np.array_equal(np.isnan(g[2]), np.isnan(o2))
+        assert abs(g[0] - float(np.real(o[0]))) < 1e-9 * max(1.0, abs(float(np.real(o[0]))))
+        fin = np.isfinite(o1)
+        if fin.any():
+            assert np.max(np.abs(g[1][fin] - o1[fin])) <= 1e-8 * np.max(np.abs(o1[fin]))
+
+
 def test_test_inputs_subset_and_unsorted_inputs():
     """xt a subset of x, x unsorted: return_ind / unique('first') semantics (gf_ep_modulator_nmf.m:58-66)."""
     D, N, T = 3, 2, 60

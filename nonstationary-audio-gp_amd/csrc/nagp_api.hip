@@ -398,8 +398,6 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
   if (o->kind == NAGP_KIND_IHGP) {
     p->NT_ih = 256;   // one wave per SIMD: 512 registers per lane (the cubature's pressure stays out of scratch memory)
     p->DG_f = pick_DG(o->lik_kind, o->n_pts, p->NT_ih, sh.D, o->cub_dim);
-    if (const char* e = getenv("NAGP_NT_IH")) p->NT_ih = atoi(e);      // developer tuning hooks
-    if (const char* e = getenv("NAGP_DG")) p->DG_f = atoi(e);
     MomCfg t = mc; t.DG = p->DG_f; t.cache_tabs = 1; t.store_a = (o->lik_kind == NAGP_LIK_POWER_NMF_SQRT) ? 1 : 0;
     p->hph_lds = 1;   // LDS budget, least valuable resident first: H PP H' table, a[d][p], cubature tables
     if (ihgp_filter_lds_doubles(sh, t, p->tb.NG, p->hph_lds) * sizeof(double) > 150 * 1024) p->hph_lds = 0;

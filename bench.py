@@ -211,19 +211,25 @@ def main():
     import torch
     import nagp
     from nagp import dist as nd
-    rank, local_rank, world = nd.init('nccl' if torch.cuda.is_available() else 'gloo')
+    rehearsal = bool(os.environ.get('NAGP_BENCH_REHEARSAL'))     # several ranks on ONE card over gloo: exercises the launch path only
+    rank, local_rank, world = nd.init('nccl' if (torch.cuda.is_available() and not rehearsal) else 'gloo')
     if a.gpus != world and rank == 0 and world > 1:
         print('warning: --gpus %d but WORLD_SIZE=%d' % (a.gpus, world), file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (no CPU fallback)')
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    nagp.build()
+    if rank == 0:
+        nagp.build()                                              # one rank compiles (if the library is stale), the others wait
+    nd.barrier()
 
-    line = run_workload(a.workload, a, rank, local_rank, world, dev, not a.no_cpu_baseline)
+    with_cpu = (not a.no_cpu_baseline) and world == 1             # the CPU baseline is timed at N = 1 only
+    line = run_workload(a.workload, a, rank, local_rank, world, dev, with_cpu)
     if a.workload == 'cfg2' and not a.no_extra and not a.T and not a.segments:
         # the north-star target is stated on the 200k-sample, 32-channel sweep (BASELINE.json configs[2])
-        extra = run_workload('cfg3', a, rank, local_rank, world, dev, not a.no_cpu_baseline)
+        extra = run_workload('cfg3', a, rank, local_rank, world, dev, with_cpu)
         line['target_workload_cfg3'] = {k: extra[k] for k in ('value', 'unit', 'ms_per_step', 'config', 'kernel_ms_per_step', 'roofline',
                                                                'cpu_baseline', 'speedup_vs_cpu_baseline') if k in extra}
     if rank == 0:

@@ -512,10 +512,12 @@ static int launch_filter(nagp_plan* p, const FilterPar& fp_in) {
   MomCfg mc = p->mc; mc.DG = p->DG_f; mc.cache_tabs = p->cache_f; mc.store_a = p->sta_f;
   if (getenv("NAGP_STAMPS")) mc.stamps = reinterpret_cast<unsigned long long*>(p->d_stamps);   // developer diagnostics
   const bool adf = ekf || fp.mom_all || fp.k_end == p->sh.T;   // launches that may call mom (or the EKF filter)
+  int nt_ekf = p->NT_f;
+  if (ekf && p->NT_f + 64 <= 512 && p->sh.N <= 64) { nt_ekf = p->NT_f + 64; fp.spl_wave = 1; }   // one extra wave for the link
   Timed t(p, adf ? NAGP_K_FILTER : NAGP_K_FILTER_LIN);
   dim3 g(p->B), bl(p->NT_f);
   if (ekf) {
-#define LF(TP) hipLaunchKernelGGL((gf_filter_kernel<TP, 1, 0>), g, bl, p->lds_filter, p->stream, p->sh, p->b, mc, fp)
+#define LF(TP) hipLaunchKernelGGL((gf_filter_kernel<TP, 1, 0>), g, dim3(nt_ekf), p->lds_filter, p->stream, p->sh, p->b, mc, fp)
     switch (p->TPT_f) { case 1: LF(1); break; case 2: LF(2); break; default: LF(4); break; }
 #undef LF
   } else {

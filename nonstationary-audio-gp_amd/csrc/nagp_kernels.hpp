@@ -68,6 +68,7 @@ struct FilterPar {
   int l_iter;           // EKF inner iterations
   int kb;               // steps per I/O block (LDS ring)
   int64_t k_begin, k_end;  // steps processed by this launch; k_begin > 0 continues from (MF, PF) of step k_begin-1
+  int spl_wave;            // EKF: the last wave of the workgroup owns no tiles and evaluates the softplus link
 };
 
 // The filtered covariance is symmetric: PF holds only the lower-triangular tiles, tile (I,J), I >= J, at
@@ -262,6 +263,27 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
         }
         if (myrow == 0) fmu[myblk] = shv[myblk] * rm;
       }
+      if (MEAS == 1 && fp.spl_wave && tid >= NT - 64 && !(yk != yk)) {
+        // EKF: the launch carries one extra wave without tiles; it evaluates softplus(g_j) and its derivative of the first
+        // inner iteration here, next to the prediction phase of the tile waves (one exp + log chain off the critical path)
+        const int j = tid - (NT - 64);
+        if (j < sh.N) {
+          const int blk = D + j, o_ = ioff[blk];
+          double g = 0.0;
+          if (pred) {
+            const double* a = sA + (size_t)blk * TS;
+#pragma unroll
+            for (int l = 0; l < 4; ++l)
+              if (l < ibsz[blk]) g = fma(a[l], m[o_ + l], g);
+          } else {
+            g = m[o_];
+          }
+          const double eg = exp(shv[blk] * g);
+          double* spl0 = ws + M + S;
+          spl0[j] = log(1.0 + eg);
+          spl0[sh.N + j] = eg / (eg + 1.0);
+        }
+      }
 #pragma unroll
       for (int q = 0; q < TPT; ++q) {
         if (own.ok[q]) {
@@ -422,12 +444,14 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
             // softplus(g_j) and its derivative once per modulator (one exp + log chain for the whole step instead of
             // N of them in every sub-band lane), then the partials of h = z' W softplus(g)
             double* spl = PJ + S;        // [N] softplus(g), [N] sigmoid(g)
-            if (tid < N) {
-              const double eg = exp(fmu[D + tid]);
-              spl[tid] = log(1.0 + eg);
-              spl[N + tid] = eg / (eg + 1.0);
+            if (it > 0 || !fp.spl_wave) {
+              if (tid < N) {
+                const double eg = exp(fmu[D + tid]);
+                spl[tid] = log(1.0 + eg);
+                spl[N + tid] = eg / (eg + 1.0);
+              }
+              lds_barrier();
             }
-            lds_barrier();
             if (tid < M) {
               double pv = 0.0;
               if (tid < D) {

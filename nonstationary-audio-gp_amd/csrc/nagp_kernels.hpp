@@ -721,6 +721,12 @@ __global__ void __launch_bounds__(512) rts_gain_kernel(Shape sh, Bufs b, GainPar
       for (int q = 0; q < TPT; ++q)
         if (own.ok[q]) {
           const int I = own.I[q], J = own.J[q];
+          {   // the first attempt solved X L' = B in place: rebuild B = PS A' before PSkp = A B + Q + jitter
+            double ps[16];
+            pf_load(ps, PFk, I, J);
+            tile_zero(Bt[q]);
+            tile_mma_nt(Bt[q], ps, sA + (size_t)J * 16);
+          }
           tile_zero(Lt[q]);
           tile_mma(Lt[q], sA + (size_t)I * 16, Bt[q]);
           if (I == J) {
@@ -743,17 +749,26 @@ __global__ void __launch_bounds__(512) rts_gain_kernel(Shape sh, Bufs b, GainPar
           tile_store(sLd + (size_t)jb * 16, Lt[q]);
         }
       lds_barrier();
+      // column jb of L (rows below the diagonal) and -- fused, it needs nothing else -- column jb of X in X L' = B
 #pragma unroll
       for (int q = 0; q < TPT; ++q)
-        if (own.ok[q] && own.J[q] == jb && own.I[q] > jb) {
-          tile_solve_Lt(Lt[q], sLd + (size_t)jb * 16);
-          tile_store(bufP + ((size_t)par * M + own.I[q]) * TS, Lt[q]);
+        if (own.ok[q] && own.J[q] == jb) {
+          if (own.I[q] > jb) {
+            tile_solve_Lt(Lt[q], sLd + (size_t)jb * 16);
+            tile_store(bufP + ((size_t)par * M + own.I[q]) * TS, Lt[q]);
+          }
+          tile_solve_Lt(Bt[q], sLd + (size_t)jb * 16);
+          tile_store(bufX + ((size_t)par * M + own.I[q]) * TS, Bt[q]);
         }
       lds_barrier();
+      // trailing updates: L (lower tiles) and the remaining columns of B
 #pragma unroll
       for (int q = 0; q < TPT; ++q)
-        if (own.ok[q] && own.J[q] > jb && own.I[q] >= own.J[q])
-          tile_mms_nt(Lt[q], bufP + ((size_t)par * M + own.I[q]) * TS, bufP + ((size_t)par * M + own.J[q]) * TS);
+        if (own.ok[q] && own.J[q] > jb) {
+          if (own.I[q] >= own.J[q])
+            tile_mms_nt(Lt[q], bufP + ((size_t)par * M + own.I[q]) * TS, bufP + ((size_t)par * M + own.J[q]) * TS);
+          tile_mms_nt(Bt[q], bufX + ((size_t)par * M + own.I[q]) * TS, bufP + ((size_t)par * M + own.J[q]) * TS);
+        }
     }
     lds_barrier();
     failed = (flag[attempt] != 0);
@@ -764,23 +779,7 @@ __global__ void __launch_bounds__(512) rts_gain_kernel(Shape sh, Bufs b, GainPar
     if (flag[0] && flag[1]) atomicAdd(&b.counters[(size_t)pb * 4 + 3], 1ull);
   }
 
-  // ---- X L' = B  (forward over block columns)
-  for (int jb = 0; jb < M; ++jb) {
-    const int par = jb & 1;
-#pragma unroll
-    for (int q = 0; q < TPT; ++q)
-      if (own.ok[q] && own.J[q] == jb) {
-        tile_solve_Lt(Bt[q], sLd + (size_t)jb * 16);
-        tile_store(bufX + ((size_t)par * M + own.I[q]) * TS, Bt[q]);
-        if (own.I[q] > jb) tile_store(bufP + ((size_t)par * M + own.I[q]) * TS, Lt[q]);
-      }
-    lds_barrier();
-#pragma unroll
-    for (int q = 0; q < TPT; ++q)
-      if (own.ok[q] && own.J[q] > jb)
-        tile_mms_nt(Bt[q], bufX + ((size_t)par * M + own.I[q]) * TS, bufP + ((size_t)par * M + own.J[q]) * TS);
-  }
-  lds_barrier();
+  // (X L' = B was solved column by column inside the factorisation loop)
   // ---- G L = X  (backward over block columns)
   for (int jb = M - 1; jb >= 0; --jb) {
     const int par = jb & 1;

@@ -634,8 +634,10 @@ __device__ __forceinline__ void tile_solve_L(double* t, const double* L) {
     }
 }
 
+// one tile per thread: capped at 128 VGPRs (four waves per SIMD; measured best of 2..6) so that two workgroups share a CU -- the kernel is a chain of ~3M short
+// barrier-separated phases and lives on latency hiding across workgroups
 template <int TPT>
-__global__ void __launch_bounds__(512) rts_gain_kernel(Shape sh, Bufs b, GainPar gp) {
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(TPT == 1 ? 4 : 2))) rts_gain_kernel(Shape sh, Bufs b, GainPar gp) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int tid = threadIdx.x, NT = blockDim.x;
   const int S = sh.S, M = sh.M;

@@ -1209,8 +1209,9 @@ __host__ __device__ inline size_t ep_lds_doubles(const Shape& s, const MomCfg& m
   return (size_t)s.D * s.N + 4 * (size_t)s.M + 8 + mom_lds_doubles(mc);
 }
 
+// throughput kernel (one workgroup per few steps): capped at 256 registers so that two workgroups share a CU
 template <int MV>
-__global__ void __launch_bounds__(256) ep_site_kernel(Shape sh, Bufs b, MomCfg mc, EpPar ep) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) ep_site_kernel(Shape sh, Bufs b, MomCfg mc, EpPar ep) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int tid = threadIdx.x, NT = blockDim.x;
   const int M = sh.M;

@@ -1036,18 +1036,40 @@ __global__ void __launch_bounds__(512) rts_compose_kernel(Shape sh, Bufs b, Span
     const double* dk = b.dbuf + ((size_t)pb * sp.chunk + kk) * S;
     if (tid < S) vv[tid] = cv[tid] + dk[tid];
     lds_barrier();
-    double accP[TPT][16], accX[TPT][16];
-#pragma unroll
-    for (int q = 0; q < TPT; ++q) { tile_zero(accP[q]); tile_zero(accX[q]); }
+    double accX[TPT][16];
     double cn = 0.0;
-    gemm_nn<TPT, true>(c, sp.LP1, accP, accX, Gk, Phi, nullptr, Cm, Dk, vv, cn);
-    __syncthreads();   // every read of Phi / C (global) and vv is done
+    if constexpr (TPT <= 2) {
+      // G [Phi | C + Delta] in one pass over the G panels (two accumulator sets)
+      double accP[TPT][16];
 #pragma unroll
-    for (int q = 0; q < TPT; ++q)
-      if (c.own.ok[q]) {
-        tile_store(Phi + (size_t)(tid + q * NT) * 16, accP[q]);
-        tile_store(Xb + (size_t)(tid + q * NT) * 16, accX[q]);
+      for (int q = 0; q < TPT; ++q) { tile_zero(accP[q]); tile_zero(accX[q]); }
+      gemm_nn<TPT, true>(c, sp.LP1, accP, accX, Gk, Phi, nullptr, Cm, Dk, vv, cn);
+      __syncthreads();   // every read of Phi / C (global) and vv is done
+#pragma unroll
+      for (int q = 0; q < TPT; ++q)
+        if (c.own.ok[q]) {
+          tile_store(Phi + (size_t)(tid + q * NT) * 16, accP[q]);
+          tile_store(Xb + (size_t)(tid + q * NT) * 16, accX[q]);
+        }
+    } else {
+      // three and more tiles per thread: two accumulator sets would not fit the registers (407 spilled VGPRs at
+      // TPT = 3) -- two passes over the G panels with one set instead
+#pragma unroll
+      for (int q = 0; q < TPT; ++q) tile_zero(accX[q]);
+      double dummy = 0.0;
+      gemm_nn<TPT, false>(c, sp.LP1, accX, accX, Gk, Phi, nullptr, nullptr, nullptr, nullptr, dummy);
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < TPT; ++q) {
+        if (c.own.ok[q]) tile_store(Phi + (size_t)(tid + q * NT) * 16, accX[q]);
+        tile_zero(accX[q]);
       }
+      gemm_nn<TPT, false>(c, sp.LP1, accX, accX, Gk, Cm, Dk, nullptr, nullptr, vv, cn);
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < TPT; ++q)
+        if (c.own.ok[q]) tile_store(Xb + (size_t)(tid + q * NT) * 16, accX[q]);
+    }
     if (tid < S) cv[tid] = cn;
     __syncthreads();   // X visible
 #pragma unroll

@@ -366,6 +366,25 @@ def test_batched_plan_equals_single_runs_and_is_deterministic_and_chunk_invarian
     plan.close(); small.close()
 
 
+def test_large_batch_of_replicas_equals_single_problem_plans():
+    """112 problems in one plan (more workgroups than half the CUs in every kernel): each must agree with its
+    single-problem plan to rounding."""
+    D, N, T = 3, 2, 90
+    probs2, ys2 = _plan_problems(D, N, T, [11, 12], False)
+    B = 112
+    probs = [probs2[q % 2] for q in range(B)]; ys = [ys2[q % 2] for q in range(B)]
+    mom = Mom('likModulatorNMFPower', p_cubature=5); kw = dict(mom=mom, ep_fraction=0.5, ep_damping=[0.5, 0.5], ep_itts=2)
+    big = Plan(L.KIND_GF_EP, probs, T, **kw); big.upload(ys); big.execute(); a = big.download()
+    t = big.timings(); assert t['launches']['scan'] == 2
+    for q in (0, 1):
+        one = Plan(L.KIND_GF_EP, probs2[q:q + 1], T, **kw); one.upload(ys2[q:q + 1]); one.execute(); o = one.download()[0]
+        for qq in (q, q + 2, B - 2 + q):
+            assert rel(a[qq].Eft, o.Eft) < 1e-11 and rel(a[qq].Varft, o.Varft) < 1e-11 and rel(a[qq].MS, o.MS) < 1e-11
+            assert rel(a[qq].ttau, o.ttau) < 1e-10 and np.allclose(a[qq].nlZ, o.nlZ, rtol=1e-12)
+        one.close()
+    big.close()
+
+
 def test_full_length_cfg2_prefix_property_and_finiteness():
     """BASELINE size (T = 84 010, S = 73) through a size-independent property: with one sweep the sites of
     step k depend only on y(1..k), so the first 1500 columns must equal the truncated golden run's filter

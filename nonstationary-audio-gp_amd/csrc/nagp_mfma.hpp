@@ -107,7 +107,8 @@ __global__ void __launch_bounds__(256) rts_apply_mfma_kernel(Shape sh, Bufs b, M
   extern __shared__ __attribute__((aligned(16))) double lds[];
   using C = MfmaCtx<NTL>;
   const int tid = threadIdx.x, j = blockIdx.x, pb = blockIdx.y;
-  const int S = sh.S, M = sh.M, Sp = sp.Sp, LD = Sp + 1;
+  constexpr int Sp = 16 * NTL, LD = Sp + 1;     // == sp.Sp: the host instantiates NTL = Sp / 16; compile-time strides
+  const int S = sh.S, M = sh.M;
   const int64_t T = sh.T;
   C c; c.wave = tid >> 6; c.Sp = Sp; c.LD = LD;
   double* Gs = lds;
@@ -143,9 +144,7 @@ __global__ void __launch_bounds__(256) rts_apply_mfma_kernel(Shape sh, Bufs b, M
   // register prefetch (one step ahead) of G_k, Delta_k, delta_k: the global latency hides under the MFMAs
   constexpr int NG = (NTL * NTL * 256 + 255) / 256;   // = NTL*NTL doubles of G per thread
   double gpre[NG]; v4d dpre[C::TW]; double dvpre = 0.0;
-  int goff[NG];
-#pragma unroll
-  for (int u = 0; u < NG; ++u) { const int i = tid + 256 * u; const int r = i / Sp; goff[u] = r * LD + (i - r * Sp); }
+  auto goff = [&](int u) { const int i = tid + 256 * u; const int r = i / Sp; return r * LD + (i - r * Sp); };   // LDS offset of dense element i
   auto prefetch = [&](int kk) {
     const double* Gk = b.Gbuf + (((size_t)pb * sp.chunk + kk) * 2) * SS;
     const double* Dk = Gk + SS;
@@ -164,7 +163,7 @@ __global__ void __launch_bounds__(256) rts_apply_mfma_kernel(Shape sh, Bufs b, M
     const int64_t k = sp.k0 + kk;
     // G -> LDS, Y = E + Delta -> LDS, ev = e + delta
 #pragma unroll
-    for (int u = 0; u < NG; ++u) Gs[goff[u]] = gpre[u];
+    for (int u = 0; u < NG; ++u) Gs[goff(u)] = gpre[u];
 #pragma unroll
     for (int q = 0; q < C::TW; ++q)
       if (c.ok(q)) {
@@ -194,31 +193,45 @@ __global__ void __launch_bounds__(256) rts_apply_mfma_kernel(Shape sh, Bufs b, M
 #pragma unroll
     for (int q = 0; q < C::TW; ++q) E[q] = (v4d){0, 0, 0, 0};
     mfma_gemm_all<NTL, C::TW, true>(Bs, Gs, LD, Sp, c.wave, E);
-    // ---- outputs
+    // ---- outputs.  Smoothed marginal variances: E(4n,4n) sits in the diagonal tile n/4, accumulator register n%4 of lane
+    // 4*(n%4) (C-layout row = (lane>>4) + 4r, col = lane&15) -- picked directly instead of scanning every element.
+    {
+      const int lane = tid & 63;
+      if ((lane & 3) == 0 && lane < 16) {
 #pragma unroll
-    for (int q = 0; q < C::TW; ++q)
-      if (c.ok(q)) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          int row, col; acc_rc(NTL, c.tile(q), r, row, col);
-          if (c.tile(q) / NTL == c.tile(q) % NTL && row == col && (row & 3) == 0 && (row >> 2) < M) {
-            const int n = row >> 2;
-            const size_t ix = ((size_t)pb * T + k) * M + n;
-            const double vnew = b.fv[ix] + hv[n] * hv[n] * E[q][r];
-            mxP = fmax(mxP, fabs(b.sv[ix] - vnew));
-            b.sv[ix] = vnew;
+        for (int q = 0; q < C::TW; ++q) {
+          const int t = c.tile(q);
+          if (c.ok(q) && t % (NTL + 1) == 0) {
+            const int rr = lane >> 2, n = 4 * (t / (NTL + 1)) + rr;
+            if (n < M) {
+              const double ev_ = (rr == 0) ? E[q][0] : ((rr == 1) ? E[q][1] : ((rr == 2) ? E[q][2] : E[q][3]));
+              const size_t ix = ((size_t)pb * T + k) * M + n;
+              const double vnew = b.fv[ix] + hv[n] * hv[n] * ev_;
+              mxP = fmax(mxP, fabs(b.sv[ix] - vnew));
+              b.sv[ix] = vnew;
+            }
           }
-          if (sp.write_PSs || k == 0) {
+        }
+      }
+    }
+    if (sp.write_PSs || k == 0) {     // rare: smoothed covariances requested, or the restart state of the next EKF sweep
+#pragma unroll 1
+      for (int q = 0; q < C::TW; ++q)
+        if (c.ok(q)) {
+#pragma unroll 1
+          for (int r = 0; r < 4; ++r) {
+            int row, col; acc_rc(NTL, c.tile(q), r, row, col);
             const int I = row >> 2, J = col >> 2;
             if (I < M && J < M) {
+              const double er = (r == 0) ? E[q][0] : ((r == 1) ? E[q][1] : ((r == 2) ? E[q][2] : E[q][3]));
               const size_t tix = (((size_t)pb * T + k) * sh.ntiles + (size_t)I * M + J) * 16 + 4 * (row & 3) + (col & 3);
-              const double ps = pf_elem(b.PF + ((size_t)pb * T + k) * pf_ntiles(sh) * 16, I, J, row & 3, col & 3) + E[q][r];
+              const double ps = pf_elem(b.PF + ((size_t)pb * T + k) * pf_ntiles(sh) * 16, I, J, row & 3, col & 3) + er;
               if (sp.write_PSs) b.PSs[tix] = ps;
               if (k == 0) b.state[(size_t)pb * ((size_t)sh.ntiles * 16 + S) + ((size_t)I * M + J) * 16 + 4 * (row & 3) + (col & 3)] = ps;
             }
           }
         }
-      }
+    }
     if (sidx >= 0) {
       const double ms = b.MF[((size_t)pb * T + k) * S + sidx] + e_cur;
       b.MS[((size_t)pb * T + k) * S + sidx] = ms;
@@ -246,7 +259,8 @@ __global__ void __launch_bounds__(256) rts_compose_mfma_kernel(Shape sh, Bufs b,
   extern __shared__ __attribute__((aligned(16))) double lds[];
   using C = MfmaCtx<NTL>;
   const int tid = threadIdx.x, j = blockIdx.x, pb = blockIdx.y;
-  const int S = sh.S, M = sh.M, Sp = sp.Sp, LD = Sp + 1;
+  constexpr int Sp = 16 * NTL, LD = Sp + 1;     // == sp.Sp: the host instantiates NTL = Sp / 16; compile-time strides
+  const int S = sh.S, M = sh.M;
   C c; c.wave = tid >> 6; c.Sp = Sp; c.LD = LD;
   double* Gs = lds;
   double* Bs = Gs + (size_t)Sp * LD;
@@ -270,9 +284,7 @@ __global__ void __launch_bounds__(256) rts_compose_mfma_kernel(Shape sh, Bufs b,
   const int a0 = j * sp.L, e0 = (a0 + sp.L < sp.nk) ? a0 + sp.L : sp.nk;
   constexpr int NG = NTL * NTL;
   double gpre[NG]; v4d dpre[C::TW]; double dvpre = 0.0;
-  int goff[NG];
-#pragma unroll
-  for (int u = 0; u < NG; ++u) { const int i = tid + 256 * u; const int r = i / Sp; goff[u] = r * LD + (i - r * Sp); }
+  auto goff = [&](int u) { const int i = tid + 256 * u; const int r = i / Sp; return r * LD + (i - r * Sp); };   // LDS offset of dense element i
   auto prefetch = [&](int kk) {
     const double* Gk = b.Gbuf + (((size_t)pb * sp.chunk + kk) * 2) * SS;
     const double* Dk = Gk + SS;
@@ -289,7 +301,7 @@ __global__ void __launch_bounds__(256) rts_compose_mfma_kernel(Shape sh, Bufs b,
   if (e0 > a0) prefetch(e0 - 1);
   for (int kk = e0 - 1; kk >= a0; --kk) {
 #pragma unroll
-    for (int u = 0; u < NG; ++u) Gs[goff[u]] = gpre[u];
+    for (int u = 0; u < NG; ++u) Gs[goff(u)] = gpre[u];
 #pragma unroll
     for (int q = 0; q < C::TW; ++q)
       if (c.ok(q)) {
@@ -354,7 +366,8 @@ __global__ void __launch_bounds__(256) rts_boundary_mfma_kernel(Shape sh, Bufs b
   extern __shared__ __attribute__((aligned(16))) double lds[];
   using C = MfmaCtx<NTL>;
   const int tid = threadIdx.x, pb = blockIdx.x;
-  const int S = sh.S, M = sh.M, Sp = sp.Sp, LD = Sp + 1;
+  constexpr int Sp = 16 * NTL, LD = Sp + 1;     // == sp.Sp: the host instantiates NTL = Sp / 16; compile-time strides
+  const int S = sh.S, M = sh.M;
   C c; c.wave = tid >> 6; c.Sp = Sp; c.LD = LD;
   double* Gs = lds;
   double* Bs = Gs + (size_t)Sp * LD;
@@ -378,9 +391,7 @@ __global__ void __launch_bounds__(256) rts_boundary_mfma_kernel(Shape sh, Bufs b
   }
   constexpr int NG = NTL * NTL;
   double gpre[NG]; v4d cpre[C::TW]; double cvpre = 0.0;
-  int goff[NG];
-#pragma unroll
-  for (int u = 0; u < NG; ++u) { const int i = tid + 256 * u; const int r = i / Sp; goff[u] = r * LD + (i - r * Sp); }
+  auto goff = [&](int u) { const int i = tid + 256 * u; const int r = i / Sp; return r * LD + (i - r * Sp); };   // LDS offset of dense element i
   auto prefetch = [&](int jj) {
     const double* Phi = sp.spanbuf + (((size_t)pb * sp.ns_max + jj) * 2) * SS;
     const double* Cm = Phi + SS;
@@ -398,7 +409,7 @@ __global__ void __launch_bounds__(256) rts_boundary_mfma_kernel(Shape sh, Bufs b
   for (int j = sp.ns - 1; j >= 0; --j) {
     double* Bj = sp.bnd + ((size_t)pb * sp.ns_max + j) * (SS + S);
 #pragma unroll
-    for (int u = 0; u < NG; ++u) Gs[goff[u]] = gpre[u];
+    for (int u = 0; u < NG; ++u) Gs[goff(u)] = gpre[u];
     v4d ccur[C::TW];
 #pragma unroll
     for (int q = 0; q < C::TW; ++q) ccur[q] = cpre[q];

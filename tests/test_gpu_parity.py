@@ -385,6 +385,21 @@ def test_large_batch_of_replicas_equals_single_problem_plans():
     big.close()
 
 
+@pytest.mark.parametrize('D,N', [(12, 3), (20, 3), (21, 3), (25, 2)])
+def test_smoother_size_classes_against_oracle(D, N):
+    """M = 15 / 23 / 24 / 27 sites: dense MFMA smoother tiles Sp = 64 and 96 (the largest that fits the LDS, instantiations
+    <4> and <6>) and the first size that falls back to the VALU span kernels (Sp = 112), two tiles per thread in the gain
+    kernel from M = 23 on."""
+    T = 36
+    pr = harness.nmf_problem(D, N, T, 400 + D); t = np.arange(1, T + 1.0); d = np.array([0.5, 0.5])
+    mom = Mom('likModulatorNMFPower', p_cubature=5); omom = olik.Mom(olik.LIK_POWER_NMF, p=5)
+    Eft, Varft, _, _, _, out = nagp.gf_ep_modulator_nmf(pr['w'], t, pr['y'], SSHandle(), mom, t, 'matern32', 'matern52', 1, D, N, 0.5, d, 2, nargout=6)
+    o = ogf.gf_ep_modulator_nmf(pr['w'], t, pr['y'], None, omom, t, 'matern32', 'matern52', 1, D, N, 0.5, d, 2)
+    assert rel(Eft, o[0]) < TOL_MEAN and rel(Varft, o[1]) < TOL_MEAN
+    assert rel(out['PS'], np.transpose(o[5]['PS'], (1, 2, 0))) < TOL_MEAN and rel(out['MS'], o[5]['MS']) < TOL_MEAN
+    assert np.allclose(out['nlZ'], o[5]['nlZ'], rtol=TOL_LOGZ, atol=1e-12)
+
+
 def test_full_length_cfg2_prefix_property_and_finiteness():
     """BASELINE size (T = 84 010, S = 73) through a size-independent property: with one sweep the sites of
     step k depend only on y(1..k), so the first 1500 columns must equal the truncated golden run's filter

@@ -400,6 +400,16 @@ def test_smoother_size_classes_against_oracle(D, N):
     assert np.allclose(out['nlZ'], o[5]['nlZ'], rtol=TOL_LOGZ, atol=1e-12)
 
 
+def test_ekf_with_two_tiles_per_thread_S146():
+    """gf_giekf_modulator_nmf at the 32-channel / 6-component shape (M = 38, 741 lower tiles -> two tiles per thread in the
+    EKF filter instantiation, three in the smoother kernels)."""
+    D, N, T = 32, 6, 24
+    pr = harness.nmf_problem(D, N, T, 77, 'constraints'); t = np.arange(1, T + 1.0)
+    r = nagp.gf_giekf_modulator_nmf(pr['w'], t, pr['y'], SSHandle(), None, t, 'matern32', 'matern52', 1, D, N, 2, 2, nargout=2)
+    o = oek.gf_giekf_modulator_nmf(pr['w'], t, pr['y'], None, None, t, 'matern32', 'matern52', 1, D, N, 2, 2)
+    assert rel(r[0], o[0]) < TOL_MEAN and rel(r[1], o[1]) < TOL_MEAN
+
+
 def test_full_length_cfg2_prefix_property_and_finiteness():
     """BASELINE size (T = 84 010, S = 73) through a size-independent property: with one sweep the sites of
     step k depend only on y(1..k), so the first 1500 columns must equal the truncated golden run's filter

@@ -225,7 +225,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     if (p->TPT_f == 3) p->TPT_f = 4;   // instantiated: 1, 2, 4 tiles per thread
     p->NT_f = std::max(roundup64((slots + p->TPT_f - 1) / p->TPT_f), std::max(roundup64(sh.S), ekf ? 128 : 384));
     // ADF launches: <= 256 threads (512 registers per lane) whenever the tiles fit
-    if (slots <= 1024 && sh.S <= 256) { p->TPT_a = slots <= 256 ? 1 : (slots <= 512 ? 2 : 4); p->NT_a = 256; p->LB_a = 256; }
+    if (slots <= 1024 && sh.S <= 256) { p->TPT_a = slots <= 256 ? 1 : (slots <= 512 ? 2 : (slots <= 768 ? 3 : 4)); p->NT_a = 256; p->LB_a = 256; }
     else { p->TPT_a = 4; p->NT_a = std::max(roundup64((slots + 3) / 4), roundup64(sh.S)); p->LB_a = 512; }
     p->wide_l = (!ekf && slots > 512 && slots <= 1024 && !getenv("NAGP_NO_WIDE")) ? 1 : 0;
     p->NT_l = p->wide_l ? roundup64(slots) : p->NT_f;
@@ -432,6 +432,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     } else {
 #define SL1(V) PLAN_TRY(set_lds(gf_filter_kernel<1, 0, V, 256>, p->lds_filter))
 #define SL2(V) PLAN_TRY(set_lds(gf_filter_kernel<2, 0, V, 256>, p->lds_filter))
+#define SL3(V) PLAN_TRY(set_lds(gf_filter_kernel<3, 0, V, 256>, p->lds_filter))
 #define SL4(V) PLAN_TRY(set_lds(gf_filter_kernel<4, 0, V, 256>, p->lds_filter))
 #define SL5(V) PLAN_TRY(set_lds(gf_filter_kernel<4, 0, V, 512>, p->lds_filter))
       if (p->LB_a == 512) { NAGP_MV_SWITCH(mom_variant(mc), SL5) }
@@ -448,6 +449,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
       }
 #undef SL1
 #undef SL2
+#undef SL3
 #undef SL4
 #undef SL5
     }
@@ -525,16 +527,19 @@ static int launch_filter(nagp_plan* p, const FilterPar& fp_in) {
       dim3 ba(p->NT_a);
 #define LF1(V) hipLaunchKernelGGL((gf_filter_kernel<1, 0, V, 256>), g, ba, p->lds_filter, p->stream, p->sh, p->b, mc, fp)
 #define LF2(V) hipLaunchKernelGGL((gf_filter_kernel<2, 0, V, 256>), g, ba, p->lds_filter, p->stream, p->sh, p->b, mc, fp)
+#define LF3(V) hipLaunchKernelGGL((gf_filter_kernel<3, 0, V, 256>), g, ba, p->lds_filter, p->stream, p->sh, p->b, mc, fp)
 #define LF4(V) hipLaunchKernelGGL((gf_filter_kernel<4, 0, V, 256>), g, ba, p->lds_filter, p->stream, p->sh, p->b, mc, fp)
 #define LF5(V) hipLaunchKernelGGL((gf_filter_kernel<4, 0, V, 512>), g, ba, p->lds_filter, p->stream, p->sh, p->b, mc, fp)
       if (p->LB_a == 512) { NAGP_MV_SWITCH(mom_variant(mc), LF5) }
       else switch (p->TPT_a) {
         case 1: NAGP_MV_SWITCH(mom_variant(mc), LF1) break;
         case 2: NAGP_MV_SWITCH(mom_variant(mc), LF2) break;
+        case 3: NAGP_MV_SWITCH(mom_variant(mc), LF3) break;
         default: NAGP_MV_SWITCH(mom_variant(mc), LF4) break;
       }
 #undef LF1
 #undef LF2
+#undef LF3
 #undef LF4
 #undef LF5
     } else if (p->wide_l) {

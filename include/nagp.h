@@ -57,6 +57,8 @@ typedef enum nagp_link { NAGP_LINK_SOFTPLUS = 0, NAGP_LINK_EXP = 1 } nagp_link;
 /* flags (nagp_opts.flags) */
 #define NAGP_FLAG_IHGP_CONSTRAINTS 0x1u /* ihgp_ep_modulator_nmf_constraints.m: R starts at 0, no abs(Varft) */
 #define NAGP_FLAG_EKF_RESET_P      0x2u /* gf_giekf_modulator_nmf_constraints.m:168: P=Pinf every global iteration */
+#define NAGP_FLAG_MIXTURE_RULE     0x8u /* experiments/{gf,ihgp}_ep_mods_nmf_mixture.m: mom at power ep_fraction in the filter too,
+                                           site <- (1-d) site + d/ep_fraction (...), clamp in the filter pass only, R starts at 0 */
 #define NAGP_FLAG_WANT_PS          0x4u /* keep the smoothed covariances so that nagp_out.PS can be filled */
 
 /* Discrete-time model of ONE problem (segment / hyper-parameter replica).

@@ -111,6 +111,15 @@ static int dalloc(nagp_plan* p, double** ptr, size_t n_doubles, bool zero = true
     default: CALL(8); break;                                                                             \
   }
 
+// the kernels without covariance tiles (IHGP filter, site refresh, mom) also exist for N = 9 (three sources x three
+// components of the source-separation mixtures, experiments/source_sep_piano.m:78-90)
+#define NAGP_MV_SWITCH9(mv, CALL)                                                                        \
+  switch (mv) {                                                                                          \
+    case 0: CALL(0); break; case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break;      \
+    case 4: CALL(4); break; case 5: CALL(5); break; case 6: CALL(6); break; case 7: CALL(7); break;      \
+    case 8: CALL(8); break; default: CALL(9); break;                                                     \
+  }
+
 static int roundup64(int x) { return ((x + 63) / 64) * 64; }
 
 // lanes per sigma point in mom (see nagp_dev.hpp).  POWER: as many as keep one trip over the points.
@@ -177,11 +186,14 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
       if (m0.M != 2 * m0.D || o->cub_dim != m0.D) FAIL(NAGP_EINVAL, "POWER likelihood needs M=2D, cub_dim=D");
     } else {
       if (m0.M != m0.D + m0.N || o->cub_dim != m0.N || !m0.Wnmf) FAIL(NAGP_EINVAL, "NMF likelihood needs M=D+N, cub_dim=N, Wnmf");
-      if (m0.N > 8) FAIL(NAGP_EUNSUPPORTED, "N=%d > 8 NMF components", m0.N);
+      const int nmax = (o->kind == NAGP_KIND_IHGP) ? MOM_MAXCD : MOM_MAXCD_GF;
+      if (m0.N > nmax) FAIL(NAGP_EUNSUPPORTED, "N=%d > %d NMF components", m0.N, nmax);
     }
   } else {
     if (m0.M != m0.D + m0.N || !m0.Wnmf || o->l_iter < 1) FAIL(NAGP_EINVAL, "EKF needs M=D+N, Wnmf, l_iter>=1");
   }
+  if ((o->flags & NAGP_FLAG_MIXTURE_RULE) && (ekf || o->mode != NAGP_MODE_PREDICT || o->lik_kind == NAGP_LIK_POWER))
+    FAIL(NAGP_EINVAL, "the mixture EP rule exists for the NMF likelihoods in predict mode only (gf_ep_mods_nmf_mixture.m:376)");
   if (o->kind == NAGP_KIND_IHGP && !tables) FAIL(NAGP_EINVAL, "IHGP tables missing");
 
   nagp_plan* p = new nagp_plan();
@@ -216,12 +228,15 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
   // ---- launch geometry
   const int nt = sh.ntiles;
   p->TPT = (nt + 511) / 512;   // <= 512 threads per workgroup: 256 VGPRs per lane for the register-resident tiles
-  if (p->TPT > 4 || sh.S > 512) { nagp_plan_destroy(p); FAIL(NAGP_EUNSUPPORTED, "M=%d / S=%d: more than 2048 tiles or 512 states", sh.M, sh.S); }
+  const bool ih = (o->kind == NAGP_KIND_IHGP);   // no covariance tiles: the tile-count limits below do not apply
+  if (ih) p->TPT = std::min(p->TPT, 4);
+  if (!ih && (p->TPT > 4 || sh.S > 512)) { nagp_plan_destroy(p); FAIL(NAGP_EUNSUPPORTED, "M=%d / S=%d: more than 2048 tiles or 512 states", sh.M, sh.S); }
   p->NT = std::max(roundup64((nt + p->TPT - 1) / p->TPT), std::max(roundup64(sh.S), 128));
   {   // filter: one thread per lower-triangular tile
     const int slots = sh.M * (sh.M + 1) / 2;
     p->TPT_f = (slots + 511) / 512;
-    if (p->TPT_f > 4) { nagp_plan_destroy(p); FAIL(NAGP_EUNSUPPORTED, "M=%d too large for the filter kernel", sh.M); }
+    if (p->TPT_f > 4 && !ih) { nagp_plan_destroy(p); FAIL(NAGP_EUNSUPPORTED, "M=%d too large for the filter kernel", sh.M); }
+    if (ih) p->TPT_f = std::min(p->TPT_f, 4);
     if (p->TPT_f == 3) p->TPT_f = 4;   // instantiated: 1, 2, 4 tiles per thread
     p->NT_f = std::max(roundup64((slots + p->TPT_f - 1) / p->TPT_f), std::max(roundup64(sh.S), ekf ? 128 : 384));
     // ADF launches: <= 256 threads (512 registers per lane) whenever the tiles fit
@@ -407,7 +422,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     p->lds_ih = ihgp_filter_lds_doubles(sh, t, p->tb.NG, p->hph_lds) * sizeof(double);
     if (getenv("NAGP_STAMPS")) fprintf(stderr, "[nagp plan] ihgp filter: LDS %zu B, hph table in LDS %d, cubature tables in LDS %d, mom LDS %zu B\n", p->lds_ih, p->hph_lds, p->cache_f, mom_lds_doubles(t) * sizeof(double));
 #define SL(V) PLAN_TRY(set_lds(ihgp_filter_kernel<V>, p->lds_ih))
-    NAGP_MV_SWITCH(mom_variant(mc), SL)
+    NAGP_MV_SWITCH9(mom_variant(mc), SL)
 #undef SL
   } else {
     if (!ekf) p->DG_f = pick_DG(o->lik_kind, o->n_pts, p->NT_a, sh.D, o->cub_dim);
@@ -473,7 +488,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     p->cache_ep = t.cache_tabs; p->sta_ep = t.store_a;
     p->lds_ep = ep_lds_doubles(sh, t) * sizeof(double);
 #define SL(V) PLAN_TRY(set_lds(ep_site_kernel<V>, p->lds_ep))
-    NAGP_MV_SWITCH(mom_variant(mc), SL)
+    NAGP_MV_SWITCH9(mom_variant(mc), SL)
 #undef SL
   }
   p->nlZ.assign((size_t)B * o->ep_itts, 0.0);
@@ -614,6 +629,8 @@ static int launch_smoother(nagp_plan* p, bool write_PSs) {
   return NAGP_OK;
 }
 
+static bool mixture_rule(const nagp_plan* p) { return (p->opts.flags & NAGP_FLAG_MIXTURE_RULE) != 0; }
+
 static int launch_ep(nagp_plan* p, double alpha, double damp, int clamp, int write_R, double* lZ_out) {
   const Shape& sh = p->sh;
   if (sh.T < 2) return NAGP_OK;
@@ -621,11 +638,13 @@ static int launch_ep(nagp_plan* p, double alpha, double damp, int clamp, int wri
   EpPar ep{};
   ep.k_end = sh.T - 1;
   ep.steps_per_wg = (int)std::max<int64_t>(1, (ep.k_end + 4095) / 4096);
-  ep.alpha = alpha; ep.ep_damp = damp; ep.clamp = clamp; ep.write_R = write_R; ep.lZ_out = lZ_out;
+  ep.alpha = alpha; ep.clamp = clamp; ep.write_R = write_R; ep.lZ_out = lZ_out;
+  if (mixture_rule(p)) { ep.w_old = 1.0 - damp; ep.w_new = damp / alpha; }
+  else { ep.w_old = 1.0 - damp * alpha; ep.w_new = damp; }
   Timed t(p, NAGP_K_EPSITE);
   dim3 g((unsigned)((ep.k_end + ep.steps_per_wg - 1) / ep.steps_per_wg), p->B), bl(256);
 #define LE(V) hipLaunchKernelGGL(ep_site_kernel<V>, g, bl, p->lds_ep, p->stream, sh, p->b, mc, ep)
-  NAGP_MV_SWITCH(mom_variant(mc), LE)
+  NAGP_MV_SWITCH9(mom_variant(mc), LE)
 #undef LE
   HIP_TRY(hipGetLastError());
   return NAGP_OK;
@@ -675,7 +694,9 @@ static int exec_gf(nagp_plan* p) {
     if (run_filter) {
       FilterPar fp{};
       fp.itt = itt; fp.ep_damp = p->damping[itt - 1]; fp.mom_all = (itt == 1);
-      fp.legacy_update = nlml; fp.clamp_always = nlml; fp.write_R = !nlml;
+      const bool mix = mixture_rule(p);
+      fp.legacy_update = nlml || mix; fp.clamp_always = nlml || mix; fp.write_R = !nlml; fp.R_raw = mix;
+      fp.w_old = 1.0 - fp.ep_damp; fp.w_new = mix ? fp.ep_damp / o.ep_fraction : fp.ep_damp; fp.mom_alpha = mix ? o.ep_fraction : 1.0;
       fp.predict_k1 = (!nlml && o.predict_at_k1) ? 1 : 0;
       fp.store_PF = p->need_PF ? 1 : 0; fp.l_iter = 0;
       fp.k_begin = 0; fp.k_end = sh.T;
@@ -697,7 +718,8 @@ static int exec_gf(nagp_plan* p) {
       RUN(seed_last_step(p));
       RUN(launch_smoother(p, p->want_PS && itt == I));
       if (itt < I) {
-        RUN(launch_ep(p, o.ep_fraction, p->damping[itt], nlml ? 0 : 1, nlml ? 0 : 1, p->b.lZ));
+        // the mixture variant leaves the clamp to the next filter pass (gf_ep_mods_nmf_mixture.m:195, 280-284)
+        RUN(launch_ep(p, o.ep_fraction, p->damping[itt], (nlml || mixture_rule(p)) ? 0 : 1, nlml ? 0 : 1, mixture_rule(p) ? nullptr : p->b.lZ));
         if (!nlml) RUN(reduce_sum(p, p->b.lZ, 0, sh.T, 0));
       }
       RUN(fetch_red(p, red));
@@ -761,7 +783,8 @@ __global__ void fill_kernel(double* p, size_t n, double v) {
 static int exec_ihgp(nagp_plan* p) {
   const Shape& sh = p->sh; const nagp_opts& o = p->opts; const int I = o.ep_itts, B = p->B;
   std::vector<double> red;
-  const bool cv = (o.flags & NAGP_FLAG_IHGP_CONSTRAINTS) != 0;
+  const bool mix = mixture_rule(p);
+  const bool cv = (o.flags & NAGP_FLAG_IHGP_CONSTRAINTS) != 0 || mix;   // the mixture variant also starts from R = 0 (:248)
   // R = exp(lik) .* ones (ihgp_ep_modulator_nmf.m:209) or zeros (constraints variant :243); problem-wise value
   for (int q = 0; q < B; ++q) {
     double sn2 = 0.0;
@@ -799,10 +822,11 @@ static int exec_ihgp(nagp_plan* p) {
     if (itt > 1) RUN(affine(0, sh.T - 1, itt));
     IhgpPar ip{itt, p->damping[itt - 1], itt == 1 ? 1 : 0, (itt == 1) ? (int64_t)0 : (int64_t)(sh.T - 1)};
     ip.hph_lds = p->hph_lds;
+    ip.w_old = 1.0 - ip.ep_damp; ip.w_new = mix ? ip.ep_damp / o.ep_fraction : ip.ep_damp; ip.mom_alpha = mix ? o.ep_fraction : 1.0;
     {
       Timed t(p, itt == 1 ? NAGP_K_FILTER : NAGP_K_FILTER_LIN);
 #define LI(V) hipLaunchKernelGGL(ihgp_filter_kernel<V>, dim3(B), dim3(p->NT_ih), p->lds_ih, p->stream, sh, p->b, mcf, p->tb, ip)
-      NAGP_MV_SWITCH(mom_variant(mcf), LI)
+      NAGP_MV_SWITCH9(mom_variant(mcf), LI)
 #undef LI
     }
     HIP_TRY(hipGetLastError());
@@ -905,7 +929,7 @@ extern "C" int nagp_plan_download(nagp_plan* p, nagp_out* outs) {
       // Varft = repmat(diag(H*P*H')) with the blocks last looked up (k = 0); abs() unless constraints variant
       std::vector<double> v0(M, 0.0);
       if (T > 1) { HIP_TRY(hipMemcpy(v0.data(), p->b.sv + oM, M * sizeof(double), hipMemcpyDeviceToHost)); }
-      const bool cv = (p->opts.flags & NAGP_FLAG_IHGP_CONSTRAINTS) != 0;
+      const bool cv = (p->opts.flags & (NAGP_FLAG_IHGP_CONSTRAINTS | NAGP_FLAG_MIXTURE_RULE)) != 0;   // neither takes abs(Varft)
       for (int64_t k = 0; k < T; ++k)
         for (int n = 0; n < M; ++n) o.Varft[(size_t)k * M + n] = cv ? v0[n] : std::fabs(v0[n]);
     }
@@ -1044,7 +1068,7 @@ extern "C" int nagp_mom_eval(const nagp_opts* o, int32_t D, int32_t N, const dou
             dev + o_lZ, dev + o_dl, dev + o_d2, n};
   const int grid = (int)std::min<int64_t>(n, 1024);
 #define LM(V) do { if (st == NAGP_OK) st = set_lds(mom_kernel<V>, lds); if (st == NAGP_OK) hipLaunchKernelGGL(mom_kernel<V>, dim3(grid), dim3(256), lds, 0, mc, mp); } while (0)
-  NAGP_MV_SWITCH(mom_variant(mc), LM)
+  NAGP_MV_SWITCH9(mom_variant(mc), LM)
 #undef LM
   ME_HIP(hipGetLastError());
   ME_HIP(hipDeviceSynchronize());

@@ -840,7 +840,7 @@ __device__ __forceinline__ void mom_power(const MomCfg& c, double sn2, double al
 __device__ inline double mom_pEP(const MomCfg& c, double sn2, double alpha) {
   return (c.lik_kind == 2) ? pow(2.0 * 3.14159265358979323846 * sn2, 0.5 * (1.0 - alpha)) / sqrt(alpha) : 1.0;
 }
-// MV: the cubature dimension the calling kernel was instantiated for (0 = POWER, 1..8 = N of the NMF likelihoods)
+// MV: the cubature dimension the calling kernel was instantiated for (0 = POWER, 1..9 = N of the NMF likelihoods)
 // LOGZ = false: *lZ receives Z itself (the sequential filters take the logarithm off the critical path)
 template <int MV, bool LOGZ = true>
 __device__ __forceinline__ void mom_eval(const MomCfg& c, const double* Wl, double pEP, double sn2, double alpha,
@@ -861,7 +861,8 @@ __device__ __forceinline__ void mom_eval(const MomCfg& c, const double* Wl, doub
 #endif
   }
 }
-constexpr int MOM_MAXCD = 8;
+constexpr int MOM_MAXCD = 9;      // IHGP filter, site refresh, mom on its own
+constexpr int MOM_MAXCD_GF = 8;   // kernels with register-resident covariance tiles
 __host__ __device__ inline int mom_variant(const MomCfg& c) { return c.lik_kind == 0 ? 0 : c.cdim; }
 
 }  // namespace nagp

@@ -65,6 +65,7 @@ struct IhgpPar {
   int64_t k_start;   // first step to process (sweeps >= 2 run only k = T-1 here; the rest is ihgp_aff_*)
   double R_init;     // exp(lik) (or 0 for the constraints variant): initial content of R(:,k)
   int hph_lds;       // filter: keep the H PP H' look-up table [M][NG] in LDS
+  double w_old, w_new, mom_alpha;   // as FilterPar: (1-d, d, 1) ihgp_ep_modulator_nmf.m:210-211 ; (1-d, d/alpha, alpha) experiments/ihgp_ep_mods_nmf_mixture.m:291-297
 };
 
 constexpr int IH_KB = 16;   // steps per I/O block of the filter (LDS ring)
@@ -149,7 +150,7 @@ __global__ void __launch_bounds__(256) ihgp_filter_kernel(Shape sh, Bufs b, MomC
     for (int i = tid; i < M * NG; i += NT) thph[i] = tab[itab_hph(sh, NG) + i];
   const double sn2 = mdl[mdl_sn2(sh)];
   mom_cache_tables(mc, ws);
-  const double pEP1 = mom_pEP(mc, sn2, 1.0);
+  const double pEP1 = mom_pEP(mc, sn2, ip.mom_alpha);
   __syncthreads();
 
   // thread n < M owns block n
@@ -226,12 +227,12 @@ __global__ void __launch_bounds__(256) ihgp_filter_kernel(Shape sh, Bufs b, MomC
       if (do_mom) {
         lds_barrier();
         if (mc.stamps && tid == 0) { st_b = __builtin_readcyclecounter(); st[4] += st_b - st_a; }
-        mom_eval<MV, false>(mc, sW, pEP1, sn2, 1.0, yk, fmu, HPH, ws, &misc[0], dl, d2l, st);
+        mom_eval<MV, false>(mc, sW, pEP1, sn2, ip.mom_alpha, yk, fmu, HPH, ws, &misc[0], dl, d2l, st);
         if (act) {
           const double d1 = dl[n], d2 = d2l[n];
           const double t_old = rtt[kk * M + n], n_old = rtn[kk * M + n];
-          tnew = (1.0 - ip.ep_damp) * t_old + ip.ep_damp * (-d2 / (1.0 + d2 * hph));
-          nnew = (1.0 - ip.ep_damp) * n_old + ip.ep_damp * ((d1 - fmun * d2) / (1.0 + d2 * hph));
+          tnew = ip.w_old * t_old + ip.w_new * (-d2 / (1.0 + d2 * hph));
+          nnew = ip.w_old * n_old + ip.w_new * ((d1 - fmun * d2) / (1.0 + d2 * hph));
           Rn = 1.0 / tnew;                      // before the clamp (:269)
         }
         if (tid == 0) rZ[kk] = misc[0];

@@ -69,6 +69,10 @@ struct FilterPar {
   int kb;               // steps per I/O block (LDS ring)
   int64_t k_begin, k_end;  // steps processed by this launch; k_begin > 0 continues from (MF, PF) of step k_begin-1
   int spl_wave;            // EKF: the last wave of the workgroup owns no tiles and evaluates the softplus link
+  // ADF site refresh  site <- w_old*site + w_new*(moment-matched site), mom evaluated at power mom_alpha:
+  //   (1-d, d, 1) in gf_ep_modulator_nmf.m:147-148 ; (1-d, d/alpha, alpha) in experiments/gf_ep_mods_nmf_mixture.m:183-187
+  double w_old, w_new, mom_alpha;
+  int R_raw;               // mixture variant: R = 1/ttau before the clamp (gf_ep_mods_nmf_mixture.m:190,195)
 };
 
 // The filtered covariance is symmetric: PF holds only the lower-triangular tiles, tile (I,J), I >= J, at
@@ -175,7 +179,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
   for (int i = tid; i < sh.D * sh.N; i += NT) sW[i] = mdl[mdl_W(sh) + i];
   const double sn2 = mdl[mdl_sn2(sh)];
   if (MEAS == 0 && MV >= 0) mom_cache_tables(mc, ws);
-  const double pEP1 = (MEAS == 0 && MV >= 0) ? mom_pEP(mc, sn2, 1.0) : 1.0;
+  const double pEP1 = (MEAS == 0 && MV >= 0) ? mom_pEP(mc, sn2, fp.mom_alpha) : 1.0;
 
   // The covariance is kept exactly symmetric: only the lower-triangular tiles (I >= J) are held (one thread
   // per tile); K*H*P and K*W' coincide, W = P H' is the only panel needed, and the filtered covariance is
@@ -341,18 +345,19 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
         if (MEAS == 0) {
           if constexpr (MV >= 0) if (do_mom) {
             if (mc.stamps && tid == 0) { st_b = __builtin_readcyclecounter(); stp[4] += st_b - st_a; }
-            mom_eval<MV, false>(mc, sW, pEP1, sn2, 1.0, yk, fmu, HPH, ws, &misc[0], dl, d2l, stp);
+            mom_eval<MV, false>(mc, sW, pEP1, sn2, fp.mom_alpha, yk, fmu, HPH, ws, &misc[0], dl, d2l, stp);
             if (mc.stamps && tid == 0) st_a = __builtin_readcyclecounter();
             if (tid < M) {
               const double d2 = d2l[tid], d1 = dl[tid], hp = HPH[tid], f = fmu[tid];
               const double t_old = rtt[kk * M + tid], n_old = rtn[kk * M + tid];
-              double tnew = (1.0 - fp.ep_damp) * t_old + fp.ep_damp * (-d2 / (1.0 + d2 * hp));
-              const double nnew = (1.0 - fp.ep_damp) * n_old + fp.ep_damp * ((d1 - f * d2) / (1.0 + d2 * hp));
+              double tnew = fp.w_old * t_old + fp.w_new * (-d2 / (1.0 + d2 * hp));
+              const double nnew = fp.w_old * n_old + fp.w_new * ((d1 - f * d2) / (1.0 + d2 * hp));
               if (!(tnew > 0.0)) ++n_clamped;
+              const double traw = tnew;
               tnew = max0(tnew);
               tt[tid] = tnew; tn[tid] = nnew;
               rtt[kk * M + tid] = tnew; rtn[kk * M + tid] = nnew;
-              if (fp.write_R) rR[kk * M + tid] = 1.0 / tnew;
+              if (fp.write_R) rR[kk * M + tid] = 1.0 / (fp.R_raw ? traw : tnew);
             }
             if (tid == 0) rZ[kk] = misc[0];
           }
@@ -1220,10 +1225,10 @@ struct EpPar {
   int64_t k_end;       // steps 0 .. k_end-1 are refreshed (T-1)
   int steps_per_wg;
   double alpha;
-  double ep_damp;
+  double w_old, w_new; // site <- w_old*site + w_new*(...): (1-d*alpha, d) gf_ep_modulator_nmf.m:259-262 ; (1-d, d/alpha) gf_ep_mods_nmf_mixture.m:280-281
   int clamp;           // gf predict mode: ttau = max(ttau,0) after the update, R = 1/ttau for all sites
   int write_R;         // 0: none (nlml), 1: all sites (gf predict), 2: updated sites only (ihgp)
-  double* lZ_out;      // [B][T] where the per-step log Z goes (gf: b.lZ ; ihgp: separate array)
+  double* lZ_out;      // [B][T] where the per-step log Z goes (gf: b.lZ ; ihgp: separate array ; null: dropped, gf_ep_mods_nmf_mixture.m:277)
   int const_var;       // ihgp: marginal variance is read from sv[k] as usual (kept for clarity)
 };
 
@@ -1273,14 +1278,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) e
       double tnew = t_old, nnew = n_old;
       if (upd) {
         const double d1 = dl[tid], d2 = d2l[tid];
-        tnew = (1.0 - ep.ep_damp * ep.alpha) * t_old + ep.ep_damp * (-d2 / (1.0 + d2 * vcav));
-        nnew = (1.0 - ep.ep_damp * ep.alpha) * n_old + ep.ep_damp * ((d1 - mcav * d2) / (1.0 + d2 * vcav));
+        tnew = ep.w_old * t_old + ep.w_new * (-d2 / (1.0 + d2 * vcav));
+        nnew = ep.w_old * n_old + ep.w_new * ((d1 - mcav * d2) / (1.0 + d2 * vcav));
       }
       if (ep.clamp) { if (!(tnew > 0.0)) ++n_clamped; tnew = max0(tnew); }
       b.ttau[ix] = tnew; b.tnu[ix] = nnew;
       if (ep.write_R == 1 || (ep.write_R == 2 && upd)) b.R[ix] = 1.0 / tnew;
     }
-    if (tid == 0) ep.lZ_out[(size_t)pb * T + k] = misc[0];
+    if (tid == 0 && ep.lZ_out) ep.lZ_out[(size_t)pb * T + k] = misc[0];
     lds_barrier();
   }
   if (tid < M && n_clamped) atomicAdd(&b.counters[(size_t)pb * 4 + 1], n_clamped);

@@ -5,7 +5,8 @@
 from ._lib import build, lib, NagpError, LIB_PATH  # noqa: F401
 from .api import (Mom, SSHandle, gf_ep_modulator, gf_ep_modulator_nmf, gf_ep_modulator_nmf_constraints,  # noqa: F401
                   ihgp_ep_modulator_nmf, ihgp_ep_modulator_nmf_constraints, gf_giekf_modulator_nmf,
-                  gf_giekf_modulator_nmf_constraints, MeasModel, ekf_update1, iekf_update1)
+                  gf_giekf_modulator_nmf_constraints, MeasModel, ekf_update1, iekf_update1,
+                  gf_ep_mods_nmf_mixture, ihgp_ep_mods_nmf_mixture)
 from .ss import ss_modulators, ss_modulators_nmf, lti_disc, sigmoid, inv_sigmoid  # noqa: F401
 from .cubature import utp_ws, gauher, mvhermgauss_unit  # noqa: F401
 from .plan import Plan  # noqa: F401

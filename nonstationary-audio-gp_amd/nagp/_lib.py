@@ -20,7 +20,7 @@ KIND_GF_EP, KIND_IHGP, KIND_GIEKF = 0, 1, 2
 MODE_PREDICT, MODE_NLML = 0, 1
 LIK_POWER, LIK_POWER_NMF, LIK_POWER_NMF_SQRT = 0, 1, 2
 LINK_SOFTPLUS, LINK_EXP = 0, 1
-FLAG_IHGP_CONSTRAINTS, FLAG_EKF_RESET_P, FLAG_WANT_PS = 0x1, 0x2, 0x4
+FLAG_IHGP_CONSTRAINTS, FLAG_EKF_RESET_P, FLAG_WANT_PS, FLAG_MIXTURE_RULE = 0x1, 0x2, 0x4, 0x8
 N_KERNELS = 8
 KERNEL_NAMES = ['filter', 'gain', 'scan', 'epsite', 'reduce', 'filter_lin', 'output', 'other']
 

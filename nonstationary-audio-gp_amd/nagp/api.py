@@ -258,13 +258,13 @@ def _unpack_constraints(w, w_fixed, tune_hypers, constraints, num_lik_params, D,
 
 
 def _run_gf(blk, Wnmf, lik_param, yall, return_ind, mom, ep_fraction, ep_damping, ep_itts, predict, nargout,
-            predict_at_k1=0, device=0):
+            predict_at_k1=0, device=0, flags=0):
     prob = _Problem(blk, Wnmf, lik_param)
     dim = blk.D if mom.kind == L.LIK_POWER else blk.N
     damp = _damping(ep_damping, ep_itts)
     want_PS = predict and nargout >= 6
     opts, keep = make_opts(L.KIND_GF_EP, L.MODE_PREDICT if predict else L.MODE_NLML, mom, dim, ep_fraction, damp,
-                           ep_itts, predict_at_k1=predict_at_k1, flags=L.FLAG_WANT_PS if want_PS else 0, device=device)
+                           ep_itts, predict_at_k1=predict_at_k1, flags=flags | (L.FLAG_WANT_PS if want_PS else 0), device=device)
     out = _Outputs(blk.M, blk.S, yall.size, ep_itts, want_PS=want_PS)
     L.check(L.lib().nagp_ep_run(C.byref(prob.model), L.dptr(yall), yall.size, C.byref(opts), C.byref(out.c)))
     return out
@@ -313,7 +313,7 @@ def gf_ep_modulator(w, x, y, ss, mom, xt=None, kernel1='matern32', kernel2='mate
     return float(out.nlZ[0]), np.zeros(np.size(w))
 
 
-def _run_ihgp(blk, Wnmf, lik_param, yall, mom, ep_fraction, ep_damping, ep_itts, constraints_variant, device=0):
+def _run_ihgp(blk, Wnmf, lik_param, yall, mom, ep_fraction, ep_damping, ep_itts, constraints_variant, device=0, flags=0):
     prob = _Problem(blk, Wnmf, lik_param, symmetrize_Q=True)                    # :97  Q=(Q+Q')/2
     r, PP, ppo, PG, pgo = ihgp_tables.build_tables(prob.A, prob.Q, blk.offsets, blk.h_val)
     r = L.f64(r, 'C'); PP = L.f64(PP, 'C'); PG = L.f64(PG, 'C')
@@ -321,7 +321,7 @@ def _run_ihgp(blk, Wnmf, lik_param, yall, mom, ep_fraction, ep_damping, ep_itts,
                         PGlist=L.dptr(PG), pg_offsets=pgo.ctypes.data_as(L.c_lp))
     damp = _damping(ep_damping, ep_itts)
     opts, keep = make_opts(L.KIND_IHGP, L.MODE_PREDICT, mom, blk.N, ep_fraction, damp, ep_itts,
-                           flags=L.FLAG_IHGP_CONSTRAINTS if constraints_variant else 0, device=device)
+                           flags=flags | (L.FLAG_IHGP_CONSTRAINTS if constraints_variant else 0), device=device)
     out = _Outputs(blk.M, blk.S, yall.size, ep_itts)
     L.check(L.lib().nagp_ihgp_run(C.byref(prob.model), C.byref(tabs), L.dptr(yall), yall.size, C.byref(opts), C.byref(out.c)))
     return out
@@ -348,6 +348,63 @@ def ihgp_ep_modulator_nmf_constraints(w, x, y, ss, mom, xt, kernel1, kernel2, nu
     lik_param, p1, p2, Wnmf = _unpack_constraints(w, w_fixed, tune_hypers, constraints, num_lik_params, D, N)
     blk = ssm.balance_blocks(_blocks_from_dense(*ss(x, p1, p2, kernel1, kernel2), D, N))
     out = _run_ihgp(blk, Wnmf, lik_param, yall, mom, ep_fraction, ep_damping, ep_itts, True, device)
+    return _returns(out, return_ind, nargout)
+
+
+def _stack_sources(ss, x, w, kernel1, kernel2, J):
+    """experiments/gf_ep_mods_nmf_mixture.m:89-128: J models side by side, all sub-band blocks first, then all
+    modulator blocks; Wnmf block diagonal.  w = {log sn2, {param1_j}, {param2_j}, {W_j}} in natural units."""
+    import scipy.linalg as sla
+    zs = [[], [], [], []]; gs = [[], [], [], []]; Ws = []
+    D = N = 0
+    for j in range(J):
+        p1 = np.asarray(w[1][j], float).ravel(); p2 = np.asarray(w[2][j], float).ravel()
+        D_ = p1.size // 3; N_ = p2.size // 2
+        D += D_; N += N_
+        Ws.append(np.atleast_2d(np.asarray(w[3][j], float)))
+        F, L_, Qc, H, Pinf = (np.asarray(a, float) for a in ss(x, p1, p2, kernel1[j], kernel2[j]))
+        LQL = L_ @ np.atleast_2d(Qc) @ L_.T
+        nz = D_ * 2 * ssm.KERNEL_ORDER[kernel1[j]]
+        for lst, a in zip(zs, (F[:nz, :nz], LQL[:nz, :nz], H[:D_, :nz], Pinf[:nz, :nz])):
+            lst.append(a)
+        for lst, a in zip(gs, (F[nz:, nz:], LQL[nz:, nz:], H[D_:, nz:], Pinf[nz:, nz:])):
+            lst.append(a)
+    F, LQL, H, Pinf = (sla.block_diag(*(z + g)) for z, g in zip(zs, gs))
+    blk = _blocks_from_dense(F, np.eye(F.shape[0]), LQL, H, Pinf, D, N)
+    return blk, sla.block_diag(*Ws), np.atleast_1d(np.asarray(w[0], float))
+
+
+def _mixture_mom(mom):
+    if mom.kind == L.LIK_POWER:
+        raise ValueError('the mixture variants take the NMF likelihoods only')
+    return mom
+
+
+def gf_ep_mods_nmf_mixture(w, x, y, ss, mom, xt, kernel1, kernel2, J, ep_fraction=0.5, ep_damping=0.1, ep_itts=30,
+                           nargout=2, device=0):
+    """matlab/experiments/gf_ep_mods_nmf_mixture.m:1 -- source separation: J stacked GT-NMF models, the older
+    Power-EP rule (mom at power ep_fraction in the filter too, d/ep_fraction scaling, clamp in the filter pass,
+    NAGP_FLAG_MIXTURE_RULE).  `mom` is the usual Mom object; its ep_frac argument is bound to ep_fraction as the
+    6-argument closure of these files does.  Scalar ep_damping."""
+    if xt is None or np.size(xt) == 0:
+        raise RuntimeError('this mixture script is not for training')            # :376
+    yall, return_ind = _merge_inputs(x, y, xt)
+    blk, Wnmf, lik_param = _stack_sources(ss, x, w, kernel1, kernel2, J)
+    out = _run_gf(blk, Wnmf, lik_param, yall, return_ind, _mixture_mom(mom), ep_fraction, float(np.ravel(ep_damping)[0]), ep_itts,
+                  True, nargout, device=device, flags=L.FLAG_MIXTURE_RULE)
+    return _returns(out, return_ind, nargout)
+
+
+def ihgp_ep_mods_nmf_mixture(w, x, y, ss, mom, xt, kernel1, kernel2, J, ep_fraction=0.5, ep_damping=0.1, ep_itts=30,
+                             nargout=2, device=0):
+    """matlab/experiments/ihgp_ep_mods_nmf_mixture.m:1 (the inference of source_sep_piano.m:137-141): as above on
+    the infinite-horizon filter/smoother; no balancing, R starts at 0, no abs(Varft)."""
+    if xt is None or np.size(xt) == 0:
+        raise RuntimeError('this mixture script is not for training')            # :547
+    yall, return_ind = _merge_inputs(x, y, xt)
+    blk, Wnmf, lik_param = _stack_sources(ss, x, w, kernel1, kernel2, J)
+    out = _run_ihgp(blk, Wnmf, lik_param, yall, _mixture_mom(mom), ep_fraction, float(np.ravel(ep_damping)[0]), ep_itts, False,
+                    device, flags=L.FLAG_MIXTURE_RULE)
     return _returns(out, return_ind, nargout)
 
 

@@ -70,6 +70,21 @@ def nmf_problem(D, N, T, seed, recipe='demo_nmf', w_lik=1e-4, kernel1='matern32'
                 param1=np.concatenate([vf, lf, om]), param2=np.concatenate([vs, ls]), w_lik=w_lik)
 
 
+def mixture_problem(shapes, T, seed, kernel1, kernel2, w_lik=1e-4):
+    """J sources of shapes [(D_j, N_j)]: the cell w = {log sn2, {param1_j}, {param2_j}, {W_j}} of
+    experiments/source_sep_piano.m:128 (natural units inside the cells) and the sum of one prior sample per source,
+    normalised to unit variance."""
+    p1s, p2s, Ws = [], [], []
+    y = np.zeros(T)
+    for j, (D_, N_) in enumerate(shapes):
+        vf, lf, om, vs, ls, W = nmf_params(D_, N_, seed + 31 * j)
+        p1s.append(np.concatenate([vf, lf, om])); p2s.append(np.concatenate([vs, ls])); Ws.append(W)
+        blk = ssm.ss_blocks_nmf(p1s[-1], p2s[-1], kernel1[j], kernel2[j])
+        y = y + sample_prior(blk, W, T, np.random.default_rng(seed + 7919 + j))
+    y = y / np.sqrt(np.var(y))
+    return dict(w=[np.array([math.log(w_lik)]), p1s, p2s, Ws], y=y, J=len(shapes), kernel1=list(kernel1), kernel2=list(kernel2))
+
+
 CONSTRAINTS_DEMO = lambda D: np.array([[0.01, 0.1], [20.0, 500.0], [0.0, 2 * math.pi], [2.0, 5.0], [200.0, 2000.0], [0.0, 2.0 / D]])
 TUNE_DEMO = [0, 0, 1, 0, 1, 1, 0]
 

@@ -12,7 +12,7 @@ import pytest
 import nagp
 from nagp import harness, Mom, SSHandle, Plan, _lib as L
 from nagp import ss as pss
-from oracle import gf_ep as ogf, ihgp as oih, giekf as oek, lik as olik, fastfb as offb
+from oracle import gf_ep as ogf, ihgp as oih, giekf as oek, lik as olik, fastfb as offb, mixture as omx
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), 'golden')
@@ -158,7 +158,8 @@ def test_every_cubature_code_path_against_oracle(D, N, p, lik):
 
 
 @pytest.mark.parametrize('D,N,p,kind', [(5, 6, 7, 'nmf'), (5, 7, 7, 'nmf'), (4, 8, 7, 'nmf'), (5, 3, 9, 'nmf'), (7, 2, 5, 'sqrt'),
-                                        (5, 7, 7, 'sqrt'), (4, 0, 5, 'power'), (3, 0, 9, 'power')])
+                                        (5, 7, 7, 'sqrt'), (4, 0, 5, 'power'), (3, 0, 9, 'power'),
+                                        (6, 9, 7, 'nmf'), (6, 9, 7, 'sqrt')])      # N = 9: three sources x three components
 def test_mom_callback_itself_against_oracle(D, N, p, kind):
     """The `mom` handle called with the reference's own arity on arbitrary (mu, s2, y): likModulatorPower,
     likModulatorNMFPower, likModulatorPreCalcwn (C ABI: nagp_mom_eval), 48 inputs per launch including tiny variances,
@@ -438,3 +439,56 @@ def test_unsupported_shapes_are_refused_not_emulated():
     t = np.arange(1, T + 1.0)
     with pytest.raises(nagp.NagpError, match='unsupported'):
         nagp.gf_ep_modulator_nmf(pr['w'], t, pr['y'], SSHandle(), Mom('likModulatorNMFPower', p_cubature=5), t, 'matern52', 'matern52', 1, D, N, 0.5, [0.5], 1)
+
+
+def _mixture_moms(lik, p, N):
+    if lik == 'likModulatorPreCalcwn':
+        from nagp import cubature
+        wn, xn = cubature.utp_ws(p, N)
+        return Mom(lik, link_shift=1.0, wn=wn, xn_unscaled=xn), olik.Mom(olik.LIK_POWER_NMF_SQRT, link=olik.softplus_link(1.0), wn=wn, xn_unscaled=xn)
+    return Mom(lik, p_cubature=p), olik.Mom(olik.LIK_POWER_NMF, p=p)
+
+
+@pytest.mark.parametrize('shapes,k1,k2,lik,p', [
+    ([(3, 1), (2, 2)], ['exp', 'matern32'], ['matern52', 'matern52'], 'likModulatorNMFPower', 7),
+    ([(4, 2), (4, 2), (3, 1)], ['exp', 'exp', 'exp'], ['matern52', 'matern32', 'matern52'], 'likModulatorPreCalcwn', 7),
+])
+def test_source_separation_mixtures_against_oracle(shapes, k1, k2, lik, p):
+    """experiments/gf_ep_mods_nmf_mixture.m and ihgp_ep_mods_nmf_mixture.m (row f-1): J stacked models with their own
+    kernels, block-diagonal Wnmf, the older EP rule (mom at power ep_fraction in the filter too, d/ep_fraction
+    scaling, clamp in the filter pass, R before the clamp); ep_fraction = 0.75 as in source_sep_piano.m:86."""
+    T = 36; t = np.arange(1, T + 1.0); J = len(shapes); N = sum(n for _, n in shapes)
+    mp = harness.mixture_problem(shapes, T, 21, k1, k2)
+    y = mp['y'].copy(); y[10:13] = np.nan
+    mom, omom = _mixture_moms(lik, p, N)
+    a = nagp.gf_ep_mods_nmf_mixture(mp['w'], t, y, SSHandle(), mom, t, k1, k2, J, 0.75, 0.2, 3, nargout=6)
+    b = omx.gf_ep_mods_nmf_mixture(mp['w'], t, y, None, omom, t, k1, k2, J, 0.75, 0.2, 3)
+    assert rel(a[0], b[0]) < TOL_MEAN and rel(a[1], b[1]) < TOL_MEAN
+    assert rel(a[5]['ttau'], b[5]['ttau']) < TOL_SITE and rel(a[5]['tnu'], b[5]['tnu']) < TOL_SITE
+    assert rel(a[5]['lZ'], b[5]['lZ']) < 1e-7 and rel(a[5]['MS'], b[5]['MS']) < TOL_MEAN
+    fin = np.isfinite(b[5]['R'])
+    assert np.array_equal(fin, np.isfinite(a[5]['R'])) and rel(a[5]['R'][fin], b[5]['R'][fin]) < 1e-6
+    assert np.all(a[5]['ttau'] >= 0)                                         # sites clamped by the last filter pass (:195)
+    c = nagp.ihgp_ep_mods_nmf_mixture(mp['w'], t, y, SSHandle(), mom, t, k1, k2, J, 0.75, 0.2, 3, nargout=6)
+    d = omx.ihgp_ep_mods_nmf_mixture(mp['w'], t, y, None, omom, t, k1, k2, J, 0.75, 0.2, 3)
+    assert rel(c[0], d[0]) < TOL_MEAN and rel(c[1], d[1]) < TOL_MEAN
+    assert rel(c[5]['ttau'], d[5]['ttau']) < TOL_SITE and rel(c[5]['tnu'], d[5]['tnu']) < TOL_SITE
+    with pytest.raises(RuntimeError):
+        nagp.gf_ep_mods_nmf_mixture(mp['w'], t, y, SSHandle(), mom, None, k1, k2, J, 0.75, 0.2, 3)
+
+
+def test_three_sources_with_nine_modulators_ihgp_mixture():
+    """The shape family of source_sep_piano.m:78-90 (three sources x three NMF components, exp sub-band kernels,
+    likModulatorPreCalcwn with the shifted softplus): cubature dimension 9 exists for the kernels without covariance
+    tiles (IHGP filter, site refresh, mom); the full-covariance path refuses it."""
+    shapes = [(4, 3)] * 3; k1 = ['exp'] * 3; k2 = ['matern52'] * 3
+    T = 28; t = np.arange(1, T + 1.0)
+    mp = harness.mixture_problem(shapes, T, 5, k1, k2)
+    mom, omom = _mixture_moms('likModulatorPreCalcwn', 7, 9)
+    c = nagp.ihgp_ep_mods_nmf_mixture(mp['w'], t, mp['y'], SSHandle(), mom, t, k1, k2, 3, 0.75, 0.2, 3, nargout=6)
+    d = omx.ihgp_ep_mods_nmf_mixture(mp['w'], t, mp['y'], None, omom, t, k1, k2, 3, 0.75, 0.2, 3)
+    assert c[0].shape == (21, T)
+    assert rel(c[0], d[0]) < TOL_MEAN and rel(c[1], d[1]) < TOL_MEAN
+    assert rel(c[5]['ttau'], d[5]['ttau']) < TOL_SITE and rel(c[5]['tnu'], d[5]['tnu']) < TOL_SITE
+    with pytest.raises(nagp.NagpError):
+        nagp.gf_ep_mods_nmf_mixture(mp['w'], t, mp['y'], SSHandle(), mom, t, k1, k2, 3, 0.75, 0.2, 3)

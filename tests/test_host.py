@@ -11,8 +11,8 @@ import pytest
 
 import nagp
 from nagp import cubature as pc, harness, ihgp_tables, ss as pss
-from nagp.api import _blocks_from_dense, _merge_inputs, _unpack_constraints, _unpack_log, Mom, SSHandle
-from oracle import cubature as oc, ss as oss, ihgp as oih, gf_ep as ogf
+from nagp.api import _blocks_from_dense, _merge_inputs, _stack_sources, _unpack_constraints, _unpack_log, Mom, SSHandle
+from oracle import cubature as oc, ss as oss, ihgp as oih, gf_ep as ogf, mixture as omx
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -76,6 +76,20 @@ def test_unpacking_and_input_merge():
     ya, ra = _merge_inputs(x, y, xt); yo, ro = ogf.merge_inputs(x, y, xt)
     assert np.array_equal(ya, yo, equal_nan=True) and np.array_equal(ra, ro)
     assert np.array_equal(ya, [10, 20, 30, np.nan], equal_nan=True) and list(ra) == [1, 3, 0]
+
+
+def test_stacked_source_models_equal_the_oracle_stacking():
+    """experiments/gf_ep_mods_nmf_mixture.m:89-128: per-source kernels, sub-band blocks first, block-diagonal Wnmf."""
+    mp = harness.mixture_problem([(2, 1), (3, 2), (1, 1)], 8, 11, ['exp', 'matern32', 'exp'], ['matern52', 'matern32', 'matern52'])
+    blk, W, lik = _stack_sources(SSHandle(), None, mp['w'], mp['kernel1'], mp['kernel2'], 3)
+    st = omx.stack_models(mp['w'], mp['kernel1'], mp['kernel2'], 3)
+    F, LQL, H, Pinf = blk.dense()
+    assert (blk.D, blk.N, blk.M) == (6, 4, 10) and np.array_equal(W, st['Wnmf']) and lik[0] == st['lik_param'][0]
+    assert np.allclose(F, st['F'], rtol=1e-14, atol=0) and np.allclose(Pinf, st['Pinf'], rtol=1e-14, atol=0)
+    assert np.allclose(LQL, st['L'] @ st['Qc'] @ st['L'].T, rtol=1e-14, atol=0) and np.array_equal(H, st['H'])
+    A, Q, _ = pss.discretise(blk)
+    Ao, Qo = oss.lti_disc(st['F'], st['L'], st['Qc'], 1.0)
+    assert np.allclose(A, Ao, rtol=1e-11, atol=1e-13) and np.allclose(Q, Qo, rtol=1e-9, atol=1e-13)
 
 
 def test_ihgp_tables_match_oracle_tables():

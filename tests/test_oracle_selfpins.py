@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from oracle import cubature as oc, ss as oss, lik as olik, gf_ep as ogf, ihgp as oih, giekf as oek
+from oracle import cubature as oc, ss as oss, lik as olik, gf_ep as ogf, ihgp as oih, giekf as oek, mixture as omx
 
 GOLD = os.path.join(os.path.dirname(__file__), 'golden')
 
@@ -233,3 +233,30 @@ def test_fastfb_steady_state_filter_equals_the_full_kalman_filter_after_burn_in(
         m = m + Kk * (y[k] - float((H @ m)[0])); P = P - np.outer(Kk, Kk) * Sx
         MF[:, k] = m
     assert np.max(np.abs(MF - MS)) < 1e-9 * np.max(np.abs(MS)) and np.max(np.abs(P - PF2)) < 1e-9 * np.max(np.abs(PF2))
+
+
+def test_mixture_variants_reduce_to_the_main_functions_for_one_source_and_full_power():
+    """experiments/{gf,ihgp}_ep_mods_nmf_mixture.m with J = 1 and ep_fraction = 1: d/alpha = d, 1 - d*alpha = 1 - d and
+    mom runs at power 1 in the filter either way, so the older EP rule and the current one coincide (the clamp only
+    moves from the smoother's refresh to the next filter pass, and the single-branch Kalman update is the split one
+    in exact arithmetic).  Two sources with different kernels: the stacked model has every sub-band block in front."""
+    from nagp import harness                      # synthetic signals only; no GPU involved
+    T = 30; t = np.arange(1, T + 1.0)
+    mom = olik.Mom(olik.LIK_POWER_NMF, p=5)
+    pr = harness.nmf_problem(3, 2, T, 5, kernel1='matern32')
+    w = [np.array([math.log(pr['w_lik'])]), [pr['param1']], [pr['param2']], [pr['W']]]
+    a = omx.gf_ep_mods_nmf_mixture(w, t, pr['y'], None, mom, t, ['matern32'], ['matern52'], 1, 1.0, 0.4, 3)
+    b = ogf.gf_ep_modulator_nmf(pr['w'], t, pr['y'], None, mom, t, 'matern32', 'matern52', 1, 3, 2, 1.0, [0.4] * 3, 3)
+    assert np.allclose(a[0], b[0], rtol=1e-8, atol=1e-10) and np.allclose(a[1], b[1], rtol=1e-8, atol=1e-12)
+    assert np.allclose(a[5]['ttau'], b[5]['ttau'], rtol=1e-7, atol=1e-10)
+    model = ogf.assemble(w[0], pr['param1'], pr['param2'], pr['W'], 'matern32', 'matern52', balance=False, symmetrize_Q=True)
+    c = omx.ihgp_ep_mods_nmf_mixture(w, t, pr['y'], None, mom, t, ['matern32'], ['matern52'], 1, 1.0, 0.4, 3)
+    d = oih.run_predict(model, pr['y'], mom, 1.0, [0.4] * 3, 3, constraints_variant=True)
+    assert np.allclose(c[0], d['Eft'], rtol=1e-9, atol=1e-12) and np.allclose(c[1], d['Varft'], rtol=1e-9, atol=1e-14)
+    assert np.allclose(c[5]['ttau'], d['ttau'], rtol=1e-9, atol=1e-12)
+    # stacking order: sub-band blocks of all sources, then all modulator blocks; Wnmf block diagonal
+    mp = harness.mixture_problem([(2, 1), (3, 2)], 8, 3, ['exp', 'matern32'], ['matern52', 'matern32'])
+    st = omx.stack_models(mp['w'], mp['kernel1'], mp['kernel2'], 2)
+    assert st['H'].shape == (8, 2 * 2 + 3 * 4 + 3 + 2 * 2) and st['Wnmf'].shape == (5, 3)
+    assert np.all(st['Wnmf'][:2, 1:] == 0) and np.all(st['Wnmf'][2:, :1] == 0)
+    assert list(np.nonzero(st['H'].sum(axis=0))[0]) == [0, 2, 4, 8, 12, 16, 19, 21]

@@ -7,6 +7,7 @@
 #include "nagp_mfma.hpp"
 #include "../../include/nagp.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -55,6 +56,8 @@ struct nagp_plan {
   int hph_lds = 0, sta_f = 0, sta_ep = 0, DG_f = 1, DG_ep = 1, cache_f = 0, cache_ep = 0, kb_f = 16;
   bool want_PS = false;
   bool need_PF = false;
+  MomSrc src_all{};     // block structure of Wnmf (n_src >= 2) and which kernels use it
+  int src_f = 0, src_ep = 0, kb_ih = 16;
   hipStream_t stream = nullptr;
   Bufs b{};
   MomCfg mc{};
@@ -119,6 +122,103 @@ static int dalloc(nagp_plan* p, double** ptr, size_t n_doubles, bool zero = true
     case 4: CALL(4); break; case 5: CALL(5); break; case 6: CALL(6); break; case 7: CALL(7); break;      \
     case 8: CALL(8); break; default: CALL(9); break;                                                     \
   }
+
+// Block structure of Wnmf (source-separation mixtures): the finest partition into contiguous (sub-band range,
+// component range) blocks that holds the non-zeros of every problem of the plan; the tables of MomSrc (nagp_dev.hpp).
+// Returns false (unstructured) whenever anything does not fit the table formats.
+static bool build_mom_src(int B, const nagp_model* models, int D, int N, int n_pts, const std::vector<unsigned char>& code,
+                          MomSrc& sc, std::vector<unsigned char>& blob) {
+  sc = MomSrc{};
+  if (N < 2 || D < 2 || n_pts > 65535 || getenv("NAGP_NO_SRC")) return false;
+  std::vector<int> par(D + N);
+  for (int i = 0; i < D + N; ++i) par[i] = i;
+  auto find = [&](int x) { while (par[x] != x) { par[x] = par[par[x]]; x = par[x]; } return x; };
+  for (int q = 0; q < B; ++q)
+    for (int n = 0; n < N; ++n)
+      for (int d = 0; d < D; ++d)
+        if (models[q].Wnmf[d + (size_t)D * n] != 0.0) par[find(d)] = find(D + n);
+  // sources in order of appearance along d; both index sets must be contiguous and in the same order
+  std::vector<int> root;
+  int d0[MOM_MAXSRC + 1] = {0}, n0[MOM_MAXSRC + 1] = {0};
+  for (int d = 0; d < D; ++d) {
+    const int r = find(d);
+    if (root.empty() || root.back() != r) {
+      for (int x : root) if (x == r) return false;          // came back to an earlier source
+      if ((int)root.size() == MOM_MAXSRC) return false;
+      d0[root.size()] = d; root.push_back(r);
+    }
+  }
+  const int ns = (int)root.size();
+  if (ns < 2) return false;
+  d0[ns] = D;
+  int cur = -1;
+  for (int n = 0; n < N; ++n) {
+    const int r = find(D + n);
+    int j = -1;
+    for (int x = 0; x < ns; ++x) if (root[x] == r) j = x;
+    if (j < 0 || j < cur || j > cur + 1) return false;      // a component without sub-bands, or out of order
+    if (j == cur + 1) { n0[j] = n; cur = j; }
+  }
+  if (cur != ns - 1) return false;
+  n0[ns] = N;
+  // tuples
+  std::vector<unsigned char> tup((size_t)ns * n_pts);
+  std::vector<std::vector<std::vector<unsigned char>>> tuples(ns);
+  for (int j = 0; j < ns; ++j) {
+    const int nc = n0[j + 1] - n0[j];
+    for (int pt = 0; pt < n_pts; ++pt) {
+      std::vector<unsigned char> key(code.begin() + (size_t)pt * N + n0[j], code.begin() + (size_t)pt * N + n0[j] + nc);
+      size_t b = 0;
+      while (b < tuples[j].size() && tuples[j][b] != key) ++b;
+      if (b == tuples[j].size()) { if (b == 255) return false; tuples[j].push_back(key); }
+      tup[(size_t)j * n_pts + pt] = (unsigned char)b;
+    }
+  }
+  int nbmax = 0, dlmax = 0;
+  for (int j = 0; j < ns; ++j) { nbmax = std::max(nbmax, (int)tuples[j].size()); dlmax = std::max(dlmax, d0[j + 1] - d0[j]); }
+  std::vector<unsigned char> tcode((size_t)ns * nbmax * N, 0);
+  for (int j = 0; j < ns; ++j)
+    for (size_t b = 0; b < tuples[j].size(); ++b)
+      for (size_t k = 0; k < tuples[j][b].size(); ++k) tcode[((size_t)j * nbmax + b) * N + k] = tuples[j][b][k];
+  // points ordered by tuple, bins cut into slices of <= 64 points (4 trips of a 16-lane group)
+  std::vector<unsigned short> perm((size_t)ns * n_pts);
+  struct Item { int j, b, start, len, bin_order; };
+  std::vector<Item> items;
+  for (int j = 0; j < ns; ++j) {
+    int pos = 0;
+    for (int b = 0; b < (int)tuples[j].size(); ++b) {
+      const int start = pos;
+      for (int pt = 0; pt < n_pts; ++pt) if (tup[(size_t)j * n_pts + pt] == b) perm[(size_t)j * n_pts + pos++] = (unsigned short)pt;
+      for (int s0 = start; s0 < pos; s0 += 64) items.push_back({j, b, s0, std::min(64, pos - s0), (int)items.size()});
+    }
+  }
+  std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.len > b.len; });
+  std::vector<int> it4(items.size() * 4), bin_first((size_t)ns * nbmax + 1, 0), bitem(items.size());
+  for (size_t e = 0; e < items.size(); ++e) {
+    it4[4 * e] = items[e].j; it4[4 * e + 1] = items[e].b; it4[4 * e + 2] = items[e].start; it4[4 * e + 3] = items[e].len;
+    ++bin_first[(size_t)items[e].j * nbmax + items[e].b + 1];
+  }
+  for (size_t t = 0; t < (size_t)ns * nbmax; ++t) bin_first[t + 1] += bin_first[t];
+  {   // items of a bin in slice order (ascending start)
+    std::vector<int> fill(bin_first.begin(), bin_first.end() - 1);
+    std::vector<int> order(items.size());
+    for (size_t e = 0; e < items.size(); ++e) order[e] = (int)e;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return items[a].bin_order < items[b].bin_order; });
+    for (int e : order) bitem[fill[(size_t)items[e].j * nbmax + items[e].b]++] = e;
+  }
+  sc.n_src = ns; sc.nbmax = nbmax; sc.dlmax = dlmax | 1; sc.n_items = (int)items.size();   // odd row stride: lanes = tuples hit distinct LDS banks
+  for (int j = 0; j <= ns; ++j) { sc.d0[j] = d0[j]; sc.n0[j] = n0[j]; }
+  for (int j = 0; j < ns; ++j) sc.nb[j] = (int)tuples[j].size();
+  auto put = [&](const void* src, size_t bytes) { const size_t o = blob.size(); blob.resize(o + ((bytes + 15) / 16) * 16); std::memcpy(blob.data() + o, src, bytes); return o; };
+  sc.off[0] = (int)put(tup.data(), tup.size());
+  sc.off[1] = (int)put(tcode.data(), tcode.size());
+  sc.off[2] = (int)put(perm.data(), perm.size() * sizeof(unsigned short));
+  sc.off[3] = (int)put(it4.data(), it4.size() * sizeof(int));
+  sc.off[4] = (int)put(bin_first.data(), bin_first.size() * sizeof(int));
+  sc.off[5] = (int)put(bitem.data(), bitem.size() * sizeof(int));
+  sc.blob_bytes = (int)blob.size();
+  return true;
+}
 
 static int roundup64(int x) { return ((x + 63) / 64) * 64; }
 
@@ -305,6 +405,18 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     mc.n_pts = o->n_pts; mc.cdim = o->cub_dim; mc.D = sh.D; mc.wn = p->d_wn;
     mc.jitter = (o->lik_kind == NAGP_LIK_POWER) ? 1e-8 : 1e-10;
     mc.DG = 1; mc.cache_tabs = 0; mc.store_a = 0; mc.stamps = nullptr;
+    if (o->lik_kind != NAGP_LIK_POWER) {
+      std::vector<unsigned char> blob;
+      MomSrc sc;
+      if (build_mom_src(B, models, sh.D, sh.N, o->n_pts, code, sc, blob)) {
+        double* dsrc = nullptr;
+        PLAN_TRY(dalloc(p, &dsrc, (blob.size() + 7) / 8, false));
+        PLAN_HIP(hipMemcpyAsync(dsrc, blob.data(), blob.size(), hipMemcpyHostToDevice, p->stream));
+        PLAN_HIP(hipStreamSynchronize(p->stream));
+        sc.blob = reinterpret_cast<const unsigned char*>(dsrc);
+        p->src_all = sc;
+      }
+    }
   }
 
   // ---- buffers
@@ -411,19 +523,30 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
 
   // ---- LDS sizes / kernel attributes
   if (o->kind == NAGP_KIND_IHGP) {
-    p->NT_ih = 256;   // one wave per SIMD: 512 registers per lane (the cubature's pressure stays out of scratch memory)
+    // one wave per SIMD: 512 registers per lane (the cubature's pressure stays out of scratch memory); the N = 9 instantiation
+    // (thousands of sigma points per step, W rows in registers) runs two waves per SIMD
+    p->NT_ih = (mom_variant(mc) >= 9) ? 512 : 256;
     p->DG_f = pick_DG(o->lik_kind, o->n_pts, p->NT_ih, sh.D, o->cub_dim);
     MomCfg t = mc; t.DG = p->DG_f; t.cache_tabs = 1; t.store_a = (o->lik_kind == NAGP_LIK_POWER_NMF_SQRT) ? 1 : 0;
+    p->kb_ih = IH_KB;
+    if (p->src_all.n_src >= 2) {   // block-structured Wnmf: the tuple tables must be resident (a shorter I/O ring makes room)
+      t.src = p->src_all;
+      while (p->kb_ih > 4 && ihgp_filter_lds_doubles(sh, t, p->tb.NG, 0, p->kb_ih) * sizeof(double) > 156 * 1024) p->kb_ih /= 2;
+      if (ihgp_filter_lds_doubles(sh, t, p->tb.NG, 0, p->kb_ih) * sizeof(double) <= 156 * 1024) p->src_f = 1;
+      else { t.src = MomSrc{}; p->kb_ih = IH_KB; }
+    }
     p->hph_lds = 1;   // LDS budget, least valuable resident first: H PP H' table, a[d][p], cubature tables
-    if (ihgp_filter_lds_doubles(sh, t, p->tb.NG, p->hph_lds) * sizeof(double) > 150 * 1024) p->hph_lds = 0;
-    if (ihgp_filter_lds_doubles(sh, t, p->tb.NG, p->hph_lds) * sizeof(double) > 150 * 1024) t.store_a = 0;
-    if (ihgp_filter_lds_doubles(sh, t, p->tb.NG, p->hph_lds) * sizeof(double) > 150 * 1024) t.cache_tabs = 0;
+    if (ihgp_filter_lds_doubles(sh, t, p->tb.NG, p->hph_lds, p->kb_ih) * sizeof(double) > 156 * 1024) p->hph_lds = 0;
+    if (ihgp_filter_lds_doubles(sh, t, p->tb.NG, p->hph_lds, p->kb_ih) * sizeof(double) > 156 * 1024) t.store_a = 0;
+    if (ihgp_filter_lds_doubles(sh, t, p->tb.NG, p->hph_lds, p->kb_ih) * sizeof(double) > 156 * 1024) t.cache_tabs = 0;
     p->cache_f = t.cache_tabs; p->sta_f = t.store_a;
-    p->lds_ih = ihgp_filter_lds_doubles(sh, t, p->tb.NG, p->hph_lds) * sizeof(double);
-    if (getenv("NAGP_STAMPS")) fprintf(stderr, "[nagp plan] ihgp filter: LDS %zu B, hph table in LDS %d, cubature tables in LDS %d, mom LDS %zu B\n", p->lds_ih, p->hph_lds, p->cache_f, mom_lds_doubles(t) * sizeof(double));
-#define SL(V) PLAN_TRY(set_lds(ihgp_filter_kernel<V>, p->lds_ih))
-    NAGP_MV_SWITCH9(mom_variant(mc), SL)
+    p->lds_ih = ihgp_filter_lds_doubles(sh, t, p->tb.NG, p->hph_lds, p->kb_ih) * sizeof(double);
+    if (getenv("NAGP_STAMPS")) fprintf(stderr, "[nagp plan] ihgp filter: LDS %zu B, hph table in LDS %d, cubature tables in LDS %d, block-structured mom %d, mom LDS %zu B\n", p->lds_ih, p->hph_lds, p->cache_f, p->src_f, mom_lds_doubles(t) * sizeof(double));
+#define SL(V) PLAN_TRY(set_lds(ihgp_filter_kernel<V, false>, p->lds_ih))
+#define SLS(V) PLAN_TRY(set_lds(ihgp_filter_kernel<V, true>, p->lds_ih))
+    if (p->src_f) { NAGP_MV_SWITCH9(mom_variant(mc), SLS) } else { NAGP_MV_SWITCH9(mom_variant(mc), SL) }
 #undef SL
+#undef SLS
   } else {
     if (!ekf) p->DG_f = pick_DG(o->lik_kind, o->n_pts, p->NT_a, sh.D, o->cub_dim);
     MomCfg t = mc; t.DG = p->DG_f; t.cache_tabs = ekf ? 0 : 1; t.store_a = (!ekf && o->lik_kind == NAGP_LIK_POWER_NMF_SQRT) ? 1 : 0;
@@ -483,8 +606,12 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
   if (!ekf) {
     p->DG_ep = pick_DG(o->lik_kind, o->n_pts, 256, sh.D, o->cub_dim);
     MomCfg t = mc; t.DG = p->DG_ep; t.cache_tabs = 1; t.store_a = (o->lik_kind == NAGP_LIK_POWER_NMF_SQRT) ? 1 : 0;
-    if (ep_lds_doubles(sh, t) * sizeof(double) > 64 * 1024) t.store_a = 0;
-    if (ep_lds_doubles(sh, t) * sizeof(double) > 64 * 1024) t.cache_tabs = 0;
+    if (p->src_all.n_src >= 2) {
+      t.src = p->src_all;
+      if (ep_lds_doubles(sh, t) * sizeof(double) <= 150 * 1024) p->src_ep = 1; else t.src = MomSrc{};
+    }
+    if (!p->src_ep && ep_lds_doubles(sh, t) * sizeof(double) > 64 * 1024) t.store_a = 0;
+    if (!p->src_ep && ep_lds_doubles(sh, t) * sizeof(double) > 64 * 1024) t.cache_tabs = 0;
     p->cache_ep = t.cache_tabs; p->sta_ep = t.store_a;
     p->lds_ep = ep_lds_doubles(sh, t) * sizeof(double);
 #define SL(V) PLAN_TRY(set_lds(ep_site_kernel<V>, p->lds_ep))
@@ -635,6 +762,7 @@ static int launch_ep(nagp_plan* p, double alpha, double damp, int clamp, int wri
   const Shape& sh = p->sh;
   if (sh.T < 2) return NAGP_OK;
   MomCfg mc = p->mc; mc.DG = p->DG_ep; mc.cache_tabs = p->cache_ep; mc.store_a = p->sta_ep;
+  if (p->src_ep) mc.src = p->src_all;
   EpPar ep{};
   ep.k_end = sh.T - 1;
   ep.steps_per_wg = (int)std::max<int64_t>(1, (ep.k_end + 4095) / 4096);
@@ -796,6 +924,7 @@ static int exec_ihgp(nagp_plan* p) {
                            sh.M * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
   }
   MomCfg mcf = p->mc; mcf.DG = p->DG_f; mcf.cache_tabs = p->cache_f; mcf.store_a = p->sta_f;
+  if (p->src_f) mcf.src = p->src_all;
   if (getenv("NAGP_STAMPS")) mcf.stamps = reinterpret_cast<unsigned long long*>(p->d_stamps);   // developer diagnostics
   auto affine = [&](int mode, int64_t kend, int itt) -> int {
     if (kend <= 0) return NAGP_OK;
@@ -821,13 +950,15 @@ static int exec_ihgp(nagp_plan* p) {
     // recursion, run parallel in time) and one ADF step at k = T-1
     if (itt > 1) RUN(affine(0, sh.T - 1, itt));
     IhgpPar ip{itt, p->damping[itt - 1], itt == 1 ? 1 : 0, (itt == 1) ? (int64_t)0 : (int64_t)(sh.T - 1)};
-    ip.hph_lds = p->hph_lds;
+    ip.hph_lds = p->hph_lds; ip.kb = p->kb_ih;
     ip.w_old = 1.0 - ip.ep_damp; ip.w_new = mix ? ip.ep_damp / o.ep_fraction : ip.ep_damp; ip.mom_alpha = mix ? o.ep_fraction : 1.0;
     {
       Timed t(p, itt == 1 ? NAGP_K_FILTER : NAGP_K_FILTER_LIN);
-#define LI(V) hipLaunchKernelGGL(ihgp_filter_kernel<V>, dim3(B), dim3(p->NT_ih), p->lds_ih, p->stream, sh, p->b, mcf, p->tb, ip)
-      NAGP_MV_SWITCH9(mom_variant(mcf), LI)
+#define LI(V) hipLaunchKernelGGL((ihgp_filter_kernel<V, false>), dim3(B), dim3(p->NT_ih), p->lds_ih, p->stream, sh, p->b, mcf, p->tb, ip)
+#define LIS(V) hipLaunchKernelGGL((ihgp_filter_kernel<V, true>), dim3(B), dim3(p->NT_ih), p->lds_ih, p->stream, sh, p->b, mcf, p->tb, ip)
+      if (p->src_f) { NAGP_MV_SWITCH9(mom_variant(mcf), LIS) } else { NAGP_MV_SWITCH9(mom_variant(mcf), LI) }
 #undef LI
+#undef LIS
     }
     HIP_TRY(hipGetLastError());
     RUN(reduce_sum(p, p->b.lZ, itt == 1 ? 0 : sh.T - 1, sh.T, 0));

@@ -16,6 +16,7 @@ typedef double v4d __attribute__((ext_vector_type(4)));   // accumulator of v_mf
 
 constexpr int MAXM = 64;        // sites (= diagonal blocks) per step
 constexpr double kSqrt2Pi = 2.5066282746310002;
+constexpr double kInvSqrt2Pi = 0.3989422804014327;
 
 // ---------------------------------------------------------------------------------------------
 // DPP helpers.  CTRL: quad_perm [1,0,3,2]=0xB1, [2,3,0,1]=0x4E, row_half_mirror=0x141, row_mirror=0x140
@@ -140,6 +141,30 @@ __device__ __forceinline__ void tile_congruence(double* t, const double* aI, con
 // only a handful of distinct coordinate values (<= 5 for ut3/5/7/9), so link(mu_g + sqrt(s2_g)*xi) is
 // evaluated once per (dimension, distinct value) -- cdim*nd transcendental evaluations instead of
 // n_pts*cdim -- and every sigma point gathers its values through a byte code table.
+// Block-structured Wnmf (source-separation mixtures, experiments/gf_ep_mods_nmf_mixture.m:101: Wnmf = blkdiag(W_j)):
+// sub-band d of source j only sees the components of source j, so a_d takes one value per DISTINCT projection of the
+// sigma points onto those components (77 for ut9 in 3 of 9 dimensions, against 3 973 points).  Host-built tables:
+constexpr int MOM_MAXSRC = 4;
+struct MomSrc {
+  int n_src;                   // < 2: unstructured
+  int d0[MOM_MAXSRC + 1];      // sub-band range of every source
+  int n0[MOM_MAXSRC + 1];      // component range of every source
+  int nb[MOM_MAXSRC];          // distinct projected points ("tuples") per source
+  int nbmax, dlmax, n_items;   // max tuples / sub-bands per source ; work items of the binning pass
+  // one byte blob (copied into LDS by mom_cache_tables; every table starts on a 16-byte boundary):
+  //   off[0] tup    u8  [n_src][n_pts]       tuple of every sigma point
+  //   off[1] tcode  u8  [n_src][nbmax][cdim] coordinate codes of the tuple's components
+  //   off[2] perm   u16 [n_src][n_pts]       sigma points ordered by tuple
+  //   off[3] items  i32 [n_items][4]         source, tuple, start in perm, length ; longest first
+  //   off[4] bin_first i32 [n_src*nbmax + 1] CSR of the items of every bin ...
+  //   off[5] bitem  i32 [n_items]            ... their positions in `items`, fixed order
+  const unsigned char* blob;
+  int blob_bytes;
+  int off[6];
+};
+typedef const unsigned short __attribute__((address_space(3))) * lds_u16p;
+typedef const int __attribute__((address_space(3))) * lds_i32p;
+
 struct MomCfg {
   int lik_kind;      // nagp_lik
   int link_kind;     // nagp_link
@@ -156,6 +181,7 @@ struct MomCfg {
   int cache_tabs;    // keep wn / code in LDS (n_pts small enough)
   int store_a;       // POWER_NMF_SQRT: keep a[d][p] = sqrt(W_d . link(xn_p)) in LDS between the phases (one sqrt per (p, d))
   unsigned long long* stamps;  // developer diagnostics: per-phase cycle sums of thread 0 (null in production)
+  MomSrc src;        // n_src >= 2: mom_src instead of the per-point evaluation (needs cache_tabs)
 };
 
 typedef const unsigned char __attribute__((address_space(3))) * lds_u8p;   // explicit LDS pointers: a select between
@@ -166,11 +192,12 @@ constexpr int MOM_MAXW = 8;   // waves per workgroup the cross-wave reduction bu
 __host__ __device__ inline int mom_chunk(const MomCfg& c) { return c.n_pts < 1024 ? c.n_pts : 1024; }
 // LDS workspace layout (offsets in doubles)
 constexpr int MOM_REP = 4;    // POWER_NMF: replicas (16-lane groups) per phase-2 task
-struct MomLay { size_t rows, c0, c1, c2, sg, lkv, xgv, xg2v, sums1, sums2, part, acc, qv, xd, core, tw, tc, total; };
+struct MomLay { size_t rows, c0, c1, c2, sg, lkv, xgv, xg2v, sums1, sums2, part, acc, qv, xd, core, tw, tc, total, atab, s2b, smb, cb, ipart; };
 __host__ __device__ inline int mom_nslots(int cd) { return cd * cd + 3 * cd + 1; }   // u, R, g1, g2, Z
 __host__ __device__ inline MomLay mom_layout(const MomCfg& c) {
   MomLay l;
-  const size_t CH = (size_t)mom_chunk(c), nout = (size_t)c.D + c.cdim + 1, tab = (size_t)c.cdim * c.nd;
+  const bool st = c.src.n_src >= 2;   // structured: no per-point arrays, no partial-sum buffers
+  const size_t CH = st ? 0 : (size_t)mom_chunk(c), nout = (size_t)c.D + c.cdim + 1, tab = (size_t)c.cdim * c.nd;
   const size_t ns = (size_t)mom_nslots(c.cdim);
   l.rows = 0;   // POWER: link(xn)[d][p] ; POWER_NMF: link(xn)[j][p] ; POWER_NMF_SQRT: a[d][p] (store_a) or none
   l.c0 = (c.lik_kind == 0) ? CH * c.D : (c.lik_kind == 1) ? CH * c.cdim : (c.store_a ? CH * c.D : 0);
@@ -179,14 +206,24 @@ __host__ __device__ inline MomLay mom_layout(const MomCfg& c) {
   l.lkv = l.sg + c.cdim; l.xgv = l.lkv + tab; l.xg2v = l.xgv + tab;
   l.sums1 = l.xg2v + tab; l.sums2 = l.sums1 + nout;
   l.part = l.sums2 + nout;   // POWER_NMF_SQRT: [MOM_MAXW][2*nout] ; POWER_NMF: [MOM_MAXW][16x16] (N <= 7) or [MOM_REP][ns]
-  l.acc = l.part + ((c.lik_kind == 0) ? 0 : (c.lik_kind == 1) ? (size_t)(c.cdim <= 7 ? MOM_MAXW * 256 : MOM_REP * ns) : (size_t)MOM_MAXW * 2 * nout);
-  l.qv = l.acc + ((c.lik_kind == 1) ? ns : 0);                           // POWER_NMF: Q = W' diag(s2_z) W [cd][cd], v = W' mu_z [cd]
-  l.xd = l.qv + ((c.lik_kind == 1) ? (size_t)c.cdim * (c.cdim + 1) : 0);
+  l.acc = l.part + (st ? 0 : (c.lik_kind == 0) ? 0 : (c.lik_kind == 1) ? (size_t)(c.cdim <= 7 ? MOM_MAXW * 256 : MOM_REP * ns) : (size_t)MOM_MAXW * 2 * nout);
+  l.qv = l.acc + ((c.lik_kind == 1 && !st) ? ns : 0);                    // POWER_NMF: Q = W' diag(s2_z) W [cd][cd], v = W' mu_z [cd]
+  l.xd = l.qv + ((c.lik_kind == 1 && !st) ? (size_t)c.cdim * (c.cdim + 1) : 0);
   l.xd = (l.xd + 1) & ~(size_t)1;
   l.core = (l.xd + c.nd + 1) & ~(size_t)1;
   l.tw = l.core;
   l.tc = l.tw + c.n_pts;
   l.total = c.cache_tabs ? l.tc + ((size_t)c.n_pts * c.cdim + 7) / 8 + 1 : l.core;
+  l.atab = l.s2b = l.smb = l.cb = l.ipart = l.total;
+  if (st) {   // wn at tw, the table blob at tc (always resident), then the per-call tuple tables
+    const size_t nbin = (size_t)c.src.n_src * c.src.nbmax;
+    l.atab = l.tc + ((size_t)c.src.blob_bytes + 7) / 8 + 1;         // a[j][b][d_local]
+    l.s2b = l.atab + nbin * c.src.dlmax;                            // sum_d a^2 s2_d per (source, tuple)
+    l.smb = l.s2b + nbin;                                           // sum_d a mu_d
+    l.cb = l.smb + nbin;                                            // binned weights c0, c1, c2
+    l.ipart = l.cb + 3 * nbin;                                      // per-item partial sums
+    l.total = l.ipart + 3 * (size_t)c.src.n_items;
+  }
   return l;
 }
 __host__ __device__ inline size_t mom_lds_doubles(const MomCfg& c) { return mom_layout(c).total; }
@@ -194,6 +231,14 @@ __host__ __device__ inline size_t mom_lds_doubles(const MomCfg& c) { return mom_
 __device__ inline void mom_cache_tables(const MomCfg& c, double* ws) {
   const MomLay l = mom_layout(c);
   for (int i = threadIdx.x; i < c.nd; i += blockDim.x) ws[l.xd + i] = c.xd[i];
+  if (c.src.n_src >= 2) {
+    double* tw = ws + l.tw;
+    unsigned int* tt = reinterpret_cast<unsigned int*>(ws + l.tc);
+    const unsigned int* sb = reinterpret_cast<const unsigned int*>(c.src.blob);
+    for (int i = threadIdx.x; i < c.n_pts; i += blockDim.x) tw[i] = c.wn[i];
+    for (int i = threadIdx.x; i < c.src.blob_bytes / 4; i += blockDim.x) tt[i] = sb[i];
+    return;
+  }
   if (!c.cache_tabs) return;
   double* tw = ws + l.tw;
   unsigned char* tc = reinterpret_cast<unsigned char*>(ws + l.tc);
@@ -730,6 +775,185 @@ __device__ __forceinline__ void mom_quad(const MomCfg& c, const double* Wl, doub
   NAGP_STAMP(3);
 }
 
+// Block-structured NMF likelihoods (see MomSrc).  With a_d a function of the tuple b = tup_j(p) of its source only,
+//   sum_d a_d^2 s2_d = sum_j S2_j[tup_j(p)],   sum_d a_d mu_d = sum_j SM_j[tup_j(p)],
+//   sum_p c1_p a_d = sum_b a_d[b] C1_j[b],     sum_p c2_p a_d^2 = sum_b a_d[b]^2 C2_j[b],   C*_j[b] = sum_{p in b} c*_p
+// and the modulator sums run over the tuples of their source as well.
+//   1t  16-lane group per (source, tuple): a for the source's sub-bands (lanes), S2, SM
+//   2   16-lane group per work item (a slice of one bin's sigma points, host-balanced): Gaussian weight of every
+//       point from three table look-ups, c0 c1 c2 summed over the slice
+//   2b  thread per bin: fixed-order sum of its items
+//   3   thread per output: sums over the tuples of its source
+// a[j] for a per-lane j without a vector load from the kernel-argument segment
+__device__ __forceinline__ int pick_src(const int* a, int j) {
+  const int a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
+  return j == 0 ? a0 : (j == 1 ? a1 : (j == 2 ? a2 : a3));
+}
+__device__ __forceinline__ int pick_src1(const int* a, int j) {   // a[j + 1], a has MOM_MAXSRC + 1 entries
+  const int a1 = a[1], a2 = a[2], a3 = a[3], a4 = a[4];
+  return j == 0 ? a1 : (j == 1 ? a2 : (j == 2 ? a3 : a4));
+}
+template <int CD, bool LOGZ>
+__device__ __forceinline__ void mom_src(const MomCfg& c, const double* Wl, double sn2, double alpha, double y,
+                                        const double* mu, const double* s2, double* ws, double* lZ, double* dl, double* d2l,
+                                        unsigned long long* acc_st, double pEP) {
+  const int tid = threadIdx.x, NT = blockDim.x;
+  const int D = c.D, nd = c.nd, npt = c.n_pts;
+  constexpr int cd = CD;
+  const int nout = D + cd + 1;
+  const MomSrc& sc = c.src;
+  const int nsrc = sc.n_src, nbmax = sc.nbmax, dlmax = sc.dlmax;
+  const bool sq = __builtin_amdgcn_readfirstlane(c.lik_kind == 2 ? 1 : 0) != 0;
+  const MomLay l = mom_layout(c);
+  const double* lkv = ws + l.lkv;
+  const double* xgv = ws + l.xgv;
+  const double* xg2v = ws + l.xg2v;
+  double* sums1 = ws + l.sums1;
+  double* sums2 = ws + l.sums2;
+  const lds_f64p lds_wn = (lds_f64p)(ws + l.tw);
+  const lds_u8p blob = (lds_u8p)(ws + l.tc);
+  const lds_u8p lds_tup = blob + sc.off[0];
+  const lds_u8p lds_tcode = blob + sc.off[1];
+  const lds_u16p lds_perm = (lds_u16p)(blob + sc.off[2]);
+  const lds_i32p lds_items = (lds_i32p)(blob + sc.off[3]);
+  const lds_i32p lds_bfirst = (lds_i32p)(blob + sc.off[4]);
+  const lds_i32p lds_bitem = (lds_i32p)(blob + sc.off[5]);
+  double* atab = ws + l.atab;
+  double* s2b = ws + l.s2b;
+  double* smb = ws + l.smb;
+  double* cb = ws + l.cb;
+  double* ipart = ws + l.ipart;
+  const double* mu_z = mu;
+  const double* s2_z = s2;
+
+  unsigned long long t_a = 0, t_b = 0;
+  if (c.stamps && tid == 0) t_a = __builtin_readcyclecounter();
+  mom_phase1a(c, l, cd, nout, mu + D, s2 + D, ws);
+  NAGP_STAMP(0);
+
+  const int grp = tid >> 4, gl = tid & 15, ngrp = NT >> 4;
+  // ---- 1t: one lane per (source, tuple); the sub-bands of the source in an unrolled loop (independent chains)
+  for (int tk = tid; tk < nsrc * nbmax; tk += NT) {
+    const int j = tk / nbmax, bq = tk - j * nbmax;
+    if (bq >= pick_src(sc.nb, j)) continue;
+    const int nj0 = pick_src(sc.n0, j), nc = pick_src1(sc.n0, j) - nj0, dj0 = pick_src(sc.d0, j), Dj = pick_src1(sc.d0, j) - dj0;
+    const lds_u8p tcp = lds_tcode + tk * cd;
+    double lk[CD];
+#pragma unroll
+    for (int k = 0; k < CD; ++k) {
+      const int kk = (k < nc) ? k : 0;
+      const double v = lkv[(nj0 + kk) * nd + tcp[kk]];
+      lk[k] = (k < nc) ? v : 0.0;                      // components of other sources: zero weight (their W entries are 0 too)
+    }
+    double s2acc = 0.0, smacc = 0.0;
+    double* ar = atab + (size_t)tk * dlmax;
+#pragma unroll 4
+    for (int dl_ = 0; dl_ < Dj; ++dl_) {
+      const int d = dj0 + dl_;
+      const double* wr = Wl + d * CD + nj0;
+      double a = 0.0;
+#pragma unroll
+      for (int k = 0; k < CD; ++k) { const int kk = (k < nc) ? k : 0; a = fma(wr[kk], lk[k], a); }
+      if (sq) a = sqrt(a);
+      ar[dl_] = a;
+      s2acc = fma(a * a, s2_z[d], s2acc);
+      smacc = fma(a, mu_z[d], smacc);
+    }
+    s2b[tk] = s2acc; smb[tk] = smacc;
+  }
+  lds_barrier();
+  NAGP_STAMP(1);
+  // ---- 2
+  const double sn2a = sn2 / alpha;
+  for (int e = grp; e < sc.n_items; e += ngrp) {
+    const int j = lds_items[4 * e], start = lds_items[4 * e + 2], len = lds_items[4 * e + 3];
+    const lds_u16p pm = lds_perm + j * npt + start;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    for (int i0 = gl; i0 < len; i0 += 32) {            // two points per lane and trip: independent dependency chains
+      double sig2[2], sam[2], okf[2];
+      int pp[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int i = i0 + 16 * u;
+        okf[u] = (i < len) ? 1.0 : 0.0;
+        pp[u] = pm[(i < len) ? i : 0];
+        sig2[u] = sn2a; sam[u] = 0.0;
+      }
+#pragma unroll
+      for (int jj = 0; jj < MOM_MAXSRC; ++jj)
+        if (jj < nsrc) {
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int t = lds_tup[jj * npt + pp[u]];
+            sig2[u] += s2b[jj * nbmax + t];
+            sam[u] += smb[jj * nbmax + t];
+          }
+        }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        // N(y; sam, sig2) through ONE reciprocal (every point is visited once per source: the divisions dominate)
+        const double inv = 1.0 / sig2[u];
+        const double dy = y - sam[u];
+        const double q = dy * inv;
+        const double pdf = exp(-0.5 * dy * q) * (sqrt(sig2[u]) * inv) * kInvSqrt2Pi;
+        const double w0 = lds_wn[pp[u]] * pdf * okf[u];
+        a0 += w0;
+        a1 = fma(w0, q, a1);
+        a2 = fma(w0, q * q - inv, a2);
+      }
+    }
+    a0 = group_sum(a0, 16); a1 = group_sum(a1, 16); a2 = group_sum(a2, 16);
+    if (gl == 0) { ipart[3 * e] = a0; ipart[3 * e + 1] = a1; ipart[3 * e + 2] = a2; }
+  }
+  lds_barrier();
+  // ---- 2b
+  for (int t = tid; t < nsrc * nbmax; t += NT) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    for (int q = lds_bfirst[t]; q < lds_bfirst[t + 1]; ++q) {
+      const int e = lds_bitem[q];
+      a0 += ipart[3 * e]; a1 += ipart[3 * e + 1]; a2 += ipart[3 * e + 2];
+    }
+    cb[3 * t] = a0; cb[3 * t + 1] = a1; cb[3 * t + 2] = a2;
+  }
+  lds_barrier();
+  NAGP_STAMP(2);
+  // ---- 3: one 16-lane group per output, lanes stride over the tuples of the output's source
+  for (int o = grp; o <= D + cd; o += ngrp) {
+    double s1 = 0.0, s2_ = 0.0;
+    if (o < D) {
+      int j = 0;
+      while (j + 1 < nsrc && o >= pick_src1(sc.d0, j)) ++j;
+      const int dl_ = o - pick_src(sc.d0, j), nbj = pick_src(sc.nb, j);
+      const double* at = atab + (size_t)j * nbmax * dlmax + dl_;
+      const double* cp = cb + (size_t)3 * j * nbmax;
+      for (int b = gl; b < nbj; b += 16) {
+        const double a = at[(size_t)b * dlmax];
+        s1 = fma(a, cp[3 * b + 1], s1);
+        s2_ = fma(a * a, cp[3 * b + 2], s2_);
+      }
+    } else if (o < D + cd) {
+      const int n = o - D;
+      int j = 0;
+      while (j + 1 < nsrc && n >= pick_src1(sc.n0, j)) ++j;
+      const int k = n - pick_src(sc.n0, j), nbj = pick_src(sc.nb, j);
+      const lds_u8p tcp = lds_tcode + j * nbmax * cd + k;
+      const double* cp = cb + (size_t)3 * j * nbmax;
+      for (int b = gl; b < nbj; b += 16) {
+        const int ix = n * nd + tcp[b * cd];
+        s1 = fma(xgv[ix], cp[3 * b], s1);
+        s2_ = fma(xg2v[ix], cp[3 * b], s2_);
+      }
+    } else {
+      for (int b = gl; b < sc.nb[0]; b += 16) s1 += cb[3 * b];   // Z: every sigma point lies in exactly one bin of source 0
+    }
+    s1 = group_sum(s1, 16); s2_ = group_sum(s2_, 16);
+    if (gl == 0) { sums1[o] = s1; sums2[o] = s2_; }
+  }
+  lds_barrier();
+  mom_phase3<LOGZ>(c, l, D + cd, pEP, ws, lZ, dl, d2l);
+  NAGP_STAMP(3);
+}
+
 // POWER likelihood (likModulatorPower.m:25-100): cubature dimension = D, a_d = link(xn_d).
 template <bool LOGZ>
 __device__ __forceinline__ void mom_power(const MomCfg& c, double sn2, double alpha, double y, const double* mu,
@@ -842,7 +1066,8 @@ __device__ inline double mom_pEP(const MomCfg& c, double sn2, double alpha) {
 }
 // MV: the cubature dimension the calling kernel was instantiated for (0 = POWER, 1..9 = N of the NMF likelihoods)
 // LOGZ = false: *lZ receives Z itself (the sequential filters take the logarithm off the critical path)
-template <int MV, bool LOGZ = true>
+// SRC = false: the block-structured path is compiled out (kernels whose register budget belongs to covariance tiles)
+template <int MV, bool LOGZ = true, bool SRC = true>
 __device__ __forceinline__ void mom_eval(const MomCfg& c, const double* Wl, double pEP, double sn2, double alpha,
                                          double y, const double* mu, const double* s2, double* ws, double* lZ, double* dl,
                                          double* d2l, unsigned long long* acc_st = nullptr) {
@@ -856,7 +1081,8 @@ __device__ __forceinline__ void mom_eval(const MomCfg& c, const double* Wl, doub
 #elif defined(NAGP_EXPERIMENT_ONLY_SQRT)
     mom_nmf<MV, LOGZ>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st, pEP);
 #else
-    if (__builtin_amdgcn_readfirstlane(c.lik_kind) == 1) mom_quad<MV, LOGZ>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st, pEP);
+    if (SRC && __builtin_amdgcn_readfirstlane(c.src.n_src) >= 2) mom_src<MV, LOGZ>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st, pEP);
+    else if (__builtin_amdgcn_readfirstlane(c.lik_kind) == 1) mom_quad<MV, LOGZ>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st, pEP);
     else mom_nmf<MV, LOGZ>(c, Wl, sn2, alpha, y, mu, s2, ws, lZ, dl, d2l, acc_st, pEP);
 #endif
   }

@@ -65,15 +65,16 @@ struct IhgpPar {
   int64_t k_start;   // first step to process (sweeps >= 2 run only k = T-1 here; the rest is ihgp_aff_*)
   double R_init;     // exp(lik) (or 0 for the constraints variant): initial content of R(:,k)
   int hph_lds;       // filter: keep the H PP H' look-up table [M][NG] in LDS
+  int kb;            // steps per I/O block of the filter (LDS ring), <= IH_KB
   double w_old, w_new, mom_alpha;   // as FilterPar: (1-d, d, 1) ihgp_ep_modulator_nmf.m:210-211 ; (1-d, d/alpha, alpha) experiments/ihgp_ep_mods_nmf_mixture.m:291-297
 };
 
-constexpr int IH_KB = 16;   // steps per I/O block of the filter (LDS ring)
+constexpr int IH_KB = 16;   // steps per I/O block of the filter (LDS ring); fewer when the LDS is needed elsewhere
 
-__host__ __device__ inline size_t ihgp_ring_doubles(const Shape& s) { return (size_t)IH_KB * (4 * s.M + s.S + 3); }
-__host__ __device__ inline size_t ihgp_filter_lds_doubles(const Shape& s, const MomCfg& mc, int NG, int hph_lds) {
+__host__ __device__ inline size_t ihgp_ring_doubles(const Shape& s, int kb) { return (size_t)kb * (4 * s.M + s.S + 3); }
+__host__ __device__ inline size_t ihgp_filter_lds_doubles(const Shape& s, const MomCfg& mc, int NG, int hph_lds, int kb = IH_KB) {
   return LDS_INT_DOUBLES + (size_t)s.D * s.N + 6 * (size_t)s.M + 8 + NG + (hph_lds ? (size_t)s.M * NG : 0) +
-         ihgp_ring_doubles(s) + mom_lds_doubles(mc);
+         ihgp_ring_doubles(s, kb) + mom_lds_doubles(mc);
 }
 
 // log10 to ~0.003 absolute (exponent + quadratic in the mantissa): only seeds the +-2 window below
@@ -113,8 +114,9 @@ __device__ __forceinline__ int nearest_idx_lds(const double* r, int NG, double l
 // All per-step global traffic goes through an LDS ring of IH_KB steps that is filled / flushed with
 // coalesced transfers once per block, so the sequential loop body contains no global-memory waits
 // except the (L2-resident) table gather.
-template <int MV>
-__global__ void __launch_bounds__(256) ihgp_filter_kernel(Shape sh, Bufs b, MomCfg mc, IhgpTabs tb, IhgpPar ip) {
+// SRC: the block-structured mom path (source-separation mixtures) and a run-time ring depth; compiled out otherwise
+template <int MV, bool SRC>
+__global__ void __launch_bounds__(MV >= 9 ? 512 : 256) ihgp_filter_kernel(Shape sh, Bufs b, MomCfg mc, IhgpTabs tb, IhgpPar ip) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int tid = threadIdx.x, NT = blockDim.x;
   const int S = sh.S, M = sh.M, NG = tb.NG;
@@ -133,15 +135,16 @@ __global__ void __launch_bounds__(256) ihgp_filter_kernel(Shape sh, Bufs b, MomC
   double* misc = d2l + M;
   double* rg = misc + 8 + 2 * M;          // [NG] look-up grid
   double* thph = rg + NG;                  // [M][NG] H PP H' table (ip.hph_lds)
+  const int KB = SRC ? ip.kb : IH_KB;
   double* ry = thph + (ip.hph_lds ? (size_t)M * NG : 0);   // ring: y[KB]
-  double* rlZ = ry + IH_KB;                //       lZ[KB]
-  double* rZ = rlZ + IH_KB;                //       Z of the steps that called mom (< 0: none); log taken at the flush
-  double* rtt = rZ + IH_KB;                //       ttau[KB][M]
-  double* rtn = rtt + (size_t)IH_KB * M;   //       tnu
-  double* rR = rtn + (size_t)IH_KB * M;    //       R
-  double* rfm = rR + (size_t)IH_KB * M;    //       H*m (filtered)
-  double* rMF = rfm + (size_t)IH_KB * M;   //       m (filtered) [KB][S]
-  double* ws = rMF + (size_t)IH_KB * S;
+  double* rlZ = ry + KB;                //       lZ[KB]
+  double* rZ = rlZ + KB;                //       Z of the steps that called mom (< 0: none); log taken at the flush
+  double* rtt = rZ + KB;                //       ttau[KB][M]
+  double* rtn = rtt + (size_t)KB * M;   //       tnu
+  double* rR = rtn + (size_t)KB * M;    //       R
+  double* rfm = rR + (size_t)KB * M;    //       H*m (filtered)
+  double* rMF = rfm + (size_t)KB * M;   //       m (filtered) [KB][S]
+  double* ws = rMF + (size_t)KB * S;
   for (int i = tid; i <= M; i += NT) ioff[i] = sh.off[i];
   for (int i = tid; i < M; i += NT) ibsz[i] = sh.bsz[i];
   for (int i = tid; i < sh.D * sh.N; i += NT) sW[i] = mdl[mdl_W(sh) + i];
@@ -187,8 +190,8 @@ __global__ void __launch_bounds__(256) ihgp_filter_kernel(Shape sh, Bufs b, MomC
   unsigned long long st_a = 0, st_b = 0, st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (mc.stamps && tid == 0) st_a = __builtin_readcyclecounter();
 
-  for (int64_t k0 = ip.k_start; k0 < T; k0 += IH_KB) {
-    const int nb = (T - k0 < IH_KB) ? (int)(T - k0) : IH_KB;
+  for (int64_t k0 = ip.k_start; k0 < T; k0 += KB) {
+    const int nb = (T - k0 < KB) ? (int)(T - k0) : KB;
     // ---- fill the ring for steps k0 .. k0+nb-1
     for (int i = tid; i < nb; i += NT) { ry[i] = yv[k0 + i]; rlZ[i] = g_lZ[k0 + i]; rZ[i] = -1.0; }
     for (int i = tid; i < nb * M; i += NT) {
@@ -227,7 +230,7 @@ __global__ void __launch_bounds__(256) ihgp_filter_kernel(Shape sh, Bufs b, MomC
       if (do_mom) {
         lds_barrier();
         if (mc.stamps && tid == 0) { st_b = __builtin_readcyclecounter(); st[4] += st_b - st_a; }
-        mom_eval<MV, false>(mc, sW, pEP1, sn2, ip.mom_alpha, yk, fmu, HPH, ws, &misc[0], dl, d2l, st);
+        mom_eval<MV, false, SRC>(mc, sW, pEP1, sn2, ip.mom_alpha, yk, fmu, HPH, ws, &misc[0], dl, d2l, st);
         if (act) {
           const double d1 = dl[n], d2 = d2l[n];
           const double t_old = rtt[kk * M + n], n_old = rtn[kk * M + n];

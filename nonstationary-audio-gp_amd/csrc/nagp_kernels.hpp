@@ -345,7 +345,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
         if (MEAS == 0) {
           if constexpr (MV >= 0) if (do_mom) {
             if (mc.stamps && tid == 0) { st_b = __builtin_readcyclecounter(); stp[4] += st_b - st_a; }
-            mom_eval<MV, false>(mc, sW, pEP1, sn2, fp.mom_alpha, yk, fmu, HPH, ws, &misc[0], dl, d2l, stp);
+            mom_eval<MV, false, false>(mc, sW, pEP1, sn2, fp.mom_alpha, yk, fmu, HPH, ws, &misc[0], dl, d2l, stp);
             if (mc.stamps && tid == 0) st_a = __builtin_readcyclecounter();
             if (tid < M) {
               const double d2 = d2l[tid], d1 = dl[tid], hp = HPH[tid], f = fmu[tid];

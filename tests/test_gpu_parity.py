@@ -492,3 +492,43 @@ def test_three_sources_with_nine_modulators_ihgp_mixture():
     assert rel(c[5]['ttau'], d[5]['ttau']) < TOL_SITE and rel(c[5]['tnu'], d[5]['tnu']) < TOL_SITE
     with pytest.raises(nagp.NagpError):
         nagp.gf_ep_mods_nmf_mixture(mp['w'], t, mp['y'], SSHandle(), mom, t, k1, k2, 3, 0.75, 0.2, 3)
+
+
+def test_block_structured_cubature_equals_per_point_evaluation(monkeypatch):
+    """With a block-diagonal Wnmf the library evaluates the amplitudes at the distinct projections of the sigma points
+    per source (mom_src) instead of at every point.  NAGP_NO_SRC=1 keeps the per-point evaluation: both must agree to
+    rounding, also when the blocks are uneven, and a Wnmf whose blocks are not contiguous must take the per-point
+    path by itself (same results as the oracle either way)."""
+    shapes = [(5, 2), (2, 1), (4, 3)]; k1 = ['exp', 'matern32', 'exp']; k2 = ['matern52'] * 3
+    T = 40; t = np.arange(1, T + 1.0)
+    mp = harness.mixture_problem(shapes, T, 8, k1, k2)
+    mom, omom = _mixture_moms('likModulatorPreCalcwn', 7, 6)
+    a = nagp.ihgp_ep_mods_nmf_mixture(mp['w'], t, mp['y'], SSHandle(), mom, t, k1, k2, 3, 0.75, 0.2, 3, nargout=6)
+    monkeypatch.setenv('NAGP_NO_SRC', '1')
+    b = nagp.ihgp_ep_mods_nmf_mixture(mp['w'], t, mp['y'], SSHandle(), mom, t, k1, k2, 3, 0.75, 0.2, 3, nargout=6)
+    monkeypatch.delenv('NAGP_NO_SRC')
+    # (rounding differences of the two summation orders, amplified by three EP sweeps)
+    assert rel(a[0], b[0]) < 1e-8 and rel(a[5]['ttau'], b[5]['ttau']) < 1e-7 and rel(a[5]['tnu'], b[5]['tnu']) < 1e-7
+    o = omx.ihgp_ep_mods_nmf_mixture(mp['w'], t, mp['y'], None, omom, t, k1, k2, 3, 0.75, 0.2, 3)
+    assert rel(a[0], o[0]) < TOL_MEAN and rel(a[5]['ttau'], o[5]['ttau']) < TOL_SITE
+    # the main functions see the same structure: a GT-NMF model whose Wnmf happens to be block diagonal ...
+    D, N = 6, 4
+    pr = harness.nmf_problem(D, N, T, 12)
+    W = pr['W'].copy(); W[:3, 2:] = 0.0; W[3:, :2] = 0.0
+    mom2 = Mom('likModulatorNMFPower', p_cubature=7); omom2 = olik.Mom(olik.LIK_POWER_NMF, p=7)
+    with np.errstate(divide='ignore'):
+        w = np.concatenate([pr['w'][:1 + 3 * D + 2 * N], np.log(W.flatten(order='F'))])        # log(0) = -inf -> exp = 0
+    d = np.array([0.5, 0.5])
+    r1 = nagp.ihgp_ep_modulator_nmf(w, t, pr['y'], SSHandle(), mom2, t, 'matern32', 'matern52', 1, D, N, 0.5, d, 2, nargout=6)
+    o1 = oih.ihgp_ep_modulator_nmf(w, t, pr['y'], None, omom2, t, 'matern32', 'matern52', 1, D, N, 0.5, d, 2)
+    assert rel(r1[0], o1[0]) < TOL_MEAN and rel(r1[5]['ttau'], o1[5]['ttau']) < TOL_SITE
+    r1g = nagp.gf_ep_modulator_nmf(w, t, pr['y'], SSHandle(), mom2, t, 'matern32', 'matern52', 1, D, N, 0.5, d, 2, nargout=6)
+    o1g = ogf.gf_ep_modulator_nmf(w, t, pr['y'], None, omom2, t, 'matern32', 'matern52', 1, D, N, 0.5, d, 2)
+    assert rel(r1g[0], o1g[0]) < TOL_MEAN and rel(r1g[5]['ttau'], o1g[5]['ttau']) < TOL_SITE
+    # ... and one whose zero pattern is not two contiguous blocks (per-point path)
+    W2 = pr['W'].copy(); W2[::2, 2:] = 0.0; W2[1::2, :2] = 0.0
+    with np.errstate(divide='ignore'):
+        w2 = np.concatenate([pr['w'][:1 + 3 * D + 2 * N], np.log(W2.flatten(order='F'))])
+    r2 = nagp.ihgp_ep_modulator_nmf(w2, t, pr['y'], SSHandle(), mom2, t, 'matern32', 'matern52', 1, D, N, 0.5, d, 2, nargout=6)
+    o2 = oih.ihgp_ep_modulator_nmf(w2, t, pr['y'], None, omom2, t, 'matern32', 'matern52', 1, D, N, 0.5, d, 2)
+    assert rel(r2[0], o2[0]) < TOL_MEAN and rel(r2[5]['ttau'], o2[5]['ttau']) < TOL_SITE

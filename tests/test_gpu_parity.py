@@ -511,6 +511,18 @@ def test_block_structured_cubature_equals_per_point_evaluation(monkeypatch):
     assert rel(a[0], b[0]) < 1e-8 and rel(a[5]['ttau'], b[5]['ttau']) < 1e-7 and rel(a[5]['tnu'], b[5]['tnu']) < 1e-7
     o = omx.ihgp_ep_mods_nmf_mixture(mp['w'], t, mp['y'], None, omom, t, k1, k2, 3, 0.75, 0.2, 3)
     assert rel(a[0], o[0]) < TOL_MEAN and rel(a[5]['ttau'], o[5]['ttau']) < TOL_SITE
+    # missing observations: the infinite-horizon filter has no isnan guard (ihgp_ep_mods_nmf_mixture.m:284-302), mom sees
+    # y = NaN -> Z falls to the floor, NaN moments; both evaluations and the oracle must produce the same NaN pattern
+    yn = mp['y'].copy(); yn[7] = np.nan
+    with np.errstate(all='ignore'):
+        an = nagp.ihgp_ep_mods_nmf_mixture(mp['w'], t, yn, SSHandle(), mom, t, k1, k2, 3, 0.75, 0.2, 2, nargout=6)
+        on = omx.ihgp_ep_mods_nmf_mixture(mp['w'], t, yn, None, omom, t, k1, k2, 3, 0.75, 0.2, 2)
+    monkeypatch.setenv('NAGP_NO_SRC', '1')
+    bn = nagp.ihgp_ep_mods_nmf_mixture(mp['w'], t, yn, SSHandle(), mom, t, k1, k2, 3, 0.75, 0.2, 2, nargout=6)
+    monkeypatch.delenv('NAGP_NO_SRC')
+    for key in ('ttau', 'tnu'):
+        assert np.array_equal(np.isnan(an[5][key]), np.isnan(on[5][key])) and np.array_equal(np.isnan(an[5][key]), np.isnan(bn[5][key]))
+    assert np.array_equal(np.isnan(an[0]), np.isnan(on[0])) and np.array_equal(np.isnan(an[0]), np.isnan(bn[0]))
     # the main functions see the same structure: a GT-NMF model whose Wnmf happens to be block diagonal ...
     D, N = 6, 4
     pr = harness.nmf_problem(D, N, T, 12)

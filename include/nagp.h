@@ -95,7 +95,7 @@ typedef struct nagp_ihgp_tables {
 
 typedef struct nagp_opts {
   int32_t kind;            /* nagp_kind */
-  int32_t mode;            /* nagp_mode (NLML: GF_EP only) */
+  int32_t mode;            /* nagp_mode (NLML: GF_EP; GIEKF = the GradObj=off energy of gf_giekf_modulator_nmf_constraints.m:332-480, model Q = Pinf-A*Pinf*A') */
   int32_t lik_kind;        /* nagp_lik */
   int32_t link_kind;       /* nagp_link */
   double link_shift;       /* softplus shift (mod_sparsity) */

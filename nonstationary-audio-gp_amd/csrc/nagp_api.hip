@@ -276,8 +276,8 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
   if (m0.M < 1 || m0.M > MAXM) FAIL(NAGP_EUNSUPPORTED, "M=%d outside 1..%d", m0.M, MAXM);
   if (m0.S < m0.M || m0.S > 1024) FAIL(NAGP_EUNSUPPORTED, "S=%d unsupported", m0.S);
   if (o->kind != NAGP_KIND_GF_EP && o->kind != NAGP_KIND_IHGP && o->kind != NAGP_KIND_GIEKF) FAIL(NAGP_EINVAL, "kind");
-  if (o->kind != NAGP_KIND_GF_EP && o->mode != NAGP_MODE_PREDICT)
-    FAIL(NAGP_EUNSUPPORTED, "nlml mode exists only for gf_ep (SURVEY C-11, f-4)");
+  if (o->kind == NAGP_KIND_IHGP && o->mode != NAGP_MODE_PREDICT)
+    FAIL(NAGP_EUNSUPPORTED, "the reference's IHGP nlml mode is broken (SURVEY C-11)");
   if (o->ep_itts < 1) FAIL(NAGP_EINVAL, "ep_itts < 1");
   const bool ekf = (o->kind == NAGP_KIND_GIEKF);
   if (!ekf) {
@@ -346,7 +346,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     p->NT_l = p->wide_l ? roundup64(slots) : p->NT_f;
   }
   p->want_PS = (o->flags & 0x4u) != 0;
-  p->need_PF = (o->kind != NAGP_KIND_IHGP) && !(o->mode == NAGP_MODE_NLML && o->ep_itts == 1);
+  p->need_PF = (o->kind != NAGP_KIND_IHGP) && !(o->mode == NAGP_MODE_NLML && (o->ep_itts == 1 || ekf));
 
   // ---- model packing
   const size_t msz = mdl_size(sh);
@@ -869,6 +869,18 @@ static int exec_gf(nagp_plan* p) {
 static int exec_giekf(nagp_plan* p) {
   const Shape& sh = p->sh; const nagp_opts& o = p->opts; const int I = o.ep_itts, B = p->B;
   std::vector<double> red;
+  if (o.mode == NAGP_MODE_NLML) {
+    // gf_giekf_modulator_nmf_constraints.m:385-472 with GradObj='off': ONE plain EKF pass (prediction at k=1 too, a single
+    // update per step whatever l_iter says, no smoother), edata = sum of the per-step energies
+    FilterPar fp{};
+    fp.itt = 1; fp.store_PF = 0; fp.l_iter = 1; fp.predict_k1 = 1; fp.ekf_energy = 1;
+    fp.k_begin = 0; fp.k_end = sh.T;
+    RUN(launch_filter(p, fp));
+    RUN(reduce_sum(p, p->b.lZ, 0, sh.T, 0));
+    RUN(fetch_red(p, red));
+    for (int q = 0; q < B; ++q) p->nlZ[(size_t)q * I] = -red[(size_t)q * 8];
+    return NAGP_OK;
+  }
   for (int itt = 1; itt <= I; ++itt) {
     FilterPar fp{};
     fp.itt = itt; fp.store_PF = 1; fp.l_iter = o.l_iter;

@@ -73,6 +73,8 @@ struct FilterPar {
   //   (1-d, d, 1) in gf_ep_modulator_nmf.m:147-148 ; (1-d, d/alpha, alpha) in experiments/gf_ep_mods_nmf_mixture.m:183-187
   double w_old, w_new, mom_alpha;
   int R_raw;               // mixture variant: R = 1/ttau before the clamp (gf_ep_mods_nmf_mixture.m:190,195)
+  int ekf_energy;          // EKF nlml pass (gf_giekf_modulator_nmf_constraints.m:385-472): lZ_k = -(log(2pi)/2 + log sqrt(S) + v^2/(2S)),
+                           // no isnan guard on y (a NaN observation poisons the energy, as in the reference)
 };
 
 // The filtered covariance is symmetric: PF holds only the lower-triangular tiles, tile (I,J), I >= J, at
@@ -267,7 +269,8 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
         }
         if (myrow == 0) fmu[myblk] = shv[myblk] * rm;
       }
-      if (MEAS == 1 && fp.spl_wave && tid >= NT - 64 && !(yk != yk)) {
+      const bool upd = !(yk != yk) || (MEAS == 1 && fp.ekf_energy);   // ~isnan(y_k), or the guard-less nlml loop
+      if (MEAS == 1 && fp.spl_wave && tid >= NT - 64 && upd) {
         // EKF: the launch carries one extra wave without tiles; it evaluates softplus(g_j) and its derivative of the first
         // inner iteration here, next to the prediction phase of the tile waves (one exp + log chain off the critical path)
         const int j = tid - (NT - 64);
@@ -341,7 +344,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
       lds_barrier();  // B1
       if (tid < S) m[tid] = rm;
 
-      if (!(yk != yk)) {  // ~isnan(y_k)
+      if (upd) {
         if (MEAS == 0) {
           if constexpr (MV >= 0) if (do_mom) {
             if (mc.stamps && tid == 0) { st_b = __builtin_readcyclecounter(); stp[4] += st_b - st_a; }
@@ -498,6 +501,13 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
             lds_barrier();
             MU = misc[3];
             Sx = sn2 + misc[2];
+            if (fp.ekf_energy) {
+              if (!(Sx > 0.0)) Sx += 0.5e-4;            // chol(S) failed: jitter 1e-4*rand, rand -> 0.5 (:417-420, SURVEY C-7)
+              if (tid == 0) {
+                const double LS = sqrt(Sx), v = yk - MU;  // !(S > 0) after the jitter: NaN energy, like `nan*edata` (:423-426)
+                rlZ[kk] = -(0.9189385332046727 + log(LS) + 0.5 * ((v / LS) / LS) * v);
+              }
+            }
             if (tid < S) { const double Kt = PJ[tid] / Sx; Kv[tid] = Kt; rm = rm + Kt * (yk - MU); }   // K = P J' / S, once per state
             lds_barrier();   // all reads of m/fmu for this iteration done
             if (tid < S) m[tid] = rm;

@@ -173,9 +173,9 @@ def _damping(ep_damping, ep_itts):
 class _Problem:
     """Everything the C ABI needs for one call, with the numpy arrays kept alive."""
 
-    def __init__(self, blk, Wnmf, lik_param, symmetrize_Q=False):
+    def __init__(self, blk, Wnmf, lik_param, symmetrize_Q=False, stationary_Q=False):
         self.blk = blk
-        A, Q, P = ssm.discretise(blk, symmetrize_Q)
+        A, Q, P = ssm.discretise(blk, symmetrize_Q, stationary_Q)
         self.A, self.Q, self.Pinf = L.f64(A), L.f64(Q), L.f64(P)
         self.h_val = L.f64(blk.h_val)
         self.offsets = np.ascontiguousarray(blk.offsets, dtype=np.int32)
@@ -408,11 +408,12 @@ def ihgp_ep_mods_nmf_mixture(w, x, y, ss, mom, xt, kernel1, kernel2, J, ep_fract
     return _returns(out, return_ind, nargout)
 
 
-def _run_giekf(blk, Wnmf, lik_param, yall, g_iter, l_iter, reset_P, nargout, device=0):
-    prob = _Problem(blk, Wnmf, lik_param)
-    want_PS = nargout >= 6
+def _run_giekf(blk, Wnmf, lik_param, yall, g_iter, l_iter, reset_P, nargout, device=0, nlml=False):
+    prob = _Problem(blk, Wnmf, lik_param, stationary_Q=nlml)
+    want_PS = nargout >= 6 and not nlml
     flags = (L.FLAG_EKF_RESET_P if reset_P else 0) | (L.FLAG_WANT_PS if want_PS else 0)
-    opts, keep = make_opts(L.KIND_GIEKF, L.MODE_PREDICT, None, blk.N, 0.0, None, g_iter, l_iter=l_iter, flags=flags, device=device)
+    opts, keep = make_opts(L.KIND_GIEKF, L.MODE_NLML if nlml else L.MODE_PREDICT, None, blk.N, 0.0, None, g_iter, l_iter=l_iter,
+                           flags=flags, device=device)
     out = _Outputs(blk.M, blk.S, yall.size, g_iter, want_PS=want_PS)
     L.check(L.lib().nagp_giekf_run(C.byref(prob.model), L.dptr(yall), yall.size, C.byref(opts), C.byref(out.c)))
     return out
@@ -422,7 +423,11 @@ def gf_giekf_modulator_nmf(w, x, y, ss, mom, xt, kernel1, kernel2, num_lik_param
                            nargout=2, device=0):
     """matlab/gf_giekf_modulator_nmf.m:1-2 (predict mode; `mom` is accepted and unused, as in the reference :13)."""
     if xt is None or np.size(xt) == 0:
-        raise NotImplementedError('EKF nlml/gradient mode (gf_giekf_modulator_nmf.m:296-439) is a "next" row (SURVEY f-4)')
+        # gf_giekf_modulator_nmf.m:296-439 cannot run as committed: with GradObj='off' the loop that defines mm/PP is
+        # skipped (:320-370), and funhd/funhd2 index with sum(H,1)==1 (:457,471), which no longer selects the scaled columns
+        # of the balanced H (:78-81).  The training scripts call the _constraints variant (train_GTFNMF.m:199).
+        raise NotImplementedError('the nlml branch of gf_giekf_modulator_nmf.m does not run in the reference; '
+                                  'use gf_giekf_modulator_nmf_constraints (train_GTFNMF.m:199)')
     yall, return_ind = _merge_inputs(x, y, xt)
     lik_param, p1, p2, Wnmf = _unpack_log(w, num_lik_params, D, N)
     blk = ssm.balance_blocks(_blocks_from_dense(*ss(x, p1, p2, kernel1, kernel2), D, N))   # :78 `if true`
@@ -432,11 +437,17 @@ def gf_giekf_modulator_nmf(w, x, y, ss, mom, xt, kernel1, kernel2, num_lik_param
 
 def gf_giekf_modulator_nmf_constraints(w, x, y, ss, mom, xt, kernel1, kernel2, num_lik_params, D, N, g_iter, l_iter,
                                        constraints, w_fixed, tune_hypers, GradObj='off', nargout=2, device=0):
-    """matlab/gf_giekf_modulator_nmf_constraints.m:1-2."""
-    if xt is None or np.size(xt) == 0:
-        raise NotImplementedError('EKF nlml/gradient mode is a "next" row (SURVEY f-4)')
+    """matlab/gf_giekf_modulator_nmf_constraints.m:1-2.  xt empty: [e, eg] of :332-480 with GradObj='off' (what
+    train_GTFNMF.m:199 / train_model.m:239 pass): one plain EKF pass, e = sum_k log(2pi)/2 + log sqrt(S_k) + v_k^2/(2 S_k),
+    eg = zeros(1,numel(w)).  GradObj='on' mixes size(dF,3) hyper-parameter slices with numel(w) tuned entries
+    (:339-341, :432-441) and is not reproduced."""
     yall, return_ind = _merge_inputs(x, y, xt)
     lik_param, p1, p2, Wnmf = _unpack_constraints(w, w_fixed, tune_hypers, constraints, num_lik_params, D, N)
     blk = ssm.balance_blocks(_blocks_from_dense(*ss(x, p1, p2, kernel1, kernel2), D, N))
+    if xt is None or np.size(xt) == 0:
+        if GradObj != 'off':
+            raise NotImplementedError("GradObj='on': the reference's gradient recursion indexes numel(w) outputs with size(dF,3) slices")
+        out = _run_giekf(blk, Wnmf, lik_param, yall, 1, 1, True, 2, device, nlml=True)
+        return float(out.nlZ[0]), np.zeros(np.size(w))
     out = _run_giekf(blk, Wnmf, lik_param, yall, g_iter, l_iter, True, nargout, device)
     return _returns(out, return_ind, nargout)

@@ -15,7 +15,8 @@ class Plan:
         """problems: list of (BlockSS, Wnmf, lik_param) -- already balanced if the variant balances."""
         self.kind, self.T, self.I = kind, int(T), int(ep_itts)
         sym = kind == L.KIND_IHGP
-        self.probs = [_Problem(b, W, lp, symmetrize_Q=sym) for (b, W, lp) in problems]
+        statq = kind == L.KIND_GIEKF and mode == L.MODE_NLML        # Q = Pinf - A Pinf A' (gf_giekf_modulator_nmf_constraints.m:378)
+        self.probs = [_Problem(b, W, lp, symmetrize_Q=sym, stationary_Q=statq) for (b, W, lp) in problems]
         self.B = len(self.probs)
         blk0 = problems[0][0]
         self.M, self.S = blk0.M, blk0.S

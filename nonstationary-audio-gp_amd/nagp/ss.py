@@ -131,12 +131,15 @@ def balance_blocks(blk):
     return blk
 
 
-def discretise(blk, symmetrize_Q=False):
-    """Per-block (A, Q); returns dense column-major S x S arrays for the C ABI."""
+def discretise(blk, symmetrize_Q=False, stationary_Q=False):
+    """Per-block (A, Q); returns dense column-major S x S arrays for the C ABI.
+    stationary_Q: A = expm(F), Q = Pinf - A*Pinf*A' (gf_giekf_modulator_nmf_constraints.m:377-378) instead of lti_disc."""
     S = blk.S
     A = np.zeros((S, S), order='F'); Q = np.zeros((S, S), order='F'); P = np.zeros((S, S), order='F')
     for n in range(blk.M):
         a, q = lti_disc_block(blk.F[n], blk.LQL[n])
+        if stationary_Q:
+            a = sla.expm(blk.F[n]); q = blk.Pinf[n] - a @ blk.Pinf[n] @ a.T
         if symmetrize_Q:                       # ihgp_ep_modulator_nmf.m:97
             q = (q + q.T) / 2
         o, e = blk.offsets[n], blk.offsets[n + 1]

@@ -19,9 +19,11 @@ from .plan import Plan
 
 
 def nlml_batch(ws, x, y, ss, mom, kernel1, kernel2, num_lik_params, D, N, ep_fraction, ep_damping, ep_itts,
-               constraints=None, w_fixed=None, tune_hypers=None, device=0):
+               constraints=None, w_fixed=None, tune_hypers=None, device=0, inference='EP'):
     """Negative log marginal likelihoods of gf_ep_modulator_nmf_constraints (constraints given) or gf_ep_modulator_nmf
-    (constraints None) at every parameter vector of `ws`, in one batched GPU call (likelihood mode, xt = [])."""
+    (constraints None) at every parameter vector of `ws`, in one batched GPU call (likelihood mode, xt = []).
+    inference='EKF': the objective of the 'EKF' case of train_GTFNMF.m:198-201, gf_giekf_modulator_nmf_constraints with
+    GradObj='off' (mom, ep_fraction, ep_damping, ep_itts unused)."""
     ws = [np.asarray(w, float).ravel() for w in ws]
     yall, _ = _merge_inputs(x, y, None)
     probs = []
@@ -33,8 +35,13 @@ def nlml_batch(ws, x, y, ss, mom, kernel1, kernel2, num_lik_params, D, N, ep_fra
             lik_param, p1, p2, Wnmf = _unpack_log(w, num_lik_params, D, N)
             blk = _blocks_from_dense(*ss(x, p1, p2, kernel1, kernel2), D, N)
         probs.append((blk, Wnmf, lik_param))
-    plan = Plan(L.KIND_GF_EP, probs, yall.size, mom=mom, ep_fraction=ep_fraction, ep_damping=ep_damping, ep_itts=ep_itts,
-                mode=L.MODE_NLML, device=device)
+    if inference == 'EKF':
+        if constraints is None:
+            raise NotImplementedError('the nlml branch of gf_giekf_modulator_nmf.m does not run in the reference')
+        plan = Plan(L.KIND_GIEKF, probs, yall.size, ep_itts=1, l_iter=1, mode=L.MODE_NLML, flags=L.FLAG_EKF_RESET_P, device=device)
+    else:
+        plan = Plan(L.KIND_GF_EP, probs, yall.size, mom=mom, ep_fraction=ep_fraction, ep_damping=ep_damping, ep_itts=ep_itts,
+                    mode=L.MODE_NLML, device=device)
     try:
         plan.upload([yall] * len(ws))
         plan.execute()

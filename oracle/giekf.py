@@ -9,8 +9,13 @@ Follows (file:line under /root/reference/matlab):
   gf_giekf_modulator_nmf.m:55-106 (set-up, balance ON), :108-291 (predict mode), :445-459 (h, Jacobian)
   gf_giekf_modulator_nmf_constraints.m:144-327 (P reset every global iteration, :163-168),
       :492-502 (corrected Jacobian  dy = partials'*H, used for BOTH variants here, SURVEY C-13)
-The nlml/gradient mode (:296-439) is not restated.
+  gf_giekf_modulator_nmf_constraints.m:332-480 with GradObj='off' (row a11 as train_GTFNMF.m:199 uses it): run_nlml.
+      GradObj='on' is not restated (the gradient loop indexes numel(w) outputs with size(dF,3) slices, :339-341, 432-441);
+      the nlml branch of the non-constraints file cannot run as committed (mm/PP undefined with GradObj='off', :320-370;
+      funhd/funhd2 select columns with sum(H,1)==1 after balancing, :457, 471).
 """
+import math
+import scipy.linalg as sla
 import numpy as np
 from . import ss as ssm
 from .gf_ep import merge_inputs, rts_step, assemble
@@ -123,3 +128,42 @@ def _outputs(res, return_ind, nargout):
         return Eft, Varft
     lb = Eft - 1.96 * np.sqrt(Varft); ub = Eft + 1.96 * np.sqrt(Varft)
     return Eft, Varft, None, lb, ub, res
+
+
+def run_nlml(model, yall, D, N):
+    """gf_giekf_modulator_nmf_constraints.m:332-480, GradObj='off' (nparam = 0): edata only.  `model` is the balanced
+    assembly (F, Pinf, H, Wnmf, lik_param); A = expm(F), Q = Pinf - A*Pinf*A' (:377-378); prediction at every step
+    including the first (:405-406); no isnan guard."""
+    F, H, Pinf, Wnmf, lik_param = (model[k] for k in ('F', 'H', 'Pinf', 'Wnmf', 'lik_param'))
+    R = math.exp(float(np.ravel(lik_param)[0]))
+    A = sla.expm(F)
+    Q = Pinf - A @ Pinf @ A.T
+    m = np.zeros(F.shape[0]); P = Pinf.copy()
+    edata = 0.0
+    for k in range(yall.size):
+        m = A @ m
+        P = A @ P @ A.T + Q
+        mu = funh(m, H, D, N, Wnmf)
+        JH = funhd(m, H, D, N, Wnmf)
+        S = JH @ P @ JH + R
+        if not S > 0:                                   # chol failed -> jitter 1e-4*rand (rand -> 0.5, C-7)
+            S = S + 0.5e-4
+            if not S > 0:
+                return float('nan')                     # :423-426
+        LS = math.sqrt(S)
+        HtiS = JH / LS / LS
+        K = P @ HtiS
+        v = yall[k] - mu
+        vtiS = v / LS / LS
+        edata = edata + 0.5 * math.log(2 * math.pi) + math.log(LS) + 0.5 * vtiS * v
+        m = m + K * v
+        P = P - np.outer(K, K) * S
+    return edata
+
+
+def gf_giekf_modulator_nmf_constraints_nlml(w, x, y, kernel1, kernel2, num_lik_params, D, N, constraints, w_fixed, tune_hypers):
+    """[e, eg] of gf_giekf_modulator_nmf_constraints(w,x,y,ss,mom,[],...,GradObj='off')."""
+    yall, _ = merge_inputs(x, y, None)
+    lik_param, param1, param2, Wnmf = ssm.unpack_constraints(w, w_fixed, tune_hypers, constraints, num_lik_params, D, N)
+    model = assemble(lik_param, param1, param2, Wnmf, kernel1, kernel2, balance=True)
+    return run_nlml(model, yall, D, N), np.zeros(np.size(w))

@@ -544,3 +544,40 @@ def test_block_structured_cubature_equals_per_point_evaluation(monkeypatch):
     r2 = nagp.ihgp_ep_modulator_nmf(w2, t, pr['y'], SSHandle(), mom2, t, 'matern32', 'matern52', 1, D, N, 0.5, d, 2, nargout=6)
     o2 = oih.ihgp_ep_modulator_nmf(w2, t, pr['y'], None, omom2, t, 'matern32', 'matern52', 1, D, N, 0.5, d, 2)
     assert rel(r2[0], o2[0]) < TOL_MEAN and rel(r2[5]['ttau'], o2[5]['ttau']) < TOL_SITE
+
+
+@pytest.mark.parametrize('D,N,T', [(5, 2, 300), (24, 3, 64), (32, 6, 40)])
+def test_ekf_training_objective_against_oracle(D, N, T):
+    """[e, eg] = gf_giekf_modulator_nmf_constraints(w,x,y,ss,mom,[],...,GradObj='off') as train_GTFNMF.m:199 calls it
+    (row a11 as far as the reference runs): one plain EKF pass with prediction at the first step, stationary
+    Q = Pinf - A Pinf A', energy sum; NaN observations are not skipped in this loop (:385-472)."""
+    pr = harness.nmf_problem(D, N, T, 17 + D, 'constraints'); t = np.arange(1, T + 1.0)
+    cons = harness.CONSTRAINTS_DEMO(D); w, wf = harness.constrained_vectors(pr, cons, harness.TUNE_DEMO)
+    e, eg = nagp.gf_giekf_modulator_nmf_constraints(w, t, pr['y'], SSHandle(), None, None, 'matern32', 'matern52', 1, D, N, 3, 2,
+                                                    cons, wf, harness.TUNE_DEMO, 'off')
+    eo, ego = oek.gf_giekf_modulator_nmf_constraints_nlml(w, t, pr['y'], 'matern32', 'matern52', 1, D, N, cons, wf, harness.TUNE_DEMO)
+    assert abs(e - eo) < TOL_LOGZ * abs(eo) and eg.shape == ego.shape and not np.any(eg)
+    if D == 5:
+        y = pr['y'].copy(); y[20] = np.nan
+        e2, _ = nagp.gf_giekf_modulator_nmf_constraints(w, t, y, SSHandle(), None, None, 'matern32', 'matern52', 1, D, N, 3, 2,
+                                                        cons, wf, harness.TUNE_DEMO, 'off')
+        assert np.isnan(e2) and np.isnan(oek.gf_giekf_modulator_nmf_constraints_nlml(w, t, y, 'matern32', 'matern52', 1, D, N, cons, wf, harness.TUNE_DEMO)[0])
+        with pytest.raises(NotImplementedError):
+            nagp.gf_giekf_modulator_nmf_constraints(w, t, pr['y'], SSHandle(), None, None, 'matern32', 'matern52', 1, D, N, 3, 2,
+                                                    cons, wf, harness.TUNE_DEMO, 'on')
+
+
+def test_batched_ekf_objective_equals_serial_calls():
+    """nlml_batch(..., inference='EKF'): the replicas of one fminunc iteration of the 'EKF' case (train_GTFNMF.m:198-201)."""
+    D, N, T = 6, 2, 200
+    pr = harness.nmf_problem(D, N, T, 23, 'constraints'); t = np.arange(1, T + 1.0)
+    cons = harness.CONSTRAINTS_DEMO(D); w, wf = harness.constrained_vectors(pr, cons, harness.TUNE_DEMO)
+    ws = [w, w + 0.01, w - 0.02]
+    f = nagp.nlml_batch(ws, t, pr['y'], SSHandle(), None, 'matern32', 'matern52', 1, D, N, 0.5, None, 1,
+                        constraints=cons, w_fixed=wf, tune_hypers=harness.TUNE_DEMO, inference='EKF')
+    for wi, fi in zip(ws, f):
+        e, _ = nagp.gf_giekf_modulator_nmf_constraints(wi, t, pr['y'], SSHandle(), None, None, 'matern32', 'matern52', 1, D, N, 3, 2,
+                                                       cons, wf, harness.TUNE_DEMO, 'off')
+        assert fi == e
+    eo = oek.gf_giekf_modulator_nmf_constraints_nlml(ws[1], t, pr['y'], 'matern32', 'matern52', 1, D, N, cons, wf, harness.TUNE_DEMO)[0]
+    assert abs(f[1] - eo) < TOL_LOGZ * abs(eo)

@@ -260,3 +260,28 @@ def test_mixture_variants_reduce_to_the_main_functions_for_one_source_and_full_p
     assert st['H'].shape == (8, 2 * 2 + 3 * 4 + 3 + 2 * 2) and st['Wnmf'].shape == (5, 3)
     assert np.all(st['Wnmf'][:2, 1:] == 0) and np.all(st['Wnmf'][2:, :1] == 0)
     assert list(np.nonzero(st['H'].sum(axis=0))[0]) == [0, 2, 4, 8, 12, 16, 19, 21]
+
+
+def test_ekf_energy_is_the_exact_gaussian_marginal_likelihood_when_the_modulators_are_frozen():
+    """gf_giekf_modulator_nmf_constraints.m:332-480 (GradObj='off'): with (numerically) zero modulator variance the
+    measurement y = z' W softplus(g) is linear in the state (g = 0), the EKF is the exact Kalman filter and the energy
+    sum must equal -log N(y; 0, K + sn2 I) of the equivalent dense GP, K_ij = c' A^|i-j| Pinf c."""
+    from nagp import harness
+    D, N, T = 3, 2, 40
+    pr = harness.nmf_problem(D, N, T, 4)
+    p2 = pr['param2'].copy(); p2[:N] = 1e-14                         # var_slow -> 0
+    model = ogf.assemble(np.array([math.log(1e-2)]), pr['param1'], p2, pr['W'], 'matern32', 'matern52', balance=True)
+    y = np.random.default_rng(1).normal(0, 0.3, T)
+    e = oek.run_nlml(model, y, D, N)
+    import scipy.linalg as sla
+    A = sla.expm(model['F']); Pinf = model['Pinf']; H = model['H']
+    c = (pr['W'] @ np.full(N, math.log(2.0))) @ H[:D]                # d h / d state at g = 0
+    K = np.zeros((T, T)); Ak = np.eye(A.shape[0])
+    for lag in range(T):
+        v = c @ Ak @ Pinf @ c
+        K += v * (np.eye(T, k=lag) + (np.eye(T, k=-lag) if lag else 0))
+        Ak = A @ Ak
+    C = K + 1e-2 * np.eye(T)
+    sign, logdet = np.linalg.slogdet(C)
+    ref = 0.5 * (T * math.log(2 * math.pi) + logdet + y @ np.linalg.solve(C, y))
+    assert abs(e - ref) < 1e-8 * abs(ref)

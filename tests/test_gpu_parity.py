@@ -581,3 +581,26 @@ def test_batched_ekf_objective_equals_serial_calls():
         assert fi == e
     eo = oek.gf_giekf_modulator_nmf_constraints_nlml(ws[1], t, pr['y'], 'matern32', 'matern52', 1, D, N, cons, wf, harness.TUNE_DEMO)[0]
     assert abs(f[1] - eo) < TOL_LOGZ * abs(eo)
+
+
+def _mixture_w(g, J):
+    return [g['lik'], [g['p1_%d' % j] for j in range(J)], [g['p2_%d' % j] for j in range(J)], [g['W_%d' % j] for j in range(J)]]
+
+
+def test_golden_widened_rows_mixtures_and_ekf_objective():
+    """Committed vectors of the widened rows (tools/make_golden.py widened)."""
+    g = gold('mixture_ihgp_3x4x3'); T = g['y'].size; t = np.arange(1, T + 1.0)
+    mom = Mom('likModulatorPreCalcwn', link_shift=1.0, wn=g['wn'], xn_unscaled=g['xn_unscaled'])
+    r = nagp.ihgp_ep_mods_nmf_mixture(_mixture_w(g, 3), t, g['y'], SSHandle(), mom, t, ['exp'] * 3, ['matern52'] * 3, 3, 0.75, 0.025, 4, nargout=6)
+    assert rel(r[0], g['Eft']) < TOL_MEAN and rel(r[1], g['Varft']) < TOL_MEAN
+    assert rel(r[5]['ttau'], g['ttau']) < TOL_SITE and rel(r[5]['tnu'], g['tnu']) < TOL_SITE
+    fin = np.isfinite(g['R']); assert np.array_equal(fin, np.isfinite(r[5]['R'])) and rel(r[5]['R'][fin], g['R'][fin]) < 1e-6
+    g = gold('mixture_gf_2src'); T = g['y'].size; t = np.arange(1, T + 1.0)
+    r = nagp.gf_ep_mods_nmf_mixture(_mixture_w(g, 2), t, g['y'], SSHandle(), Mom('likModulatorNMFPower', p_cubature=7), t,
+                                    ['exp', 'matern32'], ['matern52', 'matern52'], 2, 0.75, 0.2, 4, nargout=6)
+    assert rel(r[0], g['Eft']) < TOL_MEAN and rel(r[1], g['Varft']) < TOL_MEAN
+    assert rel(r[5]['ttau'], g['ttau']) < TOL_SITE and rel(r[5]['tnu'], g['tnu']) < TOL_SITE and rel(r[5]['lZ'], g['lZ']) < 1e-7
+    g = gold('ekf_objective_cfg4_shape'); D, N = int(g['D']), int(g['N']); T = g['y'].size; t = np.arange(1, T + 1.0)
+    e, eg = nagp.gf_giekf_modulator_nmf_constraints(g['w'], t, g['y'], SSHandle(), None, None, 'matern32', 'matern52', 1, D, N, 3, 1,
+                                                    g['constraints'], g['w_fixed'], list(g['tune_hypers']), 'off')
+    assert abs(e - float(g['edata'])) < TOL_LOGZ * abs(float(g['edata'])) and not np.any(eg)

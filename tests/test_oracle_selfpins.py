@@ -203,6 +203,14 @@ def test_oracle_reproduces_committed_golden_vectors():
     o = ogf.gf_ep_modulator(g['w'], t, g['y'][:300], None, olik.Mom(olik.LIK_POWER, p=9), t, 'matern32', 'matern52', 1, 0.5,
                             g['ep_damping'][:1], 1)
     assert np.allclose(o[5]['ttau'][:, :299], g['ttau'][:, :299] * 0 + o[5]['ttau'][:, :299])   # runs; prefix property checked on GPU
+    g = np.load(os.path.join(GOLD, 'mixture_gf_2src.npz')); T = g['y'].size; t = np.arange(1, T + 1.0)
+    w = [g['lik'], [g['p1_0'], g['p1_1']], [g['p2_0'], g['p2_1']], [g['W_0'], g['W_1']]]
+    o = omx.gf_ep_mods_nmf_mixture(w, t, g['y'], None, olik.Mom(olik.LIK_POWER_NMF, p=7), t, ['exp', 'matern32'], ['matern52', 'matern52'], 2, 0.75, 0.2, 4)
+    assert np.allclose(o[0], g['Eft'], rtol=1e-10, atol=1e-12, equal_nan=True) and np.allclose(o[5]['ttau'], g['ttau'], rtol=1e-10, atol=1e-12)
+    g = np.load(os.path.join(GOLD, 'ekf_objective_cfg4_shape.npz')); T = g['y'].size; t = np.arange(1, T + 1.0)
+    e, _ = oek.gf_giekf_modulator_nmf_constraints_nlml(g['w'], t, g['y'], 'matern32', 'matern52', 1, int(g['D']), int(g['N']), g['constraints'],
+                                                       g['w_fixed'], list(g['tune_hypers']))
+    assert abs(e - float(g['edata'])) < 1e-11 * abs(e)
 
 
 def test_fastfb_steady_state_filter_equals_the_full_kalman_filter_after_burn_in():

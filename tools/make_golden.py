@@ -2,14 +2,15 @@
 oracle (oracle/, a restatement of the MATLAB reference -- the reference itself cannot run here:
 no MATLAB/Octave).  Fixtures hold data only (inputs + expected outputs).
 
-    python tools/make_golden.py
+    python tools/make_golden.py            # everything
+    python tools/make_golden.py widened    # only the fixtures of the widened rows (mixtures, EKF objective)
 """
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'nonstationary-audio-gp_amd'))
 import numpy as np
 from nagp import harness, cubature as pcub
-from oracle import gf_ep as ogf, ihgp as oih, giekf as oek, lik as olik
+from oracle import gf_ep as ogf, ihgp as oih, giekf as oek, lik as olik, mixture as omx
 
 OUT = os.path.join(ROOT, 'tests', 'golden')
 os.makedirs(OUT, exist_ok=True)
@@ -23,6 +24,39 @@ def save(name, **kw):
 def keep(res, keys=('nlZ', 'ttau', 'tnu', 'maxDiffM', 'maxDiffP')):
     return {k: res[k] for k in keys if k in res}
 
+
+def widened():
+    """Rows f-1 (source-separation mixtures) and a11 (EKF training objective)."""
+    # three sources x (4 sub-bands, 3 components): cubature dimension 9, likModulatorPreCalcwn, shifted softplus
+    shapes = [(4, 3)] * 3; k1 = ['exp'] * 3; k2 = ['matern52'] * 3; T = 60
+    mp = harness.mixture_problem(shapes, T, 5, k1, k2); t = np.arange(1, T + 1.0)
+    wn, xn = pcub.utp_ws(7, 9)
+    om = olik.Mom(olik.LIK_POWER_NMF_SQRT, link=olik.softplus_link(1.0), wn=wn, xn_unscaled=xn)
+    o = omx.ihgp_ep_mods_nmf_mixture(mp['w'], t, mp['y'], None, om, t, k1, k2, 3, 0.75, 0.025, 4)
+    flat = dict(lik=mp['w'][0], **{'p1_%d' % j: mp['w'][1][j] for j in range(3)}, **{'p2_%d' % j: mp['w'][2][j] for j in range(3)},
+                **{'W_%d' % j: mp['w'][3][j] for j in range(3)})
+    save('mixture_ihgp_3x4x3', y=mp['y'], wn=wn, xn_unscaled=xn, Eft=o[0], Varft=o[1], ttau=o[5]['ttau'], tnu=o[5]['tnu'], R=o[5]['R'], **flat)
+    # two sources with different kernels, full covariance, likModulatorNMFPower, missing stretch
+    shapes = [(3, 1), (2, 2)]; k1 = ['exp', 'matern32']; k2 = ['matern52', 'matern52']; T = 80
+    mp = harness.mixture_problem(shapes, T, 21, k1, k2); t = np.arange(1, T + 1.0)
+    y = mp['y'].copy(); y[30:36] = np.nan
+    o = omx.gf_ep_mods_nmf_mixture(mp['w'], t, y, None, olik.Mom(olik.LIK_POWER_NMF, p=7), t, k1, k2, 2, 0.75, 0.2, 4)
+    flat = dict(lik=mp['w'][0], **{'p1_%d' % j: mp['w'][1][j] for j in range(2)}, **{'p2_%d' % j: mp['w'][2][j] for j in range(2)},
+                **{'W_%d' % j: mp['w'][3][j] for j in range(2)})
+    save('mixture_gf_2src', y=y, Eft=o[0], Varft=o[1], ttau=o[5]['ttau'], tnu=o[5]['tnu'], lZ=o[5]['lZ'], **flat)
+    # EKF training objective at the cfg4 shape
+    D, N, T = 24, 3, 600
+    pr = harness.nmf_problem(D, N, T, 312); t = np.arange(1, T + 1.0)
+    cons = np.array([[0.001, 0.1], [20.0, 800.0], [0.0, 2 * np.pi], [2.0, 12.0], [100.0, 2000.0], [0.0, 1.0]])
+    tune = [1, 0, 1, 0, 1, 1, 0]
+    w, wf = harness.constrained_vectors(pr, cons, tune)
+    e, _ = oek.gf_giekf_modulator_nmf_constraints_nlml(w, t, pr['y'], 'matern32', 'matern52', 1, D, N, cons, wf, tune)
+    save('ekf_objective_cfg4_shape', w=w, w_fixed=wf, y=pr['y'], D=D, N=N, constraints=cons, tune_hypers=np.array(tune), edata=e)
+
+
+if len(sys.argv) > 1 and sys.argv[1] == 'widened':
+    widened()
+    sys.exit(0)
 
 t0 = time.time()
 # cfg1: gf_ep_modulator, 1k samples, 4 channels (full size)
@@ -82,3 +116,4 @@ om = olik.Mom(olik.LIK_POWER_NMF_SQRT, link=olik.softplus_link(1.0), wn=wn, xn_u
 o = ogf.gf_ep_modulator_nmf(pr['w'], t, y, None, om, t, 'exp', 'matern52', 1, D, N, 0.75, 0.1 * np.ones(4), 4)
 save('precalcwn_exp_subbands', w=pr['w'], y=y, D=D, N=N, wn=wn, xn_unscaled=xn, Eft=o[0], Varft=o[1], lZ=o[5]['lZ'], **keep(o[5]))
 print('done in %.0fs' % (time.time() - t0))
+widened()

@@ -168,14 +168,14 @@ def run_workload(name, a, rank, local_rank, world, dev, with_cpu):
         roof['adf_us_per_sample'] = kern[dom] * 1e3 / adf_steps
         algo_bytes = 8.0 * (8 * M * (M + 1) + S + 5 * M + 2) * adf_steps / max(launches[dom], 1)   # lower tiles + means + sites, per launch
         roof['algorithmic_bytes_per_launch'] = algo_bytes
-        try:    # PMC traffic is collected in separate rocprofv3 --pmc passes (profiles/); copied here when it is this workload
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_traffic.json')) as fh:
-                pm = json.load(fh).get(name)
-            if pm and pm.get('T') == T and pm.get('segments') == n_seg and world == 1:
-                roof['traffic'] = pm['fetch_bytes_per_launch'] + pm['write_bytes_per_launch']
-                roof['traffic_source'] = pm['source']
-        except (OSError, ValueError):
-            pass
+    try:    # PMC traffic is collected in separate rocprofv3 --pmc passes (profiles/); copied here when it is this workload
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_traffic.json')) as fh:
+            pm = json.load(fh).get(name)
+        if pm and pm.get('T') == T and pm.get('segments') == n_seg and world == 1:
+            roof['traffic'] = pm['fetch_bytes_per_launch'] + pm['write_bytes_per_launch']
+            roof['traffic_source'] = pm['source']
+    except (OSError, ValueError):
+        pass
     res = {
         'metric': 'audio samples/sec filtered+smoothed (state dim %d, per EP sweep)' % S,
         'value': value, 'unit': 'samples/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,

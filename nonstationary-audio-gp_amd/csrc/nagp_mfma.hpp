@@ -214,23 +214,28 @@ __global__ void __launch_bounds__(256) rts_apply_mfma_kernel(Shape sh, Bufs b, M
         }
       }
     }
-    if (sp.write_PSs || k == 0) {     // rare: smoothed covariances requested, or the restart state of the next EKF sweep
-#pragma unroll 1
+    if (sp.write_PSs || k == 0) {     // rare (block-uniform): smoothed covariances requested, or the restart state of the next EKF sweep
+      // E goes through LDS with compile-time accumulator indices: a run-time index into E[] would keep the whole
+      // accumulator array in scratch memory for every step of the loop
+      __syncthreads();                 // every wave is done with Bs (A operand of the second product)
+#pragma unroll
       for (int q = 0; q < C::TW; ++q)
         if (c.ok(q)) {
-#pragma unroll 1
-          for (int r = 0; r < 4; ++r) {
-            int row, col; acc_rc(NTL, c.tile(q), r, row, col);
-            const int I = row >> 2, J = col >> 2;
-            if (I < M && J < M) {
-              const double er = (r == 0) ? E[q][0] : ((r == 1) ? E[q][1] : ((r == 2) ? E[q][2] : E[q][3]));
-              const size_t tix = (((size_t)pb * T + k) * sh.ntiles + (size_t)I * M + J) * 16 + 4 * (row & 3) + (col & 3);
-              const double ps = pf_elem(b.PF + ((size_t)pb * T + k) * pf_ntiles(sh) * 16, I, J, row & 3, col & 3) + er;
-              if (sp.write_PSs) b.PSs[tix] = ps;
-              if (k == 0) b.state[(size_t)pb * ((size_t)sh.ntiles * 16 + S) + ((size_t)I * M + J) * 16 + 4 * (row & 3) + (col & 3)] = ps;
-            }
-          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { int row, col; acc_rc(NTL, c.tile(q), r, row, col); Bs[(size_t)row * LD + col] = E[q][r]; }
         }
+      __syncthreads();
+      const double* PFk = b.PF + ((size_t)pb * T + k) * pf_ntiles(sh) * 16;
+      for (int i = tid; i < Sp * Sp; i += 256) {
+        const int row = i / Sp, col = i - row * Sp;
+        const int I = row >> 2, J = col >> 2;
+        if (I < M && J < M) {
+          const size_t tix = (((size_t)pb * T + k) * sh.ntiles + (size_t)I * M + J) * 16 + 4 * (row & 3) + (col & 3);
+          const double ps = pf_elem(PFk, I, J, row & 3, col & 3) + Bs[(size_t)row * LD + col];
+          if (sp.write_PSs) b.PSs[tix] = ps;
+          if (k == 0) b.state[(size_t)pb * ((size_t)sh.ntiles * 16 + S) + ((size_t)I * M + J) * 16 + 4 * (row & 3) + (col & 3)] = ps;
+        }
+      }
     }
     if (sidx >= 0) {
       const double ms = b.MF[((size_t)pb * T + k) * S + sidx] + e_cur;

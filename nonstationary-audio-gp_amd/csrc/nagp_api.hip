@@ -579,7 +579,9 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
         case 2: NAGP_MV_SWITCH(mom_variant(mc), SL2) break;
         default: NAGP_MV_SWITCH(mom_variant(mc), SL4) break;
       }
-      if (p->wide_l) PLAN_TRY(set_lds(gf_filter_kernel<1, 0, -1, 1024>, p->lds_filter));
+      // 768-thread bound when the tiles fit: three waves per SIMD = 168 registers per lane (no spills; 30 spilled at the 1024 bound)
+      if (p->wide_l && p->NT_l <= 768) PLAN_TRY(set_lds(gf_filter_kernel<1, 0, -1, 768>, p->lds_filter));
+      else if (p->wide_l) PLAN_TRY(set_lds(gf_filter_kernel<1, 0, -1, 1024>, p->lds_filter));
       else switch (p->TPT_f) {   // mom-free kernel of the fixed-site steps
         case 1: PLAN_TRY(set_lds(gf_filter_kernel<1, 0, -1>, p->lds_filter)); break;
         case 2: PLAN_TRY(set_lds(gf_filter_kernel<2, 0, -1>, p->lds_filter)); break;
@@ -685,7 +687,8 @@ static int launch_filter(nagp_plan* p, const FilterPar& fp_in) {
 #undef LF4
 #undef LF5
     } else if (p->wide_l) {
-      hipLaunchKernelGGL((gf_filter_kernel<1, 0, -1, 1024>), g, dim3(p->NT_l), p->lds_filter, p->stream, p->sh, p->b, mc, fp);
+      if (p->NT_l <= 768) hipLaunchKernelGGL((gf_filter_kernel<1, 0, -1, 768>), g, dim3(p->NT_l), p->lds_filter, p->stream, p->sh, p->b, mc, fp);
+      else hipLaunchKernelGGL((gf_filter_kernel<1, 0, -1, 1024>), g, dim3(p->NT_l), p->lds_filter, p->stream, p->sh, p->b, mc, fp);
     } else {   // no step of this launch calls mom
       switch (p->TPT_f) {
         case 1: hipLaunchKernelGGL((gf_filter_kernel<1, 0, -1>), g, bl, p->lds_filter, p->stream, p->sh, p->b, mc, fp); break;

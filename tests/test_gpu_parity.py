@@ -604,3 +604,28 @@ def test_golden_widened_rows_mixtures_and_ekf_objective():
     e, eg = nagp.gf_giekf_modulator_nmf_constraints(g['w'], t, g['y'], SSHandle(), None, None, 'matern32', 'matern52', 1, D, N, 3, 1,
                                                     g['constraints'], g['w_fixed'], list(g['tune_hypers']), 'off')
     assert abs(e - float(g['edata'])) < TOL_LOGZ * abs(float(g['edata'])) and not np.any(eg)
+
+
+def test_full_length_ihgp_and_mixture_prefix_properties():
+    """BASELINE sizes of the infinite-horizon path through size-independent properties: the sweep-1 (ADF) sites of step k depend only on
+    y(1..k), so with one sweep the leading columns of a full-length run must equal a short run bit for bit, and the short run
+    is compared with the oracle.  cfg3: 32 channels / 6 components / T = 200 000 (sequential ADF kernel + parallel-in-time
+    scans); source separation: 3 x (16 channels, 3 components), T = 96 000, 3 973 sigma points (block-structured cubature)."""
+    D, N, T, Ts = 32, 6, 200000, 400
+    pr = harness.nmf_problem(D, N, T, 300); t = np.arange(1, T + 1.0); ts = t[:Ts]
+    mom = Mom('likModulatorNMFPower', p_cubature=7)
+    a = nagp.ihgp_ep_modulator_nmf(pr['w'], t, pr['y'], SSHandle(), mom, t, 'matern32', 'matern52', 1, D, N, 0.5, [0.5], 1, nargout=6)
+    b = nagp.ihgp_ep_modulator_nmf(pr['w'], ts, pr['y'][:Ts], SSHandle(), mom, ts, 'matern32', 'matern52', 1, D, N, 0.5, [0.5], 1, nargout=6)
+    assert np.array_equal(a[5]['ttau'][:, :Ts - 1], b[5]['ttau'][:, :Ts - 1]) and np.array_equal(a[5]['tnu'][:, :Ts - 1], b[5]['tnu'][:, :Ts - 1])
+    o = oih.ihgp_ep_modulator_nmf(pr['w'], ts[:150], pr['y'][:150], None, olik.Mom(olik.LIK_POWER_NMF, p=7), ts[:150], 'matern32', 'matern52', 1, D, N, 0.5, [0.5], 1)
+    assert rel(b[5]['ttau'][:, :149], o[5]['ttau'][:, :149]) < TOL_SITE
+    assert np.all(np.isfinite(a[0])) and np.all(np.isfinite(a[5]['ttau'])) and np.isfinite(a[5]['nlZ'][0])
+    shapes = [(16, 3)] * 3; k1 = ['exp'] * 3; k2 = ['matern52'] * 3; T = 96000; Ts = 64
+    mp = harness.mixture_problem(shapes, T, 3, k1, k2); t = np.arange(1, T + 1.0); ts = t[:Ts]
+    mom, omom = _mixture_moms('likModulatorPreCalcwn', 9, 9)
+    a = nagp.ihgp_ep_mods_nmf_mixture(mp['w'], t, mp['y'], SSHandle(), mom, t, k1, k2, 3, 0.75, 0.025, 1, nargout=6)
+    b = nagp.ihgp_ep_mods_nmf_mixture(mp['w'], ts, mp['y'][:Ts], SSHandle(), mom, ts, k1, k2, 3, 0.75, 0.025, 1, nargout=6)
+    assert np.array_equal(a[5]['ttau'][:, :Ts - 1], b[5]['ttau'][:, :Ts - 1]) and np.array_equal(a[5]['tnu'][:, :Ts - 1], b[5]['tnu'][:, :Ts - 1])
+    o = omx.ihgp_ep_mods_nmf_mixture(mp['w'], ts[:10], mp['y'][:10], None, omom, ts[:10], k1, k2, 3, 0.75, 0.025, 1)
+    assert rel(b[5]['ttau'][:, :9], o[5]['ttau'][:, :9]) < TOL_SITE
+    assert np.all(np.isfinite(a[0])) and np.all(np.isfinite(a[5]['ttau']))

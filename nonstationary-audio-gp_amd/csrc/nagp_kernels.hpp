@@ -589,7 +589,9 @@ __host__ __device__ inline size_t gain_lds_doubles(const Shape& s) {
 }
 
 // in-place Cholesky of the leading bs x bs lower triangle of a 4x4 tile; padding -> identity.
-__device__ __forceinline__ bool tile_chol(double* t, int bs) {
+// rd[j] = 1 / L(j,j): the triangular solves below multiply by it (sixteen f64 divisions per tile solve otherwise --
+// the divisions, not the multiply-adds, were most of the instructions of the column phases)
+__device__ __forceinline__ bool tile_chol(double* t, int bs, double* rd) {
   bool ok = true;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -600,7 +602,8 @@ __device__ __forceinline__ bool tile_chol(double* t, int bs) {
         if (l < j) s = fma(-t[4 * j + l], t[4 * j + l], s);
       if (!(s > 0.0)) ok = false;
       const double d = sqrt(s);
-      t[4 * j + j] = d;
+      const double r = 1.0 / d;
+      t[4 * j + j] = d; rd[j] = r;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         if (i > j && i < bs) {
@@ -608,10 +611,10 @@ __device__ __forceinline__ bool tile_chol(double* t, int bs) {
 #pragma unroll
           for (int l = 0; l < 4; ++l)
             if (l < j) v = fma(-t[4 * i + l], t[4 * j + l], v);
-          t[4 * i + j] = v / d;
+          t[4 * i + j] = v * r;
         }
     } else {
-      t[4 * j + j] = 1.0;
+      t[4 * j + j] = 1.0; rd[j] = 1.0;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -622,7 +625,7 @@ __device__ __forceinline__ bool tile_chol(double* t, int bs) {
   }
   return ok;
 }
-// rows of t:  x * L' = t   (forward substitution, L lower 4x4 with unit padding)
+// rows of t:  x * L' = t   (forward substitution, L lower 4x4 with unit padding, RECIPROCAL diagonal)
 __device__ __forceinline__ void tile_solve_Lt(double* t, const double* L) {
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -632,10 +635,10 @@ __device__ __forceinline__ void tile_solve_Lt(double* t, const double* L) {
 #pragma unroll
       for (int l = 0; l < 4; ++l)
         if (l < c) v = fma(-t[4 * i + l], L[4 * c + l], v);
-      t[4 * i + c] = v / L[4 * c + c];
+      t[4 * i + c] = v * L[4 * c + c];
     }
 }
-// rows of t:  x * L = t   (backward substitution)
+// rows of t:  x * L = t   (backward substitution, RECIPROCAL diagonal)
 __device__ __forceinline__ void tile_solve_L(double* t, const double* L) {
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -645,7 +648,7 @@ __device__ __forceinline__ void tile_solve_L(double* t, const double* L) {
 #pragma unroll
       for (int l = 0; l < 4; ++l)
         if (l > c) v = fma(-t[4 * i + l], L[4 * l + c], v);
-      t[4 * i + c] = v / L[4 * c + c];
+      t[4 * i + c] = v * L[4 * c + c];
     }
 }
 
@@ -762,8 +765,11 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(TPT ==
 #pragma unroll
       for (int q = 0; q < TPT; ++q)
         if (own.ok[q] && own.I[q] == jb && own.J[q] == jb) {
-          if (!tile_chol(Lt[q], ibsz[jb])) flag[attempt] = 1;
+          double rd[4];
+          if (!tile_chol(Lt[q], ibsz[jb], rd)) flag[attempt] = 1;
           tile_store(sLd + (size_t)jb * 16, Lt[q]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) sLd[(size_t)jb * 16 + 5 * j] = rd[j];      // the solves want 1 / L(j,j)
         }
       lds_barrier();
       // column jb of L (rows below the diagonal) and -- fused, it needs nothing else -- column jb of X in X L' = B

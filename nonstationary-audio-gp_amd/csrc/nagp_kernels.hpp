@@ -601,8 +601,12 @@ __device__ __forceinline__ bool tile_chol(double* t, int bs, double* rd) {
       for (int l = 0; l < 4; ++l)
         if (l < j) s = fma(-t[4 * j + l], t[4 * j + l], s);
       if (!(s > 0.0)) ok = false;
-      const double d = sqrt(s);
-      const double r = 1.0 / d;
+      // 1/sqrt(s) from the hardware estimate and two Newton steps, sqrt(s) = s * (1/sqrt(s)): a third of the dependent
+      // instructions of sqrt() followed by a division, on the one thread every other thread of the column is waiting for
+      double r = __builtin_amdgcn_rsq(s);
+      double e = fma(-s * r, r, 1.0); r = fma(0.5 * r, e, r);
+      e = fma(-s * r, r, 1.0); r = fma(0.5 * r, e, r);
+      const double d = s * r;
       t[4 * j + j] = d; rd[j] = r;
 #pragma unroll
       for (int i = 0; i < 4; ++i)

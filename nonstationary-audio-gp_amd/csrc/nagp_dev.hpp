@@ -18,6 +18,26 @@ constexpr int MAXM = 64;        // sites (= diagonal blocks) per step
 constexpr double kSqrt2Pi = 2.5066282746310002;
 constexpr double kInvSqrt2Pi = 0.3989422804014327;
 
+// 1/sqrt(s) to about one ulp: hardware estimate and two Newton steps (an f64 sqrt followed by a division is a chain of
+// ~30 dependent instructions, this one of 8).  s = +inf -> 0 like 1/sqrt(inf); s <= 0 or NaN -> NaN (0 -> NaN: the
+// formulas below divide 0 by 0 there as well).
+__device__ __forceinline__ double rsqrt_nr(double s) {
+  double r = __builtin_amdgcn_rsq(s);
+  double e = fma(-s * r, r, 1.0); r = fma(0.5 * r, e, r);
+  e = fma(-s * r, r, 1.0); r = fma(0.5 * r, e, r);
+  return (s == __builtin_inf()) ? 0.0 : r;
+}
+// Gaussian weight of one sigma point: pdf = N(y; sam, sig2), q = (y - sam)/sig2, inv = 1/sig2 -- normpdf(y,mu,sigma),
+// (y-mu)./sigma2 and 1./sigma2 of likModulatorNMFPower.m:52-70 through ONE reciprocal square root instead of a square root
+// and three divisions (same values to ~2 ulp; the per-point phase of mom was half divisions)
+__device__ __forceinline__ void gauss_terms(double y, double sam, double sig2, double& pdf, double& q, double& inv) {
+  const double rs = rsqrt_nr(sig2);
+  inv = rs * rs;
+  const double dy = y - sam;
+  q = dy * inv;
+  pdf = exp(-0.5 * dy * q) * (rs * kInvSqrt2Pi);
+}
+
 // ---------------------------------------------------------------------------------------------
 // DPP helpers.  CTRL: quad_perm [1,0,3,2]=0xB1, [2,3,0,1]=0x4E, row_half_mirror=0x141, row_mirror=0x140
 template <int CTRL>
@@ -392,16 +412,14 @@ __device__ __forceinline__ void mom_nmf(const MomCfg& c, const double* Wl, doubl
     // ---- phase 1c
     for (int pl = tid; pl < npc; pl += NT) {
       const double sig2 = sn2a + c1[pl], sam = c2[pl];
-      const double sd = sqrt(sig2);
-      const double r = (y - sam) / sd;
-      const double pdf = exp(-0.5 * r * r) / (kSqrt2Pi * sd);
+      double pdf, q, inv;
+      gauss_terms(y, sam, sig2, pdf, q, inv);
       double wq;
       if (TL) wq = lds_wn[base + pl]; else wq = c.wn[base + pl];
       const double w0 = wq * pdf;
-      const double q = (y - sam) / sig2;
       c0[pl] = w0;
       c1[pl] = w0 * q;
-      c2[pl] = w0 * (q * q - 1.0 / sig2);
+      c2[pl] = w0 * (q * q - inv);
     }
     lds_barrier();
     NAGP_STAMP(1);
@@ -590,16 +608,14 @@ __device__ __forceinline__ void mom_quad(const MomCfg& c, const double* Wl, doub
         sam = fma(vv[j], lk[j], sam);
       }
       const double sig2 = sn2a + sa2;
-      const double sd = sqrt(sig2);
-      const double r = (y - sam) / sd;
-      const double pdf = exp(-0.5 * r * r) / (kSqrt2Pi * sd);
+      double pdf, q, inv;
+      gauss_terms(y, sam, sig2, pdf, q, inv);
       double wq;
       if (TL) wq = lds_wn[base + pl]; else wq = c.wn[base + pl];
       const double w0 = wq * pdf;
-      const double q = (y - sam) / sig2;
       c0[pl] = w0;
       c1[pl] = w0 * q;
-      c2[pl] = w0 * (q * q - 1.0 / sig2);
+      c2[pl] = w0 * (q * q - inv);
     }
     lds_barrier();
     NAGP_STAMP(1);
@@ -891,11 +907,8 @@ __device__ __forceinline__ void mom_src(const MomCfg& c, const double* Wl, doubl
         }
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        // N(y; sam, sig2) through ONE reciprocal (every point is visited once per source: the divisions dominate)
-        const double inv = 1.0 / sig2[u];
-        const double dy = y - sam[u];
-        const double q = dy * inv;
-        const double pdf = exp(-0.5 * dy * q) * (sqrt(sig2[u]) * inv) * kInvSqrt2Pi;
+        double pdf, q, inv;
+        gauss_terms(y, sam[u], sig2[u], pdf, q, inv);
         const double w0 = lds_wn[pp[u]] * pdf * okf[u];
         a0 += w0;
         a1 = fma(w0, q, a1);
@@ -1004,14 +1017,12 @@ __device__ __forceinline__ void mom_power(const MomCfg& c, double sn2, double al
       sam = group_sum(sam, DG);
       if (sub == 0) {
         const double sig2 = sn2a + sa2;
-        const double sd = sqrt(sig2);
-        const double r = (y - sam) / sd;
-        const double pdf = exp(-0.5 * r * r) / (kSqrt2Pi * sd);
+        double pdf, q, inv;
+        gauss_terms(y, sam, sig2, pdf, q, inv);
         const double w0 = (TL ? lds_wn[p] : c.wn[p]) * pdf;
-        const double q = (y - sam) / sig2;
         c0[pl] = w0;
         c1[pl] = w0 * q;
-        c2[pl] = w0 * (q * q - 1.0 / sig2);
+        c2[pl] = w0 * (q * q - inv);
       }
     }
     lds_barrier();

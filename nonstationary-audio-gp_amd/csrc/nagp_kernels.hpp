@@ -603,9 +603,7 @@ __device__ __forceinline__ bool tile_chol(double* t, int bs, double* rd) {
       if (!(s > 0.0)) ok = false;
       // 1/sqrt(s) from the hardware estimate and two Newton steps, sqrt(s) = s * (1/sqrt(s)): a third of the dependent
       // instructions of sqrt() followed by a division, on the one thread every other thread of the column is waiting for
-      double r = __builtin_amdgcn_rsq(s);
-      double e = fma(-s * r, r, 1.0); r = fma(0.5 * r, e, r);
-      e = fma(-s * r, r, 1.0); r = fma(0.5 * r, e, r);
+      const double r = rsqrt_nr(s);
       const double d = s * r;
       t[4 * j + j] = d; rd[j] = r;
 #pragma unroll

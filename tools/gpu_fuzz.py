@@ -76,6 +76,11 @@ def one(rng):
         big = max(np.nanmax(np.abs(np.nan_to_num(x[5][nm], posinf=0.0))) for x in (r, o) for nm in ('ttau', 'tnu'))
         if big > 1e8:      # a site update divided by 1 + d2*v ~ 1e-14: its sign and size are rounding noise in the reference too
             sens = max(sens, 1.0)
+        # a refreshed site of underflow / cancellation size (0 < |ttau| < 1e-9 of the scale): its sign decides between R = inf
+        # (smoother look-up: LAST grid row, ihgp_ep_modulator_nmf.m:382) and R ~ 1e30 (all |r - R| tie: FIRST row, C-24)
+        tts = [x[5]['ttau'] for x in (r, o)]
+        if any(np.any((np.abs(v) > 0) & (np.abs(v) < 1e-9 * np.nanmax(np.abs(v)))) for v in tts):
+            sens = max(sens, 1.0)
         if res['ihgp'] < 1e3 * sens or not np.isfinite(sens):
             desc += ' [ihgp: unstable instance, oracle self-sensitivity %.1e, device difference %.1e]' % (sens, res['ihgp']); res['ihgp'] = 0.0
     if c['li']:

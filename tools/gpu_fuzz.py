@@ -147,6 +147,8 @@ def one_widened(rng):
                 sens = max(rel(o2[0], o[0]), rel(o2[1], o[1]), rel(o2[5]['ttau'], o[5]['ttau']) * 0.1)
                 vals = np.concatenate([np.ravel(x[5][nm]) for x in (r, o) for nm in ('ttau', 'tnu')])
             singular = (not np.all(np.isfinite(vals))) or np.max(np.abs(vals)) > 1e8     # 1 + d2*v = O(1e-15): sign and size are rounding noise
+            with np.errstate(all='ignore'):    # or a site of underflow size whose sign switches the look-up rule (see the main draw)
+                singular = singular or any(np.any((np.abs(x[5]['ttau']) > 0) & (np.abs(x[5]['ttau']) < 1e-9 * np.nanmax(np.abs(x[5]['ttau'])))) for x in (r, o))
             if singular or v < 1e3 * sens or not np.isfinite(sens):
                 return 0.0, ' [%s: unstable instance, oracle self-sensitivity %.1e, device difference %.1e]' % (tag, sens, v)
         return v, ''

@@ -58,6 +58,8 @@ struct nagp_plan {
   bool need_PF = false;
   MomSrc src_all{};     // block structure of Wnmf (n_src >= 2) and which kernels use it
   int src_f = 0, src_ep = 0, kb_ih = 16;
+  MomSp sp{};           // sparse-point form of likModulatorNMFPower (nagp_momsp.hpp); sp_ih: the IHGP ADF sweep uses it
+  int sp_ih = 0, kb_sp = 16, hph_sp = 1; size_t lds_sp = 0;
   hipStream_t stream = nullptr;
   Bufs b{};
   MomCfg mc{};
@@ -405,6 +407,31 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     mc.n_pts = o->n_pts; mc.cdim = o->cub_dim; mc.D = sh.D; mc.wn = p->d_wn;
     mc.jitter = (o->lik_kind == NAGP_LIK_POWER) ? 1e-8 : 1e-10;
     mc.DG = 1; mc.cache_tabs = 0; mc.store_a = 0; mc.stamps = nullptr;
+    if (o->lik_kind == NAGP_LIK_POWER_NMF && o->cub_dim <= MSP_MAXCD && !getenv("NAGP_NO_SPARSE")) {
+      // sparse-point form: needs the coordinate value 0 and <= MSP_NZ non-centre coordinates per sigma point
+      int c0 = -1;
+      for (size_t ci = 0; ci < xd.size(); ++ci) if (xd[ci] == 0.0) c0 = (int)ci;
+      int nzmax = 0;
+      std::vector<int> pdesc((size_t)o->n_pts * MSP_NZ, -1);
+      bool okp = c0 >= 0 && (int)xd.size() * o->cub_dim <= 64;
+      for (int pt = 0; okp && pt < o->n_pts; ++pt) {
+        int nz = 0;
+        for (int j = 0; j < o->cub_dim; ++j) {
+          const int cc = code[(size_t)pt * o->cub_dim + j];
+          if (cc == c0) continue;
+          if (nz == MSP_NZ) { okp = false; break; }
+          pdesc[(size_t)pt * MSP_NZ + nz++] = j * (int)xd.size() + cc;
+        }
+        nzmax = std::max(nzmax, nz);
+      }
+      if (okp) {
+        double* dd = nullptr;
+        PLAN_TRY(dalloc(p, &dd, (pdesc.size() + 1) / 2 + 1, false));
+        PLAN_HIP(hipMemcpyAsync(dd, pdesc.data(), pdesc.size() * sizeof(int), hipMemcpyHostToDevice, p->stream));
+        PLAN_HIP(hipStreamSynchronize(p->stream));
+        p->sp.enabled = 1; p->sp.c0 = c0; p->sp.nzmax = nzmax; p->sp.pdesc = reinterpret_cast<const int*>(dd);
+      }
+    }
     if (o->lik_kind != NAGP_LIK_POWER) {
       std::vector<unsigned char> blob;
       MomSrc sc;
@@ -542,6 +569,23 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     p->cache_f = t.cache_tabs; p->sta_f = t.store_a;
     p->lds_ih = ihgp_filter_lds_doubles(sh, t, p->tb.NG, p->hph_lds, p->kb_ih) * sizeof(double);
     if (getenv("NAGP_STAMPS")) fprintf(stderr, "[nagp plan] ihgp filter: LDS %zu B, hph table in LDS %d, cubature tables in LDS %d, block-structured mom %d, mom LDS %zu B\n", p->lds_ih, p->hph_lds, p->cache_f, p->src_f, mom_lds_doubles(t) * sizeof(double));
+    // the ADF sweep in the sparse-point form (ihgp_adf_kernel): plain NMF likelihood, <= 320 sigma points, unstructured Wnmf
+    if (p->sp.enabled && !p->src_f && sh.M <= 64 && sh.D <= 4 * MSP_DT && o->n_pts <= MSP_NT + 64 && (o->n_pts + 3) / 4 <= MSP_NW * MSP_NST) {
+      p->kb_sp = IH_KB; p->hph_sp = 1;
+      auto need = [&]() { return ihgp_adf_lds_doubles(sh, o->cub_dim, mc.nd, o->n_pts, p->tb.NG, p->hph_sp, p->kb_sp) * sizeof(double) + 16; };
+      if (need() > 156 * 1024) p->kb_sp = 8;
+      if (need() > 156 * 1024) p->hph_sp = 0;
+      if (need() <= 156 * 1024) {
+        p->sp_ih = 1; p->lds_sp = need();
+        switch (o->cub_dim) {
+          case 1: PLAN_TRY(set_lds(ihgp_adf_kernel<1>, p->lds_sp)); break; case 2: PLAN_TRY(set_lds(ihgp_adf_kernel<2>, p->lds_sp)); break;
+          case 3: PLAN_TRY(set_lds(ihgp_adf_kernel<3>, p->lds_sp)); break; case 4: PLAN_TRY(set_lds(ihgp_adf_kernel<4>, p->lds_sp)); break;
+          case 5: PLAN_TRY(set_lds(ihgp_adf_kernel<5>, p->lds_sp)); break; case 6: PLAN_TRY(set_lds(ihgp_adf_kernel<6>, p->lds_sp)); break;
+          default: PLAN_TRY(set_lds(ihgp_adf_kernel<7>, p->lds_sp)); break;
+        }
+      }
+    }
+    if (getenv("NAGP_STAMPS")) fprintf(stderr, "[nagp plan] ihgp ADF sweep in the sparse-point form: %d (LDS %zu B, ring %d steps, hph table in LDS %d)\n", p->sp_ih, p->lds_sp, p->kb_sp, p->hph_sp);
 #define SL(V) PLAN_TRY(set_lds(ihgp_filter_kernel<V, false>, p->lds_ih))
 #define SLS(V) PLAN_TRY(set_lds(ihgp_filter_kernel<V, true>, p->lds_ih))
     if (p->src_f) { NAGP_MV_SWITCH9(mom_variant(mc), SLS) } else { NAGP_MV_SWITCH9(mom_variant(mc), SL) }
@@ -971,7 +1015,12 @@ static int exec_ihgp(nagp_plan* p) {
       Timed t(p, itt == 1 ? NAGP_K_FILTER : NAGP_K_FILTER_LIN);
 #define LI(V) hipLaunchKernelGGL((ihgp_filter_kernel<V, false>), dim3(B), dim3(p->NT_ih), p->lds_ih, p->stream, sh, p->b, mcf, p->tb, ip)
 #define LIS(V) hipLaunchKernelGGL((ihgp_filter_kernel<V, true>), dim3(B), dim3(p->NT_ih), p->lds_ih, p->stream, sh, p->b, mcf, p->tb, ip)
-      if (p->src_f) { NAGP_MV_SWITCH9(mom_variant(mcf), LIS) } else { NAGP_MV_SWITCH9(mom_variant(mcf), LI) }
+      if (p->sp_ih) {
+        IhgpPar ia = ip; ia.hph_lds = p->hph_sp; ia.kb = p->kb_sp;
+#define LA(V) hipLaunchKernelGGL((ihgp_adf_kernel<V>), dim3(B), dim3(MSP_NT), p->lds_sp, p->stream, sh, p->b, mcf, p->sp, p->tb, ia)
+        switch (mcf.cdim) { case 1: LA(1); break; case 2: LA(2); break; case 3: LA(3); break; case 4: LA(4); break; case 5: LA(5); break; case 6: LA(6); break; default: LA(7); break; }
+#undef LA
+      } else if (p->src_f) { NAGP_MV_SWITCH9(mom_variant(mcf), LIS) } else { NAGP_MV_SWITCH9(mom_variant(mcf), LI) }
 #undef LI
 #undef LIS
     }
@@ -1032,7 +1081,7 @@ extern "C" int nagp_plan_execute(nagp_plan* p) {
   if (getenv("NAGP_STAMPS") && p->d_stamps) {
     unsigned long long st[8];
     if (hipMemcpy(st, p->d_stamps, sizeof st, hipMemcpyDeviceToHost) == hipSuccess)
-      fprintf(stderr, "[nagp stamps] mom: p1a %llu p1b %llu p2 %llu p3 %llu | pre-mom %llu post-mom %llu | aux %llu %llu\n", st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7]);
+      fprintf(stderr, "[nagp stamps] mom: p1a %llu p1b %llu p2 %llu p3 %llu | pre-mom %llu post-mom %llu | aux %llu %llu  (sparse-point IHGP sweep: A, B+1b, 2, tail+head)\n", st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7]);
   }
 
   HIP_TRY(hipGetLastError());

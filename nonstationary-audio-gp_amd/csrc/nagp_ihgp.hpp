@@ -6,6 +6,7 @@
 // The EP refresh (:397-436) reuses ep_site_kernel (parallel over steps).
 #pragma once
 #include "nagp_kernels.hpp"
+#include "nagp_momsp.hpp"
 
 namespace nagp {
 
@@ -279,6 +280,212 @@ __global__ void __launch_bounds__(MV >= 9 ? 512 : 256) ihgp_filter_kernel(Shape 
   }
   if (act && n_clamped) atomicAdd(&b.counters[(size_t)pb * 4 + 1], n_clamped);
   if (mc.stamps && tid == 0)
+    for (int i = 0; i < 8; ++i) mc.stamps[i] += st[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// ADF sweep of the infinite-horizon filter for likModulatorNMFPower on fully symmetric sigma-point sets
+// (ihgp_ep_modulator_nmf.m:233-310 with the mom of likModulatorNMFPower.m:28-87): the same step as ihgp_filter_kernel,
+// organised around the latency of ONE sequential chain.  Wave 0 owns the sites (lane n = block n) and runs, without any
+// workgroup barrier, everything from the reduced cubature sums of step k to the inputs of the cubature of step k+1:
+//   sums -> d lZ, d2 lZ -> site update, clamp, R -> gain, mean update, ring -> table look-up for k+1 -> A m, fmu, H PP H'
+// The four waves then share the cubature stages of nagp_momsp.hpp (five barriers per step).  Every processed step calls
+// mom (sweep 1: all steps; later sweeps: launched for k = T-1 only).
+__host__ __device__ inline size_t ihgp_adf_lds_doubles(const Shape& s, int CD, int nd, int n_pts, int NG, int hph_lds, int kb) {
+  return (size_t)s.D * s.N + 2 * ((size_t)s.M + 4) + NG + (hph_lds ? (size_t)s.M * NG : 0) + ihgp_ring_doubles(s, kb) + 2 +
+         msp_lds_doubles(CD, nd, n_pts);
+}
+
+template <int CD>
+__global__ void __launch_bounds__(MSP_NT) ihgp_adf_kernel(Shape sh, Bufs b, MomCfg mc, MomSp sp, IhgpTabs tb, IhgpPar ip) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int NT = MSP_NT;
+  const int S = sh.S, M = sh.M, D = sh.D, NG = tb.NG;
+  const int64_t T = sh.T;
+  const int pb = blockIdx.x;
+  const double* mdl = b.model + (size_t)pb * mdl_size(sh);
+  const double* tab = tb.base + (size_t)pb * itab_size(sh, NG);
+
+  double* sW = lds;                                  // [D][CD]
+  double* fmu = sW + (size_t)D * CD;                 // [M + 4]
+  double* HPH = fmu + M + 4;
+  double* rg = HPH + M + 4;                          // [NG] look-up grid
+  double* thph = rg + NG;                            // [M][NG] H PP H' table (ip.hph_lds)
+  const int KB = ip.kb;
+  double* ry = thph + (ip.hph_lds ? (size_t)M * NG : 0);   // ring: y[KB]
+  double* rlZ = ry + KB;                //       lZ[KB]
+  double* rZ = rlZ + KB;                //       Z of the step; log taken at the flush
+  double* rtt = rZ + KB;                //       ttau[KB][M]
+  double* rtn = rtt + (size_t)KB * M;   //       tnu
+  double* rR = rtn + (size_t)KB * M;    //       R
+  double* rfm = rR + (size_t)KB * M;    //       H*m (filtered)
+  double* rMF = rfm + (size_t)KB * M;   //       m (filtered) [KB][S]
+  double* ws = rMF + (size_t)KB * S;
+  ws = (double*)(((uintptr_t)ws + 15) & ~(uintptr_t)15);
+  for (int i = tid; i < D * CD; i += NT) sW[i] = mdl[mdl_W(sh) + i];
+  for (int i = tid; i < NG; i += NT) rg[i] = tb.r[i];
+  if (ip.hph_lds)
+    for (int i = tid; i < M * NG; i += NT) thph[i] = tab[itab_hph(sh, NG) + i];
+  for (int i = tid; i < M + 4; i += NT) { fmu[i] = 0.0; HPH[i] = 0.0; }
+  const double sn2 = mdl[mdl_sn2(sh)];
+  const double sn2a = sn2 / ip.mom_alpha;
+  const double pEP1 = mom_pEP(mc, sn2, ip.mom_alpha);
+  __syncthreads();
+  MspCtx<CD> x;
+  msp_setup<CD>(x, mc, sp, sW, fmu, HPH, ws);
+  const MspLay lay = msp_layout(CD, mc.nd, mc.n_pts);
+  const double* acc = ws + lay.acc;
+
+  // wave 0, lane n < M owns block n
+  const int n = tid;
+  const bool act = n < M;
+  constexpr int nq = CD * (CD + 1) / 2;
+  double A4[16], mreg[4] = {0, 0, 0, 0}, wrow[CD], w2[nq];
+  double hn = 0.0;
+  int o = 0, bs = 0;
+#pragma unroll
+  for (int j = 0; j < CD; ++j) wrow[j] = 0.0;
+#pragma unroll
+  for (int q = 0; q < nq; ++q) w2[q] = 0.0;
+  tile_zero(A4);
+  if (act) {
+    tile_load(A4, mdl + mdl_A(sh) + (size_t)n * 16);
+    hn = mdl[mdl_h(sh) + n];
+    o = sh.off[n]; bs = sh.bsz[n];
+    if (n < D) {
+#pragma unroll
+      for (int j = 0; j < CD; ++j) wrow[j] = sW[n * CD + j];
+      int q = 0;
+#pragma unroll
+      for (int j = 0; j < CD; ++j)
+#pragma unroll
+        for (int j2 = j; j2 < CD; ++j2) { w2[q] = ((j == j2) ? 1.0 : 2.0) * wrow[j] * wrow[j2]; ++q; }
+    }
+    if (ip.k_start > 0) {      // continue from the filtered mean of the previous step
+      const double* mp = b.MF + ((size_t)pb * T + (ip.k_start - 1)) * S;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (i < bs) mreg[i] = mp[o + i];
+    } else if (ip.itt > 1) {   // m is NOT reset between sweeps (SURVEY C-22): smoothed mean at k=0
+      const double* ms0 = b.MS + (size_t)pb * T * S;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (i < bs) mreg[i] = ms0[o + i];
+    }
+  }
+  const double* yv = b.y + (size_t)pb * T;
+  double* g_tt = b.ttau + (size_t)pb * T * M;
+  double* g_tn = b.tnu + (size_t)pb * T * M;
+  double* g_R = b.R + (size_t)pb * T * M;
+  double* g_lZ = b.lZ + (size_t)pb * T;
+  double* g_MF = b.MF + (size_t)pb * T * S;
+  double* g_fm = b.fm + (size_t)pb * T * M;
+  double Rprev = (act && ip.k_start > 0) ? b.R[((size_t)pb * T + (ip.k_start - 1)) * M + n] : 0.0;
+  unsigned long long n_clamped = 0;
+  unsigned long long st_a = 0, st_b = 0, st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const bool stamp = mc.stamps && tid == 0;
+#define IH_STAMP(slot) do { if (stamp) { st_b = __builtin_readcyclecounter(); st[slot] += st_b - st_a; st_a = st_b; } } while (0)
+
+  // head of step k: table look-up, A m, the cubature's inputs (wave 0, no barrier)
+  double hph = 0.0, wc[4] = {0, 0, 0, 0}, Am[4] = {0, 0, 0, 0}, fmun = 0.0;
+  auto head = [&](int64_t k) {
+    if (act) {
+      if (k > 0) {
+        const int idx = nearest_idx_lds(rg, NG, tb.lr0, tb.inv_dlr, Rprev);
+        hph = ip.hph_lds ? thph[n * NG + idx] : tab[itab_hph(sh, NG) + (size_t)n * NG + idx];
+        const double* w = tab + itab_wcol(sh, NG) + ((size_t)n * NG + idx) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wc[i] = w[i];
+      } else {
+        hph = tab[itab_hph0(sh, NG) + n];
+        const double* w = tab + itab_wcol0(sh, NG) + (size_t)n * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wc[i] = w[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        double a = 0.0;
+#pragma unroll
+        for (int l = 0; l < 4; ++l) a = fma(A4[4 * i + l], mreg[l], a);
+        Am[i] = a;
+      }
+      fmun = hn * Am[0];
+      fmu[n] = fmun; HPH[n] = hph;
+    }
+  };
+  if (wave == 0) head(ip.k_start);
+  if (stamp) st_a = __builtin_readcyclecounter();
+
+  for (int64_t k0 = ip.k_start; k0 < T; k0 += KB) {
+    const int nb = (T - k0 < KB) ? (int)(T - k0) : KB;
+    // ---- fill the ring for steps k0 .. k0+nb-1
+    for (int i = tid; i < nb; i += NT) { ry[i] = yv[k0 + i]; rlZ[i] = g_lZ[k0 + i]; rZ[i] = -1.0; }
+    for (int i = tid; i < nb * M; i += NT) { rtt[i] = g_tt[(size_t)k0 * M + i]; rtn[i] = g_tn[(size_t)k0 * M + i]; }
+    __syncthreads();
+    for (int kk = 0; kk < nb; ++kk) {
+      const int64_t k = k0 + kk;
+      lds_barrier();                 // B1: fmu, HPH of step k
+      IH_STAMP(3);
+      msp_stageA<CD>(x, mc);
+      lds_barrier();                 // B2
+      IH_STAMP(0);
+      msp_stageB<CD>(x, mc, sp, ws);
+      lds_barrier();                 // B3
+      msp_stage1b<CD>(x, mc, sp, sn2a, ry[kk], ws);
+      lds_barrier();                 // B4
+      IH_STAMP(1);
+      msp_stage2<CD>(x, mc, ws);
+      lds_barrier();                 // B5
+      IH_STAMP(2);
+      if (wave == 0) {
+        msp_reduce<CD>(x);
+        msp_wave_fence();
+        if (act) {
+          double Z, d1, d2;
+          msp_outputs<CD>(acc, n, D, wrow, w2, pEP1, mc.jitter, Z, d1, d2);
+          const double t_old = rtt[kk * M + n], n_old = rtn[kk * M + n];
+          const double den1 = 1.0 + d2 * hph;
+          double tnew = ip.w_old * t_old + ip.w_new * (-d2 / den1);        // :265
+          const double nnew = ip.w_old * n_old + ip.w_new * ((d1 - fmun * d2) / den1);
+          double Rn = 1.0 / tnew;                                          // before the clamp (:269)
+          if (!(tnew > 0.0)) ++n_clamped;
+          tnew = max0(tnew);                                               // :274 (NaN -> 0, C-3)
+          const double ys = nnew / tnew;
+          if (tnew == 0.0) {
+            Rn = INFINITY;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mreg[i] = Am[i];
+          } else {
+            const double den = hph + Rn;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mreg[i] = Am[i] + (wc[i] / den) * (ys - fmun);
+          }
+          rtt[kk * M + n] = tnew; rtn[kk * M + n] = nnew; rR[kk * M + n] = Rn;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (i < bs) rMF[(size_t)kk * S + o + i] = mreg[i];
+          rfm[kk * M + n] = hn * mreg[0];
+          Rprev = Rn;
+          if (n == 0) rZ[kk] = Z;
+        }
+        if (k + 1 < T) head(k + 1);
+      }
+    }
+    // ---- flush the ring
+    __syncthreads();
+    for (int i = tid; i < nb; i += NT) g_lZ[k0 + i] = (rZ[i] < 0.0) ? rlZ[i] : log(rZ[i]);
+    for (int i = tid; i < nb * M; i += NT) {
+      g_tt[(size_t)k0 * M + i] = rtt[i]; g_tn[(size_t)k0 * M + i] = rtn[i]; g_R[(size_t)k0 * M + i] = rR[i];
+      g_fm[(size_t)k0 * M + i] = rfm[i];
+    }
+    for (int i = tid; i < nb * S; i += NT) g_MF[(size_t)k0 * S + i] = rMF[i];
+    __syncthreads();
+  }
+#undef IH_STAMP
+  if (act && n_clamped) atomicAdd(&b.counters[(size_t)pb * 4 + 1], n_clamped);
+  if (stamp)
     for (int i = 0; i < 8; ++i) mc.stamps[i] += st[i];
 }
 

@@ -14,6 +14,7 @@ PKG_ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(PKG_ROOT, 'libnagp.so')
 CSRC = os.path.join(PKG_ROOT, 'csrc')
 INCLUDE = os.path.join(os.path.dirname(PKG_ROOT), 'include')
+EXTRA_LINK = []   # filled below when the library links RCCL
 
 NAGP_OK = 0
 KIND_GF_EP, KIND_IHGP, KIND_GIEKF = 0, 1, 2
@@ -67,19 +68,43 @@ class NagpError(RuntimeError):
     pass
 
 
+def source_hash():
+    """SHA-256 over the sources libnagp.so is built from (csrc/*, include/nagp.h), in name order."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)):
+        with open(os.path.join(CSRC, f), 'rb') as fh:
+            h.update(f.encode()); h.update(fh.read())
+    with open(os.path.join(INCLUDE, 'nagp.h'), 'rb') as fh:
+        h.update(b'nagp.h'); h.update(fh.read())
+    return h.hexdigest()
+
+
+HASH_PATH = LIB_PATH + '.srchash'
+
+
 def build(force=False, verbose=False):
-    """Compile csrc/nagp_api.hip -> libnagp.so for gfx950 (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(INCLUDE, 'nagp.h')]
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
-        return LIB_PATH
+    """Compile csrc/nagp_api.hip -> libnagp.so for gfx950 (cross-compiles without a GPU).  The library is stale when
+    the hash of its sources differs from the one recorded next to it at build time (mtimes are not trusted)."""
+    want = source_hash()
+    if not force and os.path.exists(LIB_PATH) and os.path.exists(HASH_PATH):
+        with open(HASH_PATH) as fh:
+            if fh.read().strip() == want:
+                return LIB_PATH
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    tmp = LIB_PATH + '.tmp.%d' % os.getpid()
     cmd = [hipcc, '-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-shared', '-I', INCLUDE,
-           '-o', LIB_PATH, os.path.join(CSRC, 'nagp_api.hip')]
+           '-o', tmp, os.path.join(CSRC, 'nagp_api.hip')] + EXTRA_LINK
     r = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or r.returncode != 0:
         print(' '.join(cmd)); print(r.stdout); print(r.stderr)
     if r.returncode != 0:
+        if os.path.exists(tmp):
+            os.remove(tmp)
         raise NagpError('hipcc failed building libnagp.so')
+    os.replace(tmp, LIB_PATH)
+    with open(HASH_PATH, 'w') as fh:
+        fh.write(want + '\n')
     return LIB_PATH
 
 

@@ -55,3 +55,17 @@ def barrier():
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()
+
+
+def world_size():
+    """World size the initialised process group reports (1 without one)."""
+    import torch.distributed as dist
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def backend_name():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        b = dist.get_backend()
+        return 'RCCL (torch.distributed backend "nccl")' if b == 'nccl' else str(b)
+    return 'single process, no collective'

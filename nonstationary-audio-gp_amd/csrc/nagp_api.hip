@@ -3,9 +3,11 @@
 // nagp_plan_upload_y and nagp_plan_download stays in HBM.  The sweep structure follows
 // matlab/gf_ep_modulator_nmf.m:113-283 (predict) / :384-522 (nlml), ihgp_ep_modulator_nmf.m:223-454
 // and gf_giekf_modulator_nmf.m:126-221.
-#include "nagp_ihgp.hpp"
-#include "nagp_mfma.hpp"
+#include "nagp_inst.hpp"
 #include "../../include/nagp.h"
+
+// every templated kernel is instantiated in one of the inst_*.hip translation units
+NAGP_LIST_ALL(extern template __global__)
 
 #include <algorithm>
 #include <cmath>
@@ -59,7 +61,7 @@ struct nagp_plan {
   MomSrc src_all{};     // block structure of Wnmf (n_src >= 2) and which kernels use it
   int src_f = 0, src_ep = 0, kb_ih = 16;
   MomSp sp{};           // sparse-point form of likModulatorNMFPower (nagp_momsp.hpp); sp_ih: the IHGP ADF sweep uses it
-  int sp_ih = 0, kb_sp = 16, hph_sp = 1; size_t lds_sp = 0;
+  int sp_ih = 0, sp_gf = 0, kb_sp = 16, hph_sp = 1; size_t lds_sp = 0;
   hipStream_t stream = nullptr;
   Bufs b{};
   MomCfg mc{};
@@ -413,7 +415,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
       for (size_t ci = 0; ci < xd.size(); ++ci) if (xd[ci] == 0.0) c0 = (int)ci;
       int nzmax = 0;
       std::vector<int> pdesc((size_t)o->n_pts * MSP_NZ, -1);
-      bool okp = c0 >= 0 && (int)xd.size() * o->cub_dim <= 64;
+      bool okp = c0 >= 0 && (int)xd.size() * o->cub_dim <= MSP_TS - 1;
       for (int pt = 0; okp && pt < o->n_pts; ++pt) {
         int nz = 0;
         for (int j = 0; j < o->cub_dim; ++j) {
@@ -572,7 +574,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     // the ADF sweep in the sparse-point form (ihgp_adf_kernel): plain NMF likelihood, <= 320 sigma points, unstructured Wnmf
     if (p->sp.enabled && !p->src_f && sh.M <= 64 && sh.D <= 4 * MSP_DT && o->n_pts <= MSP_NT + 64 && (o->n_pts + 3) / 4 <= MSP_NW * MSP_NST) {
       p->kb_sp = IH_KB; p->hph_sp = 1;
-      auto need = [&]() { return ihgp_adf_lds_doubles(sh, o->cub_dim, mc.nd, o->n_pts, p->tb.NG, p->hph_sp, p->kb_sp) * sizeof(double) + 16; };
+      auto need = [&]() { return ihgp_adf_lds_doubles(sh, o->cub_dim, p->tb.NG, p->hph_sp, p->kb_sp) * sizeof(double) + 16; };
       if (need() > 156 * 1024) p->kb_sp = 8;
       if (need() > 156 * 1024) p->hph_sp = 0;
       if (need() <= 156 * 1024) {
@@ -594,6 +596,9 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
   } else {
     if (!ekf) p->DG_f = pick_DG(o->lik_kind, o->n_pts, p->NT_a, sh.D, o->cub_dim);
     MomCfg t = mc; t.DG = p->DG_f; t.cache_tabs = ekf ? 0 : 1; t.store_a = (!ekf && o->lik_kind == NAGP_LIK_POWER_NMF_SQRT) ? 1 : 0;
+    // ADF launches in the sparse-point form (256-thread launches, <= 320 sigma points)
+    if (!ekf && p->sp.enabled && p->LB_a == 256 && p->NT_a == MSP_NT && sh.M <= 64 && sh.D <= 4 * MSP_DT && o->n_pts <= MSP_NT + 64 &&
+        (o->n_pts + 3) / 4 <= MSP_NW * MSP_NST) { p->sp_gf = 1; t.sp = p->sp; }
     const size_t cap = 156 * 1024;
     p->kb_f = 16;
     if (filter_lds_doubles(sh, t, ekf ? 1 : 0, p->kb_f) * sizeof(double) > cap) p->kb_f = 8;
@@ -602,7 +607,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     if (filter_lds_doubles(sh, t, ekf ? 1 : 0, p->kb_f) * sizeof(double) > cap) t.cache_tabs = 0;
     p->cache_f = t.cache_tabs; p->sta_f = t.store_a;
     p->lds_filter = filter_lds_doubles(sh, t, ekf ? 1 : 0, p->kb_f) * sizeof(double);
-    if (getenv("NAGP_STAMPS")) fprintf(stderr, "[nagp plan] gf filter: LDS %zu B, ring %d steps, cubature tables in LDS %d, mom LDS %zu B\n", p->lds_filter, p->kb_f, p->cache_f, ekf ? (size_t)0 : mom_lds_doubles(t) * sizeof(double));
+    if (getenv("NAGP_STAMPS")) fprintf(stderr, "[nagp plan] gf filter: LDS %zu B, ring %d steps, cubature tables in LDS %d, mom LDS %zu B, sparse-point ADF %d\n", p->lds_filter, p->kb_f, p->cache_f, ekf ? (size_t)0 : mom_lds_doubles(t) * sizeof(double), p->sp_gf);
     p->lds_gain = gain_lds_doubles(sh) * sizeof(double);
     p->lds_scan = span_lds_doubles(sh, p->LP1, p->LP2) * sizeof(double);
     if (ekf) {
@@ -700,6 +705,7 @@ static int launch_filter(nagp_plan* p, const FilterPar& fp_in) {
   fp.kb = p->kb_f;
   const bool ekf = p->opts.kind == NAGP_KIND_GIEKF;
   MomCfg mc = p->mc; mc.DG = p->DG_f; mc.cache_tabs = p->cache_f; mc.store_a = p->sta_f;
+  mc.sp = p->sp_gf ? p->sp : MomSp{};
   if (getenv("NAGP_STAMPS")) mc.stamps = reinterpret_cast<unsigned long long*>(p->d_stamps);   // developer diagnostics
   const bool adf = ekf || fp.mom_all || fp.k_end == p->sh.T;   // launches that may call mom (or the EKF filter)
   int nt_ekf = p->NT_f;
@@ -963,7 +969,7 @@ static int exec_giekf(nagp_plan* p) {
   return NAGP_OK;
 }
 
-__global__ void fill_kernel(double* p, size_t n, double v) {
+static __global__ void fill_kernel(double* p, size_t n, double v) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
 

@@ -185,6 +185,15 @@ struct MomSrc {
 typedef const unsigned short __attribute__((address_space(3))) * lds_u16p;
 typedef const int __attribute__((address_space(3))) * lds_i32p;
 
+// sparse-point form of likModulatorNMFPower (nagp_momsp.hpp); tables built by the host
+constexpr int MSP_NZ = 4;     // non-centre coordinates per sigma point
+struct MomSp {
+  int enabled;
+  int c0;             // code of the coordinate value 0
+  int nzmax;          // largest number of non-centre coordinates of a sigma point
+  const int* pdesc;   // [n_pts][MSP_NZ]: j*nd + c of the non-centre coordinates, -1 = none
+};
+
 struct MomCfg {
   int lik_kind;      // nagp_lik
   int link_kind;     // nagp_link
@@ -202,6 +211,7 @@ struct MomCfg {
   int store_a;       // POWER_NMF_SQRT: keep a[d][p] = sqrt(W_d . link(xn_p)) in LDS between the phases (one sqrt per (p, d))
   unsigned long long* stamps;  // developer diagnostics: per-phase cycle sums of thread 0 (null in production)
   MomSrc src;        // n_src >= 2: mom_src instead of the per-point evaluation (needs cache_tabs)
+  MomSp sp;          // enabled: the kernels that have the staged form (nagp_momsp.hpp) use it instead of mom_eval
 };
 
 typedef const unsigned char __attribute__((address_space(3))) * lds_u8p;   // explicit LDS pointers: a select between

@@ -291,9 +291,36 @@ __global__ void __launch_bounds__(MV >= 9 ? 512 : 256) ihgp_filter_kernel(Shape 
 //   sums -> d lZ, d2 lZ -> site update, clamp, R -> gain, mean update, ring -> table look-up for k+1 -> A m, fmu, H PP H'
 // The four waves then share the cubature stages of nagp_momsp.hpp (five barriers per step).  Every processed step calls
 // mom (sweep 1: all steps; later sweeps: launched for k = T-1 only).
-__host__ __device__ inline size_t ihgp_adf_lds_doubles(const Shape& s, int CD, int nd, int n_pts, int NG, int hph_lds, int kb) {
-  return (size_t)s.D * s.N + 2 * ((size_t)s.M + 4) + NG + (hph_lds ? (size_t)s.M * NG : 0) + ihgp_ring_doubles(s, kb) + 2 +
-         msp_lds_doubles(CD, nd, n_pts);
+// Ring of the filtered means: [KB][M][4], block padded (two 16-byte stores per lane and step); the flush strips the padding.
+__host__ __device__ inline size_t ihgp_adf_ring_doubles(const Shape& s, int kb) { return (size_t)kb * (8 * s.M + 3); }
+__host__ __device__ inline size_t ihgp_adf_lds_doubles(const Shape& s, int CD, int NG, int hph_lds, int kb) {
+  return (size_t)s.D * s.N + 2 * 68 + NG + (hph_lds ? (size_t)s.M * NG : 0) + ihgp_adf_ring_doubles(s, kb) + (s.S + 1) / 2 + 2 +
+         msp_lds_doubles(CD, s.D);
+}
+
+// [~,ind] = min(abs(r-R)) as nearest_idx_lds, with a three-point window around the seed: the seed's error (0.003 in log10,
+// a tenth of a grid step, plus 0.02 steps between the linear and the logarithmic mid-point) keeps the minimiser inside it.
+// Grids that are not the reference's logspace(-2,4,200) (ihgp_ep_modulator_nmf.m:131) take the five-point form.
+__device__ __forceinline__ int nearest_idx3(msp_rp r, int NG, double lr0, double inv_dlr, double rmax, double R) {
+  if (!(R == R) || isinf(R)) return 0;
+  if (R > rmax) {   // rounding ties beyond the grid: first minimiser (see nearest_idx)
+    const double dmin = fabs(r[NG - 1] - R);
+    if (fabs(r[0] - R) == dmin) return 0;
+    int i = NG - 1;
+    while (i > 0 && fabs(r[i - 1] - R) == dmin) --i;
+    return i;
+  }
+  int est = 0;
+  if (R > 0.0) {
+    const double f = (coarse_log10(R) - lr0) * inv_dlr;
+    est = (f <= 0.0) ? 0 : ((f >= (double)(NG - 1)) ? NG - 1 : (int)(f + 0.5));
+  }
+  const int mid = (est < 1) ? 1 : ((est > NG - 2) ? NG - 2 : est);
+  const double d0 = fabs(r[mid - 1] - R), d1 = fabs(r[mid] - R), d2 = fabs(r[mid + 1] - R);
+  int best = mid - 1; double bd = d0;
+  if (d1 < bd) { bd = d1; best = mid; }
+  if (d2 < bd) best = mid + 1;
+  return best;
 }
 
 template <int CD>
@@ -308,60 +335,54 @@ __global__ void __launch_bounds__(MSP_NT) ihgp_adf_kernel(Shape sh, Bufs b, MomC
   const double* mdl = b.model + (size_t)pb * mdl_size(sh);
   const double* tab = tb.base + (size_t)pb * itab_size(sh, NG);
 
-  double* sW = lds;                                  // [D][CD]
-  double* fmu = sW + (size_t)D * CD;                 // [M + 4]
-  double* HPH = fmu + M + 4;
-  double* rg = HPH + M + 4;                          // [NG] look-up grid
-  double* thph = rg + NG;                            // [M][NG] H PP H' table (ip.hph_lds)
   const int KB = ip.kb;
-  double* ry = thph + (ip.hph_lds ? (size_t)M * NG : 0);   // ring: y[KB]
-  double* rlZ = ry + KB;                //       lZ[KB]
-  double* rZ = rlZ + KB;                //       Z of the step; log taken at the flush
-  double* rtt = rZ + KB;                //       ttau[KB][M]
-  double* rtn = rtt + (size_t)KB * M;   //       tnu
-  double* rR = rtn + (size_t)KB * M;    //       R
-  double* rfm = rR + (size_t)KB * M;    //       H*m (filtered)
-  double* rMF = rfm + (size_t)KB * M;   //       m (filtered) [KB][S]
-  double* ws = rMF + (size_t)KB * S;
-  ws = (double*)(((uintptr_t)ws + 15) & ~(uintptr_t)15);
+  double* rMF = lds;                                 // ring: m (filtered) [KB][M][4]   (16-byte aligned)
+  double* rtt = rMF + (size_t)KB * M * 4;            //       ttau[KB][M]
+  double* rtn = rtt + (size_t)KB * M;                //       tnu
+  double* rR = rtn + (size_t)KB * M;                 //       R
+  double* rfm = rR + (size_t)KB * M;                 //       H*m (filtered)
+  double* ry = rfm + (size_t)KB * M;                 //       y[KB]
+  double* rlZ = ry + KB;                             //       lZ[KB]
+  double* rZ = rlZ + KB;                             //       Z of the step; log taken at the flush
+  double* sW = rZ + KB;                              // [D][CD]
+  double* fmu = sW + (size_t)D * CD;                 // [68]: M sites, zero padded (stage A of the cubature reads 4*K entries)
+  double* HPH = fmu + 68;
+  double* rg = HPH + 68;                          // [NG] look-up grid
+  double* thph = rg + NG;                            // [M][NG] H PP H' table (ip.hph_lds)
+  int* smap = reinterpret_cast<int*>(thph + (ip.hph_lds ? (size_t)M * NG : 0));   // [S] state -> padded ring slot 4*block + row
+  double* ws = reinterpret_cast<double*>(smap) + (S + 1) / 2;
   for (int i = tid; i < D * CD; i += NT) sW[i] = mdl[mdl_W(sh) + i];
   for (int i = tid; i < NG; i += NT) rg[i] = tb.r[i];
   if (ip.hph_lds)
     for (int i = tid; i < M * NG; i += NT) thph[i] = tab[itab_hph(sh, NG) + i];
-  for (int i = tid; i < M + 4; i += NT) { fmu[i] = 0.0; HPH[i] = 0.0; }
+  for (int i = tid; i < 68; i += NT) { fmu[i] = 0.0; HPH[i] = 0.0; }
+  for (int i = tid; i < M; i += NT)
+    for (int r = 0; r < sh.bsz[i]; ++r) smap[sh.off[i] + r] = 4 * i + r;
   const double sn2 = mdl[mdl_sn2(sh)];
   const double sn2a = sn2 / ip.mom_alpha;
   const double pEP1 = mom_pEP(mc, sn2, ip.mom_alpha);
+  const double rmax = tb.r[NG - 1];
   __syncthreads();
   MspCtx<CD> x;
   msp_setup<CD>(x, mc, sp, sW, fmu, HPH, ws);
-  const MspLay lay = msp_layout(CD, mc.nd, mc.n_pts);
-  const double* acc = ws + lay.acc;
 
   // wave 0, lane n < M owns block n
   const int n = tid;
   const bool act = n < M;
-  constexpr int nq = CD * (CD + 1) / 2;
-  double A4[16], mreg[4] = {0, 0, 0, 0}, wrow[CD], w2[nq];
+  const bool sub = n < D;
+  const int nn = act ? n : 0;
+  double A4[16], mreg[4] = {0, 0, 0, 0}, wrow[CD];
   double hn = 0.0;
-  int o = 0, bs = 0;
 #pragma unroll
   for (int j = 0; j < CD; ++j) wrow[j] = 0.0;
-#pragma unroll
-  for (int q = 0; q < nq; ++q) w2[q] = 0.0;
   tile_zero(A4);
   if (act) {
     tile_load(A4, mdl + mdl_A(sh) + (size_t)n * 16);
     hn = mdl[mdl_h(sh) + n];
-    o = sh.off[n]; bs = sh.bsz[n];
-    if (n < D) {
+    const int o = sh.off[n], bs = sh.bsz[n];
+    if (sub) {
 #pragma unroll
       for (int j = 0; j < CD; ++j) wrow[j] = sW[n * CD + j];
-      int q = 0;
-#pragma unroll
-      for (int j = 0; j < CD; ++j)
-#pragma unroll
-        for (int j2 = j; j2 < CD; ++j2) { w2[q] = ((j == j2) ? 1.0 : 2.0) * wrow[j] * wrow[j2]; ++q; }
     }
     if (ip.k_start > 0) {      // continue from the filtered mean of the previous step
       const double* mp = b.MF + ((size_t)pb * T + (ip.k_start - 1)) * S;
@@ -375,6 +396,14 @@ __global__ void __launch_bounds__(MSP_NT) ihgp_adf_kernel(Shape sh, Bufs b, MomC
         if (i < bs) mreg[i] = ms0[o + i];
     }
   }
+  // per-lane ring / table addresses (vector registers; the step index adds an immediate-free scalar offset)
+  const msp_wp p_tt = (msp_wp)(rtt + nn), p_tn = (msp_wp)(rtn + nn), p_R = (msp_wp)(rR + nn), p_fm = (msp_wp)(rfm + nn);
+  const msp_wp p_MF = (msp_wp)(rMF + 4 * nn);
+  const msp_wp p_fmu = (msp_wp)(fmu + nn), p_HPH = (msp_wp)(HPH + nn);
+  const msp_rp p_hph = (msp_rp)(thph + (size_t)nn * NG);
+  const msp_rp p_rg = (msp_rp)rg + opaque_zero();
+  const double* g_wcol = tab + itab_wcol(sh, NG) + (size_t)nn * NG * 4;
+  const double* g_hph = tab + itab_hph(sh, NG) + (size_t)nn * NG;
   const double* yv = b.y + (size_t)pb * T;
   double* g_tt = b.ttau + (size_t)pb * T * M;
   double* g_tn = b.tnu + (size_t)pb * T * M;
@@ -383,7 +412,7 @@ __global__ void __launch_bounds__(MSP_NT) ihgp_adf_kernel(Shape sh, Bufs b, MomC
   double* g_MF = b.MF + (size_t)pb * T * S;
   double* g_fm = b.fm + (size_t)pb * T * M;
   double Rprev = (act && ip.k_start > 0) ? b.R[((size_t)pb * T + (ip.k_start - 1)) * M + n] : 0.0;
-  unsigned long long n_clamped = 0;
+  unsigned int n_clamped = 0;
   unsigned long long st_a = 0, st_b = 0, st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const bool stamp = mc.stamps && tid == 0;
 #define IH_STAMP(slot) do { if (stamp) { st_b = __builtin_readcyclecounter(); st[slot] += st_b - st_a; st_a = st_b; } } while (0)
@@ -393,11 +422,11 @@ __global__ void __launch_bounds__(MSP_NT) ihgp_adf_kernel(Shape sh, Bufs b, MomC
   auto head = [&](int64_t k) {
     if (act) {
       if (k > 0) {
-        const int idx = nearest_idx_lds(rg, NG, tb.lr0, tb.inv_dlr, Rprev);
-        hph = ip.hph_lds ? thph[n * NG + idx] : tab[itab_hph(sh, NG) + (size_t)n * NG + idx];
-        const double* w = tab + itab_wcol(sh, NG) + ((size_t)n * NG + idx) * 4;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) wc[i] = w[i];
+        const int idx = nearest_idx3(p_rg, NG, tb.lr0, tb.inv_dlr, rmax, Rprev);
+        hph = ip.hph_lds ? p_hph[idx] : g_hph[idx];
+        const double2* w = reinterpret_cast<const double2*>(g_wcol + (size_t)idx * 4);
+        const double2 w0 = w[0], w1 = w[1];
+        wc[0] = w0.x; wc[1] = w0.y; wc[2] = w1.x; wc[3] = w1.y;
       } else {
         hph = tab[itab_hph0(sh, NG) + n];
         const double* w = tab + itab_wcol0(sh, NG) + (size_t)n * 4;
@@ -406,13 +435,12 @@ __global__ void __launch_bounds__(MSP_NT) ihgp_adf_kernel(Shape sh, Bufs b, MomC
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        double a = 0.0;
-#pragma unroll
-        for (int l = 0; l < 4; ++l) a = fma(A4[4 * i + l], mreg[l], a);
-        Am[i] = a;
+        double a0 = A4[4 * i] * mreg[0], a1 = A4[4 * i + 1] * mreg[1];
+        a0 = fma(A4[4 * i + 2], mreg[2], a0); a1 = fma(A4[4 * i + 3], mreg[3], a1);
+        Am[i] = a0 + a1;
       }
       fmun = hn * Am[0];
-      fmu[n] = fmun; HPH[n] = hph;
+      *p_fmu = fmun; *p_HPH = hph;
     }
   };
   if (wave == 0) head(ip.k_start);
@@ -431,7 +459,7 @@ __global__ void __launch_bounds__(MSP_NT) ihgp_adf_kernel(Shape sh, Bufs b, MomC
       msp_stageA<CD>(x, mc);
       lds_barrier();                 // B2
       IH_STAMP(0);
-      msp_stageB<CD>(x, mc, sp, ws);
+      msp_stageB<CD>(x, mc, ws);
       lds_barrier();                 // B3
       msp_stage1b<CD>(x, mc, sp, sn2a, ry[kk], ws);
       lds_barrier();                 // B4
@@ -443,30 +471,30 @@ __global__ void __launch_bounds__(MSP_NT) ihgp_adf_kernel(Shape sh, Bufs b, MomC
         msp_reduce<CD>(x);
         msp_wave_fence();
         if (act) {
+          const int ko = kk * M;
           double Z, d1, d2;
-          msp_outputs<CD>(acc, n, D, wrow, w2, pEP1, mc.jitter, Z, d1, d2);
-          const double t_old = rtt[kk * M + n], n_old = rtn[kk * M + n];
-          const double den1 = 1.0 + d2 * hph;
-          double tnew = ip.w_old * t_old + ip.w_new * (-d2 / den1);        // :265
-          const double nnew = ip.w_old * n_old + ip.w_new * ((d1 - fmun * d2) / den1);
-          double Rn = 1.0 / tnew;                                          // before the clamp (:269)
+          msp_outputs<CD>(x.accp, sub, n - D, wrow, pEP1, mc.jitter, Z, d1, d2);
+          const double t_old = p_tt[ko], n_old = p_tn[ko];
+          // site update (:265-266): -d2/(1+d2 HPH), (d1 - fmu d2)/(1+d2 HPH) through one reciprocal
+          const double r1 = rcp_nr(fma(d2, hph, 1.0));
+          double tnew = fma(ip.w_new, -d2 * r1, ip.w_old * t_old);
+          const double nnew = fma(ip.w_new, fma(-fmun, d2, d1) * r1, ip.w_old * n_old);
           if (!(tnew > 0.0)) ++n_clamped;
           tnew = max0(tnew);                                               // :274 (NaN -> 0, C-3)
-          const double ys = nnew / tnew;
-          if (tnew == 0.0) {
-            Rn = INFINITY;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) mreg[i] = Am[i];
-          } else {
-            const double den = hph + Rn;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) mreg[i] = Am[i] + (wc[i] / den) * (ys - fmun);
-          }
-          rtt[kk * M + n] = tnew; rtn[kk * M + n] = nnew; rR[kk * M + n] = Rn;
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (i < bs) rMF[(size_t)kk * S + o + i] = mreg[i];
-          rfm[kk * M + n] = hn * mreg[0];
+          double Rn = 1.0 / tnew;                                          // R = 1/ttau: the look-up key and an output, exact division
+          // (for tnew > 0 the reference's R(:,k) = 1./ttau before the clamp is this value; otherwise :287 overwrites it with Inf)
+          double g = 0.0;
+          if (tnew == 0.0) Rn = INFINITY;
+          else g = fma(nnew, Rn, -fmun) * rcp_nr(hph + Rn);                // (ys - fmu)/(HPH + R), ys = tnu/ttau (:277, :289-292)
+          typedef double d2v __attribute__((ext_vector_type(2)));
+          d2v m01, m23;
+          mreg[0] = fma(wc[0], g, Am[0]); mreg[1] = fma(wc[1], g, Am[1]); mreg[2] = fma(wc[2], g, Am[2]); mreg[3] = fma(wc[3], g, Am[3]);
+          m01.x = mreg[0]; m01.y = mreg[1]; m23.x = mreg[2]; m23.y = mreg[3];
+          p_tt[ko] = tnew; p_tn[ko] = nnew; p_R[ko] = Rn;
+          typedef d2v __attribute__((address_space(3))) * lds_d2p;
+          lds_d2p mf = (lds_d2p)(p_MF + 4 * ko);
+          mf[0] = m01; mf[1] = m23;
+          p_fm[ko] = hn * mreg[0];
           Rprev = Rn;
           if (n == 0) rZ[kk] = Z;
         }
@@ -480,18 +508,18 @@ __global__ void __launch_bounds__(MSP_NT) ihgp_adf_kernel(Shape sh, Bufs b, MomC
       g_tt[(size_t)k0 * M + i] = rtt[i]; g_tn[(size_t)k0 * M + i] = rtn[i]; g_R[(size_t)k0 * M + i] = rR[i];
       g_fm[(size_t)k0 * M + i] = rfm[i];
     }
-    for (int i = tid; i < nb * S; i += NT) g_MF[(size_t)k0 * S + i] = rMF[i];
+    for (int i = tid; i < nb * S; i += NT) { const int q = i / S, e = i - q * S; g_MF[(size_t)k0 * S + i] = rMF[(size_t)q * M * 4 + smap[e]]; }
     __syncthreads();
   }
 #undef IH_STAMP
-  if (act && n_clamped) atomicAdd(&b.counters[(size_t)pb * 4 + 1], n_clamped);
+  if (act && n_clamped) atomicAdd(&b.counters[(size_t)pb * 4 + 1], (unsigned long long)n_clamped);
   if (stamp)
     for (int i = 0; i < 8; ++i) mc.stamps[i] += st[i];
 }
 
 // Backward mean recursion: m <- MF_k + G (m - A MF_k) with (P,G) looked up from R(:,k)
 // (Inf -> last grid row, ihgp_ep_modulator_nmf.m:379-380).  One wave per problem, thread n = block n.
-__global__ void __launch_bounds__(64) ihgp_scan_kernel(Shape sh, Bufs b, IhgpTabs tb, double* vprev /* [B][M] */) {
+static __global__ void __launch_bounds__(64) ihgp_scan_kernel(Shape sh, Bufs b, IhgpTabs tb, double* vprev /* [B][M] */) {
   const int n = threadIdx.x, pb = blockIdx.x;
   const int S = sh.S, M = sh.M, NG = tb.NG;
   const int64_t T = sh.T;

@@ -1,0 +1,68 @@
+// nagp_inst.hpp -- the kernel instantiations libnagp.so is built from, grouped by translation unit.
+// The host code (nagp_api.hip) sees every list as `extern template`; each inst_*.hip file instantiates one group, so the
+// groups compile in parallel (the cubature inlined into the sequential filters makes them the expensive part of the build).
+#pragma once
+#include "nagp_ihgp.hpp"
+#include "nagp_mfma.hpp"
+
+#define NAGP_SIG_GF (nagp::Shape, nagp::Bufs, nagp::MomCfg, nagp::FilterPar)
+#define NAGP_LIST_GF_ADF(P, TPT, LB)                                                                                       \
+  P void nagp::gf_filter_kernel<TPT, 0, 0, LB> NAGP_SIG_GF; P void nagp::gf_filter_kernel<TPT, 0, 1, LB> NAGP_SIG_GF;    \
+  P void nagp::gf_filter_kernel<TPT, 0, 2, LB> NAGP_SIG_GF; P void nagp::gf_filter_kernel<TPT, 0, 3, LB> NAGP_SIG_GF;    \
+  P void nagp::gf_filter_kernel<TPT, 0, 4, LB> NAGP_SIG_GF; P void nagp::gf_filter_kernel<TPT, 0, 5, LB> NAGP_SIG_GF;    \
+  P void nagp::gf_filter_kernel<TPT, 0, 6, LB> NAGP_SIG_GF; P void nagp::gf_filter_kernel<TPT, 0, 7, LB> NAGP_SIG_GF;    \
+  P void nagp::gf_filter_kernel<TPT, 0, 8, LB> NAGP_SIG_GF;
+#define NAGP_LIST_GF_ADF1(P) NAGP_LIST_GF_ADF(P, 1, 256)
+#define NAGP_LIST_GF_ADF2(P) NAGP_LIST_GF_ADF(P, 2, 256)
+#define NAGP_LIST_GF_ADF3(P) NAGP_LIST_GF_ADF(P, 3, 256)
+#define NAGP_LIST_GF_ADF4(P) NAGP_LIST_GF_ADF(P, 4, 256)
+#define NAGP_LIST_GF_ADF5(P) NAGP_LIST_GF_ADF(P, 4, 512)
+
+// EKF and fixed-site filters, smoother kernels
+#define NAGP_LIST_GF_REST(P)                                                                                               \
+  P void nagp::gf_filter_kernel<1, 1, 0> NAGP_SIG_GF; P void nagp::gf_filter_kernel<2, 1, 0> NAGP_SIG_GF;                \
+  P void nagp::gf_filter_kernel<4, 1, 0> NAGP_SIG_GF; P void nagp::gf_filter_kernel<1, 0, -1> NAGP_SIG_GF;               \
+  P void nagp::gf_filter_kernel<2, 0, -1> NAGP_SIG_GF; P void nagp::gf_filter_kernel<4, 0, -1> NAGP_SIG_GF;              \
+  P void nagp::gf_filter_kernel<1, 0, -1, 768> NAGP_SIG_GF; P void nagp::gf_filter_kernel<1, 0, -1, 1024> NAGP_SIG_GF;
+#define NAGP_LIST_SMOOTH_T(P, TPT)                                                                                         \
+  P void nagp::rts_gain_kernel<TPT>(nagp::Shape, nagp::Bufs, nagp::GainPar);                                             \
+  P void nagp::rts_compose_kernel<TPT>(nagp::Shape, nagp::Bufs, nagp::SpanPar);                                          \
+  P void nagp::rts_boundary_kernel<TPT>(nagp::Shape, nagp::Bufs, nagp::SpanPar);                                         \
+  P void nagp::rts_apply_kernel<TPT>(nagp::Shape, nagp::Bufs, nagp::SpanPar);
+#define NAGP_LIST_SMOOTH_M(P, NTL)                                                                                         \
+  P void nagp::rts_compose_mfma_kernel<NTL>(nagp::Shape, nagp::Bufs, nagp::MfmaPar);                                     \
+  P void nagp::rts_boundary_mfma_kernel<NTL>(nagp::Shape, nagp::Bufs, nagp::MfmaPar);                                    \
+  P void nagp::rts_apply_mfma_kernel<NTL>(nagp::Shape, nagp::Bufs, nagp::MfmaPar);
+#define NAGP_LIST_SMOOTH(P)                                                                                                \
+  NAGP_LIST_SMOOTH_T(P, 1) NAGP_LIST_SMOOTH_T(P, 2) NAGP_LIST_SMOOTH_T(P, 3) NAGP_LIST_SMOOTH_T(P, 4)                    \
+  NAGP_LIST_SMOOTH_M(P, 1) NAGP_LIST_SMOOTH_M(P, 2) NAGP_LIST_SMOOTH_M(P, 3) NAGP_LIST_SMOOTH_M(P, 4)                    \
+  NAGP_LIST_SMOOTH_M(P, 5) NAGP_LIST_SMOOTH_M(P, 6)
+
+// site refresh and mom on its own
+#define NAGP_LIST_EP_V(P, V)                                                                                               \
+  P void nagp::ep_site_kernel<V>(nagp::Shape, nagp::Bufs, nagp::MomCfg, nagp::EpPar);                                    \
+  P void nagp::mom_kernel<V>(nagp::MomCfg, nagp::MomPar);
+#define NAGP_LIST_EP(P)                                                                                                    \
+  NAGP_LIST_EP_V(P, 0) NAGP_LIST_EP_V(P, 1) NAGP_LIST_EP_V(P, 2) NAGP_LIST_EP_V(P, 3) NAGP_LIST_EP_V(P, 4)               \
+  NAGP_LIST_EP_V(P, 5) NAGP_LIST_EP_V(P, 6) NAGP_LIST_EP_V(P, 7) NAGP_LIST_EP_V(P, 8) NAGP_LIST_EP_V(P, 9)
+
+// infinite-horizon filters
+#define NAGP_SIG_IH (nagp::Shape, nagp::Bufs, nagp::MomCfg, nagp::IhgpTabs, nagp::IhgpPar)
+#define NAGP_LIST_IH_S(P, SRC)                                                                                             \
+  P void nagp::ihgp_filter_kernel<0, SRC> NAGP_SIG_IH; P void nagp::ihgp_filter_kernel<1, SRC> NAGP_SIG_IH;              \
+  P void nagp::ihgp_filter_kernel<2, SRC> NAGP_SIG_IH; P void nagp::ihgp_filter_kernel<3, SRC> NAGP_SIG_IH;              \
+  P void nagp::ihgp_filter_kernel<4, SRC> NAGP_SIG_IH; P void nagp::ihgp_filter_kernel<5, SRC> NAGP_SIG_IH;              \
+  P void nagp::ihgp_filter_kernel<6, SRC> NAGP_SIG_IH; P void nagp::ihgp_filter_kernel<7, SRC> NAGP_SIG_IH;              \
+  P void nagp::ihgp_filter_kernel<8, SRC> NAGP_SIG_IH; P void nagp::ihgp_filter_kernel<9, SRC> NAGP_SIG_IH;
+#define NAGP_LIST_IH0(P) NAGP_LIST_IH_S(P, false)
+#define NAGP_LIST_IH1(P) NAGP_LIST_IH_S(P, true)
+#define NAGP_SIG_IHA (nagp::Shape, nagp::Bufs, nagp::MomCfg, nagp::MomSp, nagp::IhgpTabs, nagp::IhgpPar)
+#define NAGP_LIST_IHA(P)                                                                                                   \
+  P void nagp::ihgp_adf_kernel<1> NAGP_SIG_IHA; P void nagp::ihgp_adf_kernel<2> NAGP_SIG_IHA;                            \
+  P void nagp::ihgp_adf_kernel<3> NAGP_SIG_IHA; P void nagp::ihgp_adf_kernel<4> NAGP_SIG_IHA;                            \
+  P void nagp::ihgp_adf_kernel<5> NAGP_SIG_IHA; P void nagp::ihgp_adf_kernel<6> NAGP_SIG_IHA;                            \
+  P void nagp::ihgp_adf_kernel<7> NAGP_SIG_IHA;
+
+#define NAGP_LIST_ALL(P)                                                                                                   \
+  NAGP_LIST_GF_ADF1(P) NAGP_LIST_GF_ADF2(P) NAGP_LIST_GF_ADF3(P) NAGP_LIST_GF_ADF4(P) NAGP_LIST_GF_ADF5(P)               \
+  NAGP_LIST_GF_REST(P) NAGP_LIST_SMOOTH(P) NAGP_LIST_EP(P) NAGP_LIST_IH0(P) NAGP_LIST_IH1(P) NAGP_LIST_IHA(P)

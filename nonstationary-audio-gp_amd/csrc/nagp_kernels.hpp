@@ -8,6 +8,7 @@
 // matlab/iekf_update1.m:110-117 + gf_giekf_modulator_nmf_constraints.m:492-502 (EKF update).
 #pragma once
 #include "nagp_dev.hpp"
+#include "nagp_momsp.hpp"
 
 namespace nagp {
 
@@ -124,8 +125,10 @@ struct TileOwner {
 __host__ __device__ inline size_t filter_ring_doubles(const Shape& s, int kb) { return (size_t)kb * (5 * s.M + s.S + 3); }
 __host__ __device__ inline size_t filter_lds_doubles(const Shape& s, const MomCfg& mc, int meas, int kb) {
   size_t n = LDS_INT_DOUBLES + 2 * (size_t)s.M * TS + s.M + (size_t)s.D * s.N + s.S + 4 * (size_t)s.M * s.M +
-             8 * (size_t)s.M + 8 + filter_ring_doubles(s, kb);
-  n += (meas == 0) ? mom_lds_doubles(mc) : (size_t)(s.M + 2 * s.S + 2 * s.N);
+             6 * (size_t)s.M + 2 * 68 + 8 + filter_ring_doubles(s, kb);
+  // mom workspace: the staged sparse-point form when the plan enabled it, else the generic one
+  const size_t wmom = (mc.sp.enabled && mc.cdim <= MSP_MAXCD) ? msp_lds_doubles(mc.cdim, s.D) : mom_lds_doubles(mc);
+  n += (meas == 0) ? wmom : (size_t)(s.M + 2 * s.S + 2 * s.N);
   return (n + 1) & ~(size_t)1;
 }
 
@@ -151,9 +154,9 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
   double* sW = shv + M;
   double* m = sW + (size_t)sh.D * sh.N;
   double* Wl = m + S;
-  double* fmu = Wl + (size_t)M * 4 * M;    // Wl[n][i][I] = h_n P(off_I+i, c_n)
-  double* HPH = fmu + M;
-  double* tt = HPH + M;
+  double* fmu = Wl + (size_t)M * 4 * M;    // Wl[n][i][I] = h_n P(off_I+i, c_n)  ; fmu, HPH: 68 entries, zero beyond the M sites
+  double* HPH = fmu + 68;                  // (stage A of the sparse-point cubature reads up to 64 of them against zero weights)
+  double* tt = HPH + 68;
   double* tn = tt + M;
   double* cA = tn + M;
   double* cm = cA + M;
@@ -179,9 +182,26 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
   }
   for (int i = tid; i < M; i += NT) shv[i] = mdl[mdl_h(sh) + i];
   for (int i = tid; i < sh.D * sh.N; i += NT) sW[i] = mdl[mdl_W(sh) + i];
+  for (int i = tid; i < 68; i += NT) { fmu[i] = 0.0; HPH[i] = 0.0; }
   const double sn2 = mdl[mdl_sn2(sh)];
-  if (MEAS == 0 && MV >= 0) mom_cache_tables(mc, ws);
+  // likModulatorNMFPower on a fully symmetric sigma-point set: the staged form of nagp_momsp.hpp (256-thread ADF launches)
+  constexpr bool SPK = (MEAS == 0 && MV >= 1 && MV <= MSP_MAXCD && LB == 256);
+  constexpr int CDX = SPK ? MV : 1;
+  const bool spk = SPK && __builtin_amdgcn_readfirstlane(mc.sp.enabled) != 0;
+  if (MEAS == 0 && MV >= 0 && !spk) mom_cache_tables(mc, ws);
   const double pEP1 = (MEAS == 0 && MV >= 0) ? mom_pEP(mc, sn2, fp.mom_alpha) : 1.0;
+  MspCtx<CDX> xsp;
+  double wrow[CDX];
+#pragma unroll
+  for (int j = 0; j < CDX; ++j) wrow[j] = 0.0;
+  if constexpr (SPK) if (spk) {
+    __syncthreads();      // sW, fmu / HPH padding
+    msp_setup<CDX>(xsp, mc, mc.sp, sW, fmu, HPH, ws);
+    if (tid < D) {
+#pragma unroll
+      for (int j = 0; j < CDX; ++j) wrow[j] = sW[tid * CDX + j];
+    }
+  }
 
   // The covariance is kept exactly symmetric: only the lower-triangular tiles (I >= J) are held (one thread
   // per tile); K*H*P and K*W' coincide, W = P H' is the only panel needed, and the filtered covariance is
@@ -348,10 +368,36 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
         if (MEAS == 0) {
           if constexpr (MV >= 0) if (do_mom) {
             if (mc.stamps && tid == 0) { st_b = __builtin_readcyclecounter(); stp[4] += st_b - st_a; }
-            mom_eval<MV, false, false>(mc, sW, pEP1, sn2, fp.mom_alpha, yk, fmu, HPH, ws, &misc[0], dl, d2l, stp);
+            double d1v = 0.0, d2v = 0.0;
+            bool staged = false;
+            if constexpr (SPK) if (spk) {
+              staged = true;
+              msp_stageA<CDX>(xsp, mc);
+              lds_barrier();
+              msp_stageB<CDX>(xsp, mc, ws);
+              lds_barrier();
+              msp_stage1b<CDX>(xsp, mc, mc.sp, sn2 / fp.mom_alpha, yk, ws);
+              lds_barrier();
+              msp_stage2<CDX>(xsp, mc, ws);
+              lds_barrier();
+              if (tid < 64) {       // the sites live in wave 0: partial sums and outputs without another workgroup barrier
+                msp_reduce<CDX>(xsp);
+                msp_wave_fence();
+                if (tid < M) {
+                  double Zv;
+                  msp_outputs<CDX>(xsp.accp, tid < D, tid - D, wrow, pEP1, mc.jitter, Zv, d1v, d2v);
+                  if (tid == 0) rZ[kk] = Zv;
+                }
+              }
+            }
+            if (!staged) {
+              mom_eval<MV, false, false>(mc, sW, pEP1, sn2, fp.mom_alpha, yk, fmu, HPH, ws, &misc[0], dl, d2l, stp);
+              if (tid < M) { d1v = dl[tid]; d2v = d2l[tid]; }
+              if (tid == 0) rZ[kk] = misc[0];
+            }
             if (mc.stamps && tid == 0) st_a = __builtin_readcyclecounter();
             if (tid < M) {
-              const double d2 = d2l[tid], d1 = dl[tid], hp = HPH[tid], f = fmu[tid];
+              const double d2 = d2v, d1 = d1v, hp = HPH[tid], f = fmu[tid];
               const double t_old = rtt[kk * M + tid], n_old = rtn[kk * M + tid];
               double tnew = fp.w_old * t_old + fp.w_new * (-d2 / (1.0 + d2 * hp));
               const double nnew = fp.w_old * n_old + fp.w_new * ((d1 - f * d2) / (1.0 + d2 * hp));
@@ -362,7 +408,6 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
               rtt[kk * M + tid] = tnew; rtn[kk * M + tid] = nnew;
               if (fp.write_R) rR[kk * M + tid] = 1.0 / (fp.R_raw ? traw : tnew);
             }
-            if (tid == 0) rZ[kk] = misc[0];
           }
           if (do_mom && fp.legacy_update) lds_barrier();
           if (do_mom && tid < M) {
@@ -1312,7 +1357,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) e
 // ---------------------------------------------------------------------------------------------
 // Deterministic reductions: out[pb*8 + slot] = sum_{k in [k_lo,k_hi)} v[pb][k]   (skipping nothing:
 // entries that were never written are zero, like the reference's zeros(1,T) initialisation).
-__global__ void __launch_bounds__(1024) sum_kernel(const double* v, int64_t T, int64_t k_lo, int64_t k_hi, double* out, int slot) {
+static __global__ void __launch_bounds__(1024) sum_kernel(const double* v, int64_t T, int64_t k_lo, int64_t k_hi, double* out, int slot) {
   __shared__ double part[16];
   const int tid = threadIdx.x, NT = blockDim.x, pb = blockIdx.x;
   const double* p = v + (size_t)pb * T;
@@ -1393,7 +1438,7 @@ struct EkfPar {
   double* K;            // [S]    out
   double* MU_S;         // [2]    out: MU, S of the last iteration
 };
-__global__ void __launch_bounds__(256) iekf_update1_kernel(EkfPar ep) {
+static __global__ void __launch_bounds__(256) iekf_update1_kernel(EkfPar ep) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int tid = threadIdx.x, NT = blockDim.x, S = ep.S, D = ep.D, N = ep.N, M = D + N;
   double* m = lds;          // [S]
@@ -1480,7 +1525,7 @@ __host__ __device__ inline size_t fb_lds_doubles(int S) { return 2 * (size_t)S *
 __host__ __device__ inline size_t fb_compose_lds_doubles(int S) { return 2 * (size_t)S * S + 2 * (size_t)(S + 4) * (S + 4) + 3 * (size_t)S + 8; }
 
 // pass 3 (and the whole job when ns == 1):  if ~isnan(y): v = y - HA*m; m = AKHA*m + K*y; else m = A*m
-__global__ void __launch_bounds__(256) fastfb_filter_kernel(FbPar fp) {
+static __global__ void __launch_bounds__(256) fastfb_filter_kernel(FbPar fp) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int tid = threadIdx.x, NT = blockDim.x, S = fp.S;
   double* At = lds;                       // At[j*S + i] = A(i,j): the column-major input is already this layout
@@ -1534,7 +1579,7 @@ __global__ void __launch_bounds__(256) fastfb_filter_kernel(FbPar fp) {
 }
 
 // pass 3:  m = MS_k + G*(m - A*MS_k), k descending inside span j of the n = T-1 smoothing steps
-__global__ void __launch_bounds__(256) fastfb_smoother_kernel(FbPar fp) {
+static __global__ void __launch_bounds__(256) fastfb_smoother_kernel(FbPar fp) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int tid = threadIdx.x, NT = blockDim.x, S = fp.S;
   double* At = lds;

@@ -13,7 +13,7 @@
 // and the MFMA.  Same arithmetic as the reference up to summation order.
 //
 // Stages (256 threads = 4 waves; a workgroup barrier between stages):
-//   A   wave 0, lane (j,c): link, xg, xg2 tables            | waves 1-3: Q, 2Q, v by 4-lane groups (static W products)
+//   A   wave 0, lane (j,c): link, xg, xg2 tables            | waves 1-3: Q, 2Q, v by 4-lane groups (static W products in LDS)
 //   B   wave 0, lane (j,c): e, t1, ve tables                | wave 1: q0, s0
 //   1b  one lane per sigma point (<= MSP_NPS per lane): Gaussian weight -> c0, c1, c2
 //   2   every wave: its share of the MFMA steps -> 16x16 partial in LDS
@@ -27,37 +27,35 @@ constexpr int MSP_NT = 256;   // threads per workgroup the stages are written fo
 constexpr int MSP_NW = 4;
 constexpr int MSP_NPS = 2;    // sigma points per lane in stage 1b
 constexpr int MSP_NST = 20;   // MFMA steps per wave in stage 2 (4 points each)
-constexpr int MSP_NZ = 4;     // non-centre coordinates per sigma point
 constexpr int MSP_DT = 16;    // sub-bands per lane of a 4-lane group in stage A (D <= 64)
 constexpr int MSP_MAXCD = 7;  // 2*CD + 2 <= 16 rows of the MFMA block
+constexpr int MSP_TS = 64;    // stride of the (dimension, coordinate) tables: CD*nd <= 63, entry 63 of e / t1 / ve stays zero
+constexpr int MSP_CS = 4 * MSP_NW * MSP_NST + 1;   // stride of c0 / c1 / c2: every point an MFMA step can address, zero beyond n_pts
 
 typedef const double __attribute__((address_space(3))) * msp_rp;   // LDS read pointer (32-bit, register resident)
 typedef double __attribute__((address_space(3))) * msp_wp;
 
-struct MomSp {
-  int enabled;
-  int c0;             // code of the coordinate value 0
-  int nzmax;          // largest number of non-centre coordinates of a sigma point
-  const int* pdesc;   // [n_pts][MSP_NZ]: j*nd + c of the non-centre coordinates, -1 = none
-};
+// terms per lane of the 4-lane groups that form Q and v (stage A): the next of 4, 8, 16 that covers D sub-bands
+__host__ __device__ inline int msp_qterms(int D) { return D <= 16 ? 4 : (D <= 32 ? 8 : 16); }
 
-// LDS workspace (offsets in doubles)
-struct MspLay { int lk, xg, xg2, e, t1, ve, one, zero, Q, Q2, v, q0, s0, c0, c1, c2, part, acc, total; };
-__host__ __device__ inline MspLay msp_layout(int CD, int nd, int n_pts) {
+// LDS workspace (offsets in doubles).  Tables lk | xg | xg2 | e | t1 | ve, MSP_TS entries each.
+struct MspLay { int lk, xg, xg2, e, t1, ve, one, zero, Q, Q2, v, q0, s0, c0, c1, c2, part, acc, wwt, total; };
+__host__ __device__ inline MspLay msp_layout(int CD, int D) {
   MspLay l;
-  const int TN = CD * nd;
-  l.lk = 0; l.xg = TN; l.xg2 = 2 * TN; l.e = 3 * TN; l.t1 = 4 * TN; l.ve = 5 * TN; l.one = 6 * TN; l.zero = 6 * TN + 1;
-  l.Q = 6 * TN + 2; l.Q2 = l.Q + CD * CD; l.v = l.Q2 + CD * CD; l.q0 = l.v + CD; l.s0 = l.q0 + 1;
+  l.lk = 0; l.xg = MSP_TS; l.xg2 = 2 * MSP_TS; l.e = 3 * MSP_TS; l.t1 = 4 * MSP_TS; l.ve = 5 * MSP_TS;
+  l.zero = l.e + MSP_TS - 1;                     // e[63] (t1[63], ve[63] are zero as well)
+  l.one = 6 * MSP_TS;
+  l.Q = l.one + 1; l.Q2 = l.Q + CD * CD; l.v = l.Q2 + CD * CD; l.q0 = l.v + CD; l.s0 = l.q0 + 1;
   int o = (l.s0 + 2) & ~1;
-  const int cs = (n_pts + 4) | 1;          // + zero-weight dummy points for the padding of the last MFMA steps
-  l.c0 = o; l.c1 = o + cs; l.c2 = o + 2 * cs;
-  o = (o + 3 * cs + 1) & ~1;
+  l.c0 = o; l.c1 = o + MSP_CS; l.c2 = o + 2 * MSP_CS;
+  o = (o + 3 * MSP_CS + 1) & ~1;
   l.part = o; o += MSP_NW * 256;
   l.acc = o; o += 64;
+  l.wwt = o; o += msp_qterms(D) * 192;            // static W products of stage A, [q][lane of waves 1..3], zero for sub-bands >= D
   l.total = o;
   return l;
 }
-__host__ __device__ inline size_t msp_lds_doubles(int CD, int nd, int n_pts) { return (size_t)msp_layout(CD, nd, n_pts).total; }
+__host__ __device__ inline size_t msp_lds_doubles(int CD, int D) { return (size_t)msp_layout(CD, D).total; }
 __host__ __device__ inline int msp_nacc(int CD) { return CD + CD * (CD + 1) / 2 + 2 * CD + 1; }   // u, R (upper), g1, g2, Z
 
 // 1/x by the hardware estimate and two Newton steps (~1 ulp); x = 0, inf, NaN are the caller's business
@@ -67,30 +65,33 @@ __device__ __forceinline__ double rcp_nr(double x) {
   e = fma(-x, r, 1.0); r = fma(r, e, r);
   return r;
 }
+// a zero the compiler cannot see through: added to a wave-uniform LDS address it keeps the address in ONE vector register
+// (uniform addresses are otherwise materialised one scalar register per constant offset, and spilled)
+__device__ __forceinline__ int opaque_zero() { int z = 0; asm volatile("" : "+v"(z)); return z; }
 
 // Register-resident state of one thread.  Everything here is computed once per kernel.
 template <int CD>
 struct MspCtx {
   // stage A / B, wave 0: lane t = j*nd + c
-  int jA; double xdc; msp_rp a_mu, a_s2, a_l0[CD], a_l0own, a_qrow, a_qjj, a_v; msp_wp a_out;   // a_out + {lk,xg,xg2,e,t1,ve}*TN; a_l0[j'] = l0 of modulator j'
+  double xdc; msp_rp a_mu, a_s2, a_l0[CD], a_l0own, a_qrow, a_qjj, a_v; msp_wp a_out;   // a_out[k*MSP_TS]: lk, xg, xg2, e, t1, ve
   // stage B, wave 1: lane L < CD*CD: Q(j,j') l0_j l0_j' ; next CD lanes: v_j l0_j
   int b_kind; msp_rp b_p0, b_p1, b_p2;
   // stage A, waves 1-3: 4-lane group -> one entry of Q (and 2Q) or v
   int q_kind;          // 0: none, 1: Q(j,j'), 2: v(j)
-  double ww[MSP_DT];   // W_dj W_dj' (or W_dj) for d = sub, sub+4, ...
-  msp_rp q_src, q_last; double ww_last;   // common operand pointer; the last term (d may pass D) has its own, aimed at a zero
+  msp_rp q_ww, q_src;  // products at q_ww[192*q] (zero for sub-bands >= D), operands at q_src[4*q]
   msp_wp q_out0, q_out1, q_out2, q_out3;
   // stage 1b
-  msp_rp p_ve[MSP_NPS][MSP_NZ], p_t1[MSP_NPS][MSP_NZ], p_e[MSP_NPS][MSP_NZ], p_q[MSP_NPS][6];
+  msp_rp p_e[MSP_NPS][MSP_NZ], p_q[MSP_NPS][6];   // e at p_e[0], t1 at [MSP_TS], ve at [2*MSP_TS]
   msp_wp p_c[MSP_NPS];
   double p_wn[MSP_NPS];
   bool p_ok[MSP_NPS];
   int p_any[MSP_NPS];  // wave-uniform: some lane of this wave owns a point in the slot
   // stage 2
-  msp_rp m_a[MSP_NST], m_b[MSP_NST], m_w[MSP_NST];
+  msp_rp m_a[MSP_NST], m_b[MSP_NST], m_w0;   // weight of step s at m_w0[16*s]
   int nst;             // steps of this wave
   // partial-sum reduction: lane o < nacc of the reducing wave
   msp_rp r_src; msp_wp r_dst;
+  msp_rp accp;         // reduced sums (one vector register, immediate offsets)
 };
 
 template <int CD>
@@ -98,15 +99,20 @@ __device__ __forceinline__ void msp_setup(MspCtx<CD>& x, const MomCfg& c, const 
                                            const double* fmu, const double* HPH, double* ws) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nd = c.nd, D = c.D, TN = CD * nd, npt = c.n_pts;
-  const MspLay l = msp_layout(CD, nd, npt);
+  const MspLay l = msp_layout(CD, D);
+  const int oz = opaque_zero();
+  // constants, zero entries of the tables, zero weights beyond the points
+  for (int i = tid; i < 6 * MSP_TS; i += MSP_NT) ws[i] = 0.0;
+  if (tid == 0) ws[l.one] = 1.0;
+  for (int i = tid; i < 3 * MSP_CS; i += MSP_NT) ws[l.c0 + i] = 0.0;
   // ---- stage A / B of wave 0
   {
     const int t = (tid < TN) ? tid : 0;
     const int j = t / nd, cc = t - j * nd;
-    x.jA = j; x.xdc = c.xd[cc];
+    x.xdc = c.xd[cc];
     x.a_mu = (msp_rp)(fmu + D + j); x.a_s2 = (msp_rp)(HPH + D + j);
 #pragma unroll
-    for (int j2 = 0; j2 < CD; ++j2) x.a_l0[j2] = (msp_rp)(ws + l.lk + j2 * nd + sp.c0);
+    for (int j2 = 0; j2 < CD; ++j2) x.a_l0[j2] = (msp_rp)(ws + l.lk + j2 * nd + sp.c0) + oz;
     x.a_l0own = (msp_rp)(ws + l.lk + j * nd + sp.c0);
     x.a_qrow = (msp_rp)(ws + l.Q + j * CD);
     x.a_qjj = (msp_rp)(ws + l.Q + j * CD + j);
@@ -128,9 +134,8 @@ __device__ __forceinline__ void msp_setup(MspCtx<CD>& x, const MomCfg& c, const 
   // ---- stage A of waves 1..3
   {
     x.q_kind = 0;
-#pragma unroll
-    for (int q = 0; q < MSP_DT; ++q) x.ww[q] = 0.0;
     x.q_out0 = x.q_out1 = x.q_out2 = x.q_out3 = (msp_wp)(ws + l.acc + 63);   // scratch slot
+    x.q_ww = x.q_src = (msp_rp)(ws + l.zero);
     const int L = tid - 64;
     if (L >= 0) {
       const int g = L >> 2, sub = L & 3;
@@ -147,23 +152,15 @@ __device__ __forceinline__ void msp_setup(MspCtx<CD>& x, const MomCfg& c, const 
         j = g - nq; x.q_kind = 2;
         x.q_out0 = (msp_wp)(ws + l.v + j);
       }
-      const int DTn = (D + 3) >> 2;
-      if (x.q_kind) {
-#pragma unroll
-        for (int q = 0; q < MSP_DT; ++q) {
-          const int d = sub + 4 * q;
-          if (d < D) x.ww[q] = (x.q_kind == 1) ? Wl[d * CD + j] * Wl[d * CD + j2] : Wl[d * CD + j];
-        }
+      // zero weights for sub-bands >= D: the operand read there (a modulator's entry, or the zero padding of fmu / HPH) is multiplied by 0
+      for (int q = 0; q < msp_qterms(D); ++q) {
+        const int d = sub + 4 * q;
+        double v = 0.0;
+        if (x.q_kind && d < D) v = (x.q_kind == 1) ? Wl[d * CD + j] * Wl[d * CD + j2] : Wl[d * CD + j];
+        ws[l.wwt + q * 192 + L] = v;
       }
-      // terms q < DTn-1 lie inside the sub-bands for every lane; the last one may not: its own pointer and weight
-      const double* srcv = (x.q_kind == 1) ? HPH : fmu;
-      x.q_src = (msp_rp)(srcv + sub);
-      const int dl = sub + 4 * (DTn - 1);
-      const bool inl = x.q_kind && dl < D;
-      x.q_last = inl ? (msp_rp)(srcv + dl) : (msp_rp)(ws + l.zero);
-      x.ww_last = inl ? ((x.q_kind == 1) ? Wl[dl * CD + j] * Wl[dl * CD + j2] : Wl[dl * CD + j]) : 0.0;
-    } else {
-      x.q_src = x.q_last = (msp_rp)(ws + l.zero); x.ww_last = 0.0;
+      x.q_ww = (msp_rp)(ws + l.wwt + L);
+      x.q_src = (msp_rp)(((x.q_kind == 1) ? HPH : fmu) + sub);
     }
   }
   // ---- stage 1b: slot 0 = point tid; slot 1 = points 256.. on the LAST wave (wave 0 carries the serial stages)
@@ -178,26 +175,25 @@ __device__ __forceinline__ void msp_setup(MspCtx<CD>& x, const MomCfg& c, const 
       if (!ok) p = 0;
       int tj[MSP_NZ];
 #pragma unroll
-      for (int r = 0; r < MSP_NZ; ++r) tj[r] = ok ? sp.pdesc[(size_t)p * MSP_NZ + r] : -1;
-#pragma unroll
       for (int r = 0; r < MSP_NZ; ++r) {
-        x.p_ve[u][r] = (tj[r] >= 0) ? (msp_rp)(ws + l.ve + tj[r]) : zero;
-        x.p_t1[u][r] = (tj[r] >= 0) ? (msp_rp)(ws + l.t1 + tj[r]) : zero;
-        x.p_e[u][r] = (tj[r] >= 0) ? (msp_rp)(ws + l.e + tj[r]) : zero;
+        tj[r] = ok ? sp.pdesc[(size_t)p * MSP_NZ + r] : -1;
+        if (tj[r] >= 0) tj[r] = (tj[r] / nd) * 64 + (tj[r] % nd);      // (j, c) packed as j*64 + c
       }
+#pragma unroll
+      for (int r = 0; r < MSP_NZ; ++r) x.p_e[u][r] = (tj[r] >= 0) ? (msp_rp)(ws + l.e + (tj[r] >> 6) * nd + (tj[r] & 63)) : zero;
       int pi = 0;
 #pragma unroll
       for (int r = 0; r < MSP_NZ; ++r)
 #pragma unroll
         for (int s = r + 1; s < MSP_NZ; ++s) {
-          x.p_q[u][pi] = (tj[r] >= 0 && tj[s] >= 0) ? (msp_rp)(ws + l.Q2 + (tj[r] / nd) * CD + (tj[s] / nd)) : zero;
+          x.p_q[u][pi] = (tj[r] >= 0 && tj[s] >= 0) ? (msp_rp)(ws + l.Q2 + (tj[r] >> 6) * CD + (tj[s] >> 6)) : zero;
           ++pi;
         }
       x.p_c[u] = (msp_wp)(ws + l.c0 + p);
       x.p_wn[u] = ok ? c.wn[p] : 0.0;
     }
   }
-  // ---- stage 2: wave w takes the steps w, w+4, ... ; lane (i = lane & 15, kq = lane >> 4) feeds row/col i with point 4*step+kq
+  // ---- stage 2: wave w takes the steps w', w'+4, ... ; lane (i = lane & 15, kq = lane >> 4) feeds row/col i with point 4*step+kq
   //   A_p = [c2 lk_0..lk_{N-1} | c1 | c0 xg2_0..xg2_{N-1} | c0]      B_p = [lk_0..lk_{N-1} | xg_0..xg_{N-1} | 1]
   {
     const int i = lane & 15, kq = lane >> 4;
@@ -206,25 +202,25 @@ __device__ __forceinline__ void msp_setup(MspCtx<CD>& x, const MomCfg& c, const 
     const int wv = (wave + MSP_NW - 1) % MSP_NW;
     x.nst = (nstep - wv + MSP_NW - 1) / MSP_NW;
     if (x.nst < 0) x.nst = 0;
-    const int cs = (npt + 4) | 1;
+    int wbase = l.c0;                                // rows without a weight multiply a zero operand
+    if (i < CD) wbase = l.c2; else if (i == CD) wbase = l.c1;
+    x.m_w0 = (msp_rp)(ws + wbase + 4 * wv + kq);     // point of step s: 4*(wv + 4s) + kq
 #pragma unroll
     for (int s = 0; s < MSP_NST; ++s) {
       const int p = 4 * (wv + MSP_NW * s) + kq;
       const bool ok = (s < x.nst) && (p < npt);
-      const int pp = ok ? p : 0;
-      int offA = l.zero, offB = l.zero, offW = l.c0 + npt;     // zero operand, zero-weight dummy point
+      int offA = l.zero, offB = l.zero;             // beyond the points: zero operands (their weights are zero too)
       if (ok) {
-        const unsigned char* cp = c.code + (size_t)pp * CD;
-        if (i < CD) { offA = l.lk + i * nd + cp[i]; offW = l.c2 + pp; }
-        else if (i == CD) { offA = l.one; offW = l.c1 + pp; }
-        else if (i <= 2 * CD) { offA = l.xg2 + (i - CD - 1) * nd + cp[i - CD - 1]; offW = l.c0 + pp; }
-        else if (i == 2 * CD + 1) { offA = l.one; offW = l.c0 + pp; }
+        const unsigned char* cp = c.code + (size_t)p * CD;
+        if (i < CD) offA = l.lk + i * nd + cp[i];
+        else if (i == CD) offA = l.one;
+        else if (i <= 2 * CD) offA = l.xg2 + (i - CD - 1) * nd + cp[i - CD - 1];
+        else if (i == 2 * CD + 1) offA = l.one;
         if (i < CD) offB = l.lk + i * nd + cp[i];
         else if (i < 2 * CD) offB = l.xg + (i - CD) * nd + cp[i - CD];
         else if (i == 2 * CD) offB = l.one;
       }
-      (void)cs;
-      x.m_a[s] = (msp_rp)(ws + offA); x.m_b[s] = (msp_rp)(ws + offB); x.m_w[s] = (msp_rp)(ws + offW);
+      x.m_a[s] = (msp_rp)(ws + offA); x.m_b[s] = (msp_rp)(ws + offB);
     }
   }
   // ---- reduction of the four 16x16 partials: lane o -> (row, col) of the block
@@ -237,11 +233,18 @@ __device__ __forceinline__ void msp_setup(MspCtx<CD>& x, const MomCfg& c, const 
     else if (o < 3 * CD + nq) { row = CD + 1 + (o - 2 * CD - nq); col = 2 * CD; } // g2_j
     else { row = 2 * CD + 1; col = 2 * CD; }                                      // Z
     x.r_src = (msp_rp)(ws + l.part + row * 16 + col);
-    x.r_dst = (msp_wp)(ws + l.acc + ((o < 64) ? o : 63));
+    x.r_dst = (msp_wp)(ws + l.acc + o);
+    x.accp = (msp_rp)(ws + l.acc) + oz;
   }
-  // constants and the dummy points
-  if (tid == 0) { ws[l.one] = 1.0; ws[l.zero] = 0.0; }
-  if (tid < 4) { ws[l.c0 + npt + tid] = 0.0; ws[l.c1 + npt + tid] = 0.0; ws[l.c2 + npt + tid] = 0.0; }
+}
+
+template <int K>
+__device__ __forceinline__ void msp_qsum(msp_rp ww, msp_rp src, double& a0, double& a1) {
+  double w[K], v[K];
+#pragma unroll
+  for (int q = 0; q < K; ++q) { w[q] = ww[192 * q]; v[q] = src[4 * q]; }
+#pragma unroll
+  for (int q = 0; q < K; q += 2) { a0 = fma(w[q], v[q], a0); a1 = fma(w[q + 1], v[q + 1], a1); }
 }
 
 // stage A.  Needs fmu / HPH of all sites visible; ends WITHOUT a barrier (the caller places it).
@@ -256,17 +259,14 @@ __device__ __forceinline__ void msp_stageA(const MspCtx<CD>& x, const MomCfg& c)
       const double xn = mu + sg * x.xdc;                                   // likModulatorNMFPower.m:34
       const double lk = link_eval(c.link_kind, c.link_shift, xn);
       const double xg = (xn - mu) * inv;                                   // (xn - mu_g)./s2_g  (:72)
-      x.a_out[0] = lk; x.a_out[TN] = xg; x.a_out[2 * TN] = xg * xg - inv;   // :79
+      x.a_out[0] = lk; x.a_out[MSP_TS] = xg; x.a_out[2 * MSP_TS] = xg * xg - inv;   // :79
     }
   } else if (x.q_kind) {
-    const int DTn = (c.D + 3) >> 2;
-    double a0 = x.ww_last * (*x.q_last), a1 = 0.0;
-#pragma unroll
-    for (int q = 0; q < MSP_DT - 1; ++q) {
-      if (q < DTn - 1) {       // uniform
-        if (q & 1) a1 = fma(x.ww[q], x.q_src[4 * q], a1); else a0 = fma(x.ww[q], x.q_src[4 * q], a0);
-      }
-    }
+    const int K = __builtin_amdgcn_readfirstlane(msp_qterms(c.D));
+    double a0 = 0.0, a1 = 0.0;
+    if (K == 4) msp_qsum<4>(x.q_ww, x.q_src, a0, a1);
+    else if (K == 8) msp_qsum<8>(x.q_ww, x.q_src, a0, a1);
+    else msp_qsum<16>(x.q_ww, x.q_src, a0, a1);
     double a = a0 + a1;
     a += dpp_mov<0xB1>(a);
     a += dpp_mov<0x4E>(a);
@@ -279,55 +279,52 @@ __device__ __forceinline__ void msp_stageA(const MspCtx<CD>& x, const MomCfg& c)
 
 // stage B.  After a barrier behind stage A; ends without a barrier.
 template <int CD>
-__device__ __forceinline__ void msp_stageB(const MspCtx<CD>& x, const MomCfg& c, const MomSp& sp, double* ws) {
-  const int tid = threadIdx.x, nd = c.nd, TN = CD * nd;
-  const MspLay l = msp_layout(CD, nd, c.n_pts);
+__device__ __forceinline__ void msp_stageB(const MspCtx<CD>& x, const MomCfg& c, double* ws) {
+  const int tid = threadIdx.x, TN = CD * c.nd;
+  const MspLay l = msp_layout(CD, c.D);
   if (tid < 64) {
     if (tid < TN) {
       const double lk = ((msp_rp)x.a_out)[0];
-      double ql = 0.0;
+      double ql0 = 0.0, ql1 = 0.0;
 #pragma unroll
-      for (int j2 = 0; j2 < CD; ++j2) ql = fma(x.a_qrow[j2], *x.a_l0[j2], ql);
-      const double l0 = *x.a_l0own;
-      const double e = lk - l0;
-      const double qjj = *x.a_qjj;
-      x.a_out[3 * TN] = e;
-      x.a_out[4 * TN] = e * fma(qjj, e, 2.0 * ql);
-      x.a_out[5 * TN] = (*x.a_v) * e;
+      for (int j2 = 0; j2 < CD; ++j2) { if (j2 & 1) ql1 = fma(x.a_qrow[j2], *x.a_l0[j2], ql1); else ql0 = fma(x.a_qrow[j2], *x.a_l0[j2], ql0); }
+      const double ql = ql0 + ql1;
+      const double e = lk - *x.a_l0own;
+      x.a_out[3 * MSP_TS] = e;
+      x.a_out[4 * MSP_TS] = e * fma(*x.a_qjj, e, 2.0 * ql);
+      x.a_out[5 * MSP_TS] = (*x.a_v) * e;
     }
   } else if (tid < 128) {
-    const int L = tid - 64;
     const double t = (*x.b_p0) * (*x.b_p1) * (*x.b_p2);      // unused lanes: zero * ...
     double tq = (x.b_kind == 1) ? t : 0.0, tsv = (x.b_kind == 2) ? t : 0.0;
     tq = wave_sum(tq);
     tsv = wave_sum(tsv);
-    if (L == 0) { ws[l.q0] = tq; ws[l.s0] = tsv; }
+    if (tid == 64) { ws[l.q0] = tq; ws[l.s0] = tsv; }
   }
 }
 
 // stage 1b.  After a barrier behind stage B; ends without a barrier.
 template <int CD>
 __device__ __forceinline__ void msp_stage1b(const MspCtx<CD>& x, const MomCfg& c, const MomSp& sp, double sn2a, double y, const double* ws) {
-  const MspLay l = msp_layout(CD, c.nd, c.n_pts);
-  const int cs = (c.n_pts + 4) | 1;
+  const MspLay l = msp_layout(CD, c.D);
   const bool four = __builtin_amdgcn_readfirstlane(sp.nzmax > 3 ? 1 : 0) != 0;
   const bool three = __builtin_amdgcn_readfirstlane(sp.nzmax > 2 ? 1 : 0) != 0;
   const double q0 = ws[l.q0], s0 = ws[l.s0];
 #pragma unroll
   for (int u = 0; u < MSP_NPS; ++u) {
     if (__builtin_amdgcn_readfirstlane(x.p_any[u]) == 0) continue;   // wave-uniform skip
-    double sam = s0 + *x.p_ve[u][0], sa2 = q0 + *x.p_t1[u][0];
-    const double e0 = *x.p_e[u][0], e1 = *x.p_e[u][1];
-    sam += *x.p_ve[u][1]; sa2 += *x.p_t1[u][1];
+    const double e0 = x.p_e[u][0][0], e1 = x.p_e[u][1][0];
+    double sam = (s0 + x.p_e[u][0][2 * MSP_TS]) + x.p_e[u][1][2 * MSP_TS];
+    double sa2 = (q0 + x.p_e[u][0][MSP_TS]) + x.p_e[u][1][MSP_TS];
     double cr = (*x.p_q[u][0]) * e0 * e1;
     if (three) {
-      const double e2 = *x.p_e[u][2];
-      sam += *x.p_ve[u][2]; sa2 += *x.p_t1[u][2];
+      const double e2 = x.p_e[u][2][0];
+      sam += x.p_e[u][2][2 * MSP_TS]; sa2 += x.p_e[u][2][MSP_TS];
       cr = fma((*x.p_q[u][1]) * e0, e2, cr);
       cr = fma((*x.p_q[u][3]) * e1, e2, cr);
       if (four) {
-        const double e3 = *x.p_e[u][3];
-        sam += *x.p_ve[u][3]; sa2 += *x.p_t1[u][3];
+        const double e3 = x.p_e[u][3][0];
+        sam += x.p_e[u][3][2 * MSP_TS]; sa2 += x.p_e[u][3][MSP_TS];
         cr = fma((*x.p_q[u][2]) * e0, e3, cr);
         cr = fma((*x.p_q[u][4]) * e1, e3, cr);
         cr = fma((*x.p_q[u][5]) * e2, e3, cr);
@@ -339,34 +336,47 @@ __device__ __forceinline__ void msp_stage1b(const MspCtx<CD>& x, const MomCfg& c
     const double w0 = x.p_wn[u] * pdf;
     if (x.p_ok[u]) {
       x.p_c[u][0] = w0;
-      x.p_c[u][cs] = w0 * q;
-      x.p_c[u][2 * cs] = w0 * (q * q - inv);
+      x.p_c[u][MSP_CS] = w0 * q;
+      x.p_c[u][2 * MSP_CS] = w0 * (q * q - inv);
     }
   }
 }
 
 // stage 2.  After a barrier behind stage 1b; leaves this wave's 16x16 partial in LDS, no barrier.
+// Two accumulators (the dependent-accumulator latency of the f64 MFMA is longer than its issue time) and the operands of
+// the next four steps in flight while the current four multiply.
 template <int CD>
 __device__ __forceinline__ void msp_stage2(const MspCtx<CD>& x, const MomCfg& c, double* ws) {
-  const MspLay l = msp_layout(CD, c.nd, c.n_pts);
+  const MspLay l = msp_layout(CD, c.D);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nst = __builtin_amdgcn_readfirstlane(x.nst);
-  v4d acc = {0.0, 0.0, 0.0, 0.0};
+  v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+  double a[4], bb[4], w[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) { a[u] = *x.m_a[u]; bb[u] = *x.m_b[u]; w[u] = x.m_w0[16 * u]; }
 #pragma unroll
   for (int s0 = 0; s0 < MSP_NST; s0 += 4) {
     if (s0 < nst) {      // uniform; steps beyond nst inside the group of four carry zero operands
-      double a[4], bb[4], w[4];
+      double an[4], bn[4], wn_[4];
+      if (s0 + 4 < MSP_NST) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { a[u] = *x.m_a[s0 + u]; bb[u] = *x.m_b[s0 + u]; w[u] = *x.m_w[s0 + u]; }
+        for (int u = 0; u < 4; ++u) { an[u] = *x.m_a[s0 + 4 + u]; bn[u] = *x.m_b[s0 + 4 + u]; wn_[u] = x.m_w0[16 * (s0 + 4 + u)]; }
+      }
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0] * w[0], bb[0], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1] * w[1], bb[1], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2] * w[2], bb[2], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3] * w[3], bb[3], acc1, 0, 0, 0);
+      if (s0 + 4 < MSP_NST) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u] * w[u], bb[u], acc, 0, 0, 0);
+        for (int u = 0; u < 4; ++u) { a[u] = an[u]; bb[u] = bn[u]; w[u] = wn_[u]; }
+      }
     }
   }
   const int i = lane & 15, kq = lane >> 4;
   double* part = ws + l.part + wave * 256;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) part[(kq + 4 * r) * 16 + i] = acc[r];
+  for (int r = 0; r < 4; ++r) part[(kq + 4 * r) * 16 + i] = acc0[r] + acc1[r];
 }
 
 // fixed-order sum of the partials: lanes o < msp_nacc(CD) of ONE wave; the same wave may read acc after msp_wave_fence()
@@ -382,29 +392,41 @@ __device__ __forceinline__ void msp_reduce(const MspCtx<CD>& x) {
 __device__ __forceinline__ void msp_wave_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // acc layout: [u: CD][R upper, row-major: CD(CD+1)/2][g1: CD][g2: CD][Z]
-// site n < D: s1 = W_n . u, s2 = W_n' R W_n (w2[] = (2 - delta) W_nj W_nj' in the order of the upper triangle);
-// site D + j: s1 = g1_j, s2 = g2_j
+// sub-band site (sub): s1 = W_n . u, s2 = W_n' R W_n ;  modulator site j: s1 = g1_j, s2 = g2_j
+// returns d lZ and d2 lZ (likModulatorNMFPower.m:59-80); Z = pEP*max(sum, jitter) (:55)
 template <int CD>
-__device__ __forceinline__ void msp_outputs(const double* acc, int n, int D, const double* wrow, const double* w2, double pEP, double jitter,
+__device__ __forceinline__ void msp_outputs(msp_rp acc, bool sub, int jmod, const double* wrow, double pEP, double jitter,
                                             double& Z, double& d1, double& d2) {
   constexpr int nq = CD * (CD + 1) / 2;
   const double Zs = acc[3 * CD + nq];
-  Z = pEP * ((Zs > jitter) ? Zs : jitter);          // max(NaN, jitter) = jitter (likModulatorNMFPower.m:55)
-  const double Zinv = pEP / Z;
+  Z = pEP * ((Zs > jitter) ? Zs : jitter);          // max(NaN, jitter) = jitter
+  const double Zinv = pEP * rcp_nr(Z);              // Z >= pEP*jitter > 0, finite (or inf: Zinv = NaN like inf/inf)
   double s1, s2;
-  if (n < D) {
-    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0;
+  if (sub) {
+    // all reads first (one LDS round trip), then arithmetic only
+    double av[CD + nq];
 #pragma unroll
-    for (int j = 0; j < CD; ++j) { if (j & 1) a1 = fma(wrow[j], acc[j], a1); else a0 = fma(wrow[j], acc[j], a0); }
+    for (int q = 0; q < CD + nq; ++q) av[q] = acc[q];
 #pragma unroll
-    for (int q = 0; q < nq; ++q) {
-      const double r = acc[CD + q];
-      if (q % 3 == 0) b0 = fma(w2[q], r, b0); else if (q % 3 == 1) b1 = fma(w2[q], r, b1); else b2 = fma(w2[q], r, b2);
+    for (int q = 0; q < CD + nq; ++q) asm volatile("" : "+v"(av[q]));
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int j = 0; j < CD; ++j) { if (j & 1) a1 = fma(wrow[j], av[j], a1); else a0 = fma(wrow[j], av[j], a0); }
+    s1 = a0 + a1;
+    // w'Rw = sum_j 2 w_j (R_jj w_j / 2 + sum_{j2 > j} R_jj2 w_j2): CD independent chains, then one
+    double b0 = 0.0, b1 = 0.0;
+    int q = 0;
+#pragma unroll
+    for (int j = 0; j < CD; ++j) {
+      double t = 0.5 * av[CD + q] * wrow[j]; ++q;
+#pragma unroll
+      for (int j2 = j + 1; j2 < CD; ++j2) { t = fma(av[CD + q], wrow[j2], t); ++q; }
+      if (j & 1) b1 = fma(2.0 * wrow[j], t, b1); else b0 = fma(2.0 * wrow[j], t, b0);
     }
-    s1 = a0 + a1; s2 = (b0 + b1) + b2;
+    s2 = b0 + b1;
   } else {
-    s1 = acc[CD + nq + (n - D)];
-    s2 = acc[2 * CD + nq + (n - D)];
+    s1 = acc[CD + nq + jmod];
+    s2 = acc[2 * CD + nq + jmod];
   }
   d1 = Zinv * s1;
   d2 = fma(-d1, d1, Zinv * s2);

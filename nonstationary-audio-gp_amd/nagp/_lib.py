@@ -83,28 +83,53 @@ def source_hash():
 HASH_PATH = LIB_PATH + '.srchash'
 
 
-def build(force=False, verbose=False):
-    """Compile csrc/nagp_api.hip -> libnagp.so for gfx950 (cross-compiles without a GPU).  The library is stale when
-    the hash of its sources differs from the one recorded next to it at build time (mtimes are not trusted)."""
+def build(force=False, verbose=False, jobs=None):
+    """Compile csrc/*.hip -> libnagp.so for gfx950 (cross-compiles without a GPU): one object per translation unit
+    (nagp_api.hip = host code, inst_*.hip = groups of kernel instantiations), compiled in parallel, then linked.  The
+    library is stale when the hash of its sources differs from the one recorded next to it at build time (mtimes are
+    not trusted)."""
     want = source_hash()
     if not force and os.path.exists(LIB_PATH) and os.path.exists(HASH_PATH):
         with open(HASH_PATH) as fh:
             if fh.read().strip() == want:
                 return LIB_PATH
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    objdir = os.path.join(PKG_ROOT, 'build', 'obj-%s-%d' % (want[:12], os.getpid()))
+    os.makedirs(objdir, exist_ok=True)
+    tus = sorted(f for f in os.listdir(CSRC) if f.endswith('.hip'))
+    flags = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-I', INCLUDE]
+
+    def compile_one(f):
+        obj = os.path.join(objdir, f[:-4] + '.o')
+        cmd = [hipcc] + flags + ['-c', '-o', obj, os.path.join(CSRC, f)]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        return f, obj, cmd, r
+
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    with ThreadPoolExecutor(max_workers=jobs or max(1, min(usable, 8))) as ex:
+        res = list(ex.map(compile_one, tus))
+    bad = [x for x in res if x[3].returncode != 0]
+    if verbose or bad:
+        for f, obj, cmd, r in (bad or res):
+            print(' '.join(cmd)); print(r.stdout); print(r.stderr)
+    if bad:
+        raise NagpError('hipcc failed on %s' % ', '.join(x[0] for x in bad))
     tmp = LIB_PATH + '.tmp.%d' % os.getpid()
-    cmd = [hipcc, '-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-shared', '-I', INCLUDE,
-           '-o', tmp, os.path.join(CSRC, 'nagp_api.hip')] + EXTRA_LINK
+    cmd = [hipcc, '--offload-arch=gfx950', '-fPIC', '-shared', '-o', tmp] + [x[1] for x in res] + EXTRA_LINK
     r = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or r.returncode != 0:
         print(' '.join(cmd)); print(r.stdout); print(r.stderr)
     if r.returncode != 0:
-        if os.path.exists(tmp):
-            os.remove(tmp)
-        raise NagpError('hipcc failed building libnagp.so')
+        raise NagpError('hipcc failed linking libnagp.so')
     os.replace(tmp, LIB_PATH)
     with open(HASH_PATH, 'w') as fh:
         fh.write(want + '\n')
+    import shutil
+    shutil.rmtree(objdir, ignore_errors=True)
     return LIB_PATH
 
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define NAGP_VERSION 100 /* 0.1.0 */
+#define NAGP_VERSION 200 /* 0.2.0 */
 
 typedef enum nagp_status {
   NAGP_OK = 0,
@@ -40,7 +40,8 @@ typedef enum nagp_status {
   NAGP_EHIP = -3,         /* HIP runtime error (see nagp_last_error) */
   NAGP_ENOMEM = -4,       /* device memory exhausted */
   NAGP_ENODEVICE = -5,    /* no gfx950 device visible */
-  NAGP_ENOTPD = -6        /* Cholesky failed even after the jitter retry */
+  NAGP_ENOTPD = -6,       /* Cholesky failed even after the jitter retry */
+  NAGP_ERCCL = -7         /* RCCL failure in nagp_batch_run (see nagp_last_error) */
 } nagp_status;
 
 typedef enum nagp_kind { NAGP_KIND_GF_EP = 0, NAGP_KIND_IHGP = 1, NAGP_KIND_GIEKF = 2 } nagp_kind;
@@ -111,6 +112,11 @@ typedef struct nagp_opts {
   uint32_t flags;
   int32_t device;          /* HIP device ordinal */
   int32_t chunk;           /* smoother chunk length (0 = default) */
+  /* Warm start (one-shot entry points; plans: nagp_plan_upload_sites): initial site parameters, M x T column-major, in
+   * place of the reference's zeros (gf_ep_modulator_nmf.m:96-97) -- e.g. the ttau / tnu a previous call returned
+   * (the `out` struct of the reference carries them for this purpose).  NULL = zeros. */
+  const double* ttau0;
+  const double* tnu0;
 } nagp_opts;
 
 /* Caller-allocated outputs of ONE problem; any pointer may be NULL. */
@@ -205,8 +211,24 @@ int nagp_plan_upload_y(nagp_plan* plan, const double* const* ys); /* n_problems 
 int nagp_plan_execute(nagp_plan* plan);                          /* enqueue all sweeps; returns after stream sync */
 int nagp_plan_timings(const nagp_plan* plan, nagp_timings* t);
 int nagp_plan_download(nagp_plan* plan, nagp_out* outs);          /* n_problems outs */
+int nagp_plan_upload_sites(nagp_plan* plan, const double* const* ttau0, const double* const* tnu0); /* warm start: n_problems pointers to
+                                                                     M x T doubles each, or NULL/NULL to return to cold starts */
 int64_t nagp_plan_device_bytes(const nagp_plan* plan);
 void nagp_plan_destroy(nagp_plan* plan);
+
+/* Multi-GPU form of the batched call (one process, the GPUs of one node) -- what a MEX caller uses to spread audio segments
+ * or the numel(w)+1 objective evaluations of a fminunc iteration (train_GTFNMF.m:186-201) over the node:
+ * problem i runs on device i mod n_gpus (nagp_batch_partition), one host thread, plan and stream per device, host buffers in
+ * and out as in nagp_plan_*; the only exchange is the sum over ALL problems of the per-sweep negative log marginal likelihood
+ * nlZ[itt] = -sum_k lZ_k (gf_ep_modulator_nmf.m:187, 277, 525), all-reduced over the devices with RCCL
+ * (ncclAllReduce, ncclDouble, ncclSum, count = ep_itts) and returned in nlZ_total (ep_itts doubles, may be NULL).
+ * opts->device is ignored.  n_gpus = 1 involves no collective unless the environment sets NAGP_FORCE_RCCL.  The RCCL
+ * communicators are created on first use and kept until nagp_shutdown(). */
+int nagp_batch_partition(int32_t n_problems, int32_t n_gpus, int32_t* device_of_problem /* n_problems */);
+int nagp_batch_run(int32_t n_problems, const nagp_model* models, const nagp_ihgp_tables* tables /* n_problems or NULL */,
+                   const double* const* ys, int64_t T, const nagp_opts* opts, nagp_out* outs, int32_t n_gpus,
+                   double* nlZ_total);
+void nagp_shutdown(void); /* releases cached RCCL communicators; never resets a device */
 
 #ifdef __cplusplus
 }

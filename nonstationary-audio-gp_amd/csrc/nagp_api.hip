@@ -14,8 +14,12 @@ NAGP_LIST_ALL(extern template __global__)
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
+
+#include <rccl/rccl.h>
 
 using namespace nagp;
 
@@ -66,6 +70,7 @@ struct nagp_plan {
   Bufs b{};
   MomCfg mc{};
   IhgpTabs tb{};
+  double* d_tt0 = nullptr; double* d_tn0 = nullptr; bool warm = false;   // warm start (nagp_plan_upload_sites)
   double* d_model = nullptr; double* d_y = nullptr; double* d_wn = nullptr; double* d_xi = nullptr;
   double* d_stamps = nullptr; double* d_lZs = nullptr; double* d_affspan = nullptr; double* d_affbnd = nullptr; int aff_L = 128, aff_ns = 1; double* d_vprev = nullptr; double* d_tab = nullptr; double* d_r = nullptr;
   std::vector<void*> allocs;
@@ -95,6 +100,7 @@ extern "C" const char* nagp_strerror(int s) {
     case NAGP_ENOMEM: return "out of device memory";
     case NAGP_ENODEVICE: return "no HIP device";
     case NAGP_ENOTPD: return "matrix not positive definite";
+    case NAGP_ERCCL: return "RCCL error";
     default: return "unknown";
   }
 }
@@ -277,6 +283,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) FAIL(NAGP_ENODEVICE, "no HIP device visible");
   if (o->device < 0 || o->device >= ndev) FAIL(NAGP_EINVAL, "device ordinal %d out of range", o->device);
   const nagp_model& m0 = models[0];
+  if (!m0.block_offsets) FAIL(NAGP_EINVAL, "problem 0: NULL block_offsets");
   if (m0.M < 1 || m0.M > MAXM) FAIL(NAGP_EUNSUPPORTED, "M=%d outside 1..%d", m0.M, MAXM);
   if (m0.S < m0.M || m0.S > 1024) FAIL(NAGP_EUNSUPPORTED, "S=%d unsupported", m0.S);
   if (o->kind != NAGP_KIND_GF_EP && o->kind != NAGP_KIND_IHGP && o->kind != NAGP_KIND_GIEKF) FAIL(NAGP_EINVAL, "kind");
@@ -312,6 +319,14 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     if (sh.bsz[n] < 1 || sh.bsz[n] > 4) { delete p; FAIL(NAGP_EUNSUPPORTED, "block %d has size %d (supported: 1..4)", n, sh.bsz[n]); }
   }
   if (sh.off[0] != 0 || sh.off[m0.M] != m0.S) { delete p; FAIL(NAGP_EINVAL, "block_offsets do not span 0..S"); }
+  for (int q = 0; q < B; ++q) {   // every pointer the packing below dereferences
+    const nagp_model& mq = models[q];
+    if (!mq.A || !mq.Q || !mq.Pinf || !mq.h_val || !mq.block_offsets) { delete p; FAIL(NAGP_EINVAL, "problem %d: NULL A / Q / Pinf / h_val / block_offsets", q); }
+    if ((ekf || o->lik_kind != NAGP_LIK_POWER) && !mq.Wnmf) { delete p; FAIL(NAGP_EINVAL, "problem %d: Wnmf missing", q); }
+    if (o->kind == NAGP_KIND_IHGP && (!tables[q].r_grid || !tables[q].PPlist || !tables[q].PGlist || !tables[q].pp_offsets || !tables[q].pg_offsets)) {
+      delete p; FAIL(NAGP_EINVAL, "problem %d: NULL IHGP table pointer", q);
+    }
+  }
   for (int q = 1; q < B; ++q) {
     const nagp_model& mq = models[q];
     bool same = mq.S == m0.S && mq.M == m0.M && mq.D == m0.D && mq.N == m0.N;
@@ -372,7 +387,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
       d[mdl_h(sh) + n] = mq.h_val[n];
       p->h_hval[(size_t)q * sh.M + n] = mq.h_val[n];
     }
-    if (mq.Wnmf)
+    if (mq.Wnmf && (ekf || o->lik_kind != NAGP_LIK_POWER))
       for (int dd = 0; dd < sh.D; ++dd)
         for (int j = 0; j < sh.N; ++j) d[mdl_W(sh) + (size_t)dd * sh.N + j] = mq.Wnmf[dd + (size_t)sh.D * j];
     d[mdl_sn2(sh)] = std::exp(mq.lik_param);
@@ -690,8 +705,32 @@ extern "C" void nagp_plan_destroy(nagp_plan* p) {
 
 extern "C" int64_t nagp_plan_device_bytes(const nagp_plan* p) { return p ? p->dev_bytes : 0; }
 
+extern "C" int nagp_plan_upload_sites(nagp_plan* p, const double* const* ttau0, const double* const* tnu0) {
+  if (!p) FAIL(NAGP_EINVAL, "null plan");
+  if (p->opts.kind == NAGP_KIND_GIEKF) FAIL(NAGP_EINVAL, "the EKF path has no sites");
+  if (!ttau0 && !tnu0) { p->warm = false; return NAGP_OK; }
+  if (!ttau0 || !tnu0) FAIL(NAGP_EINVAL, "ttau0 and tnu0 come together");
+  HIP_TRY(hipSetDevice(p->opts.device));
+  const size_t n = (size_t)p->sh.T * p->sh.M;
+  if (!p->d_tt0) {
+    int st = dalloc(p, &p->d_tt0, (size_t)p->B * n, false);
+    if (st == NAGP_OK) st = dalloc(p, &p->d_tn0, (size_t)p->B * n, false);
+    if (st != NAGP_OK) return st;
+  }
+  for (int q = 0; q < p->B; ++q) {
+    if (!ttau0[q] || !tnu0[q]) FAIL(NAGP_EINVAL, "problem %d: NULL site array", q);
+    HIP_TRY(hipMemcpyAsync(p->d_tt0 + (size_t)q * n, ttau0[q], n * sizeof(double), hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(hipMemcpyAsync(p->d_tn0 + (size_t)q * n, tnu0[q], n * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  p->warm = true;
+  return NAGP_OK;
+}
+
 extern "C" int nagp_plan_upload_y(nagp_plan* p, const double* const* ys) {
   if (!p || !ys) FAIL(NAGP_EINVAL, "null argument");
+  for (int q = 0; q < p->B; ++q)
+    if (!ys[q]) FAIL(NAGP_EINVAL, "problem %d: NULL observation array", q);
   HIP_TRY(hipSetDevice(p->opts.device));
   for (int q = 0; q < p->B; ++q)
     HIP_TRY(hipMemcpyAsync(p->d_y + (size_t)q * p->sh.T, ys[q], (size_t)p->sh.T * sizeof(double), hipMemcpyHostToDevice, p->stream));
@@ -1065,7 +1104,12 @@ extern "C" int nagp_plan_execute(nagp_plan* p) {
   p->evs.clear(); p->ev_next = 0;
   HIP_TRY(hipEventRecord(p->ev_t0, p->stream));
   // every call starts from the reference's initial state (sites zero, MS zero, ...)
-  RUN(zero_async(p, p->b.ttau, BT * sh.M * 8)); RUN(zero_async(p, p->b.tnu, BT * sh.M * 8));
+  if (p->warm) {   // warm start: the sites a previous call returned instead of zeros
+    HIP_TRY(hipMemcpyAsync(p->b.ttau, p->d_tt0, BT * sh.M * 8, hipMemcpyDeviceToDevice, p->stream));
+    HIP_TRY(hipMemcpyAsync(p->b.tnu, p->d_tn0, BT * sh.M * 8, hipMemcpyDeviceToDevice, p->stream));
+  } else {
+    RUN(zero_async(p, p->b.ttau, BT * sh.M * 8)); RUN(zero_async(p, p->b.tnu, BT * sh.M * 8));
+  }
   RUN(zero_async(p, p->b.R, BT * sh.M * 8)); RUN(zero_async(p, p->b.lZ, BT * 8));
   RUN(zero_async(p, p->b.sm, BT * sh.M * 8)); RUN(zero_async(p, p->b.sv, BT * sh.M * 8));
   RUN(zero_async(p, p->b.MS, BT * sh.S * 8)); RUN(zero_async(p, p->b.red, (size_t)p->B * 64));
@@ -1190,6 +1234,10 @@ static int run_one(const nagp_model* model, const nagp_ihgp_tables* tables, cons
   if (st != NAGP_OK) return st;
   const double* ys[1] = {y};
   st = nagp_plan_upload_y(p, ys);
+  if (st == NAGP_OK && (o.ttau0 || o.tnu0)) {
+    const double* t0[1] = {o.ttau0}; const double* n0[1] = {o.tnu0};
+    st = nagp_plan_upload_sites(p, t0, n0);
+  }
   if (st == NAGP_OK) st = nagp_plan_execute(p);
   if (st == NAGP_OK) st = nagp_plan_download(p, out);
   nagp_plan_destroy(p);
@@ -1390,4 +1438,142 @@ extern "C" int nagp_fastfb_run(int32_t S, const double* A, const double* AKHA, c
 #undef FB_HIP
   (void)hipFree(dev);
   return st;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Multi-GPU batched call (see include/nagp.h): problems round robin over the devices, one host thread + plan per device,
+// RCCL all-reduce of the per-sweep nlZ sums.
+extern "C" int nagp_batch_partition(int32_t n_problems, int32_t n_gpus, int32_t* dev_of) {
+  if (n_problems < 0 || n_gpus < 1 || (n_problems > 0 && !dev_of)) FAIL(NAGP_EINVAL, "bad partition arguments");
+  for (int i = 0; i < n_problems; ++i) dev_of[i] = i % n_gpus;      // problem i -> GPU i mod G
+  return NAGP_OK;
+}
+
+namespace {
+struct CommCache {
+  std::mutex mu;
+  int n = 0;
+  std::vector<ncclComm_t> comms;
+  std::vector<hipStream_t> streams;
+  std::vector<double*> bufs;      // per device: [2 * 64] send | recv
+};
+CommCache g_cc;
+
+void cc_release_locked() {
+  for (size_t d = 0; d < g_cc.comms.size(); ++d) {
+    (void)hipSetDevice((int)d);
+    if (g_cc.bufs[d]) (void)hipFree(g_cc.bufs[d]);
+    if (g_cc.streams[d]) (void)hipStreamDestroy(g_cc.streams[d]);
+    if (g_cc.comms[d]) (void)ncclCommDestroy(g_cc.comms[d]);
+  }
+  g_cc.comms.clear(); g_cc.streams.clear(); g_cc.bufs.clear(); g_cc.n = 0;
+}
+
+// sum over devices of part[d][0..cnt) with ncclAllReduce; every device ends with the total, device 0's copy is returned
+int allreduce_nlz(int G, int cnt, const std::vector<std::vector<double>>& part, std::vector<double>& total) {
+  std::lock_guard<std::mutex> lk(g_cc.mu);
+  if (cnt > 64) FAIL(NAGP_EUNSUPPORTED, "more than 64 EP sweeps in the nlZ reduction");
+  if (g_cc.n != G) {
+    cc_release_locked();
+    g_cc.comms.assign(G, nullptr); g_cc.streams.assign(G, nullptr); g_cc.bufs.assign(G, nullptr);
+    std::vector<int> devs(G);
+    for (int d = 0; d < G; ++d) devs[d] = d;
+    ncclResult_t r = ncclCommInitAll(g_cc.comms.data(), G, devs.data());
+    if (r != ncclSuccess) { cc_release_locked(); FAIL(NAGP_ERCCL, "ncclCommInitAll(%d) -> %s", G, ncclGetErrorString(r)); }
+    g_cc.n = G;
+    for (int d = 0; d < G; ++d) {
+      HIP_TRY(hipSetDevice(d));
+      HIP_TRY(hipStreamCreateWithFlags(&g_cc.streams[d], hipStreamNonBlocking));
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g_cc.bufs[d]), 128 * sizeof(double)));
+    }
+  }
+  for (int d = 0; d < G; ++d) {
+    HIP_TRY(hipSetDevice(d));
+    HIP_TRY(hipMemcpyAsync(g_cc.bufs[d], part[d].data(), cnt * sizeof(double), hipMemcpyHostToDevice, g_cc.streams[d]));
+  }
+  ncclResult_t r = ncclGroupStart();
+  for (int d = 0; d < G && r == ncclSuccess; ++d)
+    r = ncclAllReduce(g_cc.bufs[d], g_cc.bufs[d] + 64, (size_t)cnt, ncclDouble, ncclSum, g_cc.comms[d], g_cc.streams[d]);
+  ncclResult_t r2 = ncclGroupEnd();
+  if (r == ncclSuccess) r = r2;
+  if (r != ncclSuccess) FAIL(NAGP_ERCCL, "ncclAllReduce -> %s", ncclGetErrorString(r));
+  total.assign(cnt, 0.0);
+  for (int d = 0; d < G; ++d) {
+    HIP_TRY(hipSetDevice(d));
+    HIP_TRY(hipStreamSynchronize(g_cc.streams[d]));
+  }
+  HIP_TRY(hipSetDevice(0));
+  HIP_TRY(hipMemcpy(total.data(), g_cc.bufs[0] + 64, cnt * sizeof(double), hipMemcpyDeviceToHost));
+  return NAGP_OK;
+}
+}  // namespace
+
+extern "C" void nagp_shutdown(void) {
+  std::lock_guard<std::mutex> lk(g_cc.mu);
+  cc_release_locked();
+}
+
+extern "C" int nagp_batch_run(int32_t n_problems, const nagp_model* models, const nagp_ihgp_tables* tables, const double* const* ys,
+                              int64_t T, const nagp_opts* opts, nagp_out* outs, int32_t n_gpus, double* nlZ_total) {
+  if (n_problems < 1 || !models || !ys || !opts || !outs || n_gpus < 1) FAIL(NAGP_EINVAL, "null/empty argument");
+  if (opts->kind == NAGP_KIND_IHGP && !tables) FAIL(NAGP_EINVAL, "IHGP tables missing");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) FAIL(NAGP_ENODEVICE, "no HIP device visible");
+  if (n_gpus > ndev) FAIL(NAGP_EINVAL, "n_gpus = %d but %d device(s) visible", n_gpus, ndev);
+  const int G = std::min<int>(n_gpus, n_problems);     // a device without a problem takes no part
+  const int I = opts->ep_itts;
+  if (I < 1) FAIL(NAGP_EINVAL, "ep_itts < 1");
+  std::vector<int32_t> dev_of(n_problems);
+  (void)nagp_batch_partition(n_problems, G, dev_of.data());
+  std::vector<int> status(G, NAGP_OK);
+  std::vector<std::string> errs(G);
+  std::vector<std::vector<double>> part(G, std::vector<double>(I, 0.0));
+  auto worker = [&](int d) {
+    std::vector<int> idx;
+    for (int i = 0; i < n_problems; ++i) if (dev_of[i] == d) idx.push_back(i);
+    std::vector<nagp_model> ms; std::vector<nagp_ihgp_tables> ts; std::vector<const double*> yv; std::vector<nagp_out> os;
+    std::vector<std::vector<double>> nlz(idx.size(), std::vector<double>(I, 0.0));
+    for (size_t a = 0; a < idx.size(); ++a) {
+      ms.push_back(models[idx[a]]);
+      if (tables) ts.push_back(tables[idx[a]]);
+      yv.push_back(ys[idx[a]]);
+      nagp_out o = outs[idx[a]];
+      if (!o.nlZ) o.nlZ = nlz[a].data();        // the reduction needs them whether or not the caller wants them
+      os.push_back(o);
+    }
+    nagp_opts o = *opts;
+    o.device = d; o.ttau0 = nullptr; o.tnu0 = nullptr;
+    bool wantPS = false;
+    for (const nagp_out& q : os) wantPS = wantPS || q.PS;
+    if (wantPS) o.flags |= NAGP_FLAG_WANT_PS;
+    nagp_plan* p = nullptr;
+    int st = nagp_plan_create(&p, (int32_t)idx.size(), ms.data(), tables ? ts.data() : nullptr, T, &o);
+    if (st == NAGP_OK) st = nagp_plan_upload_y(p, yv.data());
+    if (st == NAGP_OK) st = nagp_plan_execute(p);
+    if (st == NAGP_OK) st = nagp_plan_download(p, os.data());
+    if (st == NAGP_OK)
+      for (size_t a = 0; a < idx.size(); ++a)
+        for (int i = 0; i < I; ++i) part[d][i] += os[a].nlZ[i];     // fixed order: ascending problem index
+    if (st != NAGP_OK) errs[d] = g_last_error;                       // thread-local text of this worker
+    nagp_plan_destroy(p);
+    status[d] = st;
+  };
+  if (G == 1) {
+    worker(0);
+  } else {
+    std::vector<std::thread> th;
+    for (int d = 0; d < G; ++d) th.emplace_back(worker, d);
+    for (auto& t : th) t.join();
+  }
+  for (int d = 0; d < G; ++d)
+    if (status[d] != NAGP_OK) { g_last_error = "device " + std::to_string(d) + ": " + errs[d]; return status[d]; }
+  std::vector<double> total(I, 0.0);
+  if (G > 1 || getenv("NAGP_FORCE_RCCL")) {
+    const int st = allreduce_nlz(G, I, part, total);
+    if (st != NAGP_OK) return st;
+  } else {
+    total = part[0];
+  }
+  if (nlZ_total) for (int i = 0; i < I; ++i) nlZ_total[i] = total[i];
+  return NAGP_OK;
 }

@@ -9,6 +9,6 @@ from .api import (Mom, SSHandle, gf_ep_modulator, gf_ep_modulator_nmf, gf_ep_mod
                   gf_ep_mods_nmf_mixture, ihgp_ep_mods_nmf_mixture)
 from .ss import ss_modulators, ss_modulators_nmf, lti_disc, sigmoid, inv_sigmoid  # noqa: F401
 from .cubature import utp_ws, gauher, mvhermgauss_unit  # noqa: F401
-from .plan import Plan  # noqa: F401
+from .plan import Plan, batch_run, batch_partition  # noqa: F401
 from .fastfb import get_disc_model, kernel_ss_kalmanFastFB  # noqa: F401
 from .train import nlml_batch, fd_value_and_gradient  # noqa: F401

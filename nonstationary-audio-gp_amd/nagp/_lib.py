@@ -14,7 +14,7 @@ PKG_ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(PKG_ROOT, 'libnagp.so')
 CSRC = os.path.join(PKG_ROOT, 'csrc')
 INCLUDE = os.path.join(os.path.dirname(PKG_ROOT), 'include')
-EXTRA_LINK = []   # filled below when the library links RCCL
+EXTRA_LINK = ['-L/opt/rocm/lib', '-lrccl', '-lpthread']   # nagp_batch_run: ncclAllReduce of nlZ over the GPUs of the node
 
 NAGP_OK = 0
 KIND_GF_EP, KIND_IHGP, KIND_GIEKF = 0, 1, 2
@@ -46,7 +46,7 @@ class Opts(C.Structure):
                 ('link_shift', C.c_double), ('n_pts', C.c_int32), ('cub_dim', C.c_int32), ('wn', c_dp),
                 ('xn_unscaled', c_dp), ('ep_fraction', C.c_double), ('ep_itts', C.c_int32),
                 ('ep_damping', c_dp), ('l_iter', C.c_int32), ('predict_at_k1', C.c_int32),
-                ('flags', C.c_uint32), ('device', C.c_int32), ('chunk', C.c_int32)]
+                ('flags', C.c_uint32), ('device', C.c_int32), ('chunk', C.c_int32), ('ttau0', c_dp), ('tnu0', c_dp)]
 
 
 class Out(C.Structure):
@@ -61,7 +61,8 @@ class Timings(C.Structure):
 
 EXPORTS = ['nagp_version', 'nagp_device_count', 'nagp_strerror', 'nagp_last_error', 'nagp_ep_run',
            'nagp_ihgp_run', 'nagp_giekf_run', 'nagp_plan_create', 'nagp_plan_upload_y', 'nagp_plan_execute',
-           'nagp_plan_timings', 'nagp_plan_download', 'nagp_plan_device_bytes', 'nagp_plan_destroy']
+           'nagp_plan_timings', 'nagp_plan_download', 'nagp_plan_device_bytes', 'nagp_plan_destroy', 'nagp_plan_upload_sites',
+           'nagp_batch_partition', 'nagp_batch_run', 'nagp_shutdown', 'nagp_mom_eval', 'nagp_iekf_update1', 'nagp_fastfb_run']
 
 
 class NagpError(RuntimeError):
@@ -158,12 +159,16 @@ def lib():
                                     c_dp, c_dp, c_dp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32]
     L.nagp_fastfb_run.argtypes = [C.c_int32, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, C.c_int64, c_dp, C.POINTER(C.c_double), C.c_int32]
     L.nagp_plan_upload_y.argtypes = [C.c_void_p, C.POINTER(c_dp)]
+    L.nagp_plan_upload_sites.argtypes = [C.c_void_p, C.POINTER(c_dp), C.POINTER(c_dp)]
+    L.nagp_batch_partition.argtypes = [C.c_int32, C.c_int32, c_ip]
+    L.nagp_batch_run.argtypes = [C.c_int32, C.POINTER(Model), C.POINTER(IhgpTables), C.POINTER(c_dp), C.c_int64, C.POINTER(Opts), C.POINTER(Out), C.c_int32, c_dp]
+    L.nagp_shutdown.restype = None
     L.nagp_plan_execute.argtypes = [C.c_void_p]
     L.nagp_plan_timings.argtypes = [C.c_void_p, C.POINTER(Timings)]
     L.nagp_plan_download.argtypes = [C.c_void_p, C.POINTER(Out)]
     L.nagp_plan_device_bytes.argtypes = [C.c_void_p]; L.nagp_plan_device_bytes.restype = C.c_int64
     L.nagp_plan_destroy.argtypes = [C.c_void_p]; L.nagp_plan_destroy.restype = None
-    for f in ('nagp_ep_run', 'nagp_ihgp_run', 'nagp_giekf_run', 'nagp_mom_eval', 'nagp_iekf_update1', 'nagp_fastfb_run', 'nagp_plan_create', 'nagp_plan_upload_y',
+    for f in ('nagp_plan_upload_sites', 'nagp_batch_partition', 'nagp_batch_run', 'nagp_ep_run', 'nagp_ihgp_run', 'nagp_giekf_run', 'nagp_mom_eval', 'nagp_iekf_update1', 'nagp_fastfb_run', 'nagp_plan_create', 'nagp_plan_upload_y',
               'nagp_plan_execute', 'nagp_plan_timings', 'nagp_plan_download'):
         getattr(L, f).restype = C.c_int
     _lib = L

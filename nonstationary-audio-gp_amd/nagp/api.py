@@ -89,7 +89,7 @@ class MeasModel:
         self.col = np.argmax(H != 0, axis=1).astype(np.int32); self.val = H[np.arange(D + N), self.col].copy()
 
     def h(self, x, param=None):       # only a token: the update below evaluates the model on the device
-        raise NagpError('MeasModel.h is evaluated on the GPU inside ekf_update1 / iekf_update1')
+        raise L.NagpError('MeasModel.h is evaluated on the GPU inside ekf_update1 / iekf_update1')
 
     dh = h
 

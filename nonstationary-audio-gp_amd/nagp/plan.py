@@ -47,6 +47,16 @@ class Plan:
         arr = (L.c_dp * self.B)(*[L.dptr(y) for y in ys])
         L.check(L.lib().nagp_plan_upload_y(self._h, arr))
 
+    def upload_sites(self, ttau0=None, tnu0=None):
+        """Warm start: initial site parameters (lists of M x T arrays, e.g. the ttau / tnu a previous call returned) in place
+        of the reference's zeros (gf_ep_modulator_nmf.m:96-97); None, None returns to cold starts."""
+        if ttau0 is None and tnu0 is None:
+            L.check(L.lib().nagp_plan_upload_sites(self._h, None, None)); return
+        tt = [L.f64(a) for a in ttau0]; tn = [L.f64(a) for a in tnu0]
+        assert len(tt) == self.B and len(tn) == self.B and all(a.shape == (self.M, self.T) for a in tt + tn)
+        a1 = (L.c_dp * self.B)(*[L.dptr(a) for a in tt]); a2 = (L.c_dp * self.B)(*[L.dptr(a) for a in tn])
+        L.check(L.lib().nagp_plan_upload_sites(self._h, a1, a2))
+
     def execute(self):
         L.check(L.lib().nagp_plan_execute(self._h))
 
@@ -82,3 +92,44 @@ class Plan:
             self.close()
         except Exception:
             pass
+
+
+def batch_partition(n_problems, n_gpus):
+    """problem -> device map of nagp_batch_run (problem i on device i mod n_gpus).  Pure host code."""
+    dev = np.zeros(max(n_problems, 1), dtype=np.int32)
+    L.check(L.lib().nagp_batch_partition(int(n_problems), int(n_gpus), dev.ctypes.data_as(L.c_ip)))
+    return dev[:n_problems]
+
+
+def batch_run(kind, problems, ys, T, mom=None, ep_fraction=0.5, ep_damping=None, ep_itts=3, mode=L.MODE_PREDICT, l_iter=1,
+              predict_at_k1=0, flags=0, n_gpus=1, want_PS=False, want_MS=True):
+    """nagp_batch_run: the problems spread over the GPUs of this node inside ONE process (host thread + plan per device),
+    nlZ summed over all problems by an RCCL all-reduce.  Returns (outputs per problem, nlZ_total[ep_itts])."""
+    sym = kind == L.KIND_IHGP
+    statq = kind == L.KIND_GIEKF and mode == L.MODE_NLML
+    probs = [_Problem(b, W, lp, symmetrize_Q=sym, stationary_Q=statq) for (b, W, lp) in problems]
+    B = len(probs); blk0 = problems[0][0]
+    dim = None
+    if mom is not None:
+        dim = blk0.D if mom.kind == L.LIK_POWER else blk0.N
+    damp = _damping(ep_damping, ep_itts) if ep_damping is not None else None
+    opts, keep = make_opts(kind, mode, mom, dim, ep_fraction, damp, ep_itts, l_iter=l_iter, predict_at_k1=predict_at_k1, flags=flags)
+    models = (L.Model * B)(*[p.model for p in probs])
+    tabs_arr, tabkeep = None, []
+    if kind == L.KIND_IHGP:
+        tl = []
+        for p in probs:
+            r, PP, ppo, PG, pgo = ihgp_tables.build_tables(p.A, p.Q, p.blk.offsets, p.blk.h_val)
+            r = L.f64(r, 'C'); PP = L.f64(PP, 'C'); PG = L.f64(PG, 'C')
+            tabkeep.append((r, PP, ppo, PG, pgo))
+            tl.append(L.IhgpTables(n_grid=r.size, r_grid=L.dptr(r), PPlist=L.dptr(PP), pp_offsets=ppo.ctypes.data_as(L.c_lp),
+                                   PGlist=L.dptr(PG), pg_offsets=pgo.ctypes.data_as(L.c_lp)))
+        tabs_arr = (L.IhgpTables * B)(*tl)
+    yk = [L.f64(y, 'C') for y in ys]
+    assert len(yk) == B and all(y.size == T for y in yk)
+    yarr = (L.c_dp * B)(*[L.dptr(y) for y in yk])
+    outs = [_Outputs(blk0.M, blk0.S, int(T), int(ep_itts), want_PS=want_PS, want_MS=want_MS) for _ in range(B)]
+    oarr = (L.Out * B)(*[o.c for o in outs])
+    tot = np.zeros(int(ep_itts))
+    L.check(L.lib().nagp_batch_run(B, models, tabs_arr, yarr, int(T), C.byref(opts), oarr, int(n_gpus), tot.ctypes.data_as(L.c_dp)))
+    return outs, tot

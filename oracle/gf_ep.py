@@ -129,14 +129,18 @@ def kalman_update_legacy(m, P, H, W, fs2, fmu, ttau_k, tnu_k):
     return m, P
 
 
-def run_predict(model, yall, mom, ep_fraction, ep_damping, ep_itts, predict_at_k1=False, verbose=False):
+def run_predict(model, yall, mom, ep_fraction, ep_damping, ep_itts, predict_at_k1=False, verbose=False, sites0=None):
     """gf_ep_modulator_nmf.m:92-352 on an assembled model dict
     {A,Q,H,Pinf,Wnmf,lik_param}. Returns dict with Eft,Varft (all steps), MS,PS,ttau,tnu,R,lZ,nlZ,
-    maxDiffM,maxDiffP (per sweep), MF,PF (filtered, last sweep)."""
+    maxDiffM,maxDiffP (per sweep), MF,PF (filtered, last sweep).
+    sites0 = (ttau0, tnu0): NOT in the reference (which starts from zeros, :96-97) -- the initial sites of a warm start,
+    used only to check the library's nagp_plan_upload_sites extension."""
     A, Q, H, Pinf, Wnmf, lik_param = (model[k] for k in ('A', 'Q', 'H', 'Pinf', 'Wnmf', 'lik_param'))
     S = A.shape[0]; M = H.shape[0]; T = yall.size
     MS = np.zeros((S, T)); PS = np.zeros((T, S, S))
     ttau = np.zeros((M, T)); tnu = np.zeros((M, T)); lZ = np.zeros(T); R = np.zeros((M, T))
+    if sites0 is not None:
+        ttau = np.array(sites0[0], dtype=float).copy(); tnu = np.array(sites0[1], dtype=float).copy()
     nlZ = np.zeros(ep_itts); mdM = np.zeros(ep_itts); mdP = np.zeros(ep_itts)
     damp = _damp(ep_damping, ep_itts)
     ep_damp = damp[0]

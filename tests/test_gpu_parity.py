@@ -629,3 +629,137 @@ def test_full_length_ihgp_and_mixture_prefix_properties():
     o = omx.ihgp_ep_mods_nmf_mixture(mp['w'], ts[:10], mp['y'][:10], None, omom, ts[:10], k1, k2, 3, 0.75, 0.025, 1)
     assert rel(b[5]['ttau'][:, :9], o[5]['ttau'][:, :9]) < TOL_SITE
     assert np.all(np.isfinite(a[0])) and np.all(np.isfinite(a[5]['ttau']))
+
+
+# ---------------------------------------------------------------------------------------------
+# round 2: multi-GPU entry point of the C ABI, warm start, the two cubature forms, ranks with real plans
+def _small_batch(kind_name, B=3, D=4, N=2, T=90, seed=400):
+    probs, ys = [], []
+    for q in range(B):
+        pr = harness.nmf_problem(D, N, T, seed + q, 'constraints' if kind_name == 'ihgp' else 'demo_nmf')
+        blk = pss.ss_blocks_nmf(pr['param1'], pr['param2'], 'matern32', 'matern52')
+        if kind_name == 'ihgp':
+            blk = pss.balance_blocks(blk)
+        y = pr['y'].copy(); y[7 + q] = np.nan
+        probs.append((blk, pr['W'], np.log(pr['w_lik']))); ys.append(y)
+    return probs, ys
+
+
+@pytest.mark.parametrize('kind_name', ['gf', 'ihgp'])
+def test_batch_run_one_gpu_is_bit_equal_to_the_plan_and_reduces_nlz(kind_name, monkeypatch):
+    """nagp_batch_run(n_gpus = 1): the same bits as nagp_plan_* for every problem; nlZ_total = the sum over problems, both
+    without a collective and (NAGP_FORCE_RCCL) through ncclAllReduce on a one-device communicator."""
+    kind = L.KIND_IHGP if kind_name == 'ihgp' else L.KIND_GF_EP
+    probs, ys = _small_batch(kind_name); T = ys[0].size
+    mom = Mom('likModulatorNMFPower', p_cubature=5); d = 0.5 * np.ones(3)
+    plan = Plan(kind, probs, T, mom=mom, ep_fraction=0.5, ep_damping=d, ep_itts=3)
+    plan.upload(ys); plan.execute(); ref = plan.download(); plan.close()
+    for force in (False, True):
+        if force:
+            monkeypatch.setenv('NAGP_FORCE_RCCL', '1')
+        outs, tot = nagp.batch_run(kind, probs, ys, T, mom=mom, ep_fraction=0.5, ep_damping=d, ep_itts=3, n_gpus=1)
+        for a, b in zip(outs, ref):
+            for f in ('Eft', 'Varft', 'ttau', 'tnu', 'lZ', 'nlZ', 'MS'):
+                assert np.array_equal(getattr(a, f), getattr(b, f), equal_nan=True), f
+        assert np.array_equal(tot, np.sum([b.nlZ for b in ref], axis=0))     # same order of summation as the library
+    nagp.lib().nagp_shutdown()
+    with pytest.raises(nagp.NagpError):
+        nagp.batch_run(kind, probs, ys, T, mom=mom, ep_fraction=0.5, ep_damping=d, ep_itts=3, n_gpus=64)
+
+
+def test_warm_start_sites():
+    """nagp_plan_upload_sites: zeros are the cold start (bit for bit); the sites of a finished run as the start of the next
+    agree with the oracle started from the same sites; dropping them returns to the cold start."""
+    D, N, T = 4, 2, 80
+    pr = harness.nmf_problem(D, N, T, 77); d = 0.5 * np.ones(2)
+    blk = pss.ss_blocks_nmf(pr['param1'], pr['param2'], 'matern32', 'matern52')
+    mom = Mom('likModulatorNMFPower', p_cubature=5)
+    plan = Plan(L.KIND_GF_EP, [(blk, pr['W'], np.log(pr['w_lik']))], T, mom=mom, ep_fraction=0.5, ep_damping=d, ep_itts=2)
+    plan.upload([pr['y']]); plan.execute(); cold = plan.download()[0]
+    plan.upload_sites([np.zeros((D + N, T))], [np.zeros((D + N, T))]); plan.execute(); z = plan.download()[0]
+    for f in ('Eft', 'Varft', 'ttau', 'tnu', 'nlZ'):
+        assert np.array_equal(getattr(z, f), getattr(cold, f)), f
+    plan.upload_sites([cold.ttau], [cold.tnu]); plan.execute(); warm = plan.download()[0]
+    assert not np.array_equal(warm.ttau, cold.ttau)
+    lik, p1, p2, W = oss_unpack(pr, D, N)
+    model = ogf.assemble(lik, p1, p2, W, 'matern32', 'matern52', False)
+    ref = ogf.run_predict(model, pr['y'], olik.Mom(olik.LIK_POWER_NMF, p=5), 0.5, d, 2, sites0=(cold.ttau, cold.tnu))
+    assert rel(warm.Eft, ref['Eft']) < TOL_MEAN and rel(warm.ttau, ref['ttau']) < TOL_SITE and relz(warm.nlZ, ref['nlZ']) < TOL_LOGZ
+    plan.upload_sites(None, None); plan.execute(); again = plan.download()[0]
+    assert np.array_equal(again.Eft, cold.Eft)
+    plan.close()
+
+
+def oss_unpack(pr, D, N):
+    from oracle import ss as oss
+    return oss.unpack_log(pr['w'], 1, D, N)
+
+
+@pytest.mark.parametrize('fn', ['gf', 'ihgp'])
+@pytest.mark.parametrize('shape', [(5, 2, 5), (8, 3, 7), (6, 4, 9), (9, 2, 3), (7, 7, 5), (33, 2, 9)])
+def test_sparse_point_cubature_equals_the_generic_form_and_the_oracle(fn, shape, monkeypatch):
+    """likModulatorNMFPower in the staged sparse-point form (nagp_momsp.hpp: ADF launches of gf_ep_* and the IHGP ADF sweep)
+    against the generic mom_eval (NAGP_NO_SPARSE=1) and the oracle, one ADF sweep so that nothing amplifies rounding:
+    both device forms within 1e-10 of each other and TOL of the oracle; odd sub-band counts, 1..4 non-centre coordinates."""
+    D, N, p = shape; T = 60
+    pr = harness.nmf_problem(D, N, T, 900 + D, 'constraints'); t = np.arange(1, T + 1.0)
+    y = pr['y'].copy(); y[20:23] = np.nan
+    mom = Mom('likModulatorNMFPower', p_cubature=p); d = np.array([0.5])
+    f = nagp.ihgp_ep_modulator_nmf if fn == 'ihgp' else nagp.gf_ep_modulator_nmf
+    of = oih.ihgp_ep_modulator_nmf if fn == 'ihgp' else ogf.gf_ep_modulator_nmf
+    res = {}
+    for mode in ('generic', 'sparse'):
+        if mode == 'generic':
+            monkeypatch.setenv('NAGP_NO_SPARSE', '1')
+        else:
+            monkeypatch.delenv('NAGP_NO_SPARSE', raising=False)
+        res[mode] = f(pr['w'], t, y, SSHandle(), mom, t, 'matern32', 'matern52', 1, D, N, 0.5, d, 1, nargout=6)
+    ref = of(pr['w'], t, y, None, olik.Mom(olik.LIK_POWER_NMF, p=p), t, 'matern32', 'matern52', 1, D, N, 0.5, d, 1)
+    for mode in ('generic', 'sparse'):
+        Eft, Varft, out = res[mode][0], res[mode][1], res[mode][5]
+        assert rel(Eft, ref[0]) < TOL_MEAN and relz(out['nlZ'], ref[5]['nlZ']) < TOL_LOGZ, mode
+        assert rel(out['ttau'], ref[5]['ttau']) < TOL_SITE, mode
+    a, b = res['generic'], res['sparse']
+    assert rel(a[0], b[0]) < 1e-10 and rel(a[5]['ttau'], b[5]['ttau']) < 1e-9 and relz(a[5]['nlZ'], b[5]['nlZ']) < 1e-12
+    assert np.array_equal(np.isnan(a[5]['tnu']), np.isnan(b[5]['tnu']))
+
+
+_RANK_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], 'nonstationary-audio-gp_amd'))
+import numpy as np
+import nagp
+from nagp import dist as nd, harness, Mom, Plan, _lib as L, ss as pss
+rank, lr, world = nd.init('gloo')          # two ranks share the one card of this box; RCCL needs one device per rank
+NSEG, I, D, N, T = 5, 3, 4, 2, 70
+def problem(q):
+    pr = harness.nmf_problem(D, N, T, 800 + q)
+    return (pss.ss_blocks_nmf(pr['param1'], pr['param2'], 'matern32', 'matern52'), pr['W'], np.log(pr['w_lik'])), pr['y']
+def run(idx):
+    ps = [problem(q) for q in idx]
+    plan = Plan(L.KIND_GF_EP, [p[0] for p in ps], T, mom=Mom('likModulatorNMFPower', p_cubature=5), ep_fraction=0.5, ep_damping=0.5 * np.ones(I), ep_itts=I)
+    plan.upload([p[1] for p in ps]); plan.execute(); nlz = plan.download_nlz(); plan.close()
+    return nlz
+mine = nd.shard(NSEG, rank, world)
+tot = nd.allreduce_nlz(run(mine))
+serial = run(list(range(NSEG))).sum(axis=0)
+assert np.allclose(tot, serial, rtol=1e-14), (tot, serial)
+nd.barrier()
+print('rank', rank, 'ok', tot)
+"""
+
+
+def test_two_ranks_with_real_plans_allreduce_nlz(tmp_path):
+    """The N > 1 product path end to end on one card: every rank builds a Plan for its shard of the segments, executes it on
+    the GPU and the per-sweep nlZ is all-reduced; equal to one rank running all segments."""
+    import socket, subprocess, sys
+    script = tmp_path / 'rank_worker.py'
+    script.write_text(_RANK_WORKER)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0)); port = so.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE='2')
+    procs = [subprocess.Popen([sys.executable, str(script), root], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs

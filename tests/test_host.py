@@ -128,7 +128,8 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     for sym in declared:
         assert hasattr(lib, sym), sym
     L = nagp.lib()
-    assert L.nagp_version() == 100
+    assert L.nagp_version() == 200
+    assert 'ncclAllReduce' in subprocess.run(['nm', '-D', '--undefined-only', path], capture_output=True, text=True).stdout   # RCCL linked in
     assert L.nagp_strerror(-2).decode() == 'unsupported shape'
     out = subprocess.run(['nm', '-D', '--defined-only', path], capture_output=True, text=True).stdout
     assert set(re.findall(r' T (nagp_[a-z0-9_]+)', out)) == declared
@@ -155,31 +156,82 @@ def test_product_never_imports_the_oracle():
                 assert 'oracle/' not in src, f
 
 
-_WORKER = r'''
+def test_batch_partition_round_robin():
+    """problem -> device map of nagp_batch_run (problem i -> GPU i mod G); pure host code of the C ABI."""
+    assert list(nagp.batch_partition(8, 8)) == list(range(8))
+    assert list(nagp.batch_partition(8, 2)) == [0, 1] * 4
+    assert list(nagp.batch_partition(5, 3)) == [0, 1, 2, 0, 1]
+    assert list(nagp.batch_partition(3, 1)) == [0, 0, 0]
+    assert list(nagp.batch_partition(0, 4)) == []
+    # the same map as the one-process-per-GPU layer
+    from nagp import dist as nd
+    for n, g in ((8, 2), (5, 3), (7, 4)):
+        dev = nagp.batch_partition(n, g)
+        for r in range(g):
+            assert [i for i in range(n) if dev[i] == r] == nd.shard(n, r, g)
+    with pytest.raises(nagp.NagpError):
+        nagp.batch_partition(4, 0)
+
+
+def test_measmodel_handle_raises_the_documented_error():
+    H = np.zeros((5, 7)); H[np.arange(5), [0, 1, 2, 3, 5]] = 1.0
+    mm = nagp.MeasModel(H, np.ones((3, 2)), 3, 2)
+    with pytest.raises(nagp.NagpError):
+        mm.h(np.zeros(7))
+    with pytest.raises(nagp.NagpError):
+        mm.dh(np.zeros(7))
+
+
+_WORKER = r"""
 import os, sys
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], 'nonstationary-audio-gp_amd'))
 import numpy as np
-from nagp import dist as nd
+from nagp import dist as nd, harness
+from oracle import gf_ep as ogf, lik as olik, ss as oss
 rank, lr, world = nd.init('gloo')
-mine = nd.shard(5, rank, world)
-part = np.array([[10.0 * q + 1, 10.0 * q + 2, 10.0 * q + 3] for q in mine])     # stand-in per-problem nlZ
+NSEG, I, D, N, T = 5, 2, 3, 2, 30
+def seg_nlz(q):      # what a rank's Plan returns for segment q: the per-sweep nlZ of gf_ep_modulator_nmf (here from the oracle)
+    pr = harness.nmf_problem(D, N, T, 700 + q)
+    lik, p1, p2, W = oss.unpack_log(pr['w'], 1, D, N)
+    model = ogf.assemble(lik, p1, p2, W, 'matern32', 'matern52', False)
+    return ogf.run_predict(model, pr['y'], olik.Mom(olik.LIK_POWER_NMF, p=5), 0.5, 0.5 * np.ones(I), I)['nlZ']
+mine = nd.shard(NSEG, rank, world)
+part = np.array([seg_nlz(q) for q in mine]).reshape(len(mine), I)      # (n_local_problems, ep_itts), as Plan.download_nlz()
 tot = nd.allreduce_nlz(part)
 mx = nd.allreduce_max(float(rank + 1))
 nd.barrier()
-exp = np.array([[10.0 * q + 1, 10.0 * q + 2, 10.0 * q + 3] for q in range(5)]).sum(axis=0)
-assert np.allclose(tot, exp), (tot, exp)
-assert mx == world
-assert sorted(sum([nd.shard(5, r, world) for r in range(world)], [])) == list(range(5))
+exp = np.array([seg_nlz(q) for q in range(NSEG)]).sum(axis=0)         # serial sum over all segments
+assert tot.shape == (I,) and np.allclose(tot, exp, rtol=1e-13), (tot, exp)
+assert mx == world and nd.world_size() == world
+assert sorted(sum([nd.shard(NSEG, r, world) for r in range(world)], [])) == list(range(NSEG))
+# a rank without segments (more ranks than segments) still takes part in the reduction
+none = nd.allreduce_nlz(np.zeros((0, I)).reshape(-1, I) if rank == 1 else np.ones((1, I)))
+assert np.allclose(none, 1.0)
 print('rank', rank, 'ok')
-'''
+"""
 
 
 def test_two_rank_gloo_sharding_and_nlz_allreduce(tmp_path):
-    """N>1 path on CPU: segments sharded round-robin over ranks, nlZ all-reduced (gloo stands in for RCCL)."""
+    """N>1 path on CPU: segments sharded round-robin over ranks, the per-sweep nlZ of every rank's segments (real
+    gf_ep_modulator_nmf values, here produced by the oracle) all-reduced and compared with the serial sum (gloo stands in for RCCL)."""
     script = tmp_path / 'worker.py'
     script.write_text(_WORKER)
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', WORLD_SIZE='2')
+    import socket
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0)); port = so.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE='2')
     procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=180)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
+
+
+def test_bench_refuses_a_world_size_mismatch_and_spawns_ranks_itself():
+    """bench.py --gpus N: without RANK it is the launcher (N children); with RANK set and another WORLD_SIZE it refuses."""
+    src = open(os.path.join(ROOT, 'bench.py')).read()
+    assert "if a.gpus > 1 and 'RANK' not in os.environ:" in src and 'spawn_ranks' in src
+    # the launcher decision comes before anything that could touch the GPU
+    assert src.index("sys.exit(spawn_ranks(a))") < src.index('import torch\n    import nagp')
+    env = dict(os.environ, RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT='29577')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--T', '50'], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and '--gpus 2 but WORLD_SIZE=1' in (r.stderr + r.stdout)

@@ -279,9 +279,6 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
                                 int64_t T, const nagp_opts* o) {
   if (!out || !models || !o || B < 1 || T < 1) FAIL(NAGP_EINVAL, "null/empty argument");
   *out = nullptr;
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) FAIL(NAGP_ENODEVICE, "no HIP device visible");
-  if (o->device < 0 || o->device >= ndev) FAIL(NAGP_EINVAL, "device ordinal %d out of range", o->device);
   const nagp_model& m0 = models[0];
   if (!m0.block_offsets) FAIL(NAGP_EINVAL, "problem 0: NULL block_offsets");
   if (m0.M < 1 || m0.M > MAXM) FAIL(NAGP_EUNSUPPORTED, "M=%d outside 1..%d", m0.M, MAXM);
@@ -316,7 +313,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
   for (int n = 0; n <= m0.M; ++n) sh.off[n] = m0.block_offsets[n];
   for (int n = 0; n < m0.M; ++n) {
     sh.bsz[n] = sh.off[n + 1] - sh.off[n];
-    if (sh.bsz[n] < 1 || sh.bsz[n] > 4) { delete p; FAIL(NAGP_EUNSUPPORTED, "block %d has size %d (supported: 1..4)", n, sh.bsz[n]); }
+    if (sh.bsz[n] < 1 || sh.bsz[n] > 4) { const int bsn = sh.bsz[n]; delete p; FAIL(NAGP_EUNSUPPORTED, "block %d has size %d (supported: 1..4)", n, bsn); }
   }
   if (sh.off[0] != 0 || sh.off[m0.M] != m0.S) { delete p; FAIL(NAGP_EINVAL, "block_offsets do not span 0..S"); }
   for (int q = 0; q < B; ++q) {   // every pointer the packing below dereferences
@@ -339,6 +336,12 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
 #define PLAN_TRY(expr) do { int _s = (expr); if (_s != NAGP_OK) { nagp_plan_destroy(p); return _s; } } while (0)
 #define PLAN_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { char _b[512]; snprintf(_b, sizeof _b, "%s -> %s", #expr, hipGetErrorString(_e)); g_last_error = _b; nagp_plan_destroy(p); return _e == hipErrorOutOfMemory ? NAGP_ENOMEM : NAGP_EHIP; } } while (0)
 
+  // the device is looked at only after every pure-host check has passed (those run under ASan on GPU-less machines)
+  {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { delete p; FAIL(NAGP_ENODEVICE, "no HIP device visible"); }
+    if (o->device < 0 || o->device >= ndev) { delete p; FAIL(NAGP_EINVAL, "device ordinal %d out of range", o->device); }
+  }
   PLAN_HIP(hipSetDevice(o->device));
   PLAN_HIP(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
   PLAN_HIP(hipEventCreate(&p->ev_t0));

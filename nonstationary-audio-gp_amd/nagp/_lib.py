@@ -84,27 +84,54 @@ def source_hash():
 HASH_PATH = LIB_PATH + '.srchash'
 
 
-def build(force=False, verbose=False, jobs=None):
+LIB_ASAN_PATH = os.path.join(PKG_ROOT, 'libnagp_asan.so')
+
+
+def _tu_hash(f, extra=''):
+    """hash of one translation unit: its own text, every header of csrc/ and include/nagp.h, the flags"""
+    import hashlib
+    h = hashlib.sha256(extra.encode())
+    names = [f] + sorted(x for x in os.listdir(CSRC) if x.endswith(('.hpp', '.h')))
+    for n in names:
+        with open(os.path.join(CSRC, n), 'rb') as fh:
+            h.update(n.encode()); h.update(fh.read())
+    with open(os.path.join(INCLUDE, 'nagp.h'), 'rb') as fh:
+        h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def build(force=False, verbose=False, jobs=None, asan=False):
     """Compile csrc/*.hip -> libnagp.so for gfx950 (cross-compiles without a GPU): one object per translation unit
-    (nagp_api.hip = host code, inst_*.hip = groups of kernel instantiations), compiled in parallel, then linked.  The
-    library is stale when the hash of its sources differs from the one recorded next to it at build time (mtimes are
-    not trusted)."""
+    (nagp_api.hip = host code, inst_*.hip = groups of kernel instantiations), compiled in parallel into a per-unit object
+    cache (build/obj), then linked.  The library is stale when the hash of its sources differs from the one recorded
+    next to it at build time (mtimes are not trusted).
+    asan=True: libnagp_asan.so with the HOST code of the C ABI (nagp_api.hip) under AddressSanitizer -- the kernels are
+    the ordinary objects (no GPU sanitizer on this pool); used by the CPU tests of the argument-validation paths."""
     want = source_hash()
-    if not force and os.path.exists(LIB_PATH) and os.path.exists(HASH_PATH):
-        with open(HASH_PATH) as fh:
+    lib_path = LIB_ASAN_PATH if asan else LIB_PATH
+    hash_path = lib_path + '.srchash'
+    if not force and os.path.exists(lib_path) and os.path.exists(hash_path):
+        with open(hash_path) as fh:
             if fh.read().strip() == want:
-                return LIB_PATH
+                return lib_path
     from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    objdir = os.path.join(PKG_ROOT, 'build', 'obj-%s-%d' % (want[:12], os.getpid()))
+    objdir = os.path.join(PKG_ROOT, 'build', 'obj')
     os.makedirs(objdir, exist_ok=True)
     tus = sorted(f for f in os.listdir(CSRC) if f.endswith('.hip'))
     flags = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-I', INCLUDE]
+    san = ['-fsanitize=address', '-fno-omit-frame-pointer', '-g', '-shared-libsan'] if asan else []
 
     def compile_one(f):
-        obj = os.path.join(objdir, f[:-4] + '.o')
-        cmd = [hipcc] + flags + ['-c', '-o', obj, os.path.join(CSRC, f)]
+        fl = flags + (san if f == 'nagp_api.hip' else [])
+        obj = os.path.join(objdir, '%s-%s.o' % (f[:-4], _tu_hash(f, ' '.join(fl))))
+        if os.path.exists(obj) and not force:
+            return f, obj, None, None
+        tmp = obj + '.tmp.%d' % os.getpid()
+        cmd = [hipcc] + fl + ['-c', '-o', tmp, os.path.join(CSRC, f)]
         r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode == 0:
+            os.replace(tmp, obj)
         return f, obj, cmd, r
 
     try:
@@ -113,25 +140,28 @@ def build(force=False, verbose=False, jobs=None):
         usable = os.cpu_count() or 1
     with ThreadPoolExecutor(max_workers=jobs or max(1, min(usable, 8))) as ex:
         res = list(ex.map(compile_one, tus))
-    bad = [x for x in res if x[3].returncode != 0]
+    bad = [x for x in res if x[3] is not None and x[3].returncode != 0]
     if verbose or bad:
-        for f, obj, cmd, r in (bad or res):
+        for f, obj, cmd, r in (bad or [x for x in res if x[3] is not None]):
             print(' '.join(cmd)); print(r.stdout); print(r.stderr)
     if bad:
         raise NagpError('hipcc failed on %s' % ', '.join(x[0] for x in bad))
-    tmp = LIB_PATH + '.tmp.%d' % os.getpid()
-    cmd = [hipcc, '--offload-arch=gfx950', '-fPIC', '-shared', '-o', tmp] + [x[1] for x in res] + EXTRA_LINK
+    tmp = lib_path + '.tmp.%d' % os.getpid()
+    cmd = [hipcc, '--offload-arch=gfx950', '-fPIC', '-shared', '-o', tmp] + [x[1] for x in res] + EXTRA_LINK + (['-fsanitize=address', '-shared-libsan'] if asan else [])
     r = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or r.returncode != 0:
         print(' '.join(cmd)); print(r.stdout); print(r.stderr)
     if r.returncode != 0:
-        raise NagpError('hipcc failed linking libnagp.so')
-    os.replace(tmp, LIB_PATH)
-    with open(HASH_PATH, 'w') as fh:
+        raise NagpError('hipcc failed linking %s' % os.path.basename(lib_path))
+    os.replace(tmp, lib_path)
+    with open(hash_path, 'w') as fh:
         fh.write(want + '\n')
-    import shutil
-    shutil.rmtree(objdir, ignore_errors=True)
-    return LIB_PATH
+    keep = {os.path.basename(x[1]) for x in res}                    # drop objects of older sources (both variants keep theirs)
+    for o in os.listdir(objdir):
+        stem = o.rsplit('-', 1)[0]
+        if o.endswith('.o') and o not in keep and not (stem == 'nagp_api'):
+            os.remove(os.path.join(objdir, o))
+    return lib_path
 
 
 _lib = None

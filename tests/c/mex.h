@@ -1,0 +1,43 @@
+/* mex.h -- a small MOCK of MATLAB's MEX API, just enough to compile and run matlab/nagp_mex.c without MATLAB
+ * (no MATLAB / Octave in the build image).  Test infrastructure only; the real header comes with MATLAB. */
+#ifndef NAGP_MOCK_MEX_H
+#define NAGP_MOCK_MEX_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+typedef size_t mwSize;
+typedef enum { mxDOUBLE_CLASS = 1, mxINT32_CLASS, mxINT64_CLASS, mxSTRUCT_CLASS } mxClassID;
+typedef enum { mxREAL = 0 } mxComplexity;
+typedef struct mxArray_tag mxArray;
+
+int mxIsStruct(const mxArray* a);
+int mxIsDouble(const mxArray* a);
+int mxIsComplex(const mxArray* a);
+int mxIsInt32(const mxArray* a);
+int mxIsInt64(const mxArray* a);
+int mxIsEmpty(const mxArray* a);
+mxArray* mxGetField(const mxArray* a, size_t index, const char* name);
+double mxGetScalar(const mxArray* a);
+double* mxGetPr(const mxArray* a);
+void* mxGetData(const mxArray* a);
+size_t mxGetM(const mxArray* a);
+size_t mxGetNumberOfElements(const mxArray* a);
+mxArray* mxCreateDoubleMatrix(mwSize m, mwSize n, mxComplexity c);
+mxArray* mxCreateNumericMatrix(mwSize m, mwSize n, mxClassID cls, mxComplexity c);
+mxArray* mxCreateNumericArray(mwSize ndim, const mwSize* dims, mxClassID cls, mxComplexity c);
+void mexErrMsgIdAndTxt(const char* id, const char* fmt, ...);
+
+/* what a gateway exports */
+void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]);
+
+/* constructors for the driver (not part of the real API) */
+mxArray* mock_numeric(mxClassID cls, size_t m, size_t n, const void* data); /* copies */
+mxArray* mock_struct(void);
+void mock_set(mxArray* s, const char* name, mxArray* v);
+mxArray* mock_scalar(double v);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -763,3 +763,83 @@ def test_two_ranks_with_real_plans_allreduce_nlz(tmp_path):
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=300)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
+
+
+# ---------------------------------------------------------------------------------------------
+# the C ABI from plain C, and the MEX gateway of matlab/ against a mock of the MEX API
+def _dump_fixture(dirpath, family):
+    """Raw little-endian dumps (tests/c/dump.h) of one golden fixture: the arrays a MATLAB wrapper hands to nagp_mex and the
+    fixture's expected outputs."""
+    from nagp import api as napi, ihgp_tables
+    arrs = {}
+    if family == 'gf':
+        g = gold('cfg2_gf_ep_modulator_nmf'); D, N = int(g['D']), int(g['N'])
+        lik, p1, p2, W = napi._unpack_log(g['w'], 1, D, N)
+        blk = napi._blocks_from_dense(*SSHandle()(None, p1, p2, 'matern32', 'matern52'), D, N)
+        prob = napi._Problem(blk, W, lik); kind, I, l_iter, flags = 0, 3, 0, 0
+        mom = Mom('likModulatorNMFPower', p_cubature=9); exp = dict(Eft=g['Eft'], Varft=g['Varft'], nlZ=g['nlZ'], ttau=g['ttau'], tnu=g['tnu'])
+    elif family == 'ihgp':
+        g = gold('cfg3_ihgp_ep_modulator_nmf'); D, N = int(g['D']), int(g['N'])
+        lik, p1, p2, W = napi._unpack_log(g['w'], 1, D, N)
+        blk = pss.balance_blocks(napi._blocks_from_dense(*SSHandle()(None, p1, p2, 'matern32', 'matern52'), D, N))
+        prob = napi._Problem(blk, W, lik, symmetrize_Q=True); kind, I, l_iter, flags = 1, 3, 0, 0
+        r, PP, ppo, PG, pgo = ihgp_tables.build_tables(prob.A, prob.Q, blk.offsets, blk.h_val)
+        arrs.update(r=r, PP=PP, PG=PG, pp_off=np.asarray(ppo, np.int64), pg_off=np.asarray(pgo, np.int64))
+        mom = Mom('likModulatorNMFPower', p_cubature=7); exp = dict(Eft=g['Eft'], Varft=g['Varft'], nlZ=g['nlZ'], ttau=g['ttau'], tnu=g['tnu'])
+    else:
+        g = gold('cfg4_gf_giekf_modulator_nmf'); D, N = int(g['D']), int(g['N'])
+        lik, p1, p2, W = napi._unpack_log(g['w_log'], 1, D, N)
+        blk = pss.balance_blocks(napi._blocks_from_dense(*SSHandle()(None, p1, p2, 'matern32', 'matern52'), D, N))
+        prob = napi._Problem(blk, W, lik); kind, I, l_iter, flags = 2, 2, 2, 0
+        mom = None; exp = dict(Eft=g['Eft_plain'], Varft=g['Varft_plain'])
+    arrs.update(A=prob.A, Q=prob.Q, Pinf=prob.Pinf, block_offsets=prob.offsets.astype(np.int32), h_val=prob.h_val, Wnmf=prob.W, y=g['y'],
+                S=[blk.S], M=[blk.M], D=[D], N=[N], lik_param=[float(np.ravel(lik)[0])], kind=[kind], lik_kind=[1], ep_fraction=[0.5], ep_itts=[I],
+                l_iter=[l_iter], flags=[flags])
+    if mom is not None:
+        wn, xn = mom.tables(N)
+        arrs.update(wn=wn, xn_unscaled=xn, ep_damping=0.5 * np.ones(I))
+    for k, v in exp.items():
+        arrs['exp_' + k] = v
+    with open(os.path.join(dirpath, 'meta.txt'), 'w') as meta:
+        for k, v in arrs.items():
+            a = np.asarray(v)
+            a = np.asfortranarray(a.astype({'block_offsets': np.int32, 'pp_off': np.int64, 'pg_off': np.int64}.get(k, np.float64)))
+            a.ravel(order='F').tofile(os.path.join(dirpath, k + '.bin'))
+            meta.write('%s %d\n' % (k, a.size))
+
+
+def _cc(out, srcs, extra=()):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, 'nonstationary-audio-gp_amd')
+    cmd = ['gcc', '-O1', '-std=c99', '-I', os.path.join(root, 'include'), '-I', os.path.join(root, 'tests', 'c')] + list(extra) + ['-o', out] + srcs + \
+          ['-L', pkg, '-lnagp', '-lm', '-Wl,-rpath,' + pkg, '-Wl,-rpath,/opt/rocm/lib', '-Wl,-rpath-link,/opt/rocm/lib']
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return out
+
+
+@pytest.mark.parametrize('family', ['gf', 'ihgp', 'giekf'])
+def test_c_abi_from_plain_c(family, tmp_path):
+    """tests/c/abi_golden.c: a C program (gcc, no Python, no torch in the process) links libnagp.so, feeds a golden fixture
+    through nagp_ep_run / nagp_ihgp_run / nagp_giekf_run and compares with the expected outputs."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    _dump_fixture(str(tmp_path), family)
+    exe = _cc(str(tmp_path / 'abi_golden'), [os.path.join(root, 'tests', 'c', 'abi_golden.c')])
+    r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert 'invalid call -> -1' in r.stdout
+
+
+@pytest.mark.parametrize('family', ['gf', 'ihgp', 'giekf'])
+def test_mex_gateway_against_golden_fixture(family, tmp_path):
+    """matlab/nagp_mex.c compiled against the mock MEX API of tests/c (no MATLAB here) and driven with the structs the .m
+    wrappers build: same outputs as the fixture."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    _dump_fixture(str(tmp_path), family)
+    c = os.path.join(root, 'tests', 'c')
+    exe = _cc(str(tmp_path / 'mex_driver'), [os.path.join(c, 'mex_driver.c'), os.path.join(c, 'mex_mock.c'), os.path.join(root, 'matlab', 'nagp_mex.c')])
+    r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr

@@ -235,3 +235,49 @@ def test_bench_refuses_a_world_size_mismatch_and_spawns_ranks_itself():
     env = dict(os.environ, RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT='29577')
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--T', '50'], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and '--gpus 2 but WORLD_SIZE=1' in (r.stderr + r.stdout)
+
+
+def test_c_callers_and_the_mex_gateway_compile_and_link():
+    """tests/c/abi_golden.c (plain C caller of the ABI) and matlab/nagp_mex.c (against the mock MEX API of tests/c) build with
+    gcc and link against libnagp.so; they run in the -m gpu tests."""
+    import tempfile
+    pkg = os.path.join(ROOT, 'nonstationary-audio-gp_amd'); c = os.path.join(ROOT, 'tests', 'c')
+    nagp.build()
+    with tempfile.TemporaryDirectory() as td:
+        base = ['gcc', '-Wall', '-Werror', '-O1', '-std=c99', '-I', os.path.join(ROOT, 'include'), '-I', c]
+        link = ['-L', pkg, '-lnagp', '-lm', '-Wl,-rpath,' + pkg, '-Wl,-rpath,/opt/rocm/lib', '-Wl,-rpath-link,/opt/rocm/lib']
+        for out, srcs in (('abi_golden', ['abi_golden.c']), ('mex_driver', ['mex_driver.c', 'mex_mock.c', os.path.join(ROOT, 'matlab', 'nagp_mex.c')])):
+            r = subprocess.run(base + ['-o', os.path.join(td, out)] + [os.path.join(c, f) for f in srcs] + link, capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr
+    # every reference entry point has its MATLAB wrapper, with the reference's argument list
+    sigs = {'gf_ep_modulator': 'w,x,y,ss,mom,xt,kernel1,kernel2,num_lik_params,ep_fraction,ep_damping,ep_itts',
+            'gf_ep_modulator_nmf': 'w,x,y,ss,mom,xt,kernel1,kernel2,num_lik_params,D,N,ep_fraction,ep_damping,ep_itts',
+            'gf_ep_modulator_nmf_constraints': 'w,x,y,ss,mom,xt,kernel1,kernel2,num_lik_params,D,N,ep_fraction,ep_damping,ep_itts,constraints,w_fixed,tune_hypers',
+            'ihgp_ep_modulator_nmf': 'w,x,y,ss,mom,xt,kernel1,kernel2,num_lik_params,D,N,ep_fraction,ep_damping,ep_itts',
+            'ihgp_ep_modulator_nmf_constraints': 'w,x,y,ss,mom,xt,kernel1,kernel2,num_lik_params,D,N,ep_fraction,ep_damping,ep_itts,constraints,w_fixed,tune_hypers',
+            'gf_giekf_modulator_nmf': 'w,x,y,ss,mom,xt,kernel1,kernel2,num_lik_params,D,N,g_iter,l_iter,GradObj',
+            'gf_giekf_modulator_nmf_constraints': 'w,x,y,ss,mom,xt,kernel1,kernel2,num_lik_params,D,N,g_iter,l_iter,constraints,w_fixed,tune_hypers,GradObj'}
+    for fn, args in sigs.items():
+        src = open(os.path.join(ROOT, 'matlab', fn + '.m')).read()
+        m = re.match(r'function \[varargout\] = (\w+)\(([^)]*)\)', re.sub(r'\.\.\.\s*', '', src))
+        assert m and m.group(1) == fn and re.sub(r'\s', '', m.group(2)) == args, fn
+
+
+def test_abi_error_paths_under_asan():
+    """The host code of the C ABI (nagp_api.hip) built with AddressSanitizer; tests/c/abi_errors.c walks the
+    argument-validation paths (NULL pointers, bad shapes, mismatching problems) on this GPU-less machine: every call comes
+    back with its status and ASan reports nothing."""
+    import tempfile, glob
+    lib = nagp.build(asan=True)
+    clang = '/opt/rocm/lib/llvm/bin/clang'
+    rt = glob.glob('/opt/rocm/lib/llvm/lib/clang/*/lib/linux') + glob.glob('/opt/rocm/lib/llvm/lib/clang/*/lib/x86_64-unknown-linux-gnu')
+    with tempfile.TemporaryDirectory() as td:
+        exe = os.path.join(td, 'abi_errors')
+        r = subprocess.run([clang, '-fsanitize=address', '-shared-libsan', '-g', '-O1', '-std=c99', '-I', os.path.join(ROOT, 'include'), '-o', exe,
+                            os.path.join(ROOT, 'tests', 'c', 'abi_errors.c'), lib, '-Wl,-rpath,/opt/rocm/lib', '-Wl,-rpath-link,/opt/rocm/lib'] +
+                           ['-Wl,-rpath,' + d for d in rt], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        env = dict(os.environ, ASAN_OPTIONS='detect_leaks=0:abort_on_error=0:exitcode=66', LD_LIBRARY_PATH=':'.join(rt + [os.environ.get('LD_LIBRARY_PATH', '')]))
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0 and 'all error paths returned their status' in r.stdout, r.stdout + r.stderr
+        assert 'AddressSanitizer' not in r.stderr, r.stderr

@@ -203,6 +203,19 @@ int nagp_iekf_update1(int32_t S, int32_t D, int32_t N, const int32_t* h_col, con
 int nagp_fastfb_run(int32_t S, const double* A, const double* AKHA, const double* HA, const double* K, const double* G,
                     const double* y, int64_t T, double* MS, double* sum_v2, int32_t device);
 
+/* What the drivers do next with Eft / Varft (demo_toy_modulators_nmf.m:119-158, the same block in the other
+ * demos): the reconstructed signal sig = sum_d (W link(g))_d z_d and the modulator amplitudes link(g_n) under the independent
+ * posterior marginals z_d ~ N(Eft_d, Varft_d), g_n ~ N(Eft_{D+n}, Varft_{D+n}) of every time step:
+ *   Eft_mod (N x T) = mean link(g_n), Varft_mod = var link(g_n), Esig (T) = mean sig, Vsig = var sig.
+ * n_samples = 0: the population values (Gauss-Hermite rule gh_x, gh_w of n_gh points for the standard normal weight per
+ *   modulator -- exp link: closed form -- then closed-form combination);
+ * n_samples >= 2: the reference's estimator (s = 250 there): sample mean and variance (s-1) over draws of a counter-based
+ *   generator (Philox4x32-10 keyed by `seed`, Box-Muller), reproducible on the host.
+ * Eft, Varft: M x T column-major as returned by the *_run calls; Wnmf D x N column-major. */
+int nagp_reconstruct(int32_t D, int32_t N, int64_t T, const double* Eft, const double* Varft, const double* Wnmf,
+                     int32_t link_kind, double link_shift, int32_t n_gh, const double* gh_x, const double* gh_w,
+                     int32_t n_samples, uint64_t seed, double* Esig, double* Vsig, double* Eft_mod, double* Varft_mod, int32_t device);
+
 /* Batched / device-resident form: n_problems independent problems of identical shape
  * (S, M, block structure, T) -- audio segments or hyper-parameter replicas -- run concurrently. */
 int nagp_plan_create(nagp_plan** plan, int32_t n_problems, const nagp_model* models,

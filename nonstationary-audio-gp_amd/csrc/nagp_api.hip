@@ -4,6 +4,7 @@
 // matlab/gf_ep_modulator_nmf.m:113-283 (predict) / :384-522 (nlml), ihgp_ep_modulator_nmf.m:223-454
 // and gf_giekf_modulator_nmf.m:126-221.
 #include "nagp_inst.hpp"
+#include "nagp_recon.hpp"
 #include "../../include/nagp.h"
 
 // every templated kernel is instantiated in one of the inst_*.hip translation units
@@ -1579,4 +1580,52 @@ extern "C" int nagp_batch_run(int32_t n_problems, const nagp_model* models, cons
   }
   if (nlZ_total) for (int i = 0; i < I; ++i) nlZ_total[i] = total[i];
   return NAGP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// posterior reconstruction of the signal and the modulator amplitudes (see include/nagp.h, nagp_recon.hpp)
+extern "C" int nagp_reconstruct(int32_t D, int32_t N, int64_t T, const double* Eft, const double* Varft, const double* Wnmf,
+                                int32_t link_kind, double link_shift, int32_t n_gh, const double* gh_x, const double* gh_w,
+                                int32_t n_samples, uint64_t seed, double* Esig, double* Vsig, double* Eft_mod, double* Varft_mod, int32_t device) {
+  if (!Eft || !Varft || !Wnmf || !Esig || !Vsig || !Eft_mod || !Varft_mod) FAIL(NAGP_EINVAL, "null argument");
+  if (D < 1 || N < 1 || N > MOM_MAXCD || D + N > MAXM || T < 1) FAIL(NAGP_EINVAL, "bad sizes (D=%d N=%d T=%lld)", D, N, (long long)T);
+  if (link_kind != NAGP_LINK_SOFTPLUS && link_kind != NAGP_LINK_EXP) FAIL(NAGP_EINVAL, "unknown link");
+  const bool sampling = n_samples > 0;
+  if (sampling && n_samples < 2) FAIL(NAGP_EINVAL, "sampling needs at least two draws");
+  if (!sampling && link_kind == NAGP_LINK_SOFTPLUS && (n_gh < 1 || n_gh > 256 || !gh_x || !gh_w)) FAIL(NAGP_EINVAL, "Gauss-Hermite rule missing");
+  if (hipSetDevice(device) != hipSuccess) FAIL(NAGP_EHIP, "hipSetDevice(%d)", device);
+  const int M = D + N;
+  const size_t nW = (size_t)D * N, nMT = (size_t)M * T, ngh = sampling ? 0 : (size_t)std::max(n_gh, 0);
+  const size_t o_W = 0, o_E = o_W + nW, o_V = o_E + nMT, o_gx = o_V + nMT, o_gw = o_gx + ngh, o_es = o_gw + ngh, o_vs = o_es + T,
+               o_em = o_vs + T, o_vm = o_em + (size_t)N * T, total = o_vm + (size_t)N * T;
+  double* dev = nullptr;
+  if (hipMalloc(&dev, total * sizeof(double)) != hipSuccess) FAIL(NAGP_ENOMEM, "hipMalloc(%zu)", total * sizeof(double));
+  std::vector<double> Wr(nW);
+  for (int d = 0; d < D; ++d)
+    for (int j = 0; j < N; ++j) Wr[(size_t)d * N + j] = Wnmf[d + (size_t)D * j];
+  int st = NAGP_OK;
+#define RC_HIP(x) do { if (st == NAGP_OK) { hipError_t _e = (x); if (_e != hipSuccess) { g_last_error = std::string("nagp_reconstruct: " #x " -> ") + hipGetErrorString(_e); st = NAGP_EHIP; } } } while (0)
+  RC_HIP(hipMemcpy(dev + o_W, Wr.data(), nW * 8, hipMemcpyHostToDevice));
+  RC_HIP(hipMemcpy(dev + o_E, Eft, nMT * 8, hipMemcpyHostToDevice));      // M x T column-major = [T][M]
+  RC_HIP(hipMemcpy(dev + o_V, Varft, nMT * 8, hipMemcpyHostToDevice));
+  if (ngh) { RC_HIP(hipMemcpy(dev + o_gx, gh_x, ngh * 8, hipMemcpyHostToDevice)); RC_HIP(hipMemcpy(dev + o_gw, gh_w, ngh * 8, hipMemcpyHostToDevice)); }
+  ReconPar rp{D, N, M, T, link_kind, link_shift, dev + o_W, dev + o_E, dev + o_V, (int)ngh, dev + o_gx, dev + o_gw, n_samples, seed,
+              dev + o_es, dev + o_vs, dev + o_em, dev + o_vm};
+  if (st == NAGP_OK) {
+    if (sampling) {
+      const unsigned grid = (unsigned)std::min<int64_t>(T, 65536);
+      hipLaunchKernelGGL(recon_sample_kernel, dim3(grid), dim3(64), nW * sizeof(double), 0, rp);
+    } else {
+      hipLaunchKernelGGL(recon_moments_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), (nW + 2 * ngh) * sizeof(double), 0, rp);
+    }
+  }
+  RC_HIP(hipGetLastError());
+  RC_HIP(hipDeviceSynchronize());
+  RC_HIP(hipMemcpy(Esig, dev + o_es, (size_t)T * 8, hipMemcpyDeviceToHost));
+  RC_HIP(hipMemcpy(Vsig, dev + o_vs, (size_t)T * 8, hipMemcpyDeviceToHost));
+  RC_HIP(hipMemcpy(Eft_mod, dev + o_em, (size_t)N * T * 8, hipMemcpyDeviceToHost));
+  RC_HIP(hipMemcpy(Varft_mod, dev + o_vm, (size_t)N * T * 8, hipMemcpyDeviceToHost));
+#undef RC_HIP
+  (void)hipFree(dev);
+  return st;
 }

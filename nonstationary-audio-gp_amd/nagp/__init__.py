@@ -12,3 +12,4 @@ from .cubature import utp_ws, gauher, mvhermgauss_unit  # noqa: F401
 from .plan import Plan, batch_run, batch_partition  # noqa: F401
 from .fastfb import get_disc_model, kernel_ss_kalmanFastFB  # noqa: F401
 from .train import nlml_batch, fd_value_and_gradient  # noqa: F401
+from .recon import reconstruct_signal  # noqa: F401

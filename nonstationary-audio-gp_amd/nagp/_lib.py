@@ -62,7 +62,7 @@ class Timings(C.Structure):
 EXPORTS = ['nagp_version', 'nagp_device_count', 'nagp_strerror', 'nagp_last_error', 'nagp_ep_run',
            'nagp_ihgp_run', 'nagp_giekf_run', 'nagp_plan_create', 'nagp_plan_upload_y', 'nagp_plan_execute',
            'nagp_plan_timings', 'nagp_plan_download', 'nagp_plan_device_bytes', 'nagp_plan_destroy', 'nagp_plan_upload_sites',
-           'nagp_batch_partition', 'nagp_batch_run', 'nagp_shutdown', 'nagp_mom_eval', 'nagp_iekf_update1', 'nagp_fastfb_run']
+           'nagp_batch_partition', 'nagp_batch_run', 'nagp_shutdown', 'nagp_reconstruct', 'nagp_mom_eval', 'nagp_iekf_update1', 'nagp_fastfb_run']
 
 
 class NagpError(RuntimeError):
@@ -193,6 +193,9 @@ def lib():
     L.nagp_batch_partition.argtypes = [C.c_int32, C.c_int32, c_ip]
     L.nagp_batch_run.argtypes = [C.c_int32, C.POINTER(Model), C.POINTER(IhgpTables), C.POINTER(c_dp), C.c_int64, C.POINTER(Opts), C.POINTER(Out), C.c_int32, c_dp]
     L.nagp_shutdown.restype = None
+    L.nagp_reconstruct.argtypes = [C.c_int32, C.c_int32, C.c_int64, c_dp, c_dp, c_dp, C.c_int32, C.c_double, C.c_int32, c_dp, c_dp,
+                                   C.c_int32, C.c_uint64, c_dp, c_dp, c_dp, c_dp, C.c_int32]
+    L.nagp_reconstruct.restype = C.c_int
     L.nagp_plan_execute.argtypes = [C.c_void_p]
     L.nagp_plan_timings.argtypes = [C.c_void_p, C.POINTER(Timings)]
     L.nagp_plan_download.argtypes = [C.c_void_p, C.POINTER(Out)]

@@ -843,3 +843,35 @@ def test_mex_gateway_against_golden_fixture(family, tmp_path):
     exe = _cc(str(tmp_path / 'mex_driver'), [os.path.join(c, 'mex_driver.c'), os.path.join(c, 'mex_mock.c'), os.path.join(root, 'matlab', 'nagp_mex.c')])
     r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize('link', ['softplus', 'exp'])
+def test_posterior_reconstruction_of_signal_and_amplitudes(link):
+    """Row f-4 (demo_toy_modulators_nmf.m:119-158): Esig, Vsig, Eft_mod, Varft_mod from the marginals of a real run.
+    Sampling form = the .m statement by statement on the library's reproducible draws (oracle/recon.py) to 1e-10; the moments
+    form = the population values, which 40 000 draws estimate to Monte-Carlo accuracy."""
+    from oracle import recon as orc
+    D, N, T = 6, 3, 200
+    pr = harness.nmf_problem(D, N, T, 55); t = np.arange(1, T + 1.0); d = 0.5 * np.ones(2)
+    shift = 0.0
+    Eft, Varft = nagp.gf_ep_modulator_nmf(pr['w'], t, pr['y'], SSHandle(), Mom('likModulatorNMFPower', link=link, p_cubature=5), t,
+                                          'matern32', 'matern52', 1, D, N, 0.5, d, 2)
+    if link == 'exp':
+        Eft = Eft.copy(); Eft[D:] *= 0.2; Varft = Varft.copy(); Varft[D:] = np.minimum(Varft[D:], 0.5)    # keep exp(g) tame
+    lk = (lambda g: np.log(1.0 + np.exp(g - shift))) if link == 'softplus' else np.exp
+    W = pr['W']
+    got = nagp.reconstruct_signal(Eft, Varft, W, link=link, n_samples=250, seed=2019)
+    ref = orc.sampling(Eft, Varft, W, lk, 250, 2019)
+    for k in ('Esig', 'Vsig', 'Eft_mod', 'Varft_mod'):
+        assert rel(got[k], ref[k]) < 1e-10, k
+    from nagp.cubature import gauher
+    gx, gw = gauher(32)
+    mom_ = nagp.reconstruct_signal(Eft, Varft, W, link=link)
+    refm = orc.moments(Eft, Varft, W, lk, gx, gw, exp_link=(link == 'exp'))
+    for k in ('Esig', 'Vsig', 'Eft_mod', 'Varft_mod'):
+        assert rel(mom_[k], refm[k]) < 1e-12, k
+    big = orc.sampling(Eft, Varft, W, lk, 40000, 7)
+    assert rel(mom_['Esig'], big['Esig']) < 0.03 and rel(mom_['Eft_mod'], big['Eft_mod']) < 0.03
+    assert rel(mom_['Vsig'], big['Vsig']) < 0.1 and rel(mom_['Varft_mod'], big['Varft_mod']) < 0.1
+    with pytest.raises(nagp.NagpError):
+        nagp.reconstruct_signal(Eft, Varft, W, link=link, n_samples=1)

@@ -265,20 +265,56 @@ def test_batched_nlml_driver_equals_serial_calls_and_finite_differences():
     assert abs(g[i] - go) < 1e-3 * abs(go)
 
 
-def test_randomised_configurations_against_oracle():
-    """tools/gpu_fuzz.py with a fixed seed: 30 random draws of shape, kernels, likelihood, link, cubature order, power,
-    damping, sweeps and missing data through all three function families.  Instances the reference itself cannot
-    reproduce (site updates divided by 1 + d2*v ~ 1e-14, arg-min ties of the IHGP grid: detected by re-running the ORACLE
-    on y*(1+1e-13)) are excused and must stay rare."""
-    import importlib.util
-    spec = importlib.util.spec_from_file_location('gpu_fuzz', os.path.join(os.path.dirname(__file__), '..', 'tools', 'gpu_fuzz.py'))
+def _fuzz_module():
+    import importlib.util, sys
+    tools = os.path.join(os.path.dirname(__file__), '..', 'tools')
+    if tools not in sys.path:
+        sys.path.insert(0, tools)
+    spec = importlib.util.spec_from_file_location('gpu_fuzz', os.path.join(tools, 'gpu_fuzz.py'))
     fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
-    rng = np.random.default_rng(2024); excused = 0
-    for _ in range(30):
-        desc, res, _cfg = fz.one(rng)
-        excused += desc.count('unstable instance')
-        assert max(res.values()) < TOL_MEAN, (desc, res)
-    assert excused <= 4
+    return fz
+
+
+def _excused(name):
+    import json
+    with open(os.path.join(GOLD, name)) as fh:
+        d = json.load(fh)
+    return d, {(e['draw'], e['family']) for e in d['excused']}
+
+
+def test_randomised_configurations_against_oracle():
+    """30 random draws (seed 2024) of shape, kernels, likelihood, link, cubature order, power, damping, sweeps and missing data
+    through all three function families, every one compared at the full tolerance -- except the (draw, family) pairs listed in
+    tests/golden/fuzz_excused_main.json.  That list is NOT computed here and does not look at the device: tools/fuzz_conditioning.py
+    derives it from the oracle alone (the reference algorithm run twice, on y and y*(1+1e-13); listed when it moves by > 1e-8 or a
+    site parameter passes 1e8).  At most one of the 60 gf / ihgp comparisons may be on it."""
+    fz = _fuzz_module()
+    meta, skip = _excused('fuzz_excused_main.json')
+    assert meta['seed'] == 2024 and meta['n_draws'] == 30 and len(skip) <= 1
+    rng = np.random.default_rng(2024)
+    for i in range(30):
+        desc, res, _cfg = fz.one(rng, raw=True)
+        for fam, v in res.items():
+            if (i, fam) in skip:
+                continue
+            assert v < TOL_MEAN, (i, fam, desc, res)
+
+
+def test_randomised_mixtures_and_ekf_objective_against_oracle():
+    """The widened rows under the same rule: 12 draws (seed 7) of J = 2-3 stacked sources through both mixture variants
+    (missing data, block-structured cubature whenever Wnmf allows) and of the EKF objective; excusals only from the committed,
+    oracle-derived tests/golden/fuzz_excused_widened.json (the older EP rule of the mixtures, d/alpha scaling, divides by
+    1 + d2*v ~ 0 far more often -- DESIGN.md section 2)."""
+    fz = _fuzz_module()
+    meta, skip = _excused('fuzz_excused_widened.json')
+    assert meta['seed'] == 7 and meta['n_draws'] == 12 and len(skip) <= 6
+    rng = np.random.default_rng(7)
+    for i in range(12):
+        desc, res, _ = fz.one_widened(rng, raw=True)
+        for fam, v in res.items():
+            if (i, fam) in skip:
+                continue
+            assert v < TOL_MEAN, (i, fam, desc, res)
 
 
 @pytest.mark.parametrize('link', ['exp', 'softplus'])
@@ -875,3 +911,77 @@ def test_posterior_reconstruction_of_signal_and_amplitudes(link):
     assert rel(mom_['Vsig'], big['Vsig']) < 0.1 and rel(mom_['Varft_mod'], big['Varft_mod']) < 0.1
     with pytest.raises(nagp.NagpError):
         nagp.reconstruct_signal(Eft, Varft, W, link=link, n_samples=1)
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE sizes of configs[3] and configs[4] through size-independent properties; multi-segment plans at S = 146
+def _constrained_problem(g):
+    from nagp import api as napi
+    D, N = int(g['D']), int(g['N'])
+    lik, p1, p2, W = napi._unpack_constraints(g['w'], g['w_fixed'], list(g['tune_hypers']), g['constraints'], 1, D, N)
+    blk = pss.balance_blocks(napi._blocks_from_dense(*SSHandle()(None, p1, p2, 'matern32', 'matern52'), D, N))
+    return blk, W, lik
+
+
+def test_full_length_cfg4_ekf_energy_prefix_property():
+    """configs[3] at its native length (T = 88 200, 24 channels / 3 components, S = 105), EKF energy mode
+    (gf_giekf_modulator_nmf_constraints.m:385-472): the energy of step k depends on y(1..k) only, so the per-step energies of the
+    first 599 steps equal those of the 600-step run bit for bit, and the 600-step run is the golden one (compared with the oracle)."""
+    g = gold('ekf_objective_cfg4_shape'); Tg = g['y'].size; T = 88200
+    blk, W, lik = _constrained_problem(g)
+    y = np.tile(g['y'], T // Tg + 1)[:T]
+    def run(yy):
+        plan = Plan(L.KIND_GIEKF, [(blk, W, lik)], yy.size, ep_itts=1, mode=L.MODE_NLML, l_iter=1)
+        plan.upload([yy]); plan.execute(); o = plan.download(want_MS=False)[0]; plan.close()
+        return o
+    full, short = run(y), run(g['y'])
+    assert blk.S == 105 and np.array_equal(full.lZ[:Tg - 1], short.lZ[:Tg - 1])
+    assert abs(short.nlZ[0] - float(g['edata'])) < TOL_LOGZ * abs(float(g['edata']))
+    assert abs(-np.sum(full.lZ[:Tg]) - float(g['edata'])) < 1e-9 * abs(float(g['edata']))
+    assert np.all(np.isfinite(full.lZ)) and np.isfinite(full.nlZ[0])
+    assert abs(full.nlZ[0] + np.sum(full.lZ)) < 1e-9 * abs(full.nlZ[0])
+
+
+def test_full_length_cfg5_prefix_property_and_finiteness():
+    """configs[4], one segment at full length (T = 100 000, 32 channels / 6 components, S = 146: 9.5 GB of filtered covariances,
+    chunked smoother): with one sweep the sites of step k depend on y(1..k) only -- the leading 499 columns equal the 500-step
+    run bit for bit, which in turn is compared with the oracle; everything finite, variances positive."""
+    g = gold('cfg5_gf_ep_modulator_nmf_constraints'); Tg = g['y'].size; T = 100000
+    blk, W, lik = _constrained_problem(g)
+    y = np.tile(g['y'], T // Tg + 1)[:T]
+    mom = Mom('likModulatorNMFPower', p_cubature=7)
+    def run(yy):
+        plan = Plan(L.KIND_GF_EP, [(blk, W, lik)], yy.size, mom=mom, ep_fraction=0.5, ep_damping=[0.5], ep_itts=1)
+        plan.upload([yy]); plan.execute(); o = plan.download(want_MS=False)[0]; nb = plan.device_bytes(); plan.close()
+        return o, nb
+    (full, nbytes), (short, _) = run(y), run(g['y'])
+    assert blk.S == 146 and nbytes > 9e9
+    assert np.array_equal(full.ttau[:, :Tg - 1], short.ttau[:, :Tg - 1]) and np.array_equal(full.lZ[:Tg - 1], short.lZ[:Tg - 1])
+    To = 120; to = np.arange(1, To + 1.0)
+    o = ogf.gf_ep_modulator_nmf_constraints(g['w'], to, g['y'][:To], None, olik.Mom(olik.LIK_POWER_NMF, p=7), to, 'matern32', 'matern52', 1,
+                                            int(g['D']), int(g['N']), 0.5, [0.5], 1, g['constraints'], g['w_fixed'], list(g['tune_hypers']))
+    assert rel(short.ttau[:, :To - 1], o[5]['ttau'][:, :To - 1]) < TOL_SITE and rel(short.lZ[:To - 1], o[5]['lZ'][:To - 1]) < 1e-7
+    assert np.all(np.isfinite(full.Eft)) and np.all(full.Varft > 0) and np.isfinite(full.nlZ[0]) and full.counters[0] == 0
+
+
+def test_eight_segments_at_S146_equal_their_single_problem_plans():
+    """configs[4] as the bench runs it (several 32-channel / 6-component segments in one plan, three tiles per thread, the VALU
+    smoother passes with eight problems per launch): every segment of the 8-segment plan equals the plan of that segment alone."""
+    D, N, T = 32, 6, 160
+    probs, ys = [], []
+    for q in range(8):
+        pr = harness.nmf_problem(D, N, T, 5000 + q, 'constraints')
+        blk = pss.balance_blocks(pss.ss_blocks_nmf(pr['param1'], pr['param2'], 'matern32', 'matern52'))
+        y = pr['y'].copy(); y[11 * q + 3] = np.nan
+        probs.append((blk, pr['W'], np.log(pr['w_lik']))); ys.append(y)
+    mom = Mom('likModulatorNMFPower', p_cubature=7); d = 0.5 * np.ones(3)
+    plan = Plan(L.KIND_GF_EP, probs, T, mom=mom, ep_fraction=0.5, ep_damping=d, ep_itts=3)
+    plan.upload(ys); plan.execute(); outs = plan.download(); plan.close()
+    for q in (0, 3, 7):
+        one = Plan(L.KIND_GF_EP, [probs[q]], T, mom=mom, ep_fraction=0.5, ep_damping=d, ep_itts=3)
+        one.upload([ys[q]]); one.execute(); o = one.download()[0]; one.close()
+        for f in ('Eft', 'Varft', 'ttau', 'tnu', 'lZ', 'nlZ', 'MS', 'maxDiffP'):
+            assert np.array_equal(getattr(outs[q], f), getattr(o, f), equal_nan=True), (q, f)
+    ref = ogf.run_predict(ogf.assemble(np.log(1e-4) * np.ones(1), *[harness.nmf_problem(D, N, T, 5003, 'constraints')[k] for k in ('param1', 'param2', 'W')],
+                                       'matern32', 'matern52', True), ys[3], olik.Mom(olik.LIK_POWER_NMF, p=7), 0.5, d, 3)
+    assert rel(outs[3].Eft, ref['Eft']) < TOL_MEAN and relz(outs[3].nlZ, ref['nlZ']) < TOL_LOGZ

@@ -4,7 +4,7 @@ python tools/gpu_fuzz.py [n_cases] [seed]
 python tools/gpu_fuzz.py widened [n_cases] [seed]     # mixtures (block-structured cubature included) and the EKF objective"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'nonstationary-audio-gp_amd'))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'nonstationary-audio-gp_amd')); sys.path.insert(0, os.path.join(ROOT, 'tools'))
 import numpy as np
 import nagp
 from nagp import harness, Mom, SSHandle, cubature
@@ -18,34 +18,12 @@ def rel(a, b):
     return float(np.nanmax(np.abs(a - b)) / (np.nanmax(np.abs(b)) + 1e-300)) if a.size else 0.0
 
 
-def draw(rng):
-    D = int(rng.integers(2, 9)); N = int(rng.integers(1, 7)); T = int(rng.integers(20, 90))
-    p = int(rng.choice([5, 7, 9] if N <= 4 else [7]))
-    kind = str(rng.choice(['nmf', 'nmf', 'sqrt']))
-    link = str(rng.choice(['softplus', 'softplus', 'exp'])); shift = float(rng.choice([0.0, 1.0])) if link == 'softplus' else 0.0
-    k1 = str(rng.choice(['exp', 'matern32'])); k2 = str(rng.choice(['matern32', 'matern52']))
-    itts = int(rng.integers(1, 4)); alpha = float(rng.choice([0.5, 0.75, 1.0])); damp = rng.uniform(0.1, 0.6, itts)
-    if itts > 1 and alpha == 1.0:
-        # full-EP cavities 1/(1/v - ttau) are routinely near-singular (v_cav ~ 1e12 ... Inf, exp-link overflow to NaN): their
-        # size is rounding noise in the reference as well, so multi-sweep draws use the fractional powers the paper uses
-        alpha = 0.75
-    pr = harness.nmf_problem(D, N, T, int(rng.integers(1, 10 ** 6)), str(rng.choice(['demo_nmf', 'constraints'])), kernel1=k1, kernel2=k2)
-    y = pr['y'].copy(); y[rng.random(T) < 0.1] = np.nan
-    li = int(rng.integers(1, 4)) if (link == 'softplus' and shift == 0.0) else 0
-    return dict(D=D, N=N, T=T, p=p, kind=kind, link=link, shift=shift, k1=k1, k2=k2, itts=itts, alpha=alpha, damp=damp, pr=pr, y=y, li=li)
+from gpu_fuzz_draws import draw, moms, draw_widened   # the draws live in a GPU-free module (tools/fuzz_conditioning.py shares them)
 
 
-def moms(c):
-    olink = olik.softplus_link(c['shift']) if c['link'] == 'softplus' else olik.exp_link()
-    if c['kind'] == 'sqrt':
-        wn, xn = cubature.utp_ws(c['p'], c['N'])
-        return (Mom('likModulatorPreCalcwn', link=c['link'], link_shift=c['shift'], wn=wn, xn_unscaled=xn),
-                olik.Mom(olik.LIK_POWER_NMF_SQRT, link=olink, wn=wn, xn_unscaled=xn))
-    return (Mom('likModulatorNMFPower', link=c['link'], link_shift=c['shift'], p_cubature=c['p']),
-            olik.Mom(olik.LIK_POWER_NMF, link=olink, p=c['p']))
-
-
-def one(rng):
+def one(rng, raw=False):
+    """raw=True: plain device-vs-oracle differences, nothing excused (the tests decide from the committed lists of
+    tests/golden/fuzz_excused_*.json, which tools/fuzz_conditioning.py derives from the oracle alone)"""
     c = draw(rng)
     D, N, T, p, k1, k2, itts, alpha, damp, pr, y = (c[k] for k in ('D', 'N', 'T', 'p', 'k1', 'k2', 'itts', 'alpha', 'damp', 'pr', 'y'))
     t = np.arange(1, T + 1.0)
@@ -55,7 +33,7 @@ def one(rng):
     r = nagp.gf_ep_modulator_nmf(pr['w'], t, y, SSHandle(), mom, t, k1, k2, 1, D, N, alpha, damp, itts, nargout=6)
     o = ogf.gf_ep_modulator_nmf(pr['w'], t, y, None, omom, t, k1, k2, 1, D, N, alpha, damp, itts)
     res['gf'] = max(rel(r[0], o[0]), rel(r[1], o[1]), rel(r[5]['nlZ'], o[5]['nlZ']))
-    if res['gf'] > 1e-7:
+    if res['gf'] > 1e-7 and not raw:
         o2 = ogf.gf_ep_modulator_nmf(pr['w'], t, y * (1 + 1e-13), None, omom, t, k1, k2, 1, D, N, alpha, damp, itts)
         sens = max(rel(o2[0], o[0]), rel(o2[1], o[1]))
         big = max(np.nanmax(np.abs(np.nan_to_num(x[5][nm], posinf=0.0))) for x in (r, o) for nm in ('ttau', 'tnu'))
@@ -67,7 +45,7 @@ def one(rng):
     r = nagp.ihgp_ep_modulator_nmf(pr['w'], t, yi, SSHandle(), mom, t, k1, k2, 1, D, N, alpha, damp, itts, nargout=6)
     o = oih.ihgp_ep_modulator_nmf(pr['w'], t, yi, None, omom, t, k1, k2, 1, D, N, alpha, damp, itts)
     res['ihgp'] = max(rel(r[0], o[0]), rel(r[1], o[1]), rel(r[5]['nlZ'], o[5]['nlZ']))
-    if res['ihgp'] > 1e-7:
+    if res['ihgp'] > 1e-7 and not raw:
         # is the instance itself unstable?  (site updates -d2/(1+d2*v) with 1+d2*v ~ 0 under full-EP cavities, or an
         # arg-min over the R grid sitting on a midpoint: the reference's own result then moves by percents under a
         # 1e-13 relative change of y, and there is nothing to compare)
@@ -118,28 +96,17 @@ def diagnose_ihgp(c):
                 print('   sweep-1 sites at k=%d: ttau' % k, r1[5]['ttau'][:, k], 'R', r1[5]['R'][:, k], 'Varft', r1[1][:, k], 'Eft', r1[0][:, k])
 
 
-def one_widened(rng):
+def one_widened(rng, raw=False):
     """a mixture draw (both variants) and an EKF-objective draw"""
-    J = int(rng.integers(2, 4))
-    shapes = [(int(rng.integers(1, 6)), int(rng.integers(1, 4))) for _ in range(J)]
-    while sum(n for _, n in shapes) > 8:
-        shapes[int(rng.integers(0, J))] = (2, 1)
-    k1 = [str(rng.choice(['exp', 'matern32'])) for _ in range(J)]; k2 = [str(rng.choice(['matern32', 'matern52'])) for _ in range(J)]
-    T = int(rng.integers(20, 70)); N = sum(n for _, n in shapes)
-    p = int(rng.choice([5, 7] if N <= 4 else [7]))
-    kind = str(rng.choice(['nmf', 'sqrt'])); shift = float(rng.choice([0.0, 1.0]))
-    alpha = float(rng.choice([0.5, 0.75])); damp = float(rng.uniform(0.02, 0.4)); itts = int(rng.integers(1, 4))
-    mp = harness.mixture_problem(shapes, T, int(rng.integers(1, 10 ** 6)), k1, k2)
-    c = dict(kind=kind, link='softplus', shift=shift, p=p, N=N)
+    w = draw_widened(rng)
+    c, mp, t, y, k1, k2, J, alpha, damp, itts, desc = (w[k] for k in ('c', 'mp', 't', 'y', 'k1', 'k2', 'J', 'alpha', 'damp', 'itts', 'desc'))
+    T = t.size
     mom, omom = moms(c)
-    t = np.arange(1, T + 1.0)
-    y = mp['y'].copy(); y[rng.random(T) < 0.08] = np.nan
-    desc = 'J=%d %s T=%d p=%d %s softplus(%g) %s/%s itts=%d alpha=%.2f damp=%.2f' % (J, shapes, T, p, kind, shift, '+'.join(k1), '+'.join(k2), itts, alpha, damp)
     res = {}
     def judge(tag, r, o, rerun):
         with np.errstate(all='ignore'):
             v = max(rel(r[0], o[0]), rel(r[1], o[1]), rel(r[5]['ttau'], o[5]['ttau']) * 0.1)
-        if v > 1e-7:
+        if v > 1e-7 and not raw:
             # unstable instance?  a site update divided by 1 + d2*v ~ 1e-9 (|ttau| or |tnu| beyond 1e8, or non-finite), or an
             # oracle that itself moves under a 1e-13 relative change of y: nothing to compare (same rule as the main draw)
             o2 = rerun()
@@ -160,8 +127,8 @@ def one_widened(rng):
     o = omx.ihgp_ep_mods_nmf_mixture(mp['w'], t, mp['y'], None, omom, t, k1, k2, J, alpha, damp, itts)
     res['mix_ihgp'], note = judge('ihgp mixture', r, o, lambda: omx.ihgp_ep_mods_nmf_mixture(mp['w'], t, mp['y'] * (1 + 1e-13), None, omom, t, k1, k2, J, alpha, damp, itts))
     desc += note
-    D = int(rng.integers(2, 12)); N = int(rng.integers(1, 5)); T = int(rng.integers(30, 200))
-    pr = harness.nmf_problem(D, N, T, int(rng.integers(1, 10 ** 6)), 'constraints')
+    D, N, T, eseed = w['ekf']
+    pr = harness.nmf_problem(D, N, T, eseed, 'constraints')
     cons = harness.CONSTRAINTS_DEMO(D); w, wf = harness.constrained_vectors(pr, cons, harness.TUNE_DEMO)
     e, _ = nagp.gf_giekf_modulator_nmf_constraints(w, t[:0], pr['y'], SSHandle(), None, None, 'matern32', 'matern52', 1, D, N, 3, 2, cons, wf,
                                                    harness.TUNE_DEMO, 'off') if False else nagp.gf_giekf_modulator_nmf_constraints(

@@ -1,0 +1,63 @@
+"""The random draws of the fuzz comparison, importable without a GPU (tools/fuzz_conditioning.py decides from the oracle alone
+which of them are ill-conditioned; tests/test_gpu_parity.py and tools/gpu_fuzz.py run the same draws on the device)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'nonstationary-audio-gp_amd'))
+import numpy as np
+from nagp import harness, cubature
+from oracle import lik as olik
+
+
+def draw(rng):
+    D = int(rng.integers(2, 9)); N = int(rng.integers(1, 7)); T = int(rng.integers(20, 90))
+    p = int(rng.choice([5, 7, 9] if N <= 4 else [7]))
+    kind = str(rng.choice(['nmf', 'nmf', 'sqrt']))
+    link = str(rng.choice(['softplus', 'softplus', 'exp'])); shift = float(rng.choice([0.0, 1.0])) if link == 'softplus' else 0.0
+    k1 = str(rng.choice(['exp', 'matern32'])); k2 = str(rng.choice(['matern32', 'matern52']))
+    itts = int(rng.integers(1, 4)); alpha = float(rng.choice([0.5, 0.75, 1.0])); damp = rng.uniform(0.1, 0.6, itts)
+    if itts > 1 and alpha == 1.0:
+        # full-EP cavities 1/(1/v - ttau) are routinely near-singular (v_cav ~ 1e12 ... Inf, exp-link overflow to NaN): their
+        # size is rounding noise in the reference as well, so multi-sweep draws use the fractional powers the paper uses
+        alpha = 0.75
+    pr = harness.nmf_problem(D, N, T, int(rng.integers(1, 10 ** 6)), str(rng.choice(['demo_nmf', 'constraints'])), kernel1=k1, kernel2=k2)
+    y = pr['y'].copy(); y[rng.random(T) < 0.1] = np.nan
+    li = int(rng.integers(1, 4)) if (link == 'softplus' and shift == 0.0) else 0
+    return dict(D=D, N=N, T=T, p=p, kind=kind, link=link, shift=shift, k1=k1, k2=k2, itts=itts, alpha=alpha, damp=damp, pr=pr, y=y, li=li)
+
+
+def moms(c, host_only=False):
+    """(device Mom descriptor or None, oracle Mom)"""
+    olink = olik.softplus_link(c['shift']) if c['link'] == 'softplus' else olik.exp_link()
+    if c['kind'] == 'sqrt':
+        wn, xn = cubature.utp_ws(c['p'], c['N'])
+        om = olik.Mom(olik.LIK_POWER_NMF_SQRT, link=olink, wn=wn, xn_unscaled=xn)
+        if host_only:
+            return None, om
+        from nagp import Mom
+        return Mom('likModulatorPreCalcwn', link=c['link'], link_shift=c['shift'], wn=wn, xn_unscaled=xn), om
+    om = olik.Mom(olik.LIK_POWER_NMF, link=olink, p=c['p'])
+    if host_only:
+        return None, om
+    from nagp import Mom
+    return Mom('likModulatorNMFPower', link=c['link'], link_shift=c['shift'], p_cubature=c['p']), om
+
+
+def draw_widened(rng):
+    """a mixture problem (both variants share it)"""
+    J = int(rng.integers(2, 4))
+    shapes = [(int(rng.integers(1, 6)), int(rng.integers(1, 4))) for _ in range(J)]
+    while sum(n for _, n in shapes) > 8:
+        shapes[int(rng.integers(0, J))] = (2, 1)
+    k1 = [str(rng.choice(['exp', 'matern32'])) for _ in range(J)]; k2 = [str(rng.choice(['matern32', 'matern52'])) for _ in range(J)]
+    T = int(rng.integers(20, 70)); N = sum(n for _, n in shapes)
+    p = int(rng.choice([5, 7] if N <= 4 else [7]))
+    kind = str(rng.choice(['nmf', 'sqrt'])); shift = float(rng.choice([0.0, 1.0]))
+    alpha = float(rng.choice([0.5, 0.75])); damp = float(rng.uniform(0.02, 0.4)); itts = int(rng.integers(1, 4))
+    mp = harness.mixture_problem(shapes, T, int(rng.integers(1, 10 ** 6)), k1, k2)
+    c = dict(kind=kind, link='softplus', shift=shift, p=p, N=N)
+    t = np.arange(1, T + 1.0)
+    y = mp['y'].copy(); y[rng.random(T) < 0.08] = np.nan
+    desc = 'J=%d %s T=%d p=%d %s softplus(%g) %s/%s itts=%d alpha=%.2f damp=%.2f' % (J, shapes, T, p, kind, shift, '+'.join(k1), '+'.join(k2), itts, alpha, damp)
+    # the EKF-objective part of the draw (consumed here so that every user of the stream stays in step)
+    eD = int(rng.integers(2, 12)); eN = int(rng.integers(1, 5)); eT = int(rng.integers(30, 200)); eseed = int(rng.integers(1, 10 ** 6))
+    return dict(c=c, mp=mp, t=t, y=y, k1=k1, k2=k2, J=J, alpha=alpha, damp=damp, itts=itts, desc=desc, shapes=shapes, ekf=(eD, eN, eT, eseed))

@@ -248,8 +248,9 @@ def run_workload(name, a, rank, local_rank, world, dev, with_cpu, steps, warmup)
             with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as fh:
                 pm = json.load(fh).get(name)
             if pm and pm.get('T') == T and pm.get('segments') == n_seg and world == 1 and pm.get('source_hash') == source_hash():
-                roof['traffic'] = pm['fetch_bytes_per_launch'] + pm['write_bytes_per_launch']
-                roof['traffic_source'] = pm['source']
+                per_exec = max(launches[dom] / steps, 1.0)            # launches of the dominant kernel in one execute
+                roof['traffic'] = (pm['fetch_bytes_per_execute'] + pm['write_bytes_per_execute']) / per_exec
+                roof['traffic_source'] = pm['source'] + ' (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, this build)'
         except (OSError, ValueError, KeyError):
             pass
     res = {

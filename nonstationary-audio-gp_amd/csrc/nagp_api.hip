@@ -617,7 +617,9 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     MomCfg t = mc; t.DG = p->DG_f; t.cache_tabs = ekf ? 0 : 1; t.store_a = (!ekf && o->lik_kind == NAGP_LIK_POWER_NMF_SQRT) ? 1 : 0;
     // ADF launches in the sparse-point form (256-thread launches, <= 320 sigma points)
     if (!ekf && p->sp.enabled && p->LB_a == 256 && p->NT_a == MSP_NT && sh.M <= 64 && sh.D <= 4 * MSP_DT && o->n_pts <= MSP_NT + 64 &&
-        (o->n_pts + 3) / 4 <= MSP_NW * MSP_NST) { p->sp_gf = 1; t.sp = p->sp; }
+        (o->n_pts + 3) / 4 <= MSP_NW * MSP_NST) {
+      p->sp_gf = 1; t.sp = p->sp;
+    }
     const size_t cap = 156 * 1024;
     p->kb_f = 16;
     if (filter_lds_doubles(sh, t, ekf ? 1 : 0, p->kb_f) * sizeof(double) > cap) p->kb_f = 8;
@@ -641,12 +643,19 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
 #define SL3(V) PLAN_TRY(set_lds(gf_filter_kernel<3, 0, V, 256>, p->lds_filter))
 #define SL4(V) PLAN_TRY(set_lds(gf_filter_kernel<4, 0, V, 256>, p->lds_filter))
 #define SL5(V) PLAN_TRY(set_lds(gf_filter_kernel<4, 0, V, 512>, p->lds_filter))
-      if (p->LB_a == 512) { NAGP_MV_SWITCH(mom_variant(mc), SL5) }
+#define NAGP_SP_SWITCH(TP, CALLSP) switch (mom_variant(mc)) { case 1: CALLSP(TP, 1); break; case 2: CALLSP(TP, 2); break; case 3: CALLSP(TP, 3); break; \
+        case 4: CALLSP(TP, 4); break; case 5: CALLSP(TP, 5); break; case 6: CALLSP(TP, 6); break; default: CALLSP(TP, 7); break; }
+#define SLSP(TP, V) PLAN_TRY(set_lds(gf_filter_kernel<TP, 0, V, 256, true>, p->lds_filter))
+      if (p->sp_gf) {
+        switch (p->TPT_a) { case 1: NAGP_SP_SWITCH(1, SLSP) break; case 2: NAGP_SP_SWITCH(2, SLSP) break; case 3: NAGP_SP_SWITCH(3, SLSP) break; default: NAGP_SP_SWITCH(4, SLSP) break; }
+      } else if (p->LB_a == 512) { NAGP_MV_SWITCH(mom_variant(mc), SL5) }
       else switch (p->TPT_a) {
         case 1: NAGP_MV_SWITCH(mom_variant(mc), SL1) break;
         case 2: NAGP_MV_SWITCH(mom_variant(mc), SL2) break;
+        case 3: NAGP_MV_SWITCH(mom_variant(mc), SL3) break;
         default: NAGP_MV_SWITCH(mom_variant(mc), SL4) break;
       }
+#undef SLSP
       // 768-thread bound when the tiles fit: three waves per SIMD = 168 registers per lane (no spills; 30 spilled at the 1024 bound)
       if (p->wide_l && p->NT_l <= 768) PLAN_TRY(set_lds(gf_filter_kernel<1, 0, -1, 768>, p->lds_filter));
       else if (p->wide_l) PLAN_TRY(set_lds(gf_filter_kernel<1, 0, -1, 1024>, p->lds_filter));
@@ -767,6 +776,11 @@ static int launch_filter(nagp_plan* p, const FilterPar& fp_in) {
 #define LF3(V) hipLaunchKernelGGL((gf_filter_kernel<3, 0, V, 256>), g, ba, p->lds_filter, p->stream, p->sh, p->b, mc, fp)
 #define LF4(V) hipLaunchKernelGGL((gf_filter_kernel<4, 0, V, 256>), g, ba, p->lds_filter, p->stream, p->sh, p->b, mc, fp)
 #define LF5(V) hipLaunchKernelGGL((gf_filter_kernel<4, 0, V, 512>), g, ba, p->lds_filter, p->stream, p->sh, p->b, mc, fp)
+#define LFSP(TP, V) hipLaunchKernelGGL((gf_filter_kernel<TP, 0, V, 256, true>), g, ba, p->lds_filter, p->stream, p->sh, p->b, mc, fp)
+      if (p->sp_gf) {
+        switch (p->TPT_a) { case 1: NAGP_SP_SWITCH(1, LFSP) break; case 2: NAGP_SP_SWITCH(2, LFSP) break; case 3: NAGP_SP_SWITCH(3, LFSP) break; default: NAGP_SP_SWITCH(4, LFSP) break; }
+      } else
+#undef LFSP
       if (p->LB_a == 512) { NAGP_MV_SWITCH(mom_variant(mc), LF5) }
       else switch (p->TPT_a) {
         case 1: NAGP_MV_SWITCH(mom_variant(mc), LF1) break;
@@ -1135,7 +1149,7 @@ extern "C" int nagp_plan_execute(nagp_plan* p) {
   if (getenv("NAGP_STAMPS") && p->d_stamps) {
     unsigned long long st[8];
     if (hipMemcpy(st, p->d_stamps, sizeof st, hipMemcpyDeviceToHost) == hipSuccess)
-      fprintf(stderr, "[nagp stamps] mom: p1a %llu p1b %llu p2 %llu p3 %llu | pre-mom %llu post-mom %llu | aux %llu %llu  (sparse-point IHGP sweep: A, B+1b, 2, tail+head)\n", st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7]);
+      fprintf(stderr, "[nagp stamps] mom: p1a %llu p1b %llu p2 %llu p3 %llu | pre-mom %llu post-mom %llu | aux %llu %llu  (sparse-point IHGP sweep: p1a..p3 = A, B+1b, 2, wait at B1 ; pre..aux = reduce+outputs, site+state+ring, look-up, A m)\n", st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7]);
   }
 
   HIP_TRY(hipGetLastError());

@@ -286,10 +286,13 @@ __global__ void __launch_bounds__(MV >= 9 ? 512 : 256) ihgp_filter_kernel(Shape 
 // ---------------------------------------------------------------------------------------------
 // ADF sweep of the infinite-horizon filter for likModulatorNMFPower on fully symmetric sigma-point sets
 // (ihgp_ep_modulator_nmf.m:233-310 with the mom of likModulatorNMFPower.m:28-87): the same step as ihgp_filter_kernel,
-// organised around the latency of ONE sequential chain.  Wave 0 owns the sites (lane n = block n) and runs, without any
-// workgroup barrier, everything from the reduced cubature sums of step k to the inputs of the cubature of step k+1:
+// organised around the latency of ONE sequential chain.  Wave 0 owns the sub-band sites (lane d = block d), wave 1 the modulator
+// sites (lane j = block D+j); each runs, without any workgroup barrier, everything from the reduced cubature sums of step k to the
+// inputs of the cubature of step k+1:
 //   sums -> d lZ, d2 lZ -> site update, clamp, R -> gain, mean update, ring -> table look-up for k+1 -> A m, fmu, H PP H'
-// The four waves then share the cubature stages of nagp_momsp.hpp (five barriers per step).  Every processed step calls
+// The modulator sites have the short tail (their sums come ready-made out of the cubature), so wave 1 goes straight on to the
+// link tables of step k+1 -- the exp / log chain of the step -- while wave 0 still forms W_d'RW_d for the sub-bands.
+// The four waves then share the remaining cubature stages of nagp_momsp.hpp (five barriers per step).  Every processed step calls
 // mom (sweep 1: all steps; later sweeps: launched for k = T-1 only).
 // Ring of the filtered means: [KB][M][4], block padded (two 16-byte stores per lane and step); the flush strips the padding.
 __host__ __device__ inline size_t ihgp_adf_ring_doubles(const Shape& s, int kb) { return (size_t)kb * (8 * s.M + 3); }
@@ -364,12 +367,13 @@ __global__ void __launch_bounds__(MSP_NT) ihgp_adf_kernel(Shape sh, Bufs b, MomC
   const double rmax = tb.r[NG - 1];
   __syncthreads();
   MspCtx<CD> x;
-  msp_setup<CD>(x, mc, sp, sW, fmu, HPH, ws);
+  msp_setup<CD>(x, mc, sp, sW, fmu, HPH, ws, 1);
 
-  // wave 0, lane n < M owns block n
-  const int n = tid;
-  const bool act = n < M;
-  const bool sub = n < D;
+  // wave 0, lane d < D owns sub-band block d; wave 1, lane j < N owns modulator block D + j
+  const int lane = tid & 63;
+  const bool sub = (wave == 0) && lane < D;
+  const bool act = sub || ((wave == 1) && lane < sh.N);
+  const int n = (wave == 0) ? lane : D + lane;
   const int nn = act ? n : 0;
   double A4[16], mreg[4] = {0, 0, 0, 0}, wrow[CD];
   double hn = 0.0;
@@ -414,7 +418,7 @@ __global__ void __launch_bounds__(MSP_NT) ihgp_adf_kernel(Shape sh, Bufs b, MomC
   double Rprev = (act && ip.k_start > 0) ? b.R[((size_t)pb * T + (ip.k_start - 1)) * M + n] : 0.0;
   unsigned int n_clamped = 0;
   unsigned long long st_a = 0, st_b = 0, st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const bool stamp = mc.stamps && tid == 0;
+  const bool stamp = mc.stamps && tid == 0;      // wave 0's time line
 #define IH_STAMP(slot) do { if (stamp) { st_b = __builtin_readcyclecounter(); st[slot] += st_b - st_a; st_a = st_b; } } while (0)
 
   // head of step k: table look-up, A m, the cubature's inputs (wave 0, no barrier)
@@ -423,6 +427,7 @@ __global__ void __launch_bounds__(MSP_NT) ihgp_adf_kernel(Shape sh, Bufs b, MomC
     if (act) {
       if (k > 0) {
         const int idx = nearest_idx3(p_rg, NG, tb.lr0, tb.inv_dlr, rmax, Rprev);
+        if (stamp) { asm volatile("" :: "v"(idx)); IH_STAMP(6); }
         hph = ip.hph_lds ? p_hph[idx] : g_hph[idx];
         const double2* w = reinterpret_cast<const double2*>(g_wcol + (size_t)idx * 4);
         const double2 w0 = w[0], w1 = w[1];
@@ -441,9 +446,11 @@ __global__ void __launch_bounds__(MSP_NT) ihgp_adf_kernel(Shape sh, Bufs b, MomC
       }
       fmun = hn * Am[0];
       *p_fmu = fmun; *p_HPH = hph;
+      if (stamp) { IH_STAMP(7); }
     }
   };
-  if (wave == 0) head(ip.k_start);
+  if (wave <= 1) head(ip.k_start);
+  if (wave == 1) { msp_wave_fence(); msp_link<CD>(x, mc); }      // link tables of the first step
   if (stamp) st_a = __builtin_readcyclecounter();
 
   for (int64_t k0 = ip.k_start; k0 < T; k0 += KB) {
@@ -454,9 +461,9 @@ __global__ void __launch_bounds__(MSP_NT) ihgp_adf_kernel(Shape sh, Bufs b, MomC
     __syncthreads();
     for (int kk = 0; kk < nb; ++kk) {
       const int64_t k = k0 + kk;
-      lds_barrier();                 // B1: fmu, HPH of step k
+      lds_barrier();                 // B1: fmu, HPH of step k; its link tables (written by wave 1 on its way here)
       IH_STAMP(3);
-      msp_stageA<CD>(x, mc);
+      msp_qv<CD>(x, mc);             // waves 0, 2, 3
       lds_barrier();                 // B2
       IH_STAMP(0);
       msp_stageB<CD>(x, mc, ws);
@@ -467,13 +474,14 @@ __global__ void __launch_bounds__(MSP_NT) ihgp_adf_kernel(Shape sh, Bufs b, MomC
       msp_stage2<CD>(x, mc, ws);
       lds_barrier();                 // B5
       IH_STAMP(2);
-      if (wave == 0) {
+      if (wave <= 1) {
         msp_reduce<CD>(x);
         msp_wave_fence();
         if (act) {
           const int ko = kk * M;
           double Z, d1, d2;
           msp_outputs<CD>(x.accp, sub, n - D, wrow, pEP1, mc.jitter, Z, d1, d2);
+          if (stamp) { asm volatile("" :: "v"(d2)); IH_STAMP(4); }
           const double t_old = p_tt[ko], n_old = p_tn[ko];
           // site update (:265-266): -d2/(1+d2 HPH), (d1 - fmu d2)/(1+d2 HPH) through one reciprocal
           const double r1 = rcp_nr(fma(d2, hph, 1.0));
@@ -497,8 +505,12 @@ __global__ void __launch_bounds__(MSP_NT) ihgp_adf_kernel(Shape sh, Bufs b, MomC
           p_fm[ko] = hn * mreg[0];
           Rprev = Rn;
           if (n == 0) rZ[kk] = Z;
+          if (stamp) { asm volatile("" :: "v"(Rprev)); IH_STAMP(5); }
         }
-        if (k + 1 < T) head(k + 1);
+        if (k + 1 < T) {
+          head(k + 1);
+          if (wave == 1) { msp_wave_fence(); msp_link<CD>(x, mc); }     // fmu / HPH of the modulators just written by this wave
+        }
       }
     }
     // ---- flush the ring

@@ -18,6 +18,15 @@
 #define NAGP_LIST_GF_ADF4(P) NAGP_LIST_GF_ADF(P, 4, 256)
 #define NAGP_LIST_GF_ADF5(P) NAGP_LIST_GF_ADF(P, 4, 512)
 
+// ADF launches in the sparse-point form (likModulatorNMFPower, 1..7 components), 256-thread launches
+#define NAGP_LIST_GF_SP(P, TPT)                                                                                            \
+  P void nagp::gf_filter_kernel<TPT, 0, 1, 256, true> NAGP_SIG_GF; P void nagp::gf_filter_kernel<TPT, 0, 2, 256, true> NAGP_SIG_GF;    \
+  P void nagp::gf_filter_kernel<TPT, 0, 3, 256, true> NAGP_SIG_GF; P void nagp::gf_filter_kernel<TPT, 0, 4, 256, true> NAGP_SIG_GF;    \
+  P void nagp::gf_filter_kernel<TPT, 0, 5, 256, true> NAGP_SIG_GF; P void nagp::gf_filter_kernel<TPT, 0, 6, 256, true> NAGP_SIG_GF;    \
+  P void nagp::gf_filter_kernel<TPT, 0, 7, 256, true> NAGP_SIG_GF;
+#define NAGP_LIST_GF_SP12(P) NAGP_LIST_GF_SP(P, 1) NAGP_LIST_GF_SP(P, 2)
+#define NAGP_LIST_GF_SP34(P) NAGP_LIST_GF_SP(P, 3) NAGP_LIST_GF_SP(P, 4)
+
 // EKF and fixed-site filters, smoother kernels
 #define NAGP_LIST_GF_REST(P)                                                                                               \
   P void nagp::gf_filter_kernel<1, 1, 0> NAGP_SIG_GF; P void nagp::gf_filter_kernel<2, 1, 0> NAGP_SIG_GF;                \
@@ -65,4 +74,4 @@
 
 #define NAGP_LIST_ALL(P)                                                                                                   \
   NAGP_LIST_GF_ADF1(P) NAGP_LIST_GF_ADF2(P) NAGP_LIST_GF_ADF3(P) NAGP_LIST_GF_ADF4(P) NAGP_LIST_GF_ADF5(P)               \
-  NAGP_LIST_GF_REST(P) NAGP_LIST_SMOOTH(P) NAGP_LIST_EP(P) NAGP_LIST_IH0(P) NAGP_LIST_IH1(P) NAGP_LIST_IHA(P)
+  NAGP_LIST_GF_SP12(P) NAGP_LIST_GF_SP34(P) NAGP_LIST_GF_REST(P) NAGP_LIST_SMOOTH(P) NAGP_LIST_EP(P) NAGP_LIST_IH0(P) NAGP_LIST_IH1(P) NAGP_LIST_IHA(P)

@@ -137,7 +137,9 @@ __host__ __device__ inline size_t filter_lds_doubles(const Shape& s, const MomCf
 // instantiated with MV = 0 only
 // LB: launch bound.  The ADF launches (MV >= 0) run with <= 256 threads whenever the tiles fit: one wave per SIMD
 // may then use all 512 registers (the cubature's pressure lands in AGPRs instead of scratch memory).
-template <int TPT, int MEAS, int MV, int LB = 512>
+// SP: the ADF steps use the staged sparse-point form of likModulatorNMFPower (nagp_momsp.hpp) and the generic mom_eval is not
+// compiled into the instantiation at all (both side by side cost hundreds of registers)
+template <int TPT, int MEAS, int MV, int LB = 512, bool SP = false>
 __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg mc, FilterPar fp) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int tid = threadIdx.x, NT = blockDim.x;
@@ -185,16 +187,16 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
   for (int i = tid; i < 68; i += NT) { fmu[i] = 0.0; HPH[i] = 0.0; }
   const double sn2 = mdl[mdl_sn2(sh)];
   // likModulatorNMFPower on a fully symmetric sigma-point set: the staged form of nagp_momsp.hpp (256-thread ADF launches)
-  constexpr bool SPK = (MEAS == 0 && MV >= 1 && MV <= MSP_MAXCD && LB == 256);
+  constexpr bool SPK = SP && (MEAS == 0 && MV >= 1 && MV <= MSP_MAXCD);
+  static_assert(!SP || SPK, "the sparse-point form exists for the NMF likelihood with 1..7 components");
   constexpr int CDX = SPK ? MV : 1;
-  const bool spk = SPK && __builtin_amdgcn_readfirstlane(mc.sp.enabled) != 0;
-  if (MEAS == 0 && MV >= 0 && !spk) mom_cache_tables(mc, ws);
+  if constexpr (MEAS == 0 && MV >= 0 && !SPK) mom_cache_tables(mc, ws);
   const double pEP1 = (MEAS == 0 && MV >= 0) ? mom_pEP(mc, sn2, fp.mom_alpha) : 1.0;
   MspCtx<CDX> xsp;
   double wrow[CDX];
 #pragma unroll
   for (int j = 0; j < CDX; ++j) wrow[j] = 0.0;
-  if constexpr (SPK) if (spk) {
+  if constexpr (SPK) {
     __syncthreads();      // sW, fmu / HPH padding
     msp_setup<CDX>(xsp, mc, mc.sp, sW, fmu, HPH, ws);
     if (tid < D) {
@@ -369,9 +371,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
           if constexpr (MV >= 0) if (do_mom) {
             if (mc.stamps && tid == 0) { st_b = __builtin_readcyclecounter(); stp[4] += st_b - st_a; }
             double d1v = 0.0, d2v = 0.0;
-            bool staged = false;
-            if constexpr (SPK) if (spk) {
-              staged = true;
+            if constexpr (SPK) {
               msp_stageA<CDX>(xsp, mc);
               lds_barrier();
               msp_stageB<CDX>(xsp, mc, ws);
@@ -390,7 +390,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
                 }
               }
             }
-            if (!staged) {
+            if constexpr (!SPK) {
               mom_eval<MV, false, false>(mc, sW, pEP1, sn2, fp.mom_alpha, yk, fmu, HPH, ws, &misc[0], dl, d2l, stp);
               if (tid < M) { d1v = dl[tid]; d2v = d2l[tid]; }
               if (tid == 0) rZ[kk] = misc[0];

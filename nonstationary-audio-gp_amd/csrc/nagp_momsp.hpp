@@ -50,7 +50,7 @@ __host__ __device__ inline MspLay msp_layout(int CD, int D) {
   l.c0 = o; l.c1 = o + MSP_CS; l.c2 = o + 2 * MSP_CS;
   o = (o + 3 * MSP_CS + 1) & ~1;
   l.part = o; o += MSP_NW * 256;
-  l.acc = o; o += 64;
+  l.acc = o; o += 128;
   l.wwt = o; o += msp_qterms(D) * 192;            // static W products of stage A, [q][lane of waves 1..3], zero for sub-bands >= D
   l.total = o;
   return l;
@@ -72,7 +72,8 @@ __device__ __forceinline__ int opaque_zero() { int z = 0; asm volatile("" : "+v"
 // Register-resident state of one thread.  Everything here is computed once per kernel.
 template <int CD>
 struct MspCtx {
-  // stage A / B, wave 0: lane t = j*nd + c
+  int lw, qw;          // wave that evaluates the link tables / wave that forms q0, s0 (wave-uniform)
+  // stage A / B, wave lw: lane t = j*nd + c
   double xdc; msp_rp a_mu, a_s2, a_l0[CD], a_l0own, a_qrow, a_qjj, a_v; msp_wp a_out;   // a_out[k*MSP_TS]: lk, xg, xg2, e, t1, ve
   // stage B, wave 1: lane L < CD*CD: Q(j,j') l0_j l0_j' ; next CD lanes: v_j l0_j
   int b_kind; msp_rp b_p0, b_p1, b_p2;
@@ -96,18 +97,24 @@ struct MspCtx {
 
 template <int CD>
 __device__ __forceinline__ void msp_setup(MspCtx<CD>& x, const MomCfg& c, const MomSp& sp, const double* Wl /* LDS D x CD */,
-                                           const double* fmu, const double* HPH, double* ws) {
+                                           const double* fmu, const double* HPH, double* ws, int LW = 0) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nd = c.nd, D = c.D, TN = CD * nd, npt = c.n_pts;
   const MspLay l = msp_layout(CD, D);
   const int oz = opaque_zero();
+  // roles: the link tables on wave LW (0: the wave that owns the sites; 1: a kernel that gives the modulator sites to wave 1
+  // lets their link evaluation run beside the sub-band sites' serial work), Q / v on the three other waves, q0 / s0 on wave qw
+  x.lw = LW; x.qw = (LW == 1) ? 2 : 1;
+  const int tl = tid - 64 * LW;                                  // lane index on the link wave
+  const int wq = (wave < LW) ? wave : wave - 1;                  // rank among the Q / v waves
+  const int Lq = (wave != LW && wave < MSP_NW) ? wq * 64 + lane : -1;   // 0 .. 191
   // constants, zero entries of the tables, zero weights beyond the points
   for (int i = tid; i < 6 * MSP_TS; i += MSP_NT) ws[i] = 0.0;
   if (tid == 0) ws[l.one] = 1.0;
   for (int i = tid; i < 3 * MSP_CS; i += MSP_NT) ws[l.c0 + i] = 0.0;
   // ---- stage A / B of wave 0
   {
-    const int t = (tid < TN) ? tid : 0;
+    const int t = (tl >= 0 && tl < TN) ? tl : 0;
     const int j = t / nd, cc = t - j * nd;
     x.xdc = c.xd[cc];
     x.a_mu = (msp_rp)(fmu + D + j); x.a_s2 = (msp_rp)(HPH + D + j);
@@ -119,9 +126,9 @@ __device__ __forceinline__ void msp_setup(MspCtx<CD>& x, const MomCfg& c, const 
     x.a_v = (msp_rp)(ws + l.v + j);
     x.a_out = (msp_wp)(ws + t);
   }
-  // ---- stage B of wave 1
+  // ---- stage B: q0, s0 on wave qw
   {
-    const int L = tid - 64;
+    const int L = tid - 64 * x.qw;
     x.b_kind = 0; x.b_p0 = x.b_p1 = x.b_p2 = (msp_rp)(ws + l.zero);
     if (L >= 0 && L < CD * CD) {
       const int j = L / CD, j2 = L - j * CD;
@@ -134,10 +141,10 @@ __device__ __forceinline__ void msp_setup(MspCtx<CD>& x, const MomCfg& c, const 
   // ---- stage A of waves 1..3
   {
     x.q_kind = 0;
-    x.q_out0 = x.q_out1 = x.q_out2 = x.q_out3 = (msp_wp)(ws + l.acc + 63);   // scratch slot
+    x.q_out0 = x.q_out1 = x.q_out2 = x.q_out3 = (msp_wp)(ws + l.acc + 127);   // scratch slot
     x.q_ww = x.q_src = (msp_rp)(ws + l.zero);
-    const int L = tid - 64;
-    if (L >= 0) {
+    const int L = Lq;
+    if (L >= 0 && L < 192) {      // the three waves beside the link wave (a larger workgroup's further waves take no part in the cubature)
       const int g = L >> 2, sub = L & 3;
       const int nq = CD * (CD + 1) / 2;
       int j = 0, j2 = 0;
@@ -169,7 +176,7 @@ __device__ __forceinline__ void msp_setup(MspCtx<CD>& x, const MomCfg& c, const 
 #pragma unroll
     for (int u = 0; u < MSP_NPS; ++u) {
       int p = (u == 0) ? tid : (MSP_NT * u + (tid - (MSP_NT - 64)));
-      const bool ok = (u == 0) ? (p < npt) : (tid >= MSP_NT - 64 && p < npt);
+      const bool ok = (tid < MSP_NT) && ((u == 0) ? (p < npt) : (tid >= MSP_NT - 64 && p < npt));
       x.p_ok[u] = ok;
       x.p_any[u] = (__builtin_amdgcn_ballot_w64(ok) != 0) ? 1 : 0;
       if (!ok) p = 0;
@@ -201,14 +208,14 @@ __device__ __forceinline__ void msp_setup(MspCtx<CD>& x, const MomCfg& c, const 
     // wave 0 goes on to the serial part of the step: it takes the short share
     const int wv = (wave + MSP_NW - 1) % MSP_NW;
     x.nst = (nstep - wv + MSP_NW - 1) / MSP_NW;
-    if (x.nst < 0) x.nst = 0;
+    if (x.nst < 0 || wave >= MSP_NW) x.nst = 0;
     int wbase = l.c0;                                // rows without a weight multiply a zero operand
     if (i < CD) wbase = l.c2; else if (i == CD) wbase = l.c1;
     x.m_w0 = (msp_rp)(ws + wbase + 4 * wv + kq);     // point of step s: 4*(wv + 4s) + kq
 #pragma unroll
     for (int s = 0; s < MSP_NST; ++s) {
       const int p = 4 * (wv + MSP_NW * s) + kq;
-      const bool ok = (s < x.nst) && (p < npt);
+      const bool ok = (s < x.nst) && (p < npt) && (wave < MSP_NW);
       int offA = l.zero, offB = l.zero;             // beyond the points: zero operands (their weights are zero too)
       if (ok) {
         const unsigned char* cp = c.code + (size_t)p * CD;
@@ -233,8 +240,9 @@ __device__ __forceinline__ void msp_setup(MspCtx<CD>& x, const MomCfg& c, const 
     else if (o < 3 * CD + nq) { row = CD + 1 + (o - 2 * CD - nq); col = 2 * CD; } // g2_j
     else { row = 2 * CD + 1; col = 2 * CD; }                                      // Z
     x.r_src = (msp_rp)(ws + l.part + row * 16 + col);
-    x.r_dst = (msp_wp)(ws + l.acc + o);
-    x.accp = (msp_rp)(ws + l.acc) + oz;
+    const int ab = (wave == 1) ? 64 : 0;                           // waves 0 and 1 may both reduce: own buffers
+    x.r_dst = (msp_wp)(ws + l.acc + ab + o);
+    x.accp = (msp_rp)(ws + l.acc + ab) + oz;
   }
 }
 
@@ -247,21 +255,24 @@ __device__ __forceinline__ void msp_qsum(msp_rp ww, msp_rp src, double& a0, doub
   for (int q = 0; q < K; q += 2) { a0 = fma(w[q], v[q], a0); a1 = fma(w[q + 1], v[q + 1], a1); }
 }
 
-// stage A.  Needs fmu / HPH of all sites visible; ends WITHOUT a barrier (the caller places it).
+// stage A, link part (wave lw): needs fmu / HPH of the MODULATOR sites; no barrier
 template <int CD>
-__device__ __forceinline__ void msp_stageA(const MspCtx<CD>& x, const MomCfg& c) {
-  const int tid = threadIdx.x, TN = CD * c.nd;
-  if (tid < 64) {
-    if (tid < TN) {
-      const double mu = *x.a_mu, s2 = *x.a_s2;
-      const double rs = rsqrt_nr(s2);
-      const double sg = s2 * rs, inv = rs * rs;
-      const double xn = mu + sg * x.xdc;                                   // likModulatorNMFPower.m:34
-      const double lk = link_eval(c.link_kind, c.link_shift, xn);
-      const double xg = (xn - mu) * inv;                                   // (xn - mu_g)./s2_g  (:72)
-      x.a_out[0] = lk; x.a_out[MSP_TS] = xg; x.a_out[2 * MSP_TS] = xg * xg - inv;   // :79
-    }
-  } else if (x.q_kind) {
+__device__ __forceinline__ void msp_link(const MspCtx<CD>& x, const MomCfg& c) {
+  const int tl = (int)threadIdx.x - 64 * x.lw, TN = CD * c.nd;
+  if (tl >= 0 && tl < TN) {
+    const double mu = *x.a_mu, s2 = *x.a_s2;
+    const double rs = rsqrt_nr(s2);
+    const double sg = s2 * rs, inv = rs * rs;
+    const double xn = mu + sg * x.xdc;                                   // likModulatorNMFPower.m:34
+    const double lk = link_eval(c.link_kind, c.link_shift, xn);
+    const double xg = (xn - mu) * inv;                                   // (xn - mu_g)./s2_g  (:72)
+    x.a_out[0] = lk; x.a_out[MSP_TS] = xg; x.a_out[2 * MSP_TS] = xg * xg - inv;   // :79
+  }
+}
+// stage A, Q / 2Q / v part (the three other waves): needs fmu / HPH of the SUB-BAND sites; no barrier
+template <int CD>
+__device__ __forceinline__ void msp_qv(const MspCtx<CD>& x, const MomCfg& c) {
+  if (x.q_kind) {
     const int K = __builtin_amdgcn_readfirstlane(msp_qterms(c.D));
     double a0 = 0.0, a1 = 0.0;
     if (K == 4) msp_qsum<4>(x.q_ww, x.q_src, a0, a1);
@@ -270,11 +281,18 @@ __device__ __forceinline__ void msp_stageA(const MspCtx<CD>& x, const MomCfg& c)
     double a = a0 + a1;
     a += dpp_mov<0xB1>(a);
     a += dpp_mov<0x4E>(a);
-    if ((tid & 3) == 0) {
+    if ((threadIdx.x & 3) == 0) {
       if (x.q_kind == 1) { *x.q_out0 = a; *x.q_out1 = a; *x.q_out2 = 2.0 * a; *x.q_out3 = 2.0 * a; }
       else *x.q_out0 = a;
     }
   }
+}
+// stage A.  Needs fmu / HPH of all sites visible; ends WITHOUT a barrier (the caller places it).
+template <int CD>
+__device__ __forceinline__ void msp_stageA(const MspCtx<CD>& x, const MomCfg& c) {
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  if (wave >= MSP_NW) return;
+  if (wave == __builtin_amdgcn_readfirstlane(x.lw)) msp_link<CD>(x, c); else msp_qv<CD>(x, c);
 }
 
 // stage B.  After a barrier behind stage A; ends without a barrier.
@@ -282,8 +300,9 @@ template <int CD>
 __device__ __forceinline__ void msp_stageB(const MspCtx<CD>& x, const MomCfg& c, double* ws) {
   const int tid = threadIdx.x, TN = CD * c.nd;
   const MspLay l = msp_layout(CD, c.D);
-  if (tid < 64) {
-    if (tid < TN) {
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (wave == __builtin_amdgcn_readfirstlane(x.lw)) {
+    if ((tid & 63) < TN) {
       const double lk = ((msp_rp)x.a_out)[0];
       double ql0 = 0.0, ql1 = 0.0;
 #pragma unroll
@@ -294,12 +313,12 @@ __device__ __forceinline__ void msp_stageB(const MspCtx<CD>& x, const MomCfg& c,
       x.a_out[4 * MSP_TS] = e * fma(*x.a_qjj, e, 2.0 * ql);
       x.a_out[5 * MSP_TS] = (*x.a_v) * e;
     }
-  } else if (tid < 128) {
+  } else if (wave == __builtin_amdgcn_readfirstlane(x.qw)) {
     const double t = (*x.b_p0) * (*x.b_p1) * (*x.b_p2);      // unused lanes: zero * ...
     double tq = (x.b_kind == 1) ? t : 0.0, tsv = (x.b_kind == 2) ? t : 0.0;
     tq = wave_sum(tq);
     tsv = wave_sum(tsv);
-    if (tid == 64) { ws[l.q0] = tq; ws[l.s0] = tsv; }
+    if ((tid & 63) == 0) { ws[l.q0] = tq; ws[l.s0] = tsv; }
   }
 }
 
@@ -350,6 +369,7 @@ __device__ __forceinline__ void msp_stage2(const MspCtx<CD>& x, const MomCfg& c,
   const MspLay l = msp_layout(CD, c.D);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (wave >= MSP_NW) return;
   const int nst = __builtin_amdgcn_readfirstlane(x.nst);
   v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
   double a[4], bb[4], w[4];

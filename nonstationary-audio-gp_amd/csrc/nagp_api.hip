@@ -267,11 +267,13 @@ struct Timed {
   }
 };
 
+// The dynamic-LDS limit of a kernel is a per-process attribute: it is raised to the full 160 KiB once and never lowered, so that
+// plans with different LDS needs can be alive at the same time (a later, smaller plan must not shrink it under a live one).
 template <typename K>
 static int set_lds(K kernel, size_t bytes) {
   if (bytes > 160 * 1024) FAIL(NAGP_EUNSUPPORTED, "kernel needs %zu B of LDS (> 160 KiB)", bytes);
   if (bytes > 48 * 1024)
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   return NAGP_OK;
 }
 
@@ -489,9 +491,18 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
   if (p->chunk > T) p->chunk = (int)T;
   PLAN_TRY(dalloc(p, &p->d_stamps, 8));
   if (o->kind != NAGP_KIND_IHGP) {
-    // keep the (G, Delta) chunk buffer under ~8 GiB
+    // the (G, Delta) chunk buffer: at most 24 GiB and at most a quarter of the device memory that is free once the
+    // per-step arrays (filtered covariances, means, sites) of this plan are counted
     const double per_step = (double)B * 2.0 * std::max<double>(nt * 16.0, 96.0 * 96.0) * 8.0;
-    while (p->chunk > 64 && per_step * p->chunk > 24.0 * 1073741824.0) p->chunk = (p->chunk + 1) / 2;
+    double cap_bytes = 24.0 * 1073741824.0;
+    {
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        const double fixed = (double)BT * ((p->need_PF ? pf_ntiles(sh) * 16.0 : 0.0) + (p->want_PS ? nt * 16.0 : 0.0) + 2.0 * sh.S) * 8.0;
+        cap_bytes = std::min(cap_bytes, std::max(0.25 * ((double)free_b - fixed), 64.0 * per_step));
+      }
+    }
+    while (p->chunk > 64 && per_step * p->chunk > cap_bytes) p->chunk = (p->chunk + 1) / 2;
     if (p->need_PF) PLAN_TRY(dalloc(p, &b.PF, BT * pf_ntiles(sh) * 16, false));   // lower-triangular tiles only
     if (p->want_PS) PLAN_TRY(dalloc(p, &b.PSs, BT * nt * 16, false));
     {   // FP64 MFMA smoother for padded dimensions up to 96 (set NAGP_NO_MFMA=1 to force the VALU passes)

@@ -58,6 +58,9 @@ struct nagp_plan {
   int chunk = 2048, LP1 = 1, LP2 = 1, ns_max = 1;
   SpanPar spar{};
   int mfma_sp = 0;      // > 0: FP64-MFMA smoother passes on dense Sp x Sp matrices
+  int big_sp = 0;       // 1: Sp > 96, the column-owner kernels of nagp_mfma_big.hpp
+  bool gbuf_tiled = false;   // the chunk buffer last held tile-major matrices: zero it before the next dense use (padding rows)
+  size_t gbuf_doubles = 0;
   MfmaPar mpar{};
   size_t lds_mfma = 0;
   int hph_lds = 0, sta_f = 0, sta_ep = 0, DG_f = 1, DG_ep = 1, cache_f = 0, cache_ep = 0, kb_f = 16;
@@ -493,7 +496,8 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
   if (o->kind != NAGP_KIND_IHGP) {
     // the (G, Delta) chunk buffer: at most 24 GiB and at most a quarter of the device memory that is free once the
     // per-step arrays (filtered covariances, means, sites) of this plan are counted
-    const double per_step = (double)B * 2.0 * std::max<double>(nt * 16.0, 96.0 * 96.0) * 8.0;
+    const int Sp_dense = ((4 * sh.M + 15) / 16) * 16;
+    const double per_step = (double)B * 2.0 * std::max<double>(std::max<double>(nt * 16.0, 96.0 * 96.0), (Sp_dense <= 160) ? (double)Sp_dense * Sp_dense : 0.0) * 8.0;
     double cap_bytes = 24.0 * 1073741824.0;
     {
       size_t free_b = 0, total_b = 0;
@@ -508,9 +512,13 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     {   // FP64 MFMA smoother for padded dimensions up to 96 (set NAGP_NO_MFMA=1 to force the VALU passes)
       const int Sp = ((4 * sh.M + 15) / 16) * 16;
       if (Sp <= 96 && !getenv("NAGP_NO_MFMA")) p->mfma_sp = Sp;
+      // 96 < Sp <= 160: state and G no longer fit LDS side by side; column-owner kernels
+      // (a sweep that stores the smoothed covariances runs the VALU passes instead: see launch_smoother)
+      else if (Sp <= 160 && !getenv("NAGP_NO_MFMA") && !getenv("NAGP_NO_MFMA_BIG")) { p->mfma_sp = Sp; p->big_sp = 1; }
     }
     const size_t mat = p->mfma_sp ? (size_t)p->mfma_sp * p->mfma_sp : (size_t)nt * 16;
     PLAN_TRY(dalloc(p, &b.Gbuf, (size_t)B * p->chunk * 2 * mat, true));
+    p->gbuf_doubles = (size_t)B * p->chunk * 2 * mat;
     PLAN_TRY(dalloc(p, &b.dbuf, (size_t)B * p->chunk * sh.S, false));
     // panel widths: one tile per thread per operand panel, panels (double buffered) within 72 KiB of LDS
     const double cap = 72.0 * 1024.0;
@@ -533,7 +541,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
       PLAN_TRY(dalloc(p, &p->mpar.spanvec, (size_t)B * p->ns_max * sh.S, false));
       PLAN_TRY(dalloc(p, &p->mpar.bnd, (size_t)B * p->ns_max * (SS + sh.S), false));
       PLAN_TRY(dalloc(p, &p->mpar.stateD, (size_t)B * (SS + sh.S), true));
-      p->lds_mfma = mfma_lds_doubles(p->mfma_sp) * sizeof(double);
+      p->lds_mfma = (p->big_sp ? big_lds_doubles(p->mfma_sp / 16) : mfma_lds_doubles(p->mfma_sp)) * sizeof(double);
     }
   } else {
     PLAN_TRY(dalloc(p, &p->d_lZs, BT));
@@ -688,7 +696,12 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
       default: PLAN_TRY(set_lds(rts_gain_kernel<4>, p->lds_gain)); PLAN_TRY(set_lds(rts_compose_kernel<4>, p->lds_scan)); PLAN_TRY(set_lds(rts_boundary_kernel<4>, p->lds_scan)); PLAN_TRY(set_lds(rts_apply_kernel<4>, p->lds_scan)); break;
     }
   }
-  if (p->mfma_sp) {
+  if (p->big_sp) {
+#define SETB(N) PLAN_TRY(set_lds(rts_big_kernel<N, 0>, p->lds_mfma)); PLAN_TRY(set_lds(rts_big_kernel<N, 1>, p->lds_mfma)); \
+    PLAN_TRY(set_lds(rts_big_kernel<N, 2>, p->lds_mfma)); PLAN_TRY(set_lds(rts_big_phi_kernel<N>, p->lds_mfma))
+    switch (p->mfma_sp / 16) { case 7: SETB(7); break; case 8: SETB(8); break; case 9: SETB(9); break; default: SETB(10); break; }
+#undef SETB
+  } else if (p->mfma_sp) {
 #define SETM(N) PLAN_TRY(set_lds(rts_compose_mfma_kernel<N>, p->lds_mfma)); PLAN_TRY(set_lds(rts_boundary_mfma_kernel<N>, p->lds_mfma)); PLAN_TRY(set_lds(rts_apply_mfma_kernel<N>, p->lds_mfma))
     switch (p->mfma_sp / 16) { case 1: SETM(1); break; case 2: SETM(2); break; case 3: SETM(3); break; case 4: SETM(4); break; case 5: SETM(5); break; default: SETM(6); break; }
 #undef SETM
@@ -826,7 +839,11 @@ static int launch_smoother(nagp_plan* p, bool write_PSs) {
   for (int64_t k1 = nsm; k1 > 0;) {
     const int nk = (int)std::min<int64_t>(p->chunk, k1);
     const int64_t k0 = k1 - nk;
-    GainPar gp{k0, nk, p->chunk, p->mfma_sp};
+    const bool use_big = p->big_sp && !write_PSs;            // the column-owner kernels have no smoothed-covariance output
+    const bool use_mfma = p->mfma_sp && !p->big_sp;
+    GainPar gp{k0, nk, p->chunk, (use_big || use_mfma) ? p->mfma_sp : 0};
+    if (gp.dense_sp && p->gbuf_tiled) { HIP_TRY(hipMemsetAsync(p->b.Gbuf, 0, p->gbuf_doubles * sizeof(double), p->stream)); p->gbuf_tiled = false; }
+    if (!gp.dense_sp && p->mfma_sp) p->gbuf_tiled = true;
     {
       Timed t(p, NAGP_K_GAIN);
       dim3 g(nk, p->B), bl(p->NT);
@@ -847,7 +864,21 @@ static int launch_smoother(nagp_plan* p, bool write_PSs) {
       sp.L = (nk + ns - 1) / ns;
       sp.ns = (nk + sp.L - 1) / sp.L;
     }
-    if (p->mfma_sp) {
+    if (use_big) {
+      MfmaPar mp = p->mpar;
+      mp.k0 = k0; mp.nk = nk; mp.chunk = p->chunk; mp.L = sp.L; mp.ns = sp.ns; mp.ns_max = p->ns_max; mp.Sp = p->mfma_sp;
+      mp.first = first ? 1 : 0; mp.write_PSs = 0;
+      Timed t(p, NAGP_K_SCAN);
+      const int ntl = p->mfma_sp / 16;
+      dim3 g(mp.ns, p->B), g2(p->B), bl(64 * ntl);
+#define LB(N) do { \
+        hipLaunchKernelGGL((rts_big_phi_kernel<N>), g, bl, p->lds_mfma, p->stream, sh, p->b, mp); \
+        hipLaunchKernelGGL((rts_big_kernel<N, 0>), g, bl, p->lds_mfma, p->stream, sh, p->b, mp); \
+        hipLaunchKernelGGL((rts_big_kernel<N, 1>), g2, bl, p->lds_mfma, p->stream, sh, p->b, mp); \
+        hipLaunchKernelGGL((rts_big_kernel<N, 2>), g, bl, p->lds_mfma, p->stream, sh, p->b, mp); } while (0)
+      switch (ntl) { case 7: LB(7); break; case 8: LB(8); break; case 9: LB(9); break; default: LB(10); break; }
+#undef LB
+    } else if (use_mfma) {
       MfmaPar mp = p->mpar;
       mp.k0 = k0; mp.nk = nk; mp.chunk = p->chunk; mp.L = sp.L; mp.ns = sp.ns; mp.ns_max = p->ns_max; mp.Sp = p->mfma_sp;
       mp.first = first ? 1 : 0; mp.write_PSs = write_PSs ? 1 : 0;

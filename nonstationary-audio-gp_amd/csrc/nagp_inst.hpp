@@ -4,6 +4,7 @@
 #pragma once
 #include "nagp_ihgp.hpp"
 #include "nagp_mfma.hpp"
+#include "nagp_mfma_big.hpp"
 
 #define NAGP_SIG_GF (nagp::Shape, nagp::Bufs, nagp::MomCfg, nagp::FilterPar)
 #define NAGP_LIST_GF_ADF(P, TPT, LB)                                                                                       \
@@ -47,6 +48,14 @@
   NAGP_LIST_SMOOTH_M(P, 1) NAGP_LIST_SMOOTH_M(P, 2) NAGP_LIST_SMOOTH_M(P, 3) NAGP_LIST_SMOOTH_M(P, 4)                    \
   NAGP_LIST_SMOOTH_M(P, 5) NAGP_LIST_SMOOTH_M(P, 6)
 
+// MFMA smoother passes for 96 < Sp <= 160
+#define NAGP_LIST_BIG_N(P, NTL)                                                                                            \
+  P void nagp::rts_big_kernel<NTL, 0>(nagp::Shape, nagp::Bufs, nagp::MfmaPar);                                           \
+  P void nagp::rts_big_kernel<NTL, 1>(nagp::Shape, nagp::Bufs, nagp::MfmaPar);                                           \
+  P void nagp::rts_big_kernel<NTL, 2>(nagp::Shape, nagp::Bufs, nagp::MfmaPar);                                           \
+  P void nagp::rts_big_phi_kernel<NTL>(nagp::Shape, nagp::Bufs, nagp::MfmaPar);
+#define NAGP_LIST_BIG(P) NAGP_LIST_BIG_N(P, 7) NAGP_LIST_BIG_N(P, 8) NAGP_LIST_BIG_N(P, 9) NAGP_LIST_BIG_N(P, 10)
+
 // site refresh and mom on its own
 #define NAGP_LIST_EP_V(P, V)                                                                                               \
   P void nagp::ep_site_kernel<V>(nagp::Shape, nagp::Bufs, nagp::MomCfg, nagp::EpPar);                                    \
@@ -74,4 +83,4 @@
 
 #define NAGP_LIST_ALL(P)                                                                                                   \
   NAGP_LIST_GF_ADF1(P) NAGP_LIST_GF_ADF2(P) NAGP_LIST_GF_ADF3(P) NAGP_LIST_GF_ADF4(P) NAGP_LIST_GF_ADF5(P)               \
-  NAGP_LIST_GF_SP12(P) NAGP_LIST_GF_SP34(P) NAGP_LIST_GF_REST(P) NAGP_LIST_SMOOTH(P) NAGP_LIST_EP(P) NAGP_LIST_IH0(P) NAGP_LIST_IH1(P) NAGP_LIST_IHA(P)
+  NAGP_LIST_GF_SP12(P) NAGP_LIST_GF_SP34(P) NAGP_LIST_GF_REST(P) NAGP_LIST_SMOOTH(P) NAGP_LIST_BIG(P) NAGP_LIST_EP(P) NAGP_LIST_IH0(P) NAGP_LIST_IH1(P) NAGP_LIST_IHA(P)

@@ -964,6 +964,41 @@ def test_full_length_cfg5_prefix_property_and_finiteness():
     assert np.all(np.isfinite(full.Eft)) and np.all(full.Varft > 0) and np.isfinite(full.nlZ[0]) and full.counters[0] == 0
 
 
+@pytest.mark.parametrize('D,N,k1', [(22, 4, 'matern32'), (28, 4, 'matern32'), (30, 5, 'matern32'), (34, 6, 'matern32'), (30, 6, 'exp')])
+def test_column_owner_mfma_smoother_against_valu_passes_and_oracle(D, N, k1):
+    """Padded state dimensions 112 .. 160 (25 .. 40 sites): the MFMA smoother passes of nagp_mfma_big.hpp (7, 8, 9, 10 waves, one
+    tile column each; full tiles at 32 and 40 sites, 2-state sub-band blocks in the last case) against the VALU passes on the
+    same plan inputs and against the oracle; two problems per plan, chunks of 24 steps (several spans per chunk, the carry of the
+    boundary state between chunks), a missing observation."""
+    T = 70
+    probs, ys = [], []
+    for q in range(2):
+        pr = harness.nmf_problem(D, N, T, 8100 + q, 'constraints')
+        blk = pss.balance_blocks(pss.ss_blocks_nmf(pr['param1'], pr['param2'], k1, 'matern52'))
+        y = pr['y'].copy(); y[17 + q] = np.nan
+        probs.append((blk, pr['W'], np.log(pr['w_lik']))); ys.append(y)
+    assert 96 < 16 * ((4 * blk.M + 15) // 16) <= 160
+    mom = Mom('likModulatorNMFPower', p_cubature=3); d = np.array([0.6, 0.5, 0.5])
+    res = {}
+    for mode in ('big', 'valu'):
+        if mode == 'valu': os.environ['NAGP_NO_MFMA_BIG'] = '1'
+        try:
+            plan = Plan(L.KIND_GF_EP, probs, T, mom=mom, ep_fraction=0.5, ep_damping=d, ep_itts=3, chunk=24)
+            plan.upload(ys); plan.execute(); res[mode] = plan.download(); plan.close()
+        finally:
+            os.environ.pop('NAGP_NO_MFMA_BIG', None)
+    for q in range(2):
+        a, v = res['big'][q], res['valu'][q]
+        for f, tol in (('Eft', 1e-8), ('Varft', 1e-8), ('MS', 1e-8), ('lZ', 1e-8), ('ttau', TOL_SITE), ('tnu', TOL_SITE)):
+            assert rel(getattr(a, f), getattr(v, f)) < tol, (q, f)
+        assert relz(a.nlZ, v.nlZ) < 1e-9 and abs(a.maxDiffP[-1] - v.maxDiffP[-1]) <= 1e-7 * max(1.0, abs(v.maxDiffP[-1]))
+    pr = harness.nmf_problem(D, N, T, 8101, 'constraints')
+    ref = ogf.run_predict(ogf.assemble(np.log(1e-4) * np.ones(1), pr['param1'], pr['param2'], pr['W'], k1, 'matern52', True), ys[1],
+                          olik.Mom(olik.LIK_POWER_NMF, p=3), 0.5, d, 3)
+    assert rel(res['big'][1].Eft, ref['Eft']) < TOL_MEAN and rel(res['big'][1].Varft, ref['Varft']) < TOL_MEAN
+    assert relz(res['big'][1].nlZ, ref['nlZ']) < TOL_LOGZ
+
+
 def test_eight_segments_at_S146_equal_their_single_problem_plans():
     """configs[4] as the bench runs it (several 32-channel / 6-component segments in one plan, three tiles per thread, the VALU
     smoother passes with eight problems per launch): every segment of the 8-segment plan equals the plan of that segment alone."""

@@ -861,6 +861,18 @@ static int launch_smoother(nagp_plan* p, bool write_PSs) {
     {
       int ns = (int)std::lround(std::sqrt(2.5 * (double)nk));
       ns = std::max(1, std::min(std::min(ns, p->ns_max), (nk + 7) / 8));
+      if (use_big) {
+        // column-owner kernels: a step of the three span passes costs ~90 us of one CU (Phi 19, C 34, apply 37; measured at
+        // Sp = 160), a span of the sequential boundary pass ~47 us.  Spans run in rounds of one workgroup per CU.
+        const int n_cu = 256;
+        double best = 1e300;
+        for (int c = 1; c <= std::max(1, std::min(p->ns_max, (nk + 7) / 8)); ++c) {
+          const int L = (nk + c - 1) / c, cc = (nk + L - 1) / L;
+          const double rounds = std::ceil((double)cc * p->B / n_cu);
+          const double cost = rounds * L * 90.0 + cc * 47.0;
+          if (cost < best) { best = cost; ns = cc; }
+        }
+      }
       sp.L = (nk + ns - 1) / ns;
       sp.ns = (nk + sp.L - 1) / sp.L;
     }

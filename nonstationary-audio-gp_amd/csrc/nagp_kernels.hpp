@@ -725,8 +725,29 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(TPT ==
   if (tid == 0) { flag[0] = 0; flag[1] = 0; }
   lds_barrier();
 
+  // B = PS A' (all M x M tiles; becomes X, then G) and PSkp = A B + Q (symmetric: only the lower tiles are factored; becomes L).
+  // Three or four tiles per thread (SPLIT): the lower triangle has its own owners, TPL tiles per thread instead of one PSkp tile
+  // beside every B tile.  One or two tiles per thread: the owner of B(I,J) also holds PSkp(I,J).
+  constexpr bool SPLIT = TPT >= 3;
+  constexpr int TPL = SPLIT ? (TPT + 2) / 2 : TPT;
   TileOwner<TPT> own;
   own.init(M, sh.ntiles);
+  struct { int I[TPL], J[TPL]; bool ok[TPL]; } low;
+#pragma unroll
+  for (int q = 0; q < TPL; ++q) {
+    if constexpr (SPLIT) {
+      const int nlow = M * (M + 1) / 2;
+      const int t = tid + q * NT;
+      low.ok[q] = t < nlow;
+      const int tt_ = low.ok[q] ? t : 0;
+      int I = (int)((sqrt(8.0 * tt_ + 1.0) - 1.0) * 0.5);
+      while ((I + 1) * (I + 2) / 2 <= tt_) ++I;
+      while (I * (I + 1) / 2 > tt_) --I;
+      low.I[q] = I; low.J[q] = tt_ - I * (I + 1) / 2;
+    } else {
+      low.I[q] = own.I[q]; low.J[q] = own.J[q]; low.ok[q] = own.ok[q] && own.I[q] >= own.J[q];
+    }
+  }
   const double* PFk = b.PF + ((size_t)pb * T + k) * pf_ntiles(sh) * 16;
   const double* PFk1 = PFk + (size_t)pf_ntiles(sh) * 16;
   const size_t mstride = gp.dense_sp ? (size_t)gp.dense_sp * gp.dense_sp : (size_t)sh.ntiles * 16;
@@ -746,27 +767,73 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(TPT ==
       tile_store(base + ((size_t)I * sh.M + J) * 16, t16);
     }
   };
+  // PSkp(I,J) = A_I PS(I,J) A_J' (+ Q, + the jitter of the second attempt), I >= J
+  auto pskp_tile = [&](double* Lq, int I, int J, bool jitter) {
+    double ps[16], bt[16];
+    pf_load(ps, PFk, I, J);
+    tile_zero(bt);
+    tile_mma_nt(bt, ps, sA + (size_t)J * 16);
+    tile_zero(Lq);
+    tile_mma(Lq, sA + (size_t)I * 16, bt);
+    if (I == J) {
+      const double* Qb = mdl + mdl_Q(sh) + (size_t)I * 16;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) Lq[e] += Qb[e];
+      if (jitter) {      // sqrt(1e-4)*diag(rand): deterministic 0.5 in place of rand
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (i < ibsz[I]) Lq[5 * i] += 0.01 * 0.5;
+      }
+    }
+  };
 
-  double Bt[TPT][16], Lt[TPT][16];
+  double Bt[TPT][16], Lt[TPL][16];
+  // (the lower-triangle owners first: their temporaries are dead before the B tiles come to life)
+  if constexpr (SPLIT) {
+#pragma unroll
+    for (int q = 0; q < TPL; ++q) {
+      tile_zero(Lt[q]);
+      if (low.ok[q]) {
+        const int I = low.I[q], J = low.J[q];
+        pskp_tile(Lt[q], I, J, false);                            // PSkp = A B (+Q)
+        double d[16];
+        pf_load(d, PFk1, I, J);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) d[e] -= Lt[q][e];
+        put_tile(Dout, I, J, d);                                  // Delta_k, and its mirror tile
+        if (I != J) {
+          double dt[16];
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dt[4 * i + j] = d[4 * j + i];
+          put_tile(Dout, J, I, dt);
+        }
+      }
+    }
+  }
 #pragma unroll
   for (int q = 0; q < TPT; ++q) {
-    tile_zero(Bt[q]); tile_zero(Lt[q]);
+    tile_zero(Bt[q]);
+    if constexpr (!SPLIT) tile_zero(Lt[q]);
     if (own.ok[q]) {
-      const int I = own.I[q], J = own.J[q], t = tid + q * NT;
+      const int I = own.I[q], J = own.J[q];
       double ps[16];
       pf_load(ps, PFk, I, J);
       tile_mma_nt(Bt[q], ps, sA + (size_t)J * 16);          // B = PS A'
-      tile_mma(Lt[q], sA + (size_t)I * 16, Bt[q]);          // PSkp = A B (+Q)
-      if (I == J) {
-        const double* Qb = mdl + mdl_Q(sh) + (size_t)I * 16;
+      if constexpr (!SPLIT) {
+        tile_mma(Lt[q], sA + (size_t)I * 16, Bt[q]);        // PSkp = A B (+Q)
+        if (I == J) {
+          const double* Qb = mdl + mdl_Q(sh) + (size_t)I * 16;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) Lt[q][e] += Qb[e];
+          for (int e = 0; e < 16; ++e) Lt[q][e] += Qb[e];
+        }
+        double d[16];
+        pf_load(d, PFk1, I, J);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) d[e] -= Lt[q][e];
+        put_tile(Dout, I, J, d);                            // Delta_k
       }
-      double d[16];
-      pf_load(d, PFk1, I, J);
-#pragma unroll
-      for (int e = 0; e < 16; ++e) d[e] -= Lt[q][e];
-      put_tile(Dout, I, J, d);                              // Delta_k
     }
   }
   // delta_k = MF_{k+1} - A MF_k
@@ -784,34 +851,39 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(TPT ==
   bool failed = false;
   for (int attempt = 0; attempt < 2; ++attempt) {
     if (attempt == 1) {
+      // the first attempt solved X L' = B in place: rebuild B = PS A' and PSkp = A B + Q + jitter
 #pragma unroll
       for (int q = 0; q < TPT; ++q)
         if (own.ok[q]) {
-          const int I = own.I[q], J = own.J[q];
-          {   // the first attempt solved X L' = B in place: rebuild B = PS A' before PSkp = A B + Q + jitter
-            double ps[16];
-            pf_load(ps, PFk, I, J);
-            tile_zero(Bt[q]);
-            tile_mma_nt(Bt[q], ps, sA + (size_t)J * 16);
-          }
-          tile_zero(Lt[q]);
-          tile_mma(Lt[q], sA + (size_t)I * 16, Bt[q]);
-          if (I == J) {
-            const double* Qb = mdl + mdl_Q(sh) + (size_t)I * 16;
-            // sqrt(1e-4)*diag(rand): deterministic 0.5 in place of rand
+          double ps[16];
+          pf_load(ps, PFk, own.I[q], own.J[q]);
+          tile_zero(Bt[q]);
+          tile_mma_nt(Bt[q], ps, sA + (size_t)own.J[q] * 16);
+        }
 #pragma unroll
-            for (int e = 0; e < 16; ++e) Lt[q][e] += Qb[e];
+      for (int q = 0; q < TPL; ++q)
+        if (low.ok[q]) {
+          if constexpr (SPLIT) pskp_tile(Lt[q], low.I[q], low.J[q], true);
+          else {
+            const int I = low.I[q];
+            tile_zero(Lt[q]);
+            tile_mma(Lt[q], sA + (size_t)I * 16, Bt[q]);
+            if (I == low.J[q]) {
+              const double* Qb = mdl + mdl_Q(sh) + (size_t)I * 16;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-              if (i < ibsz[I]) Lt[q][5 * i] += 0.01 * 0.5;
+              for (int e = 0; e < 16; ++e) Lt[q][e] += Qb[e];
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+                if (i < ibsz[I]) Lt[q][5 * i] += 0.01 * 0.5;      // sqrt(1e-4)*diag(rand): deterministic 0.5 in place of rand
+            }
           }
         }
     }
     for (int jb = 0; jb < M; ++jb) {
       const int par = jb & 1;
 #pragma unroll
-      for (int q = 0; q < TPT; ++q)
-        if (own.ok[q] && own.I[q] == jb && own.J[q] == jb) {
+      for (int q = 0; q < TPL; ++q)
+        if (low.ok[q] && low.I[q] == jb && low.J[q] == jb) {
           double rd[4];
           if (!tile_chol(Lt[q], ibsz[jb], rd)) flag[attempt] = 1;
           tile_store(sLd + (size_t)jb * 16, Lt[q]);
@@ -821,23 +893,30 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(TPT ==
       lds_barrier();
       // column jb of L (rows below the diagonal) and -- fused, it needs nothing else -- column jb of X in X L' = B
 #pragma unroll
+      for (int q = 0; q < TPL; ++q)
+        if (low.ok[q] && low.J[q] == jb && low.I[q] > jb) {
+          tile_solve_Lt(Lt[q], sLd + (size_t)jb * 16);
+          tile_store(bufP + ((size_t)par * M + low.I[q]) * TS, Lt[q]);
+        }
+#pragma unroll
       for (int q = 0; q < TPT; ++q)
         if (own.ok[q] && own.J[q] == jb) {
-          if (own.I[q] > jb) {
-            tile_solve_Lt(Lt[q], sLd + (size_t)jb * 16);
-            tile_store(bufP + ((size_t)par * M + own.I[q]) * TS, Lt[q]);
-          }
           tile_solve_Lt(Bt[q], sLd + (size_t)jb * 16);
           tile_store(bufX + ((size_t)par * M + own.I[q]) * TS, Bt[q]);
         }
       lds_barrier();
       // trailing updates: L (lower tiles) and the remaining columns of B
 #pragma unroll
+      for (int q = 0; q < TPL; ++q)
+        if (low.ok[q] && low.J[q] > jb) {
+          tile_mms_nt(Lt[q], bufP + ((size_t)par * M + low.I[q]) * TS, bufP + ((size_t)par * M + low.J[q]) * TS);
+          __builtin_amdgcn_sched_barrier(0);      // one tile's operands at a time: the reads of all slots hoisted together spill
+        }
+#pragma unroll
       for (int q = 0; q < TPT; ++q)
         if (own.ok[q] && own.J[q] > jb) {
-          if (own.I[q] >= own.J[q])
-            tile_mms_nt(Lt[q], bufP + ((size_t)par * M + own.I[q]) * TS, bufP + ((size_t)par * M + own.J[q]) * TS);
           tile_mms_nt(Bt[q], bufX + ((size_t)par * M + own.I[q]) * TS, bufP + ((size_t)par * M + own.J[q]) * TS);
+          __builtin_amdgcn_sched_barrier(0);
         }
     }
     lds_barrier();
@@ -855,18 +934,20 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(TPT ==
     const int par = jb & 1;
 #pragma unroll
     for (int q = 0; q < TPT; ++q)
-      if (own.ok[q]) {
-        if (own.J[q] == jb) {
-          tile_solve_L(Bt[q], sLd + (size_t)jb * 16);
-          tile_store(bufX + ((size_t)par * M + own.I[q]) * TS, Bt[q]);
-        }
-        if (own.I[q] == jb && own.J[q] < jb) tile_store(bufP + ((size_t)par * M + own.J[q]) * TS, Lt[q]);
+      if (own.ok[q] && own.J[q] == jb) {
+        tile_solve_L(Bt[q], sLd + (size_t)jb * 16);
+        tile_store(bufX + ((size_t)par * M + own.I[q]) * TS, Bt[q]);
       }
+#pragma unroll
+    for (int q = 0; q < TPL; ++q)
+      if (low.ok[q] && low.I[q] == jb && low.J[q] < jb) tile_store(bufP + ((size_t)par * M + low.J[q]) * TS, Lt[q]);
     lds_barrier();
 #pragma unroll
     for (int q = 0; q < TPT; ++q)
-      if (own.ok[q] && own.J[q] < jb)
+      if (own.ok[q] && own.J[q] < jb) {
         tile_mms(Bt[q], bufX + ((size_t)par * M + own.I[q]) * TS, bufP + ((size_t)par * M + own.J[q]) * TS);
+        __builtin_amdgcn_sched_barrier(0);
+      }
   }
 #pragma unroll
   for (int q = 0; q < TPT; ++q)

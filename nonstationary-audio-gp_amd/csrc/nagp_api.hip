@@ -70,6 +70,7 @@ struct nagp_plan {
   int src_f = 0, src_ep = 0, kb_ih = 16;
   MomSp sp{};           // sparse-point form of likModulatorNMFPower (nagp_momsp.hpp); sp_ih: the IHGP ADF sweep uses it
   int sp_ih = 0, sp_gf = 0, kb_sp = 16, hph_sp = 1; size_t lds_sp = 0;
+  int sp_ih8 = 0; size_t lds_sp8 = 0;   // the role-specialised 512-thread form of the same sweep (ihgp_adf8_kernel)
   hipStream_t stream = nullptr;
   Bufs b{};
   MomCfg mc{};
@@ -623,9 +624,21 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
           case 5: PLAN_TRY(set_lds(ihgp_adf_kernel<5>, p->lds_sp)); break; case 6: PLAN_TRY(set_lds(ihgp_adf_kernel<6>, p->lds_sp)); break;
           default: PLAN_TRY(set_lds(ihgp_adf_kernel<7>, p->lds_sp)); break;
         }
+        // role-specialised waves: two serial + six worker waves, one sigma point per worker lane, <= 80 MFMA steps
+        const size_t need8 = ihgp_adf8_lds_doubles(sh, o->cub_dim, p->tb.NG, p->hph_sp, p->kb_sp) * sizeof(double) + 16;
+        const char* er = getenv("NAGP_IH_ROLES");
+        if (o->n_pts <= 64 * MSR_NWK && (o->n_pts + 3) / 4 <= 4 * MSR_NST && need8 <= 156 * 1024 && !(er && er[0] == '0')) {
+          p->sp_ih8 = 1; p->lds_sp8 = need8;
+          switch (o->cub_dim) {
+            case 1: PLAN_TRY(set_lds(ihgp_adf8_kernel<1>, need8)); break; case 2: PLAN_TRY(set_lds(ihgp_adf8_kernel<2>, need8)); break;
+            case 3: PLAN_TRY(set_lds(ihgp_adf8_kernel<3>, need8)); break; case 4: PLAN_TRY(set_lds(ihgp_adf8_kernel<4>, need8)); break;
+            case 5: PLAN_TRY(set_lds(ihgp_adf8_kernel<5>, need8)); break; case 6: PLAN_TRY(set_lds(ihgp_adf8_kernel<6>, need8)); break;
+            default: PLAN_TRY(set_lds(ihgp_adf8_kernel<7>, need8)); break;
+          }
+        }
       }
     }
-    if (getenv("NAGP_STAMPS")) fprintf(stderr, "[nagp plan] ihgp ADF sweep in the sparse-point form: %d (LDS %zu B, ring %d steps, hph table in LDS %d)\n", p->sp_ih, p->lds_sp, p->kb_sp, p->hph_sp);
+    if (getenv("NAGP_STAMPS")) fprintf(stderr, "[nagp plan] ihgp ADF sweep in the sparse-point form: %d (LDS %zu B, ring %d steps, hph table in LDS %d), role-specialised waves %d (LDS %zu B)\n", p->sp_ih, p->lds_sp, p->kb_sp, p->hph_sp, p->sp_ih8, p->lds_sp8);
 #define SL(V) PLAN_TRY(set_lds(ihgp_filter_kernel<V, false>, p->lds_ih))
 #define SLS(V) PLAN_TRY(set_lds(ihgp_filter_kernel<V, true>, p->lds_ih))
     if (p->src_f) { NAGP_MV_SWITCH9(mom_variant(mc), SLS) } else { NAGP_MV_SWITCH9(mom_variant(mc), SL) }
@@ -1135,8 +1148,11 @@ static int exec_ihgp(nagp_plan* p) {
       if (p->sp_ih) {
         IhgpPar ia = ip; ia.hph_lds = p->hph_sp; ia.kb = p->kb_sp;
 #define LA(V) hipLaunchKernelGGL((ihgp_adf_kernel<V>), dim3(B), dim3(MSP_NT), p->lds_sp, p->stream, sh, p->b, mcf, p->sp, p->tb, ia)
-        switch (mcf.cdim) { case 1: LA(1); break; case 2: LA(2); break; case 3: LA(3); break; case 4: LA(4); break; case 5: LA(5); break; case 6: LA(6); break; default: LA(7); break; }
+#define LA8(V) hipLaunchKernelGGL((ihgp_adf8_kernel<V>), dim3(B), dim3(MSR_NT), p->lds_sp8, p->stream, sh, p->b, mcf, p->sp, p->tb, ia)
+        if (p->sp_ih8) switch (mcf.cdim) { case 1: LA8(1); break; case 2: LA8(2); break; case 3: LA8(3); break; case 4: LA8(4); break; case 5: LA8(5); break; case 6: LA8(6); break; default: LA8(7); break; }
+        else switch (mcf.cdim) { case 1: LA(1); break; case 2: LA(2); break; case 3: LA(3); break; case 4: LA(4); break; case 5: LA(5); break; case 6: LA(6); break; default: LA(7); break; }
 #undef LA
+#undef LA8
       } else if (p->src_f) { NAGP_MV_SWITCH9(mom_variant(mcf), LIS) } else { NAGP_MV_SWITCH9(mom_variant(mcf), LI) }
 #undef LI
 #undef LIS

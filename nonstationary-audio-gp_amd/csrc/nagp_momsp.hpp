@@ -40,22 +40,28 @@ __host__ __device__ inline int msp_qterms(int D) { return D <= 16 ? 4 : (D <= 32
 
 // LDS workspace (offsets in doubles).  Tables lk | xg | xg2 | e | t1 | ve, MSP_TS entries each.
 struct MspLay { int lk, xg, xg2, e, t1, ve, one, zero, Q, Q2, v, q0, s0, c0, c1, c2, part, acc, wwt, total; };
-__host__ __device__ inline MspLay msp_layout(int CD, int D) {
+// LAY 0: the 256-thread layout (four waves share every stage); LAY 1: the role layout of 512 threads (nagp_ihgp.hpp:
+// two serial waves, six worker waves: six partial blocks, 96 addressable MFMA steps)
+constexpr int MSR_NWK = 6;     // worker waves of the role layout
+constexpr int MSR_NST = 20;    // MFMA steps of a worker wave that has its SIMD's matrix core to itself (the others take half)
+constexpr int MSR_CS = 4 * 4 * MSR_NST + 4 * 4 + 1;    // 80 steps, and the zero-weight steps a group of four may run over
+__host__ __device__ inline MspLay msp_layout(int CD, int D, int LAY = 0) {
   MspLay l;
+  const int cs = LAY ? MSR_CS : MSP_CS, nparts = LAY ? MSR_NWK : MSP_NW;
   l.lk = 0; l.xg = MSP_TS; l.xg2 = 2 * MSP_TS; l.e = 3 * MSP_TS; l.t1 = 4 * MSP_TS; l.ve = 5 * MSP_TS;
   l.zero = l.e + MSP_TS - 1;                     // e[63] (t1[63], ve[63] are zero as well)
   l.one = 6 * MSP_TS;
   l.Q = l.one + 1; l.Q2 = l.Q + CD * CD; l.v = l.Q2 + CD * CD; l.q0 = l.v + CD; l.s0 = l.q0 + 1;
   int o = (l.s0 + 2) & ~1;
-  l.c0 = o; l.c1 = o + MSP_CS; l.c2 = o + 2 * MSP_CS;
-  o = (o + 3 * MSP_CS + 1) & ~1;
-  l.part = o; o += MSP_NW * 256;
+  l.c0 = o; l.c1 = o + cs; l.c2 = o + 2 * cs;
+  o = (o + 3 * cs + 1) & ~1;
+  l.part = o; o += nparts * 256;
   l.acc = o; o += 128;
   l.wwt = o; o += msp_qterms(D) * 192;            // static W products of stage A, [q][lane of waves 1..3], zero for sub-bands >= D
   l.total = o;
   return l;
 }
-__host__ __device__ inline size_t msp_lds_doubles(int CD, int D) { return (size_t)msp_layout(CD, D).total; }
+__host__ __device__ inline size_t msp_lds_doubles(int CD, int D, int LAY = 0) { return (size_t)msp_layout(CD, D, LAY).total; }
 __host__ __device__ inline int msp_nacc(int CD) { return CD + CD * (CD + 1) / 2 + 2 * CD + 1; }   // u, R (upper), g1, g2, Z
 
 // 1/x by the hardware estimate and two Newton steps (~1 ulp); x = 0, inf, NaN are the caller's business
@@ -72,6 +78,7 @@ __device__ __forceinline__ int opaque_zero() { int z = 0; asm volatile("" : "+v"
 // Register-resident state of one thread.  Everything here is computed once per kernel.
 template <int CD>
 struct MspCtx {
+  static constexpr int NPS = MSP_NPS, NST = MSP_NST, WSTR = 4 * MSP_NW, NPART = MSP_NW, CS = MSP_CS;
   int lw, qw;          // wave that evaluates the link tables / wave that forms q0, s0 (wave-uniform)
   // stage A / B, wave lw: lane t = j*nd + c
   double xdc; msp_rp a_mu, a_s2, a_l0[CD], a_l0own, a_qrow, a_qjj, a_v; msp_wp a_out;   // a_out[k*MSP_TS]: lk, xg, xg2, e, t1, ve
@@ -88,8 +95,9 @@ struct MspCtx {
   bool p_ok[MSP_NPS];
   int p_any[MSP_NPS];  // wave-uniform: some lane of this wave owns a point in the slot
   // stage 2
-  msp_rp m_a[MSP_NST], m_b[MSP_NST], m_w0;   // weight of step s at m_w0[16*s]
-  int nst;             // steps of this wave
+  msp_rp m_a[MSP_NST], m_b[MSP_NST], m_w0;   // weight of step s at m_w0[WSTR*s]
+  msp_wp m_part;       // this wave's 16x16 partial block, + lane
+  int nst, m_on;       // steps of this wave; the wave takes part in stage 2 (wave-uniform)
   // partial-sum reduction: lane o < nacc of the reducing wave
   msp_rp r_src; msp_wp r_dst;
   msp_rp accp;         // reduced sums (one vector register, immediate offsets)
@@ -212,6 +220,8 @@ __device__ __forceinline__ void msp_setup(MspCtx<CD>& x, const MomCfg& c, const 
     int wbase = l.c0;                                // rows without a weight multiply a zero operand
     if (i < CD) wbase = l.c2; else if (i == CD) wbase = l.c1;
     x.m_w0 = (msp_rp)(ws + wbase + 4 * wv + kq);     // point of step s: 4*(wv + 4s) + kq
+    x.m_part = (msp_wp)(ws + l.part + ((wave < MSP_NW) ? wave : 0) * 256 + kq * 16 + i);
+    x.m_on = (wave < MSP_NW) ? 1 : 0;
 #pragma unroll
     for (int s = 0; s < MSP_NST; ++s) {
       const int p = 4 * (wv + MSP_NW * s) + kq;
@@ -256,8 +266,8 @@ __device__ __forceinline__ void msp_qsum(msp_rp ww, msp_rp src, double& a0, doub
 }
 
 // stage A, link part (wave lw): needs fmu / HPH of the MODULATOR sites; no barrier
-template <int CD>
-__device__ __forceinline__ void msp_link(const MspCtx<CD>& x, const MomCfg& c) {
+template <int CD, class X>
+__device__ __forceinline__ void msp_link(const X& x, const MomCfg& c) {
   const int tl = (int)threadIdx.x - 64 * x.lw, TN = CD * c.nd;
   if (tl >= 0 && tl < TN) {
     const double mu = *x.a_mu, s2 = *x.a_s2;
@@ -270,8 +280,8 @@ __device__ __forceinline__ void msp_link(const MspCtx<CD>& x, const MomCfg& c) {
   }
 }
 // stage A, Q / 2Q / v part (the three other waves): needs fmu / HPH of the SUB-BAND sites; no barrier
-template <int CD>
-__device__ __forceinline__ void msp_qv(const MspCtx<CD>& x, const MomCfg& c) {
+template <int CD, class X>
+__device__ __forceinline__ void msp_qv(const X& x, const MomCfg& c) {
   if (x.q_kind) {
     const int K = __builtin_amdgcn_readfirstlane(msp_qterms(c.D));
     double a0 = 0.0, a1 = 0.0;
@@ -295,42 +305,49 @@ __device__ __forceinline__ void msp_stageA(const MspCtx<CD>& x, const MomCfg& c)
   if (wave == __builtin_amdgcn_readfirstlane(x.lw)) msp_link<CD>(x, c); else msp_qv<CD>(x, c);
 }
 
+// stage B, table part (lanes t < CD*nd of the link wave): e, t1, ve from lk, Q, v
+template <int CD, class X>
+__device__ __forceinline__ void msp_tables(const X& x, const MomCfg& c) {
+  const int TN = CD * c.nd;
+  if (((int)threadIdx.x & 63) < TN) {
+    const double lk = ((msp_rp)x.a_out)[0];
+    double ql0 = 0.0, ql1 = 0.0;
+#pragma unroll
+    for (int j2 = 0; j2 < CD; ++j2) { if (j2 & 1) ql1 = fma(x.a_qrow[j2], *x.a_l0[j2], ql1); else ql0 = fma(x.a_qrow[j2], *x.a_l0[j2], ql0); }
+    const double ql = ql0 + ql1;
+    const double e = lk - *x.a_l0own;
+    x.a_out[3 * MSP_TS] = e;
+    x.a_out[4 * MSP_TS] = e * fma(*x.a_qjj, e, 2.0 * ql);
+    x.a_out[5 * MSP_TS] = (*x.a_v) * e;
+  }
+}
+// stage B, q0 = l0' Q l0 and s0 = v' l0 (one wave)
+template <class X>
+__device__ __forceinline__ void msp_q0s0(const X& x, double* q0, double* s0) {
+  const double t = (*x.b_p0) * (*x.b_p1) * (*x.b_p2);      // unused lanes: zero * ...
+  double tq = (x.b_kind == 1) ? t : 0.0, tsv = (x.b_kind == 2) ? t : 0.0;
+  tq = wave_sum(tq);
+  tsv = wave_sum(tsv);
+  if (((int)threadIdx.x & 63) == 0) { *q0 = tq; *s0 = tsv; }
+}
 // stage B.  After a barrier behind stage A; ends without a barrier.
 template <int CD>
 __device__ __forceinline__ void msp_stageB(const MspCtx<CD>& x, const MomCfg& c, double* ws) {
-  const int tid = threadIdx.x, TN = CD * c.nd;
   const MspLay l = msp_layout(CD, c.D);
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if (wave == __builtin_amdgcn_readfirstlane(x.lw)) {
-    if ((tid & 63) < TN) {
-      const double lk = ((msp_rp)x.a_out)[0];
-      double ql0 = 0.0, ql1 = 0.0;
-#pragma unroll
-      for (int j2 = 0; j2 < CD; ++j2) { if (j2 & 1) ql1 = fma(x.a_qrow[j2], *x.a_l0[j2], ql1); else ql0 = fma(x.a_qrow[j2], *x.a_l0[j2], ql0); }
-      const double ql = ql0 + ql1;
-      const double e = lk - *x.a_l0own;
-      x.a_out[3 * MSP_TS] = e;
-      x.a_out[4 * MSP_TS] = e * fma(*x.a_qjj, e, 2.0 * ql);
-      x.a_out[5 * MSP_TS] = (*x.a_v) * e;
-    }
-  } else if (wave == __builtin_amdgcn_readfirstlane(x.qw)) {
-    const double t = (*x.b_p0) * (*x.b_p1) * (*x.b_p2);      // unused lanes: zero * ...
-    double tq = (x.b_kind == 1) ? t : 0.0, tsv = (x.b_kind == 2) ? t : 0.0;
-    tq = wave_sum(tq);
-    tsv = wave_sum(tsv);
-    if ((tid & 63) == 0) { ws[l.q0] = tq; ws[l.s0] = tsv; }
-  }
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  if (wave == __builtin_amdgcn_readfirstlane(x.lw)) msp_tables<CD>(x, c);
+  else if (wave == __builtin_amdgcn_readfirstlane(x.qw)) msp_q0s0(x, ws + l.q0, ws + l.s0);
 }
 
 // stage 1b.  After a barrier behind stage B; ends without a barrier.
-template <int CD>
-__device__ __forceinline__ void msp_stage1b(const MspCtx<CD>& x, const MomCfg& c, const MomSp& sp, double sn2a, double y, const double* ws) {
-  const MspLay l = msp_layout(CD, c.D);
+template <int CD, class X>
+__device__ __forceinline__ void msp_stage1b(const X& x, const MomCfg& c, const MomSp& sp, double sn2a, double y, const double* ws) {
+  const MspLay l = msp_layout(CD, c.D);      // q0, s0 sit at the same offsets in both layouts
   const bool four = __builtin_amdgcn_readfirstlane(sp.nzmax > 3 ? 1 : 0) != 0;
   const bool three = __builtin_amdgcn_readfirstlane(sp.nzmax > 2 ? 1 : 0) != 0;
   const double q0 = ws[l.q0], s0 = ws[l.s0];
 #pragma unroll
-  for (int u = 0; u < MSP_NPS; ++u) {
+  for (int u = 0; u < X::NPS; ++u) {
     if (__builtin_amdgcn_readfirstlane(x.p_any[u]) == 0) continue;   // wave-uniform skip
     const double e0 = x.p_e[u][0][0], e1 = x.p_e[u][1][0];
     double sam = (s0 + x.p_e[u][0][2 * MSP_TS]) + x.p_e[u][1][2 * MSP_TS];
@@ -355,8 +372,8 @@ __device__ __forceinline__ void msp_stage1b(const MspCtx<CD>& x, const MomCfg& c
     const double w0 = x.p_wn[u] * pdf;
     if (x.p_ok[u]) {
       x.p_c[u][0] = w0;
-      x.p_c[u][MSP_CS] = w0 * q;
-      x.p_c[u][2 * MSP_CS] = w0 * (q * q - inv);
+      x.p_c[u][X::CS] = w0 * q;
+      x.p_c[u][2 * X::CS] = w0 * (q * q - inv);
     }
   }
 }
@@ -364,47 +381,45 @@ __device__ __forceinline__ void msp_stage1b(const MspCtx<CD>& x, const MomCfg& c
 // stage 2.  After a barrier behind stage 1b; leaves this wave's 16x16 partial in LDS, no barrier.
 // Two accumulators (the dependent-accumulator latency of the f64 MFMA is longer than its issue time) and the operands of
 // the next four steps in flight while the current four multiply.
-template <int CD>
-__device__ __forceinline__ void msp_stage2(const MspCtx<CD>& x, const MomCfg& c, double* ws) {
-  const MspLay l = msp_layout(CD, c.D);
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (wave >= MSP_NW) return;
+template <int CD, class X>
+__device__ __forceinline__ void msp_stage2(const X& x, const MomCfg& c, double* ws) {
+  if (__builtin_amdgcn_readfirstlane(x.m_on) == 0) return;      // a wave outside the stage has no partial block
   const int nst = __builtin_amdgcn_readfirstlane(x.nst);
+  constexpr int NST = X::NST, WS = X::WSTR;
   v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
   double a[4], bb[4], w[4];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) { a[u] = *x.m_a[u]; bb[u] = *x.m_b[u]; w[u] = x.m_w0[16 * u]; }
+  for (int u = 0; u < 4; ++u) { a[u] = *x.m_a[u]; bb[u] = *x.m_b[u]; w[u] = x.m_w0[WS * u]; }
 #pragma unroll
-  for (int s0 = 0; s0 < MSP_NST; s0 += 4) {
+  for (int s0 = 0; s0 < NST; s0 += 4) {
     if (s0 < nst) {      // uniform; steps beyond nst inside the group of four carry zero operands
       double an[4], bn[4], wn_[4];
-      if (s0 + 4 < MSP_NST) {
+      if (s0 + 4 < NST) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { an[u] = *x.m_a[s0 + 4 + u]; bn[u] = *x.m_b[s0 + 4 + u]; wn_[u] = x.m_w0[16 * (s0 + 4 + u)]; }
+        for (int u = 0; u < 4; ++u) { an[u] = *x.m_a[s0 + 4 + u]; bn[u] = *x.m_b[s0 + 4 + u]; wn_[u] = x.m_w0[WS * (s0 + 4 + u)]; }
       }
       acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0] * w[0], bb[0], acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1] * w[1], bb[1], acc1, 0, 0, 0);
       acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2] * w[2], bb[2], acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3] * w[3], bb[3], acc1, 0, 0, 0);
-      if (s0 + 4 < MSP_NST) {
+      if (s0 + 4 < NST) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) { a[u] = an[u]; bb[u] = bn[u]; w[u] = wn_[u]; }
       }
     }
   }
-  const int i = lane & 15, kq = lane >> 4;
-  double* part = ws + l.part + wave * 256;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) part[(kq + 4 * r) * 16 + i] = acc0[r] + acc1[r];
+  for (int r = 0; r < 4; ++r) x.m_part[64 * r] = acc0[r] + acc1[r];      // element (kq + 4r, i) of the block
 }
 
 // fixed-order sum of the partials: lanes o < msp_nacc(CD) of ONE wave; the same wave may read acc after msp_wave_fence()
-template <int CD>
-__device__ __forceinline__ void msp_reduce(const MspCtx<CD>& x) {
+template <int CD, class X>
+__device__ __forceinline__ void msp_reduce(const X& x) {
   const int lane = threadIdx.x & 63;
   if (lane < msp_nacc(CD)) {
-    const double a = ((x.r_src[0] + x.r_src[256]) + x.r_src[512]) + x.r_src[768];
+    double a = x.r_src[0];
+#pragma unroll
+    for (int w = 1; w < X::NPART; ++w) a += x.r_src[256 * w];
     *x.r_dst = a;
   }
 }
@@ -450,6 +465,187 @@ __device__ __forceinline__ void msp_outputs(msp_rp acc, bool sub, int jmod, cons
   }
   d1 = Zinv * s1;
   d2 = fma(-d1, d1, Zinv * s2);
+}
+
+// =====================================================================================================================
+// Role layout (LAY = 1): 512 threads.  Waves 0 and 1 carry the serial stages of the caller (wave 1 also evaluates the link
+// tables and e / t1 / ve); waves 2 .. 7 carry the parallel ones: Q / 2Q / v on waves 2..4, q0 / s0 on wave 5, one sigma
+// point per lane of the six (<= 384 points), the MFMA steps round the six.  The two roles run in separate loops of the
+// kernel, so a wave holds the registers of its own role only: two waves per SIMD within 256 registers each.
+constexpr int MSR_NT = 512;
+constexpr int MSR_W0 = 2;      // first worker wave
+
+template <int CD>
+struct MsrS {
+  static constexpr int NPART = MSR_NWK;
+  int lw;
+  double xdc; msp_rp a_mu, a_s2, a_l0[CD], a_l0own, a_qrow, a_qjj, a_v; msp_wp a_out;
+  msp_rp r_src; msp_wp r_dst; msp_rp accp;
+};
+template <int CD>
+struct MsrW {
+  static constexpr int NPS = 1, NST = MSR_NST, WSTR = 4, CS = MSR_CS;
+  int q_kind; msp_rp q_ww, q_src; msp_wp q_out0, q_out1, q_out2, q_out3;
+  int b_kind; msp_rp b_p0, b_p1, b_p2;
+  msp_rp p_e[1][MSP_NZ], p_q[1][6]; msp_wp p_c[1]; double p_wn[1]; bool p_ok[1]; int p_any[1];
+  msp_rp m_a[MSR_NST], m_b[MSR_NST], m_w0; msp_wp m_part; int nst, m_on;
+};
+
+// constants, zero entries of the tables, zero weights beyond the points (every thread of the workgroup)
+__device__ __forceinline__ void msr_init(int CD, int D, double* ws) {
+  const MspLay l = msp_layout(CD, D, 1);
+  for (int i = threadIdx.x; i < 6 * MSP_TS; i += MSR_NT) ws[i] = 0.0;
+  if (threadIdx.x == 0) ws[l.one] = 1.0;
+  for (int i = threadIdx.x; i < 3 * MSR_CS; i += MSR_NT) ws[l.c0 + i] = 0.0;
+}
+
+template <int CD>
+__device__ __forceinline__ void msr_setup_S(MsrS<CD>& x, const MomCfg& c, const MomSp& sp, const double* fmu, const double* HPH, double* ws) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nd = c.nd, D = c.D, TN = CD * nd;
+  const MspLay l = msp_layout(CD, D, 1);
+  const int oz = opaque_zero();
+  x.lw = 1;
+  {
+    const int tl = tid - 64;
+    const int t = (tl >= 0 && tl < TN) ? tl : 0;
+    const int j = t / nd, cc = t - j * nd;
+    x.xdc = c.xd[cc];
+    x.a_mu = (msp_rp)(fmu + D + j); x.a_s2 = (msp_rp)(HPH + D + j);
+#pragma unroll
+    for (int j2 = 0; j2 < CD; ++j2) x.a_l0[j2] = (msp_rp)(ws + l.lk + j2 * nd + sp.c0) + oz;
+    x.a_l0own = (msp_rp)(ws + l.lk + j * nd + sp.c0);
+    x.a_qrow = (msp_rp)(ws + l.Q + j * CD);
+    x.a_qjj = (msp_rp)(ws + l.Q + j * CD + j);
+    x.a_v = (msp_rp)(ws + l.v + j);
+    x.a_out = (msp_wp)(ws + t);
+  }
+  {
+    const int o = lane, nq = CD * (CD + 1) / 2;
+    int row = 0, col = 0;
+    if (o < CD) { row = CD; col = o; }
+    else if (o < CD + nq) { int r = o - CD, j = 0; while (r >= CD - j) { r -= CD - j; ++j; } row = j; col = j + r; }
+    else if (o < 2 * CD + nq) { row = 2 * CD + 1; col = CD + (o - CD - nq); }
+    else if (o < 3 * CD + nq) { row = CD + 1 + (o - 2 * CD - nq); col = 2 * CD; }
+    else { row = 2 * CD + 1; col = 2 * CD; }
+    x.r_src = (msp_rp)(ws + l.part + row * 16 + col);
+    const int ab = (wave == 1) ? 64 : 0;
+    x.r_dst = (msp_wp)(ws + l.acc + ab + o);
+    x.accp = (msp_rp)(ws + l.acc + ab) + oz;
+  }
+}
+
+template <int CD>
+__device__ __forceinline__ void msr_setup_W(MsrW<CD>& x, const MomCfg& c, const MomSp& sp, const double* Wl /* LDS D x CD */,
+                                             const double* fmu, const double* HPH, double* ws) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave - MSR_W0;     // wr = 0 .. 5
+  const int nd = c.nd, D = c.D, npt = c.n_pts;
+  const MspLay l = msp_layout(CD, D, 1);
+  // ---- q0, s0 on worker 3
+  {
+    const int L = tid - 64 * (MSR_W0 + 3);
+    x.b_kind = 0; x.b_p0 = x.b_p1 = x.b_p2 = (msp_rp)(ws + l.zero);
+    if (L >= 0 && L < CD * CD) {
+      const int j = L / CD, j2 = L - j * CD;
+      x.b_kind = 1; x.b_p0 = (msp_rp)(ws + l.Q + L); x.b_p1 = (msp_rp)(ws + l.lk + j * nd + sp.c0); x.b_p2 = (msp_rp)(ws + l.lk + j2 * nd + sp.c0);
+    } else if (L >= CD * CD && L < CD * CD + CD) {
+      const int j = L - CD * CD;
+      x.b_kind = 2; x.b_p0 = (msp_rp)(ws + l.v + j); x.b_p1 = (msp_rp)(ws + l.lk + j * nd + sp.c0); x.b_p2 = (msp_rp)(ws + l.one);
+    }
+  }
+  // ---- Q / 2Q / v on workers 0..2: 4-lane group -> one entry
+  {
+    x.q_kind = 0;
+    x.q_out0 = x.q_out1 = x.q_out2 = x.q_out3 = (msp_wp)(ws + l.acc + 127);
+    x.q_ww = x.q_src = (msp_rp)(ws + l.zero);
+    const int L = (wr >= 0 && wr < 3) ? wr * 64 + lane : -1;
+    if (L >= 0) {
+      const int g = L >> 2, sub = L & 3;
+      const int nq = CD * (CD + 1) / 2;
+      int j = 0, j2 = 0;
+      if (g < nq) {
+        int r = g; j = 0;
+        while (r >= CD - j) { r -= CD - j; ++j; }
+        j2 = j + r;
+        x.q_kind = 1;
+        x.q_out0 = (msp_wp)(ws + l.Q + j * CD + j2); x.q_out1 = (msp_wp)(ws + l.Q + j2 * CD + j);
+        x.q_out2 = (msp_wp)(ws + l.Q2 + j * CD + j2); x.q_out3 = (msp_wp)(ws + l.Q2 + j2 * CD + j);
+      } else if (g < nq + CD) {
+        j = g - nq; x.q_kind = 2;
+        x.q_out0 = (msp_wp)(ws + l.v + j);
+      }
+      for (int q = 0; q < msp_qterms(D); ++q) {
+        const int d = sub + 4 * q;
+        double v = 0.0;
+        if (x.q_kind && d < D) v = (x.q_kind == 1) ? Wl[d * CD + j] * Wl[d * CD + j2] : Wl[d * CD + j];
+        ws[l.wwt + q * 192 + L] = v;
+      }
+      x.q_ww = (msp_rp)(ws + l.wwt + L);
+      x.q_src = (msp_rp)(((x.q_kind == 1) ? HPH : fmu) + sub);
+    }
+  }
+  // ---- stage 1b: worker lane (tid - 128) = point
+  {
+    const msp_rp zero = (msp_rp)(ws + l.zero);
+    int p = tid - 64 * MSR_W0;
+    const bool ok = p >= 0 && p < npt;
+    x.p_ok[0] = ok;
+    x.p_any[0] = (__builtin_amdgcn_ballot_w64(ok) != 0) ? 1 : 0;
+    if (!ok) p = 0;
+    int tj[MSP_NZ];
+#pragma unroll
+    for (int r = 0; r < MSP_NZ; ++r) {
+      tj[r] = ok ? sp.pdesc[(size_t)p * MSP_NZ + r] : -1;
+      if (tj[r] >= 0) tj[r] = (tj[r] / nd) * 64 + (tj[r] % nd);
+    }
+#pragma unroll
+    for (int r = 0; r < MSP_NZ; ++r) x.p_e[0][r] = (tj[r] >= 0) ? (msp_rp)(ws + l.e + (tj[r] >> 6) * nd + (tj[r] & 63)) : zero;
+    int pi = 0;
+#pragma unroll
+    for (int r = 0; r < MSP_NZ; ++r)
+#pragma unroll
+      for (int s_ = r + 1; s_ < MSP_NZ; ++s_) {
+        x.p_q[0][pi] = (tj[r] >= 0 && tj[s_] >= 0) ? (msp_rp)(ws + l.Q2 + (tj[r] >> 6) * CD + (tj[s_] >> 6)) : zero;
+        ++pi;
+      }
+    x.p_c[0] = (msp_wp)(ws + l.c0 + p);
+    x.p_wn[0] = ok ? c.wn[p] : 0.0;
+  }
+  // ---- stage 2: contiguous step ranges.  A wave's FP64 MFMA holds its SIMD's issue, so two workers on one SIMD gain nothing
+  // over one: waves w and w+4 share a SIMD, the serial waves 0 / 1 sit out this stage, hence workers 2 and 3 (waves 4, 5) have
+  // a matrix core to themselves and take a double share; the steps are dealt in eight slots (the first nstep % 8 one longer).
+  {
+    const int i = lane & 15, kq = lane >> 4;
+    const int nstep = (npt + 3) >> 2;
+    const bool on = wr >= 0 && wr < MSR_NWK;
+    const int base = nstep >> 3, rem = nstep & 7;
+    auto slot_start = [&](int sl) { return sl * base + (sl < rem ? sl : rem); };     // first step of slot sl (sl = 8: nstep)
+    const int sl0 = (wr <= 2) ? ((wr == 2) ? 2 : wr) : ((wr == 3) ? 4 : wr + 2), sl1 = (wr == 2 || wr == 3) ? sl0 + 2 : sl0 + 1;
+    const int st0 = on ? slot_start(sl0) : 0, st1 = on ? slot_start(sl1) : 0;
+    x.m_on = on ? 1 : 0;
+    x.nst = st1 - st0;
+    int wbase = l.c0;
+    if (i < CD) wbase = l.c2; else if (i == CD) wbase = l.c1;
+    x.m_w0 = (msp_rp)(ws + wbase + 4 * st0 + kq);
+    x.m_part = (msp_wp)(ws + l.part + (on ? wr : 0) * 256 + kq * 16 + i);
+#pragma unroll
+    for (int s_ = 0; s_ < MSR_NST; ++s_) {
+      const int p = 4 * (st0 + s_) + kq;
+      const bool ok = on && (s_ < x.nst) && (p < npt);
+      int offA = l.zero, offB = l.zero;
+      if (ok) {
+        const unsigned char* cp = c.code + (size_t)p * CD;
+        if (i < CD) offA = l.lk + i * nd + cp[i];
+        else if (i == CD) offA = l.one;
+        else if (i <= 2 * CD) offA = l.xg2 + (i - CD - 1) * nd + cp[i - CD - 1];
+        else if (i == 2 * CD + 1) offA = l.one;
+        if (i < CD) offB = l.lk + i * nd + cp[i];
+        else if (i < 2 * CD) offB = l.xg + (i - CD) * nd + cp[i - CD];
+        else if (i == 2 * CD) offB = l.one;
+      }
+      x.m_a[s_] = (msp_rp)(ws + offA); x.m_b[s_] = (msp_rp)(ws + offB);
+    }
+  }
 }
 
 }  // namespace nagp

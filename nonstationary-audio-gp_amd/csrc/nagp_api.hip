@@ -70,7 +70,7 @@ struct nagp_plan {
   int src_f = 0, src_ep = 0, kb_ih = 16;
   MomSp sp{};           // sparse-point form of likModulatorNMFPower (nagp_momsp.hpp); sp_ih: the IHGP ADF sweep uses it
   int sp_ih = 0, sp_gf = 0, kb_sp = 16, hph_sp = 1; size_t lds_sp = 0;
-  int sp_ih8 = 0; size_t lds_sp8 = 0;   // the role-specialised 512-thread form of the same sweep (ihgp_adf8_kernel)
+  int sp_ih8 = 0, sp_pack = 0, sp_maxmem = 0; size_t lds_sp8 = 0;   // sp_maxmem: most points sharing one non-centre (dimension, coordinate)   // the role-specialised 512-thread form of the same sweep (ihgp_adf8_kernel)
   hipStream_t stream = nullptr;
   Bufs b{};
   MomCfg mc{};
@@ -457,6 +457,13 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
         PLAN_HIP(hipMemcpyAsync(dd, pdesc.data(), pdesc.size() * sizeof(int), hipMemcpyHostToDevice, p->stream));
         PLAN_HIP(hipStreamSynchronize(p->stream));
         p->sp.enabled = 1; p->sp.c0 = c0; p->sp.nzmax = nzmax; p->sp.pdesc = reinterpret_cast<const int*>(dd);
+        for (int j = 0; j < o->cub_dim; ++j)
+          for (int cc = 0; cc < (int)xd.size(); ++cc) {
+            if (cc == c0) continue;
+            int cnt = 0;
+            for (int q = 0; q < o->n_pts; ++q) cnt += (code[(size_t)q * o->cub_dim + j] == cc) ? 1 : 0;
+            p->sp_maxmem = std::max(p->sp_maxmem, cnt);
+          }
       }
     }
     if (o->lik_kind != NAGP_LIK_POWER) {
@@ -629,16 +636,22 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
         const char* er = getenv("NAGP_IH_ROLES");
         if (o->n_pts <= 64 * MSR_NWK && (o->n_pts + 3) / 4 <= 4 * MSR_NST && need8 <= 156 * 1024 && !(er && er[0] == '0')) {
           p->sp_ih8 = 1; p->lds_sp8 = need8;
-          switch (o->cub_dim) {
-            case 1: PLAN_TRY(set_lds(ihgp_adf8_kernel<1>, need8)); break; case 2: PLAN_TRY(set_lds(ihgp_adf8_kernel<2>, need8)); break;
-            case 3: PLAN_TRY(set_lds(ihgp_adf8_kernel<3>, need8)); break; case 4: PLAN_TRY(set_lds(ihgp_adf8_kernel<4>, need8)); break;
-            case 5: PLAN_TRY(set_lds(ihgp_adf8_kernel<5>, need8)); break; case 6: PLAN_TRY(set_lds(ihgp_adf8_kernel<6>, need8)); break;
-            default: PLAN_TRY(set_lds(ihgp_adf8_kernel<7>, need8)); break;
+          // packed form (eight points per MFMA step, g1 / g2 from marginal sums): <= 6 components, <= 16 marginals per marginal wave, each of <= 64 members
+          {
+            const int CDp = o->cub_dim, ndp = mc.nd;
+            bool pk = CDp <= 6 && (ndp - 1) * ((CDp + 1) / 2) <= 16 && (ndp - 1) * CDp <= MSR_NMARG && (o->n_pts + 7) / 8 <= 40 && p->sp_maxmem <= 4 * MSR_NMEM;   // 3 of 8 slots <= MSR_NSTP steps
+            const char* ep = getenv("NAGP_IH_PACK");
+            if (ep && ep[0] == '0') pk = false;
+            p->sp_pack = pk ? 1 : 0;
           }
+#define SL8(V, PK) PLAN_TRY(set_lds(ihgp_adf8_kernel<V, PK>, need8))
+          if (p->sp_pack) switch (o->cub_dim) { case 1: SL8(1, true); break; case 2: SL8(2, true); break; case 3: SL8(3, true); break; case 4: SL8(4, true); break; case 5: SL8(5, true); break; default: SL8(6, true); break; }
+          else switch (o->cub_dim) { case 1: SL8(1, false); break; case 2: SL8(2, false); break; case 3: SL8(3, false); break; case 4: SL8(4, false); break; case 5: SL8(5, false); break; case 6: SL8(6, false); break; default: SL8(7, false); break; }
+#undef SL8
         }
       }
     }
-    if (getenv("NAGP_STAMPS")) fprintf(stderr, "[nagp plan] ihgp ADF sweep in the sparse-point form: %d (LDS %zu B, ring %d steps, hph table in LDS %d), role-specialised waves %d (LDS %zu B)\n", p->sp_ih, p->lds_sp, p->kb_sp, p->hph_sp, p->sp_ih8, p->lds_sp8);
+    if (getenv("NAGP_STAMPS")) fprintf(stderr, "[nagp plan] ihgp ADF sweep in the sparse-point form: %d (LDS %zu B, ring %d steps, hph table in LDS %d), role-specialised waves %d (LDS %zu B), packed MFMA steps %d\n", p->sp_ih, p->lds_sp, p->kb_sp, p->hph_sp, p->sp_ih8, p->lds_sp8, p->sp_pack);
 #define SL(V) PLAN_TRY(set_lds(ihgp_filter_kernel<V, false>, p->lds_ih))
 #define SLS(V) PLAN_TRY(set_lds(ihgp_filter_kernel<V, true>, p->lds_ih))
     if (p->src_f) { NAGP_MV_SWITCH9(mom_variant(mc), SLS) } else { NAGP_MV_SWITCH9(mom_variant(mc), SL) }
@@ -1148,8 +1161,9 @@ static int exec_ihgp(nagp_plan* p) {
       if (p->sp_ih) {
         IhgpPar ia = ip; ia.hph_lds = p->hph_sp; ia.kb = p->kb_sp;
 #define LA(V) hipLaunchKernelGGL((ihgp_adf_kernel<V>), dim3(B), dim3(MSP_NT), p->lds_sp, p->stream, sh, p->b, mcf, p->sp, p->tb, ia)
-#define LA8(V) hipLaunchKernelGGL((ihgp_adf8_kernel<V>), dim3(B), dim3(MSR_NT), p->lds_sp8, p->stream, sh, p->b, mcf, p->sp, p->tb, ia)
-        if (p->sp_ih8) switch (mcf.cdim) { case 1: LA8(1); break; case 2: LA8(2); break; case 3: LA8(3); break; case 4: LA8(4); break; case 5: LA8(5); break; case 6: LA8(6); break; default: LA8(7); break; }
+#define LA8(V, PK) hipLaunchKernelGGL((ihgp_adf8_kernel<V, PK>), dim3(B), dim3(MSR_NT), p->lds_sp8, p->stream, sh, p->b, mcf, p->sp, p->tb, ia)
+        if (p->sp_ih8 && p->sp_pack) switch (mcf.cdim) { case 1: LA8(1, true); break; case 2: LA8(2, true); break; case 3: LA8(3, true); break; case 4: LA8(4, true); break; case 5: LA8(5, true); break; default: LA8(6, true); break; }
+        else if (p->sp_ih8) switch (mcf.cdim) { case 1: LA8(1, false); break; case 2: LA8(2, false); break; case 3: LA8(3, false); break; case 4: LA8(4, false); break; case 5: LA8(5, false); break; case 6: LA8(6, false); break; default: LA8(7, false); break; }
         else switch (mcf.cdim) { case 1: LA(1); break; case 2: LA(2); break; case 3: LA(3); break; case 4: LA(4); break; case 5: LA(5); break; case 6: LA(6); break; default: LA(7); break; }
 #undef LA
 #undef LA8

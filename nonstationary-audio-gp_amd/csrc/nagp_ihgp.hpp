@@ -535,7 +535,7 @@ __global__ void __launch_bounds__(MSP_NT) ihgp_adf_kernel(Shape sh, Bufs b, MomC
 // The same sweep with role-specialised waves (nagp_momsp.hpp, role layout): 512 threads, waves 0 / 1 as above, waves 2..7 run the
 // parallel stages of the cubature in their own loop.  A wave holds the registers of its role only, which is what lets two
 // waves share a SIMD (the sigma points take one round, the MFMA steps of two waves alternate on the matrix core).
-template <int CD>
+template <int CD, bool PACK>
 __global__ void __launch_bounds__(MSR_NT) ihgp_adf8_kernel(Shape sh, Bufs b, MomCfg mc, MomSp sp, IhgpTabs tb, IhgpPar ip) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int tid = threadIdx.x;
@@ -588,8 +588,8 @@ __global__ void __launch_bounds__(MSR_NT) ihgp_adf8_kernel(Shape sh, Bufs b, Mom
   if (wave >= MSR_W0) {
     // ================= worker role: the parallel stages of the cubature; the same barriers as the serial role below
     const MspLay lay = msp_layout(CD, D, 1);
-    MsrW<CD> xw;
-    msr_setup_W<CD>(xw, mc, sp, sW, fmu, HPH, ws);
+    MsrW<CD, PACK> xw;
+    msr_setup_W<CD, PACK>(xw, mc, sp, sW, fmu, HPH, ws);
   for (int64_t k0 = ip.k_start; k0 < T; k0 += KB) {
     const int nb = (T - k0 < KB) ? (int)(T - k0) : KB;
     // ---- fill the ring for steps k0 .. k0+nb-1
@@ -604,6 +604,7 @@ __global__ void __launch_bounds__(MSR_NT) ihgp_adf8_kernel(Shape sh, Bufs b, Mom
       lds_barrier();                 // B3
       msp_stage1b<CD>(xw, mc, sp, sn2a, ry[kk], ws);
       lds_barrier();                 // B4
+      if constexpr (PACK) { if (wave >= MSR_W0 + MSR_NWK - 2) msr_marginals<CD>(xw); }
       msp_stage2<CD>(xw, mc, ws);
       lds_barrier();                 // B5
     }
@@ -620,8 +621,8 @@ __global__ void __launch_bounds__(MSR_NT) ihgp_adf8_kernel(Shape sh, Bufs b, Mom
     return;
   }
   // ================= serial role (waves 0 and 1)
-  MsrS<CD> x;
-  msr_setup_S<CD>(x, mc, sp, fmu, HPH, ws);
+  MsrS<CD, PACK> x;
+  msr_setup_S<CD, PACK>(x, mc, sp, fmu, HPH, ws);
 
   // wave 0, lane d < D owns sub-band block d; wave 1, lane j < N owns modulator block D + j
   const int lane = tid & 63;

@@ -82,10 +82,13 @@
   P void nagp::ihgp_adf_kernel<7> NAGP_SIG_IHA;
 
 #define NAGP_LIST_IHA8(P)                                                                                                  \
-  P void nagp::ihgp_adf8_kernel<1> NAGP_SIG_IHA; P void nagp::ihgp_adf8_kernel<2> NAGP_SIG_IHA;                          \
-  P void nagp::ihgp_adf8_kernel<3> NAGP_SIG_IHA; P void nagp::ihgp_adf8_kernel<4> NAGP_SIG_IHA;                          \
-  P void nagp::ihgp_adf8_kernel<5> NAGP_SIG_IHA; P void nagp::ihgp_adf8_kernel<6> NAGP_SIG_IHA;                          \
-  P void nagp::ihgp_adf8_kernel<7> NAGP_SIG_IHA;
+  P void nagp::ihgp_adf8_kernel<1, false> NAGP_SIG_IHA; P void nagp::ihgp_adf8_kernel<2, false> NAGP_SIG_IHA;            \
+  P void nagp::ihgp_adf8_kernel<3, false> NAGP_SIG_IHA; P void nagp::ihgp_adf8_kernel<4, false> NAGP_SIG_IHA;            \
+  P void nagp::ihgp_adf8_kernel<5, false> NAGP_SIG_IHA; P void nagp::ihgp_adf8_kernel<6, false> NAGP_SIG_IHA;            \
+  P void nagp::ihgp_adf8_kernel<7, false> NAGP_SIG_IHA;                                                                  \
+  P void nagp::ihgp_adf8_kernel<1, true> NAGP_SIG_IHA; P void nagp::ihgp_adf8_kernel<2, true> NAGP_SIG_IHA;              \
+  P void nagp::ihgp_adf8_kernel<3, true> NAGP_SIG_IHA; P void nagp::ihgp_adf8_kernel<4, true> NAGP_SIG_IHA;              \
+  P void nagp::ihgp_adf8_kernel<5, true> NAGP_SIG_IHA; P void nagp::ihgp_adf8_kernel<6, true> NAGP_SIG_IHA;
 
 #define NAGP_LIST_ALL(P)                                                                                                   \
   NAGP_LIST_GF_ADF1(P) NAGP_LIST_GF_ADF2(P) NAGP_LIST_GF_ADF3(P) NAGP_LIST_GF_ADF4(P) NAGP_LIST_GF_ADF5(P)               \

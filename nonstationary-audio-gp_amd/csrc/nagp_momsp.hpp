@@ -39,12 +39,15 @@ typedef double __attribute__((address_space(3))) * msp_wp;
 __host__ __device__ inline int msp_qterms(int D) { return D <= 16 ? 4 : (D <= 32 ? 8 : 16); }
 
 // LDS workspace (offsets in doubles).  Tables lk | xg | xg2 | e | t1 | ve, MSP_TS entries each.
-struct MspLay { int lk, xg, xg2, e, t1, ve, one, zero, Q, Q2, v, q0, s0, c0, c1, c2, part, acc, wwt, total; };
+struct MspLay { int lk, xg, xg2, e, t1, ve, one, zero, Q, Q2, v, q0, s0, c0, c1, c2, part, acc, marg, wwt, total; };
 // LAY 0: the 256-thread layout (four waves share every stage); LAY 1: the role layout of 512 threads (nagp_ihgp.hpp:
 // two serial waves, six worker waves: six partial blocks, 96 addressable MFMA steps)
 constexpr int MSR_NWK = 6;     // worker waves of the role layout
 constexpr int MSR_NST = 20;    // MFMA steps of a worker wave that has its SIMD's matrix core to itself (the others take half)
-constexpr int MSR_CS = 4 * 4 * MSR_NST + 4 * 4 + 1;    // 80 steps, and the zero-weight steps a group of four may run over
+constexpr int MSR_NSTP = 16;   // ... in the packed form (eight points per step, four MFMA workers)
+constexpr int MSR_NMEM = 16;   // members of a marginal sum per lane (four lanes per marginal)
+constexpr int MSR_NMARG = 32;  // marginal sums (non-centre (dimension, coordinate) pairs)
+constexpr int MSR_CS = 8 * 48 + 8 * MSR_NSTP + 1;      // every point a (zero-padded) MFMA step can address
 __host__ __device__ inline MspLay msp_layout(int CD, int D, int LAY = 0) {
   MspLay l;
   const int cs = LAY ? MSR_CS : MSP_CS, nparts = LAY ? MSR_NWK : MSP_NW;
@@ -57,6 +60,7 @@ __host__ __device__ inline MspLay msp_layout(int CD, int D, int LAY = 0) {
   o = (o + 3 * cs + 1) & ~1;
   l.part = o; o += nparts * 256;
   l.acc = o; o += 128;
+  l.marg = o; o += LAY ? MSR_NMARG : 0;
   l.wwt = o; o += msp_qterms(D) * 192;            // static W products of stage A, [q][lane of waves 1..3], zero for sub-bands >= D
   l.total = o;
   return l;
@@ -79,6 +83,7 @@ __device__ __forceinline__ int opaque_zero() { int z = 0; asm volatile("" : "+v"
 template <int CD>
 struct MspCtx {
   static constexpr int NPS = MSP_NPS, NST = MSP_NST, WSTR = 4 * MSP_NW, NPART = MSP_NW, CS = MSP_CS;
+  static constexpr bool PACKED = false;
   int lw, qw;          // wave that evaluates the link tables / wave that forms q0, s0 (wave-uniform)
   // stage A / B, wave lw: lane t = j*nd + c
   double xdc; msp_rp a_mu, a_s2, a_l0[CD], a_l0own, a_qrow, a_qjj, a_v; msp_wp a_out;   // a_out[k*MSP_TS]: lk, xg, xg2, e, t1, ve
@@ -386,17 +391,18 @@ __device__ __forceinline__ void msp_stage2(const X& x, const MomCfg& c, double* 
   if (__builtin_amdgcn_readfirstlane(x.m_on) == 0) return;      // a wave outside the stage has no partial block
   const int nst = __builtin_amdgcn_readfirstlane(x.nst);
   constexpr int NST = X::NST, WS = X::WSTR;
+  constexpr bool SAMEB = X::PACKED;      // packed form: the column operand is the unweighted row operand (no second read)
   v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
   double a[4], bb[4], w[4];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) { a[u] = *x.m_a[u]; bb[u] = *x.m_b[u]; w[u] = x.m_w0[WS * u]; }
+  for (int u = 0; u < 4; ++u) { a[u] = *x.m_a[u]; bb[u] = SAMEB ? a[u] : *x.m_b[u]; w[u] = x.m_w0[WS * u]; }
 #pragma unroll
   for (int s0 = 0; s0 < NST; s0 += 4) {
     if (s0 < nst) {      // uniform; steps beyond nst inside the group of four carry zero operands
       double an[4], bn[4], wn_[4];
       if (s0 + 4 < NST) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { an[u] = *x.m_a[s0 + 4 + u]; bn[u] = *x.m_b[s0 + 4 + u]; wn_[u] = x.m_w0[WS * (s0 + 4 + u)]; }
+        for (int u = 0; u < 4; ++u) { an[u] = *x.m_a[s0 + 4 + u]; bn[u] = SAMEB ? an[u] : *x.m_b[s0 + 4 + u]; wn_[u] = x.m_w0[WS * (s0 + 4 + u)]; }
       }
       acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0] * w[0], bb[0], acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1] * w[1], bb[1], acc1, 0, 0, 0);
@@ -408,15 +414,26 @@ __device__ __forceinline__ void msp_stage2(const X& x, const MomCfg& c, double* 
       }
     }
   }
+  if constexpr (X::PACKED) {
+    // the two diagonal 8x8 blocks (points 8s+kq / 8s+4+kq) added in registers: element (8+r, 8+c) sits in lane i = c + 8 of the
+    // same 16-lane row, register 2 + r/4; the partial block that goes to LDS is 8 x 8
+    const v4d a = acc0 + acc1;
+    const double t0 = a[0] + dpp_mov<0x108>(a[2]), t1 = a[1] + dpp_mov<0x108>(a[3]);     // row_shl:8
+    if (((int)threadIdx.x & 15) < 8) { x.m_part[0] = t0; x.m_part[64] = t1; }
+  } else {
 #pragma unroll
-  for (int r = 0; r < 4; ++r) x.m_part[64 * r] = acc0[r] + acc1[r];      // element (kq + 4r, i) of the block
+    for (int r = 0; r < 4; ++r) x.m_part[64 * r] = acc0[r] + acc1[r];      // element (kq + 4r, i) of the block
+  }
 }
 
 // fixed-order sum of the partials: lanes o < msp_nacc(CD) of ONE wave; the same wave may read acc after msp_wave_fence()
 template <int CD, class X>
 __device__ __forceinline__ void msp_reduce(const X& x) {
   const int lane = threadIdx.x & 63;
-  if (lane < msp_nacc(CD)) {
+  constexpr int nq = CD * (CD + 1) / 2;
+  bool on = lane < msp_nacc(CD);
+  if constexpr (X::PACKED) on = on && !(lane >= CD + nq && lane < 3 * CD + nq);     // g1, g2 come from the marginal sums
+  if (on) {
     double a = x.r_src[0];
 #pragma unroll
     for (int w = 1; w < X::NPART; ++w) a += x.r_src[256 * w];
@@ -475,20 +492,29 @@ __device__ __forceinline__ void msp_outputs(msp_rp acc, bool sub, int jmod, cons
 constexpr int MSR_NT = 512;
 constexpr int MSR_W0 = 2;      // first worker wave
 
-template <int CD>
+// PACK (<= 6 components): an MFMA step takes EIGHT points -- rows / columns 0..7 of the block belong to points 8s+kq, rows /
+// columns 8..15 to points 8s+4+kq; A_p = [c2 lk_0.. | c1 | c0], B_p = [lk_0.. | 1], and the two diagonal 8x8 blocks are summed.
+// Half the MFMA steps; the sums over c0 xg_j and c0 xg2_j, which no longer fit the block, come from the marginal sums
+// C0(j,c) = sum of c0 over the points with coordinate c in dimension j (static member lists, two lanes of one worker wave per
+// marginal, beside the MFMA steps):  g1_j = sum_c C0(j,c) xg(j,c),  g2_j = sum_c C0(j,c) xg2(j,c),  C0(j,centre) = sum c0 - rest.
+template <int CD, bool PACK>
 struct MsrS {
   static constexpr int NPART = MSR_NWK;
+  static constexpr bool PACKED = PACK;
   int lw;
   double xdc; msp_rp a_mu, a_s2, a_l0[CD], a_l0own, a_qrow, a_qjj, a_v; msp_wp a_out;
   msp_rp r_src; msp_wp r_dst; msp_rp accp;
 };
-template <int CD>
+template <int CD, bool PACK>
 struct MsrW {
-  static constexpr int NPS = 1, NST = MSR_NST, WSTR = 4, CS = MSR_CS;
+  static constexpr int NPS = 1, NST = PACK ? MSR_NSTP : MSR_NST, WSTR = PACK ? 8 : 4, CS = MSR_CS;
+  static constexpr bool PACKED = PACK;
   int q_kind; msp_rp q_ww, q_src; msp_wp q_out0, q_out1, q_out2, q_out3;
   int b_kind; msp_rp b_p0, b_p1, b_p2;
   msp_rp p_e[1][MSP_NZ], p_q[1][6]; msp_wp p_c[1]; double p_wn[1]; bool p_ok[1]; int p_any[1];
-  msp_rp m_a[MSR_NST], m_b[MSR_NST], m_w0; msp_wp m_part; int nst, m_on;
+  msp_rp m_a[NST], m_b[NST], m_w0; msp_wp m_part; int nst, m_on;
+  msp_rp g_mem[PACK ? MSR_NMEM : 1]; msp_wp g_out;              // last worker: members of this lane's half of a marginal
+  msp_rp h_marg, h_xg, h_xg2, h_c0p; msp_wp h_acc; int h_nd, h_c0, h_nj;   // ... lane < h_nj: g1_j, g2_j of its dimension; every lane: its share of sum c0
 };
 
 // constants, zero entries of the tables, zero weights beyond the points (every thread of the workgroup)
@@ -499,8 +525,8 @@ __device__ __forceinline__ void msr_init(int CD, int D, double* ws) {
   for (int i = threadIdx.x; i < 3 * MSR_CS; i += MSR_NT) ws[l.c0 + i] = 0.0;
 }
 
-template <int CD>
-__device__ __forceinline__ void msr_setup_S(MsrS<CD>& x, const MomCfg& c, const MomSp& sp, const double* fmu, const double* HPH, double* ws) {
+template <int CD, bool PACK>
+__device__ __forceinline__ void msr_setup_S(MsrS<CD, PACK>& x, const MomCfg& c, const MomSp& sp, const double* fmu, const double* HPH, double* ws) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nd = c.nd, D = c.D, TN = CD * nd;
   const MspLay l = msp_layout(CD, D, 1);
@@ -528,6 +554,10 @@ __device__ __forceinline__ void msr_setup_S(MsrS<CD>& x, const MomCfg& c, const 
     else if (o < 2 * CD + nq) { row = 2 * CD + 1; col = CD + (o - CD - nq); }
     else if (o < 3 * CD + nq) { row = CD + 1 + (o - 2 * CD - nq); col = 2 * CD; }
     else { row = 2 * CD + 1; col = 2 * CD; }
+    if constexpr (PACK) {       // block rows [c2 lk_j | c1 | c0], columns [lk_j | 1]: u and R sit where they sat; the g1 / g2 lanes
+      if (o >= CD + nq && o < 3 * CD + nq) { row = 0; col = 7; }      // read a zero column, Z is (c0 row, column of ones)
+      else if (o >= 3 * CD + nq) { row = CD + 1; col = CD; }
+    }
     x.r_src = (msp_rp)(ws + l.part + row * 16 + col);
     const int ab = (wave == 1) ? 64 : 0;
     x.r_dst = (msp_wp)(ws + l.acc + ab + o);
@@ -535,8 +565,8 @@ __device__ __forceinline__ void msr_setup_S(MsrS<CD>& x, const MomCfg& c, const 
   }
 }
 
-template <int CD>
-__device__ __forceinline__ void msr_setup_W(MsrW<CD>& x, const MomCfg& c, const MomSp& sp, const double* Wl /* LDS D x CD */,
+template <int CD, bool PACK>
+__device__ __forceinline__ void msr_setup_W(MsrW<CD, PACK>& x, const MomCfg& c, const MomSp& sp, const double* Wl /* LDS D x CD */,
                                              const double* fmu, const double* HPH, double* ws) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave - MSR_W0;     // wr = 0 .. 5
   const int nd = c.nd, D = c.D, npt = c.n_pts;
@@ -615,36 +645,140 @@ __device__ __forceinline__ void msr_setup_W(MsrW<CD>& x, const MomCfg& c, const 
   // over one: waves w and w+4 share a SIMD, the serial waves 0 / 1 sit out this stage, hence workers 2 and 3 (waves 4, 5) have
   // a matrix core to themselves and take a double share; the steps are dealt in eight slots (the first nstep % 8 one longer).
   {
+    constexpr int PPS = PACK ? 8 : 4;                 // points per step
+    constexpr int NSTX = MsrW<CD, PACK>::NST;
     const int i = lane & 15, kq = lane >> 4;
-    const int nstep = (npt + 3) >> 2;
+    const int grp = PACK ? (i >> 3) : 0, f = PACK ? (i & 7) : i;
+    const int nstep = (npt + PPS - 1) / PPS;
     const bool on = wr >= 0 && wr < MSR_NWK;
+    // PACK: the last two workers form the marginal sums instead, on the SIMDs of workers 0 and 1 -- which therefore take one
+    // slot each, workers 2 and 3 three
     const int base = nstep >> 3, rem = nstep & 7;
     auto slot_start = [&](int sl) { return sl * base + (sl < rem ? sl : rem); };     // first step of slot sl (sl = 8: nstep)
-    const int sl0 = (wr <= 2) ? ((wr == 2) ? 2 : wr) : ((wr == 3) ? 4 : wr + 2), sl1 = (wr == 2 || wr == 3) ? sl0 + 2 : sl0 + 1;
-    const int st0 = on ? slot_start(sl0) : 0, st1 = on ? slot_start(sl1) : 0;
-    x.m_on = on ? 1 : 0;
+    int sl0, sl1;
+    if (PACK) { sl0 = (wr <= 1) ? wr : ((wr == 2) ? 2 : 5); sl1 = (wr <= 1) ? wr + 1 : ((wr == 2) ? 5 : 8); }
+    else { sl0 = (wr <= 2) ? ((wr == 2) ? 2 : wr) : ((wr == 3) ? 4 : wr + 2); sl1 = (wr == 2 || wr == 3) ? sl0 + 2 : sl0 + 1; }
+    const bool mf = on && (!PACK || wr < 4);
+    const int st0 = mf ? slot_start(sl0) : 0, st1 = mf ? slot_start(sl1) : 0;
+    x.m_on = on ? 1 : 0;            // a worker without steps still writes its (zero) partial block
     x.nst = st1 - st0;
     int wbase = l.c0;
-    if (i < CD) wbase = l.c2; else if (i == CD) wbase = l.c1;
-    x.m_w0 = (msp_rp)(ws + wbase + 4 * st0 + kq);
+    if (PACK) { if (f < CD) wbase = l.c2; else if (f == CD) wbase = l.c1; }
+    else { if (i < CD) wbase = l.c2; else if (i == CD) wbase = l.c1; }
+    x.m_w0 = (msp_rp)(ws + wbase + PPS * st0 + 4 * grp + kq);
     x.m_part = (msp_wp)(ws + l.part + (on ? wr : 0) * 256 + kq * 16 + i);
 #pragma unroll
-    for (int s_ = 0; s_ < MSR_NST; ++s_) {
-      const int p = 4 * (st0 + s_) + kq;
+    for (int s_ = 0; s_ < NSTX; ++s_) {
+      const int p = PPS * (st0 + s_) + 4 * grp + kq;
       const bool ok = on && (s_ < x.nst) && (p < npt);
       int offA = l.zero, offB = l.zero;
       if (ok) {
         const unsigned char* cp = c.code + (size_t)p * CD;
-        if (i < CD) offA = l.lk + i * nd + cp[i];
-        else if (i == CD) offA = l.one;
-        else if (i <= 2 * CD) offA = l.xg2 + (i - CD - 1) * nd + cp[i - CD - 1];
-        else if (i == 2 * CD + 1) offA = l.one;
-        if (i < CD) offB = l.lk + i * nd + cp[i];
-        else if (i < 2 * CD) offB = l.xg + (i - CD) * nd + cp[i - CD];
-        else if (i == 2 * CD) offB = l.one;
+        if constexpr (PACK) {
+          if (f < CD) { offA = l.lk + f * nd + cp[f]; offB = offA; }
+          else if (f == CD || f == CD + 1) { offA = l.one; offB = l.one; }     // (column CD+1 duplicates the column of ones: unused sums)
+        } else {
+          if (i < CD) offA = l.lk + i * nd + cp[i];
+          else if (i == CD) offA = l.one;
+          else if (i <= 2 * CD) offA = l.xg2 + (i - CD - 1) * nd + cp[i - CD - 1];
+          else if (i == 2 * CD + 1) offA = l.one;
+          if (i < CD) offB = l.lk + i * nd + cp[i];
+          else if (i < 2 * CD) offB = l.xg + (i - CD) * nd + cp[i - CD];
+          else if (i == 2 * CD) offB = l.one;
+        }
       }
       x.m_a[s_] = (msp_rp)(ws + offA); x.m_b[s_] = (msp_rp)(ws + offB);
     }
+  }
+  // ---- marginal sums (PACK): workers 4 and 5 take the dimensions below / from jsplit; lane = 4 * (local marginal) + quarter,
+  // the members of a marginal go round its four lanes
+  x.g_out = (msp_wp)(ws + l.acc + 127);
+  if constexpr (PACK) {
+    const msp_rp zero = (msp_rp)(ws + l.zero);
+    const int jsplit = (CD + 1) / 2;
+    const int jlo = (wr == MSR_NWK - 2) ? 0 : jsplit, jhi = (wr == MSR_NWK - 2) ? jsplit : CD;
+    const int ml = lane >> 2, quarter = lane & 3;
+    const int jj = jlo + ml / (nd - 1), cc = ml % (nd - 1);
+    const bool valid = (wr >= MSR_NWK - 2) && jj < jhi;
+    const int j = valid ? jj : 0;
+    const int code = (cc < sp.c0) ? cc : cc + 1;
+    if (valid && quarter == 0) x.g_out = (msp_wp)(ws + l.marg + j * (nd - 1) + cc);
+    {   // g1_j, g2_j of modulator j = jlo + lane, written into the copy of the reduced sums that wave 1 (the modulator sites) reads
+      const int nq = CD * (CD + 1) / 2;
+      const int jm = (jlo + lane < jhi) ? jlo + lane : 0;
+      x.h_nd = nd; x.h_c0 = sp.c0; x.h_nj = (wr >= MSR_NWK - 2) ? jhi - jlo : 0;
+      x.h_marg = (msp_rp)(ws + l.marg + jm * (nd - 1));
+      x.h_xg = (msp_rp)(ws + l.xg + jm * nd);
+      x.h_xg2 = (msp_rp)(ws + l.xg2 + jm * nd);
+      x.h_acc = (msp_wp)(ws + l.acc + 64 + CD + nq + jm);
+      x.h_c0p = (msp_rp)(ws + l.c0 + lane);
+    }
+    int pos = 0, cnt = 0;
+#pragma unroll
+    for (int k = 0; k < MSR_NMEM; ++k) {
+      int found = -1;
+      while (valid && pos < npt && found < 0) {
+        if (c.code[(size_t)pos * CD + j] == code) {
+          if ((cnt & 3) == quarter) found = pos;
+          ++cnt;
+        }
+        ++pos;
+      }
+      x.g_mem[k] = (found >= 0) ? (msp_rp)(ws + l.c0 + found) : zero;
+    }
+  }
+}
+
+// marginal sums of c0, then g1_j, g2_j of this wave's dimensions (workers 4 and 5, beside the MFMA steps of the others;
+// after the barrier behind stage 1b)
+template <int CD, class X>
+__device__ __forceinline__ void msr_marginals(const X& x) {
+  const int lane = threadIdx.x & 63;
+  const int nd = __builtin_amdgcn_readfirstlane(x.h_nd), c0 = __builtin_amdgcn_readfirstlane(x.h_c0);
+  // everything that does not depend on the marginals first (one LDS round trip): members, this lane's share of sum c0, the
+  // table values of the g1 / g2 lanes (the other lanes read dimension 0's)
+  double mem[MSR_NMEM];
+#pragma unroll
+  for (int k = 0; k < MSR_NMEM; ++k) mem[k] = *x.g_mem[k];
+  const double z0 = x.h_c0p[0] + x.h_c0p[64], z1 = x.h_c0p[128] + x.h_c0p[192], z2 = x.h_c0p[256] + x.h_c0p[320];
+  const bool small = nd <= 5;
+  double a[4], b[4];
+#pragma unroll
+  for (int cc = 0; cc < 4; ++cc) {
+    const int ci = (cc < nd - 1) ? cc : 0;
+    const int code = (ci < c0) ? ci : ci + 1;
+    a[cc] = x.h_xg[code]; b[cc] = x.h_xg2[code];
+  }
+  const double bc = x.h_xg2[c0];
+  double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+  for (int k = 0; k < MSR_NMEM; k += 2) { s0 += mem[k]; s1 += mem[k + 1]; }
+  double s_ = s0 + s1;
+  s_ += dpp_mov<0xB1>(s_);
+  s_ += dpp_mov<0x4E>(s_);            // the four lanes of the marginal
+  *x.g_out = s_;                      // lanes other than the first of a marginal: scratch slot
+  const double zraw = wave_sum((z0 + z1) + z2);      // the weights beyond n_pts are zero; MSR_CS >= 384
+  msp_wave_fence();
+  if (lane < __builtin_amdgcn_readfirstlane(x.h_nj)) {
+    double g1 = 0.0, g2 = 0.0, ms = 0.0;
+    if (small) {
+      double m[4];
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) m[cc] = x.h_marg[(cc < nd - 1) ? cc : 0];
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        const double mm = (cc < nd - 1) ? m[cc] : 0.0;
+        g1 = fma(mm, a[cc], g1); g2 = fma(mm, b[cc], g2); ms += mm;
+      }
+    } else {
+      for (int cc = 0; cc < nd - 1; ++cc) {
+        const int code = (cc < c0) ? cc : cc + 1;
+        const double mm = x.h_marg[cc];
+        g1 = fma(mm, x.h_xg[code], g1); g2 = fma(mm, x.h_xg2[code], g2); ms += mm;
+      }
+    }
+    g2 = fma(zraw - ms, bc, g2);      // xg of the centre coordinate is zero
+    x.h_acc[0] = g1; x.h_acc[CD] = g2;
   }
 }
 

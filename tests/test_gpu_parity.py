@@ -744,22 +744,23 @@ def test_sparse_point_cubature_equals_the_generic_form_and_the_oracle(fn, shape,
     f = nagp.ihgp_ep_modulator_nmf if fn == 'ihgp' else nagp.gf_ep_modulator_nmf
     of = oih.ihgp_ep_modulator_nmf if fn == 'ihgp' else ogf.gf_ep_modulator_nmf
     res = {}
-    modes = ('generic', 'sparse', 'sparse4') if fn == 'ihgp' else ('generic', 'sparse')
-    for mode in modes:      # sparse: IHGP runs the role-specialised 512-thread kernel; sparse4: the four-wave kernel (NAGP_IH_ROLES=0)
-        if mode == 'generic':
-            monkeypatch.setenv('NAGP_NO_SPARSE', '1')
-        else:
-            monkeypatch.delenv('NAGP_NO_SPARSE', raising=False)
-        if mode == 'sparse4':
-            monkeypatch.setenv('NAGP_IH_ROLES', '0')
-        else:
-            monkeypatch.delenv('NAGP_IH_ROLES', raising=False)
+    modes = ('generic', 'sparse', 'sparse16', 'sparse4') if fn == 'ihgp' else ('generic', 'sparse')
+    # sparse: IHGP runs the role-specialised 512-thread kernel, eight points per MFMA step where the rule allows it;
+    # sparse16: the same with four points per step (NAGP_IH_PACK=0); sparse4: the four-wave kernel (NAGP_IH_ROLES=0)
+    for mode in modes:
+        for k_ in ('NAGP_NO_SPARSE', 'NAGP_IH_ROLES', 'NAGP_IH_PACK'):
+            monkeypatch.delenv(k_, raising=False)
+        if mode == 'generic': monkeypatch.setenv('NAGP_NO_SPARSE', '1')
+        if mode == 'sparse4': monkeypatch.setenv('NAGP_IH_ROLES', '0')
+        if mode == 'sparse16': monkeypatch.setenv('NAGP_IH_PACK', '0')
         res[mode] = f(pr['w'], t, y, SSHandle(), mom, t, 'matern32', 'matern52', 1, D, N, 0.5, d, 1, nargout=6)
-    monkeypatch.delenv('NAGP_IH_ROLES', raising=False)
+    for k_ in ('NAGP_NO_SPARSE', 'NAGP_IH_ROLES', 'NAGP_IH_PACK'):
+        monkeypatch.delenv(k_, raising=False)
     ref = of(pr['w'], t, y, None, olik.Mom(olik.LIK_POWER_NMF, p=p), t, 'matern32', 'matern52', 1, D, N, 0.5, d, 1)
     if fn == 'ihgp':
-        a, b = res['sparse4'], res['sparse']
-        assert rel(a[0], b[0]) < 1e-10 and rel(a[5]['ttau'], b[5]['ttau']) < 1e-9 and relz(a[5]['nlZ'], b[5]['nlZ']) < 1e-12
+        for other in ('sparse4', 'sparse16'):
+            a, b = res[other], res['sparse']
+            assert rel(a[0], b[0]) < 1e-10 and rel(a[5]['ttau'], b[5]['ttau']) < 1e-9 and relz(a[5]['nlZ'], b[5]['nlZ']) < 1e-12, other
     for mode in modes:
         Eft, Varft, out = res[mode][0], res[mode][1], res[mode][5]
         assert rel(Eft, ref[0]) < TOL_MEAN and relz(out['nlZ'], ref[5]['nlZ']) < TOL_LOGZ, mode

@@ -1009,6 +1009,30 @@ def test_column_owner_mfma_smoother_against_valu_passes_and_oracle(D, N, k1):
     assert relz(res['big'][1].nlZ, ref['nlZ']) < TOL_LOGZ
 
 
+def test_column_owner_passes_with_smoothed_covariances_requested_and_plan_reuse():
+    """A plan that stores the smoothed covariances runs the last sweep through the VALU passes (tile-major chunk buffer) and the
+    earlier ones through the MFMA passes (dense buffer with zero padding rows): executing it twice must give the same result
+    (the buffer is zeroed when the layout switches back), equal to the all-VALU plan within rounding."""
+    D, N, T = 26, 4, 50                     # 30 sites -> Sp = 128, 8 rows of padding
+    pr = harness.nmf_problem(D, N, T, 8200, 'constraints')
+    blk = pss.balance_blocks(pss.ss_blocks_nmf(pr['param1'], pr['param2'], 'matern32', 'matern52'))
+    assert 16 * ((4 * blk.M + 15) // 16) == 128 and 4 * blk.M < 128
+    mom = Mom('likModulatorNMFPower', p_cubature=3); d = np.array([0.6, 0.5, 0.5])
+    prob = [(blk, pr['W'], np.log(pr['w_lik']))]
+    plan = Plan(L.KIND_GF_EP, prob, T, mom=mom, ep_fraction=0.5, ep_damping=d, ep_itts=3, chunk=20, flags=L.FLAG_WANT_PS)
+    plan.upload([pr['y']]); plan.execute(); first = plan.download(want_PS=True)[0]
+    plan.execute(); second = plan.download(want_PS=True)[0]; plan.close()
+    for f in ('Eft', 'Varft', 'MS', 'PS', 'ttau', 'lZ', 'nlZ'):
+        assert np.array_equal(getattr(first, f), getattr(second, f), equal_nan=True), f
+    os.environ['NAGP_NO_MFMA_BIG'] = '1'
+    try:
+        ref = Plan(L.KIND_GF_EP, prob, T, mom=mom, ep_fraction=0.5, ep_damping=d, ep_itts=3, chunk=20, flags=L.FLAG_WANT_PS)
+        ref.upload([pr['y']]); ref.execute(); v = ref.download(want_PS=True)[0]; ref.close()
+    finally:
+        os.environ.pop('NAGP_NO_MFMA_BIG', None)
+    assert rel(first.PS, v.PS) < 1e-8 and rel(first.MS, v.MS) < 1e-8 and rel(first.Eft, v.Eft) < 1e-8 and relz(first.nlZ, v.nlZ) < 1e-9
+
+
 def test_eight_segments_at_S146_equal_their_single_problem_plans():
     """configs[4] as the bench runs it (several 32-channel / 6-component segments in one plan, three tiles per thread, the VALU
     smoother passes with eight problems per launch): every segment of the 8-segment plan equals the plan of that segment alone."""

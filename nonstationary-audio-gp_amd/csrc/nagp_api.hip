@@ -59,6 +59,7 @@ struct nagp_plan {
   SpanPar spar{};
   int mfma_sp = 0;      // > 0: FP64-MFMA smoother passes on dense Sp x Sp matrices
   int big_sp = 0;       // 1: Sp > 96, the column-owner kernels of nagp_mfma_big.hpp
+  int gain768 = 0;      // rts_gain_kernel<2, 768>: 1025..1536 tiles with a lower triangle of <= 768 tiles
   bool gbuf_tiled = false;   // the chunk buffer last held tile-major matrices: zero it before the next dense use (padding rows)
   size_t gbuf_doubles = 0;
   MfmaPar mpar{};
@@ -715,6 +716,10 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
 #undef SL4
 #undef SL5
     }
+    if (nt > 1024 && nt <= 1536 && sh.M * (sh.M + 1) / 2 <= 768 && sh.S <= 768 && !getenv("NAGP_NO_GAIN768")) {
+      p->gain768 = 1;
+      PLAN_TRY(set_lds(rts_gain_kernel<2, 768>, p->lds_gain));
+    }
     switch (p->TPT) {
       case 1: PLAN_TRY(set_lds(rts_gain_kernel<1>, p->lds_gain)); PLAN_TRY(set_lds(rts_compose_kernel<1>, p->lds_scan)); PLAN_TRY(set_lds(rts_boundary_kernel<1>, p->lds_scan)); PLAN_TRY(set_lds(rts_apply_kernel<1>, p->lds_scan)); break;
       case 2: PLAN_TRY(set_lds(rts_gain_kernel<2>, p->lds_gain)); PLAN_TRY(set_lds(rts_compose_kernel<2>, p->lds_scan)); PLAN_TRY(set_lds(rts_boundary_kernel<2>, p->lds_scan)); PLAN_TRY(set_lds(rts_apply_kernel<2>, p->lds_scan)); break;
@@ -873,7 +878,8 @@ static int launch_smoother(nagp_plan* p, bool write_PSs) {
     {
       Timed t(p, NAGP_K_GAIN);
       dim3 g(nk, p->B), bl(p->NT);
-      switch (p->TPT) {
+      if (p->gain768) hipLaunchKernelGGL((rts_gain_kernel<2, 768>), g, dim3(768), p->lds_gain, p->stream, sh, p->b, gp);
+      else switch (p->TPT) {
         case 1: hipLaunchKernelGGL((rts_gain_kernel<1>), g, bl, p->lds_gain, p->stream, sh, p->b, gp); break;
         case 2: hipLaunchKernelGGL((rts_gain_kernel<2>), g, bl, p->lds_gain, p->stream, sh, p->b, gp); break;
         case 3: hipLaunchKernelGGL((rts_gain_kernel<3>), g, bl, p->lds_gain, p->stream, sh, p->b, gp); break;

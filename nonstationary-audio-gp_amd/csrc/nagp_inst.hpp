@@ -44,6 +44,7 @@
   P void nagp::rts_boundary_mfma_kernel<NTL>(nagp::Shape, nagp::Bufs, nagp::MfmaPar);                                    \
   P void nagp::rts_apply_mfma_kernel<NTL>(nagp::Shape, nagp::Bufs, nagp::MfmaPar);
 #define NAGP_LIST_SMOOTH(P)                                                                                                \
+  P void nagp::rts_gain_kernel<2, 768>(nagp::Shape, nagp::Bufs, nagp::GainPar);                                         \
   NAGP_LIST_SMOOTH_T(P, 1) NAGP_LIST_SMOOTH_T(P, 2) NAGP_LIST_SMOOTH_T(P, 3) NAGP_LIST_SMOOTH_T(P, 4)                    \
   NAGP_LIST_SMOOTH_M(P, 1) NAGP_LIST_SMOOTH_M(P, 2) NAGP_LIST_SMOOTH_M(P, 3) NAGP_LIST_SMOOTH_M(P, 4)                    \
   NAGP_LIST_SMOOTH_M(P, 5) NAGP_LIST_SMOOTH_M(P, 6)

@@ -701,8 +701,10 @@ __device__ __forceinline__ void tile_solve_L(double* t, const double* L) {
 
 // one tile per thread: capped at 128 VGPRs (four waves per SIMD; measured best of 2..6) so that two workgroups share a CU -- the kernel is a chain of ~3M short
 // barrier-separated phases and lives on latency hiding across workgroups
-template <int TPT>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(TPT == 1 ? 4 : 2))) rts_gain_kernel(Shape sh, Bufs b, GainPar gp) {
+// LB = 768 (two tiles of B and ONE of the lower triangle per thread, 168 registers): the shapes with 1025 .. 1536 tiles whose lower
+// triangle fits 768 threads (32-channel / 6-component: 1444 and 741) -- three tiles per thread under the 512 bound spill ~280 registers
+template <int TPT, int LB = 512>
+__global__ void __launch_bounds__(LB) __attribute__((amdgpu_waves_per_eu(LB > 512 ? 3 : (TPT == 1 ? 4 : 2)))) rts_gain_kernel(Shape sh, Bufs b, GainPar gp) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int tid = threadIdx.x, NT = blockDim.x;
   const int S = sh.S, M = sh.M;
@@ -728,8 +730,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(TPT ==
   // B = PS A' (all M x M tiles; becomes X, then G) and PSkp = A B + Q (symmetric: only the lower tiles are factored; becomes L).
   // Three or four tiles per thread (SPLIT): the lower triangle has its own owners, TPL tiles per thread instead of one PSkp tile
   // beside every B tile.  One or two tiles per thread: the owner of B(I,J) also holds PSkp(I,J).
-  constexpr bool SPLIT = TPT >= 3;
-  constexpr int TPL = SPLIT ? (TPT + 2) / 2 : TPT;
+  constexpr bool SPLIT = TPT >= 3 || LB > 512;
+  constexpr int TPL = SPLIT ? (LB > 512 ? 1 : (TPT + 2) / 2) : TPT;
   TileOwner<TPT> own;
   own.init(M, sh.ntiles);
   struct { int I[TPL], J[TPL]; bool ok[TPL]; } low;

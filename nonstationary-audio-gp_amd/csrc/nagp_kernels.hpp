@@ -721,31 +721,34 @@ __global__ void __launch_bounds__(LB) __attribute__((amdgpu_waves_per_eu(LB > 51
   double* bufP = bufX + 2 * (size_t)M * TS;    // [2][M][TS]
   int* flag = reinterpret_cast<int*>(bufP + 2 * (size_t)M * TS);
 
-  for (int i = tid; i <= M; i += NT) ioff[i] = sh.off[i];
-  for (int i = tid; i < M; i += NT) ibsz[i] = sh.bsz[i];
-  for (int i = tid; i < M * 16; i += NT) sA[i] = mdl[mdl_A(sh) + i];
-  if (tid == 0) { flag[0] = 0; flag[1] = 0; }
-  lds_barrier();
-
   // B = PS A' (all M x M tiles; becomes X, then G) and PSkp = A B + Q (symmetric: only the lower tiles are factored; becomes L).
   // Three or four tiles per thread (SPLIT): the lower triangle has its own owners, TPL tiles per thread instead of one PSkp tile
   // beside every B tile.  One or two tiles per thread: the owner of B(I,J) also holds PSkp(I,J).
   constexpr bool SPLIT = TPT >= 3 || LB > 512;
   constexpr int TPL = SPLIT ? (LB > 512 ? 1 : (TPT + 2) / 2) : TPT;
+  // COLUMN-major ownership (tile t = J*M + I): the phases of block column jb touch the tiles of one column (the solves) or of the
+  // columns behind it (the trailing updates) -- consecutive threads, so whole waves skip a phase they have no tile in.  With the
+  // row-major order of the span kernels every wave executed every phase for one or two active lanes.
   TileOwner<TPT> own;
-  own.init(M, sh.ntiles);
+#pragma unroll
+  for (int q = 0; q < TPT; ++q) {
+    const int t = tid + q * NT;
+    own.ok[q] = t < sh.ntiles;
+    const int tt_ = own.ok[q] ? t : 0;
+    own.J[q] = tt_ / M; own.I[q] = tt_ - own.J[q] * M;
+  }
   struct { int I[TPL], J[TPL]; bool ok[TPL]; } low;
 #pragma unroll
   for (int q = 0; q < TPL; ++q) {
     if constexpr (SPLIT) {
+      // lower triangle, column by column: column J holds rows J .. M-1 and starts at J*M - J(J-1)/2
       const int nlow = M * (M + 1) / 2;
       const int t = tid + q * NT;
       low.ok[q] = t < nlow;
       const int tt_ = low.ok[q] ? t : 0;
-      int I = (int)((sqrt(8.0 * tt_ + 1.0) - 1.0) * 0.5);
-      while ((I + 1) * (I + 2) / 2 <= tt_) ++I;
-      while (I * (I + 1) / 2 > tt_) --I;
-      low.I[q] = I; low.J[q] = tt_ - I * (I + 1) / 2;
+      int J = 0;
+      while (J + 1 < M && (J + 1) * M - (J + 1) * J / 2 <= tt_) ++J;
+      low.J[q] = J; low.I[q] = J + (tt_ - (J * M - J * (J - 1) / 2));
     } else {
       low.I[q] = own.I[q]; low.J[q] = own.J[q]; low.ok[q] = own.ok[q] && own.I[q] >= own.J[q];
     }
@@ -789,15 +792,34 @@ __global__ void __launch_bounds__(LB) __attribute__((amdgpu_waves_per_eu(LB > 51
     }
   };
 
+  // The raw tiles first: PS_k for B, PS_{k+1} where PSkp will live (Delta = PS_{k+1} - PSkp).
+  // Their global latency runs beside the LDS fill and its barrier instead of in front of every product.
   double Bt[TPT][16], Lt[TPL][16];
-  // (the lower-triangle owners first: their temporaries are dead before the B tiles come to life)
+  // (one or two tiles per thread only: with separate lower-triangle owners the early loads cost more in spilled registers than the
+  // latency they hide -- measured at the 32-channel shape)
+  constexpr bool HOIST = !SPLIT;
+#pragma unroll
+  for (int q = 0; q < TPT; ++q) {
+    tile_zero(Bt[q]);
+    if (HOIST && own.ok[q]) pf_load(Bt[q], PFk, own.I[q], own.J[q]);
+  }
+#pragma unroll
+  for (int q = 0; q < TPL; ++q) {
+    tile_zero(Lt[q]);
+    if (HOIST && own.ok[q]) pf_load(Lt[q], PFk1, own.I[q], own.J[q]);
+  }
+  for (int i = tid; i <= M; i += NT) ioff[i] = sh.off[i];
+  for (int i = tid; i < M; i += NT) ibsz[i] = sh.bsz[i];
+  for (int i = tid; i < M * 16; i += NT) sA[i] = mdl[mdl_A(sh) + i];
+  if (tid == 0) { flag[0] = 0; flag[1] = 0; }
+  lds_barrier();
+
   if constexpr (SPLIT) {
 #pragma unroll
-    for (int q = 0; q < TPL; ++q) {
-      tile_zero(Lt[q]);
+    for (int q = 0; q < TPL; ++q)
       if (low.ok[q]) {
         const int I = low.I[q], J = low.J[q];
-        pskp_tile(Lt[q], I, J, false);                            // PSkp = A B (+Q)
+        pskp_tile(Lt[q], I, J, false);                            // PSkp = A (PS A') (+Q)
         double d[16];
         pf_load(d, PFk1, I, J);
 #pragma unroll
@@ -812,28 +834,32 @@ __global__ void __launch_bounds__(LB) __attribute__((amdgpu_waves_per_eu(LB > 51
           put_tile(Dout, J, I, dt);
         }
       }
-    }
   }
 #pragma unroll
   for (int q = 0; q < TPT; ++q) {
-    tile_zero(Bt[q]);
-    if constexpr (!SPLIT) tile_zero(Lt[q]);
     if (own.ok[q]) {
       const int I = own.I[q], J = own.J[q];
       double ps[16];
-      pf_load(ps, PFk, I, J);
+      if constexpr (HOIST) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) ps[e] = Bt[q][e];
+        tile_zero(Bt[q]);
+      } else {
+        pf_load(ps, PFk, I, J);
+      }
       tile_mma_nt(Bt[q], ps, sA + (size_t)J * 16);          // B = PS A'
       if constexpr (!SPLIT) {
-        tile_mma(Lt[q], sA + (size_t)I * 16, Bt[q]);        // PSkp = A B (+Q)
+        double pk[16];
+        tile_zero(pk);
+        tile_mma(pk, sA + (size_t)I * 16, Bt[q]);           // PSkp = A B (+Q)
         if (I == J) {
           const double* Qb = mdl + mdl_Q(sh) + (size_t)I * 16;
 #pragma unroll
-          for (int e = 0; e < 16; ++e) Lt[q][e] += Qb[e];
+          for (int e = 0; e < 16; ++e) pk[e] += Qb[e];
         }
         double d[16];
-        pf_load(d, PFk1, I, J);
 #pragma unroll
-        for (int e = 0; e < 16; ++e) d[e] -= Lt[q][e];
+        for (int e = 0; e < 16; ++e) { d[e] = Lt[q][e] - pk[e]; Lt[q][e] = pk[e]; }
         put_tile(Dout, I, J, d);                            // Delta_k
       }
     }

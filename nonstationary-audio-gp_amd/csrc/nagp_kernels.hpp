@@ -125,7 +125,7 @@ struct TileOwner {
 __host__ __device__ inline size_t filter_ring_doubles(const Shape& s, int kb) { return (size_t)kb * (5 * s.M + s.S + 3); }
 __host__ __device__ inline size_t filter_lds_doubles(const Shape& s, const MomCfg& mc, int meas, int kb) {
   size_t n = LDS_INT_DOUBLES + 2 * (size_t)s.M * TS + s.M + (size_t)s.D * s.N + s.S + 4 * (size_t)s.M * s.M +
-             6 * (size_t)s.M + 2 * 68 + 8 + filter_ring_doubles(s, kb);
+             6 * (size_t)s.M + 2 * 68 + 8 + 2 /* the W panel starts on a 16-byte boundary */ + filter_ring_doubles(s, kb);
   // mom workspace: the staged sparse-point form when the plan enabled it, else the generic one
   const size_t wmom = (mc.sp.enabled && mc.cdim <= MSP_MAXCD) ? msp_lds_doubles(mc.cdim, s.D) : mom_lds_doubles(mc);
   n += (meas == 0) ? wmom : (size_t)(s.M + 2 * s.S + 2 * s.N);

@@ -447,6 +447,20 @@ def test_ekf_with_two_tiles_per_thread_S146():
     assert rel(r[0], o[0]) < TOL_MEAN and rel(r[1], o[1]) < TOL_MEAN
 
 
+def test_ekf_two_state_blocks_odd_lds_offset():
+    """gf_giekf_modulator_nmf with 2-state blocks only (cos x exp sub-bands, Matern-3/2 modulators; 11 sites, 22 states): the
+    arrays in front of the W panel of the filter kernel add up to an odd number of doubles, the panel moves to the next 16-byte
+    boundary and the EKF workspace behind it is used to its last element (found by a fresh-seed run of tools/gpu_fuzz.py:
+    the LDS size did not count the alignment pad and the last gain entry fell off the allocation)."""
+    D, N, T = 7, 4, 62
+    pr = harness.nmf_problem(D, N, T, 4242); t = np.arange(1, T + 1.0)
+    y = pr['y'].copy(); y[[5, 30, 31]] = np.nan
+    for g_iter in (1, 3):
+        r = nagp.gf_giekf_modulator_nmf(pr['w'], t, y, SSHandle(), None, t, 'exp', 'matern32', 1, D, N, g_iter, 2, nargout=2)
+        o = oek.gf_giekf_modulator_nmf(pr['w'], t, y, None, None, t, 'exp', 'matern32', 1, D, N, g_iter, 2)
+        assert rel(r[0], o[0]) < TOL_MEAN and rel(r[1], o[1]) < TOL_MEAN, g_iter
+
+
 def test_full_length_cfg2_prefix_property_and_finiteness():
     """BASELINE size (T = 84 010, S = 73) through a size-independent property: with one sweep the sites of
     step k depend only on y(1..k), so the first 1500 columns must equal the truncated golden run's filter

@@ -447,6 +447,31 @@ def test_ekf_with_two_tiles_per_thread_S146():
     assert rel(r[0], o[0]) < TOL_MEAN and rel(r[1], o[1]) < TOL_MEAN
 
 
+def test_ihgp_adf_sites_of_underflow_size():
+    """Draw 8 of seed 99 of tools/gpu_fuzz.py (7 channels / 6 components, p = 7): from step 27 on the likelihood underflows, the sites
+    are denormal (ttau ~ 6e-310), R = 1/ttau overflows to inf while ys = tnu/ttau stays finite.  The reciprocal-based tail of the
+    staged IHGP ADF kernels multiplied a denormal by inf there (NaN); the reference's own divisions give gain 0.  All three kernel
+    forms against the oracle."""
+    fz = _fuzz_module()
+    rng = np.random.default_rng(99)
+    for _ in range(9):
+        c = fz.draw(rng)
+    D, N, T, k1, k2, alpha, damp, pr = (c[k] for k in ('D', 'N', 'T', 'k1', 'k2', 'alpha', 'damp', 'pr'))
+    t = np.arange(1, T + 1.0); mom, omom = fz.moms(c)
+    o = oih.ihgp_ep_modulator_nmf(pr['w'], t, pr['y'], None, omom, t, k1, k2, 1, D, N, alpha, damp[:1], 1)
+    assert np.nanmin(np.abs(o[5]['ttau'][o[5]['ttau'] != 0])) < 1e-300          # the case is what it claims to be
+    for env in ({}, {'NAGP_IH_PACK': '0'}, {'NAGP_IH_ROLES': '0'}):
+        for k_ in ('NAGP_IH_PACK', 'NAGP_IH_ROLES'):
+            os.environ.pop(k_, None)
+        os.environ.update(env)
+        try:
+            r = nagp.ihgp_ep_modulator_nmf(pr['w'], t, pr['y'], SSHandle(), mom, t, k1, k2, 1, D, N, alpha, damp[:1], 1, nargout=6)
+        finally:
+            for k_ in env: os.environ.pop(k_, None)
+        assert rel(r[0], o[0]) < TOL_MEAN and rel(r[1], o[1]) < TOL_MEAN and relz(r[5]['nlZ'], o[5]['nlZ']) < TOL_LOGZ, env
+        assert not np.any(np.isnan(r[5]['tnu'])), env
+
+
 def test_ekf_two_state_blocks_odd_lds_offset():
     """gf_giekf_modulator_nmf with 2-state blocks only (cos x exp sub-bands, Matern-3/2 modulators; 11 sites, 22 states): the
     arrays in front of the W panel of the filter kernel add up to an odd number of doubles, the panel moves to the next 16-byte

@@ -496,8 +496,12 @@ __global__ void __launch_bounds__(MSP_NT) ihgp_adf_kernel(Shape sh, Bufs b, MomC
           // (for tnew > 0 the reference's R(:,k) = 1./ttau before the clamp is this value; otherwise :287 overwrites it with Inf)
           double g = 0.0;
           if (tnew == 0.0) Rn = INFINITY;
-          else if (Rn < 1e300) g = fma(nnew, Rn, -fmun) * rcp_nr(hph + Rn);     // (ys - fmu)/(HPH + R), ys = tnu/ttau (:277, :289-292)
-          else g = (nnew / tnew - fmun) / (hph + Rn);      // ttau of underflow size (1/ttau overflows): the reference's own divisions
+          else g = fma(nnew, Rn, -fmun) * rcp_nr(hph + Rn);                // (ys - fmu)/(HPH + R), ys = tnu/ttau (:277, :289-292)
+          // ttau of underflow size: 1/ttau overflows, ys = tnu/ttau stays finite -- the reference's own divisions (gain 0), behind a
+          // wave-uniform branch that the common case skips
+          if (__builtin_amdgcn_ballot_w64(tnew != 0.0 && !(Rn < 1e300)) != 0) {
+            if (tnew != 0.0 && !(Rn < 1e300)) g = (nnew / tnew - fmun) / (hph + Rn);
+          }
           typedef double d2v __attribute__((ext_vector_type(2)));
           d2v m01, m23;
           mreg[0] = fma(wc[0], g, Am[0]); mreg[1] = fma(wc[1], g, Am[1]); mreg[2] = fma(wc[2], g, Am[2]); mreg[3] = fma(wc[3], g, Am[3]);
@@ -742,8 +746,12 @@ __global__ void __launch_bounds__(MSR_NT) ihgp_adf8_kernel(Shape sh, Bufs b, Mom
           // (for tnew > 0 the reference's R(:,k) = 1./ttau before the clamp is this value; otherwise :287 overwrites it with Inf)
           double g = 0.0;
           if (tnew == 0.0) Rn = INFINITY;
-          else if (Rn < 1e300) g = fma(nnew, Rn, -fmun) * rcp_nr(hph + Rn);     // (ys - fmu)/(HPH + R), ys = tnu/ttau (:277, :289-292)
-          else g = (nnew / tnew - fmun) / (hph + Rn);      // ttau of underflow size (1/ttau overflows): the reference's own divisions
+          else g = fma(nnew, Rn, -fmun) * rcp_nr(hph + Rn);                // (ys - fmu)/(HPH + R), ys = tnu/ttau (:277, :289-292)
+          // ttau of underflow size: 1/ttau overflows, ys = tnu/ttau stays finite -- the reference's own divisions (gain 0), behind a
+          // wave-uniform branch that the common case skips
+          if (__builtin_amdgcn_ballot_w64(tnew != 0.0 && !(Rn < 1e300)) != 0) {
+            if (tnew != 0.0 && !(Rn < 1e300)) g = (nnew / tnew - fmun) / (hph + Rn);
+          }
           typedef double d2v __attribute__((ext_vector_type(2)));
           d2v m01, m23;
           mreg[0] = fma(wc[0], g, Am[0]); mreg[1] = fma(wc[1], g, Am[1]); mreg[2] = fma(wc[2], g, Am[2]); mreg[3] = fma(wc[3], g, Am[3]);

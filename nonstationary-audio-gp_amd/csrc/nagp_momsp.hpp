@@ -69,11 +69,12 @@ __host__ __device__ inline size_t msp_lds_doubles(int CD, int D, int LAY = 0) { 
 __host__ __device__ inline int msp_nacc(int CD) { return CD + CD * (CD + 1) / 2 + 2 * CD + 1; }   // u, R (upper), g1, g2, Z
 
 // 1/x by the hardware estimate and two Newton steps (~1 ulp)
+// (x = 0, inf or of underflow size: the refinement is NaN -- callers on such values branch to true divisions)
 __device__ __forceinline__ double rcp_nr(double x) {
-  const double r0 = __builtin_amdgcn_rcp(x);
-  double e = fma(-x, r0, 1.0), r = fma(r0, e, r0);
+  double r = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, r, 1.0); r = fma(r, e, r);
   e = fma(-x, r, 1.0); r = fma(r, e, r);
-  return (r == r) ? r : r0;         // x = 0, inf or of underflow size: the refinement is NaN, the estimate (inf, 0, inf) is 1/x
+  return r;
 }
 // a zero the compiler cannot see through: added to a wave-uniform LDS address it keeps the address in ONE vector register
 // (uniform addresses are otherwise materialised one scalar register per constant offset, and spilled)

@@ -494,14 +494,10 @@ __global__ void __launch_bounds__(MSP_NT) ihgp_adf_kernel(Shape sh, Bufs b, MomC
           tnew = max0(tnew);                                               // :274 (NaN -> 0, C-3)
           double Rn = 1.0 / tnew;                                          // R = 1/ttau: the look-up key and an output, exact division
           // (for tnew > 0 the reference's R(:,k) = 1./ttau before the clamp is this value; otherwise :287 overwrites it with Inf)
+          // R = inf: ttau = 0, or ttau of underflow size (1/ttau overflows while ys = tnu/ttau stays finite): the reference's
+          // (ys - fmu)/(HPH + R) is 0 there; the reciprocal form below would multiply inf by 0
           double g = 0.0;
-          if (tnew == 0.0) Rn = INFINITY;
-          else g = fma(nnew, Rn, -fmun) * rcp_nr(hph + Rn);                // (ys - fmu)/(HPH + R), ys = tnu/ttau (:277, :289-292)
-          // ttau of underflow size: 1/ttau overflows, ys = tnu/ttau stays finite -- the reference's own divisions (gain 0), behind a
-          // wave-uniform branch that the common case skips
-          if (__builtin_amdgcn_ballot_w64(tnew != 0.0 && !(Rn < 1e300)) != 0) {
-            if (tnew != 0.0 && !(Rn < 1e300)) g = (nnew / tnew - fmun) / (hph + Rn);
-          }
+          if (Rn < INFINITY) g = fma(nnew, Rn, -fmun) * rcp_nr(hph + Rn);  // (ys - fmu)/(HPH + R), ys = tnu/ttau (:277, :289-292)
           typedef double d2v __attribute__((ext_vector_type(2)));
           d2v m01, m23;
           mreg[0] = fma(wc[0], g, Am[0]); mreg[1] = fma(wc[1], g, Am[1]); mreg[2] = fma(wc[2], g, Am[2]); mreg[3] = fma(wc[3], g, Am[3]);
@@ -744,14 +740,10 @@ __global__ void __launch_bounds__(MSR_NT) ihgp_adf8_kernel(Shape sh, Bufs b, Mom
           tnew = max0(tnew);                                               // :274 (NaN -> 0, C-3)
           double Rn = 1.0 / tnew;                                          // R = 1/ttau: the look-up key and an output, exact division
           // (for tnew > 0 the reference's R(:,k) = 1./ttau before the clamp is this value; otherwise :287 overwrites it with Inf)
+          // R = inf: ttau = 0, or ttau of underflow size (1/ttau overflows while ys = tnu/ttau stays finite): the reference's
+          // (ys - fmu)/(HPH + R) is 0 there; the reciprocal form below would multiply inf by 0
           double g = 0.0;
-          if (tnew == 0.0) Rn = INFINITY;
-          else g = fma(nnew, Rn, -fmun) * rcp_nr(hph + Rn);                // (ys - fmu)/(HPH + R), ys = tnu/ttau (:277, :289-292)
-          // ttau of underflow size: 1/ttau overflows, ys = tnu/ttau stays finite -- the reference's own divisions (gain 0), behind a
-          // wave-uniform branch that the common case skips
-          if (__builtin_amdgcn_ballot_w64(tnew != 0.0 && !(Rn < 1e300)) != 0) {
-            if (tnew != 0.0 && !(Rn < 1e300)) g = (nnew / tnew - fmun) / (hph + Rn);
-          }
+          if (Rn < INFINITY) g = fma(nnew, Rn, -fmun) * rcp_nr(hph + Rn);  // (ys - fmu)/(HPH + R), ys = tnu/ttau (:277, :289-292)
           typedef double d2v __attribute__((ext_vector_type(2)));
           d2v m01, m23;
           mreg[0] = fma(wc[0], g, Am[0]); mreg[1] = fma(wc[1], g, Am[1]); mreg[2] = fma(wc[2], g, Am[2]); mreg[3] = fma(wc[3], g, Am[3]);

@@ -1072,6 +1072,21 @@ def test_column_owner_passes_with_smoothed_covariances_requested_and_plan_reuse(
     assert rel(first.PS, v.PS) < 1e-8 and rel(first.MS, v.MS) < 1e-8 and rel(first.Eft, v.Eft) < 1e-8 and relz(first.nlZ, v.nlZ) < 1e-9
 
 
+def test_large_shape_fuzz_against_oracle():
+    """Fixed-seed subset of tools/gpu_fuzz_large.py: random shapes with 22..40 sites (padded dimensions 96..160), kernels, cubature
+    orders, sweep counts, chunk sizes and missing samples through both EP families -- the column-owner MFMA smoother passes, the
+    768-thread gain kernel and the two/three-tiles-per-thread filters at the full tolerance."""
+    import subprocess, sys
+    tool = os.path.join(os.path.dirname(__file__), '..', 'tools', 'gpu_fuzz_large.py')
+    r = subprocess.run([sys.executable, tool, '6', '5'], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert lines[-1].startswith('worst'), r.stdout[-1000:]
+    assert not any('<<<<' in ln for ln in lines), r.stdout[-2000:]
+    worst = eval(lines[-1].split('worst', 1)[1].rsplit('}', 1)[0] + '}')
+    assert worst['gf'] < TOL_MEAN and worst['ihgp'] < TOL_MEAN
+
+
 def test_eight_segments_at_S146_equal_their_single_problem_plans():
     """configs[4] as the bench runs it (several 32-channel / 6-component segments in one plan, three tiles per thread, the VALU
     smoother passes with eight problems per launch): every segment of the 8-segment plan equals the plan of that segment alone."""

@@ -155,8 +155,9 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
   double* shv = sQ + (size_t)M * TS;
   double* sW = shv + M;
   double* m = sW + (size_t)sh.D * sh.N;
-  // Wl[n][I][i] = h_n P(off_I+i, c_n): the four rows of block I contiguous (16-byte aligned), so that the rank-M update reads a
-  // site's column vector with two 16-byte loads per operand (the update is bound by instruction issue, not by LDS cycles)
+  // Wl[n][h][I][2] = h_n P(off_I + 2h + {0,1}, c_n): rows 0-1 and rows 2-3 of block I in two planes, 16-byte aligned: the rank-M
+  // update reads a site's column vector with two 16-byte loads per operand, and consecutive blocks sit 16 bytes apart (conflict-free
+  // ds_read_b128; with the four rows contiguous the 32-byte stride halves the LDS rate of the three-waves-per-SIMD launches)
   double* Wl = lds + ((((size_t)((m + S) - lds)) + 1) & ~(size_t)1);
   double* fmu = Wl + (size_t)M * 4 * M;    // fmu, HPH: 68 entries, zero beyond the M sites
   double* HPH = fmu + 68;                  // (stage A of the sparse-point cubature reads up to 64 of them against zero weights)
@@ -330,7 +331,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
           const double hJ = shv[J], hI = shv[I];
           // P(rows of I, c_J)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) Wl[((size_t)J * M + I) * 4 + i] = hJ * P[q][4 * i];
+          for (int i = 0; i < 4; ++i) Wl[(((size_t)J * 2 + (i >> 1)) * M + I) * 2 + (i & 1)] = hJ * P[q][4 * i];
           if (I == J) {
             const double hp = hI * hI * P[q][0];
             HPH[I] = hp;
@@ -361,7 +362,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
             }
           } else {             // P(rows of J, c_I) = P(c_I, cols of J) by symmetry
 #pragma unroll
-            for (int j = 0; j < 4; ++j) Wl[((size_t)I * M + J) * 4 + j] = hI * P[q][j];
+            for (int j = 0; j < 4; ++j) Wl[(((size_t)I * 2 + (j >> 1)) * M + J) * 2 + (j & 1)] = hI * P[q][j];
           }
         }
       }
@@ -434,7 +435,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
           if (do_mom) lds_barrier();  // B4
           if (tid < S) {
             double a0 = rm, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-            const double* wp = Wl + (size_t)myblk * 4 + myrow;
+            const double* wp = Wl + ((size_t)(myrow >> 1) * M + myblk) * 2 + (myrow & 1);
             int n = 0;
             for (; n + 4 <= M; n += 4) {
               a0 = fma(wp[(size_t)(n + 0) * 4 * M], cm[n + 0], a0);
@@ -450,8 +451,8 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
 #pragma unroll
           for (int q = 0; q < TPT; ++q) {
             if (own.ok[q]) {
-              const double* wbase = Wl + (size_t)own.I[q] * 4;
-              const double* rbase = Wl + (size_t)own.J[q] * 4;
+              const double* wbase = Wl + (size_t)own.I[q] * 2;
+              const double* rbase = Wl + (size_t)own.J[q] * 2;
               int n0 = 0;
               for (; n0 + 2 <= M; n0 += 2) {   // two sites per trip: eight 16-byte LDS reads in flight before the FMAs
                 double w4[2][4], r4[2][4];
@@ -460,7 +461,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
                   const double c = -cA[n0 + u];
                   const double2* wq = reinterpret_cast<const double2*>(wbase + (size_t)(n0 + u) * 4 * M);
                   const double2* rq = reinterpret_cast<const double2*>(rbase + (size_t)(n0 + u) * 4 * M);
-                  const double2 w01 = wq[0], w23 = wq[1], r01 = rq[0], r23 = rq[1];
+                  const double2 w01 = wq[0], w23 = wq[M], r01 = rq[0], r23 = rq[M];      // second plane: 2*M doubles on
                   w4[u][0] = w01.x * c; w4[u][1] = w01.y * c; w4[u][2] = w23.x * c; w4[u][3] = w23.y * c;
                   r4[u][0] = r01.x; r4[u][1] = r01.y; r4[u][2] = r23.x; r4[u][3] = r23.y;
                 }
@@ -475,9 +476,9 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
                 const double c = -cA[n0];
                 double w1[4], r1[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) w1[i] = wbase[(size_t)n0 * 4 * M + i] * c;
+                for (int i = 0; i < 4; ++i) w1[i] = wbase[(size_t)n0 * 4 * M + (size_t)(i >> 1) * 2 * M + (i & 1)] * c;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) r1[j] = rbase[(size_t)n0 * 4 * M + j];
+                for (int j = 0; j < 4; ++j) r1[j] = rbase[(size_t)n0 * 4 * M + (size_t)(j >> 1) * 2 * M + (j & 1)];
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -528,7 +529,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
             lds_barrier();
             if (tid < S) {
               double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-              const double* wp = Wl + (size_t)myblk * 4 + myrow;
+              const double* wp = Wl + ((size_t)(myrow >> 1) * M + myblk) * 2 + (myrow & 1);
               int n = 0;
               for (; n + 4 <= M; n += 4) {
                 a0 = fma(wp[(size_t)(n + 0) * 4 * M], part[n + 0], a0); a1 = fma(wp[(size_t)(n + 1) * 4 * M], part[n + 1], a1);

@@ -1048,6 +1048,28 @@ def test_column_owner_mfma_smoother_against_valu_passes_and_oracle(D, N, k1):
     assert relz(res['big'][1].nlZ, ref['nlZ']) < TOL_LOGZ
 
 
+@pytest.mark.parametrize('T', [1, 2, 3, 9, 17])
+def test_column_owner_passes_edge_lengths(T):
+    """T = 1 (no smoothing step), 2, 3, and lengths around the chunk size (chunk = 8: one-step spans, a chunk of one step, the carry
+    of the boundary state over three chunks) at 30 sites: the MFMA passes of nagp_mfma_big.hpp against the VALU passes."""
+    D, N = 26, 4
+    pr = harness.nmf_problem(D, N, max(T, 4), 8300 + T, 'constraints')
+    y = pr['y'][:T].copy()
+    blk = pss.balance_blocks(pss.ss_blocks_nmf(pr['param1'], pr['param2'], 'matern32', 'matern52'))
+    mom = Mom('likModulatorNMFPower', p_cubature=3); d = np.array([0.6, 0.5])
+    res = {}
+    for mode in ('big', 'valu'):
+        if mode == 'valu': os.environ['NAGP_NO_MFMA_BIG'] = '1'
+        try:
+            plan = Plan(L.KIND_GF_EP, [(blk, pr['W'], np.log(pr['w_lik']))] * 2, T, mom=mom, ep_fraction=0.5, ep_damping=d, ep_itts=2, chunk=8)
+            plan.upload([y, y[::-1].copy()]); plan.execute(); res[mode] = plan.download(); plan.close()
+        finally:
+            os.environ.pop('NAGP_NO_MFMA_BIG', None)
+    for q in range(2):
+        for f in ('Eft', 'Varft', 'MS', 'nlZ'):
+            assert rel(getattr(res['big'][q], f), getattr(res['valu'][q], f)) < 1e-10, (q, f)
+
+
 def test_column_owner_passes_with_smoothed_covariances_requested_and_plan_reuse():
     """A plan that stores the smoothed covariances runs the last sweep through the VALU passes (tile-major chunk buffer) and the
     earlier ones through the MFMA passes (dense buffer with zero padding rows): executing it twice must give the same result

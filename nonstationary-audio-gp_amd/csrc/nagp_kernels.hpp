@@ -128,7 +128,7 @@ __host__ __device__ inline size_t filter_lds_doubles(const Shape& s, const MomCf
              6 * (size_t)s.M + 2 * 68 + 8 + 2 /* the W panel starts on a 16-byte boundary */ + filter_ring_doubles(s, kb);
   // mom workspace: the staged sparse-point form when the plan enabled it, else the generic one
   const size_t wmom = (mc.sp.enabled && mc.cdim <= MSP_MAXCD) ? msp_lds_doubles(mc.cdim, s.D) : mom_lds_doubles(mc);
-  n += (meas == 0) ? wmom : (size_t)(s.M + 2 * s.S + 2 * s.N);
+  n += (meas == 0) ? wmom : (size_t)(2 * s.M + 2 * s.S + 2 * s.N);
   return (n + 1) & ~(size_t)1;
 }
 
@@ -493,15 +493,13 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
           double* Kv = PJ + S + 2 * sh.N;   // [S] gain of the last inner iteration
           const int N = sh.N;
           double Sx = 1.0, MU = 0.0;
+          // Three barriers per inner iteration: partials | P J' | everything else.  S = R + J P J' and MU = h(m) are summed by EVERY
+          // wave for itself (same terms, same order: no broadcast, no barrier in front of the gain); the state lanes write fmu -- and
+          // the modulators' softplus / sigmoid -- of the NEXT iteration straight from their updated mean.
+          double* mp = Kv + S;             // [M] z_d * dh/dz_d: the terms of MU
           for (int it = 0; it < fp.l_iter; ++it) {
-            if (it > 0) {
-              if (tid < M) fmu[tid] = shv[tid] * m[ioff[tid]];
-              lds_barrier();
-            }
-            // softplus(g_j) and its derivative once per modulator (one exp + log chain for the whole step instead of
-            // N of them in every sub-band lane), then the partials of h = z' W softplus(g)
             double* spl = PJ + S;        // [N] softplus(g), [N] sigmoid(g)
-            if (it > 0 || !fp.spl_wave) {
+            if (it == 0 && !fp.spl_wave) {
               if (tid < N) {
                 const double eg = exp(fmu[D + tid]);
                 spl[tid] = log(1.0 + eg);
@@ -525,6 +523,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
                 pv = ((z0 + z1) + (z2 + z3)) * spl[N + j];
               }
               part[tid] = pv;
+              mp[tid] = (tid < D) ? fmu[tid] * pv : 0.0;
             }
             lds_barrier();
             if (tid < S) {
@@ -539,17 +538,13 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
               PJ[tid] = (a0 + a1) + (a2 + a3);
             }
             lds_barrier();
-            // S = R + J P J' and MU = h(m): one term per lane of wave 0, DPP sums, broadcast through LDS
-            if (tid < 64) {
+            {
               double tj = 0.0, tm = 0.0;
-              for (int n = tid; n < M; n += 64) tj = fma(part[n] * shv[n], PJ[ioff[n]], tj);
-              for (int d = tid; d < D; d += 64) tm = fma(fmu[d], part[d], tm);
+              for (int n = tid & 63; n < M; n += 64) { tj = fma(part[n] * shv[n], PJ[ioff[n]], tj); tm += mp[n]; }
               tj = wave_sum(tj); tm = wave_sum(tm);
-              if (tid == 0) { misc[2] = tj; misc[3] = tm; }
+              MU = tm;
+              Sx = sn2 + tj;
             }
-            lds_barrier();
-            MU = misc[3];
-            Sx = sn2 + misc[2];
             if (fp.ekf_energy) {
               if (!(Sx > 0.0)) Sx += 0.5e-4;            // chol(S) failed: jitter 1e-4*rand, rand -> 0.5 (:417-420, SURVEY C-7)
               if (tid == 0) {
@@ -557,10 +552,20 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
                 rlZ[kk] = -(0.9189385332046727 + log(LS) + 0.5 * ((v / LS) / LS) * v);
               }
             }
-            if (tid < S) { const double Kt = PJ[tid] / Sx; Kv[tid] = Kt; rm = rm + Kt * (yk - MU); }   // K = P J' / S, once per state
-            lds_barrier();   // all reads of m/fmu for this iteration done
-            if (tid < S) m[tid] = rm;
-            if (it + 1 < fp.l_iter) lds_barrier();
+            if (tid < S) {
+              const double Kt = PJ[tid] / Sx; Kv[tid] = Kt; rm = rm + Kt * (yk - MU);     // K = P J' / S, once per state
+              if (it + 1 < fp.l_iter && myrow == 0) {
+                const double f = shv[myblk] * rm;
+                fmu[myblk] = f;
+                if (myblk >= D) {
+                  const double eg = exp(f);
+                  spl[myblk - D] = log(1.0 + eg);
+                  spl[N + myblk - D] = eg / (eg + 1.0);
+                }
+              }
+              if (it + 1 == fp.l_iter) m[tid] = rm;
+            }
+            lds_barrier();   // Kv (and fmu, spl of the next iteration) visible
           }
           // P -= K S K'
 #pragma unroll

@@ -19,7 +19,6 @@ process touches the GPU; under `python -m torch.distributed.run` (RANK set) the 
 import argparse
 import json
 import os
-import socket
 import subprocess
 import sys
 import time
@@ -277,13 +276,13 @@ def run_workload(name, a, rank, local_rank, world, dev, with_cpu, steps, warmup)
 
 def spawn_ranks(a):
     """--gpus N without a launcher: N fresh child processes, one per GPU.  Nothing in THIS process has touched the GPU."""
-    with socket.socket() as s:
-        s.bind(('127.0.0.1', 0))
-        port = s.getsockname()[1]
+    import tempfile
+    from nagp import dist as nd                                  # pure Python: no GPU call
+    rdv = tempfile.mkdtemp(prefix='nagp_bench_')
     procs = []
     for r in range(a.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), NAGP_BENCH_SELF_SPAWNED='1',
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'), **nd.file_rendezvous_env(rdv, a.gpus))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
     pending = list(procs)
@@ -298,6 +297,8 @@ def spawn_ranks(a):
                 for other in pending:       # exact PIDs of our own children
                     other.terminate()
         time.sleep(0.2)
+    import shutil
+    shutil.rmtree(rdv, ignore_errors=True)
     return rc
 
 
@@ -336,7 +337,7 @@ def main():
     with_cpu = (not a.no_cpu_baseline) and world == 1             # the CPU baseline is timed at N = 1 only
     line = run_workload(a.workload, a, rank, local_rank, world, dev, with_cpu, a.steps, a.warmup)
     line['rccl_world_size'] = nd.world_size()
-    line['launch'] = 'self-spawned ranks' if os.environ.get('MASTER_PORT') and 'TORCHELASTIC_RUN_ID' not in os.environ and world > 1 else ('torch.distributed.run' if world > 1 else 'single process')
+    line['launch'] = 'self-spawned ranks (file-store rendezvous)' if os.environ.get('NAGP_BENCH_SELF_SPAWNED') and world > 1 else ('torch.distributed.run' if world > 1 else 'single process')
     extras = []
     if a.extras == 'default':
         if a.workload == 'cfg3' and not a.T and not a.segments:

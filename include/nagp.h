@@ -235,7 +235,8 @@ void nagp_plan_destroy(nagp_plan* plan);
  * and out as in nagp_plan_*; the only exchange is the sum over ALL problems of the per-sweep negative log marginal likelihood
  * nlZ[itt] = -sum_k lZ_k (gf_ep_modulator_nmf.m:187, 277, 525), all-reduced over the devices with RCCL
  * (ncclAllReduce, ncclDouble, ncclSum, count = ep_itts) and returned in nlZ_total (ep_itts doubles, may be NULL).
- * opts->device is ignored.  n_gpus = 1 involves no collective unless the environment sets NAGP_FORCE_RCCL.  The RCCL
+ * opts->device is ignored; opts->ttau0 / tnu0 must be NULL (they describe ONE problem: NAGP_EINVAL otherwise -- warm-started
+ * batches go through nagp_plan_create + nagp_plan_upload_sites).  n_gpus = 1 involves no collective unless the environment sets NAGP_FORCE_RCCL.  The RCCL
  * communicators are created on first use and kept until nagp_shutdown(). */
 int nagp_batch_partition(int32_t n_problems, int32_t n_gpus, int32_t* device_of_problem /* n_problems */);
 int nagp_batch_run(int32_t n_problems, const nagp_model* models, const nagp_ihgp_tables* tables /* n_problems or NULL */,

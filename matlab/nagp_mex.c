@@ -49,7 +49,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
   nagp_ihgp_tables tb;
   const mxArray *sm, *so, *f;
   size_t n, nd, T;
-  int st, i;
+  int st;
   mwSize dims3[3];
 
   if (nrhs < 3 || nrhs > 4) mexErrMsgIdAndTxt("nagp:arg", "usage: [...] = nagp_mex(model, y, opts [, tables])");
@@ -111,7 +111,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
   if (nlhs > 11) o.flags |= NAGP_FLAG_WANT_PS;
 
   /* ---- outputs (column-major M x T etc.: exactly the library's layout) */
-  for (i = 0; i < 12; ++i) plhs[i] = NULL;
+  /* MATLAB guarantees max(nlhs, 1) slots in plhs and no more: only those are touched */
   plhs[0] = mxCreateDoubleMatrix(m.M, T, mxREAL); out.Eft = mxGetPr(plhs[0]);
   if (nlhs > 1) { plhs[1] = mxCreateDoubleMatrix(m.M, T, mxREAL); out.Varft = mxGetPr(plhs[1]); }
   if (nlhs > 2) { plhs[2] = mxCreateDoubleMatrix(m.M, T, mxREAL); out.ttau = mxGetPr(plhs[2]); }

@@ -780,8 +780,8 @@ extern "C" int nagp_plan_upload_sites(nagp_plan* p, const double* const* ttau0, 
   if (!ttau0 || !tnu0) FAIL(NAGP_EINVAL, "ttau0 and tnu0 come together");
   HIP_TRY(hipSetDevice(p->opts.device));
   const size_t n = (size_t)p->sh.T * p->sh.M;
-  if (!p->d_tt0) {
-    int st = dalloc(p, &p->d_tt0, (size_t)p->B * n, false);
+  if (!p->d_tt0 || !p->d_tn0) {   // (a first call whose second allocation failed leaves d_tt0 set: test both)
+    int st = p->d_tt0 ? NAGP_OK : dalloc(p, &p->d_tt0, (size_t)p->B * n, false);
     if (st == NAGP_OK) st = dalloc(p, &p->d_tn0, (size_t)p->B * n, false);
     if (st != NAGP_OK) return st;
   }
@@ -1588,12 +1588,18 @@ int allreduce_nlz(int G, int cnt, const std::vector<std::vector<double>>& part, 
     for (int d = 0; d < G; ++d) devs[d] = d;
     ncclResult_t r = ncclCommInitAll(g_cc.comms.data(), G, devs.data());
     if (r != ncclSuccess) { cc_release_locked(); FAIL(NAGP_ERCCL, "ncclCommInitAll(%d) -> %s", G, ncclGetErrorString(r)); }
-    g_cc.n = G;
+    // the cache counts as initialised (g_cc.n = G) only once every per-device stream and buffer exists; a failure on the
+    // way releases what was created, so that the next call starts over instead of using null streams / buffers
     for (int d = 0; d < G; ++d) {
-      HIP_TRY(hipSetDevice(d));
-      HIP_TRY(hipStreamCreateWithFlags(&g_cc.streams[d], hipStreamNonBlocking));
-      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g_cc.bufs[d]), 128 * sizeof(double)));
+      hipError_t e = hipSetDevice(d);
+      if (e == hipSuccess) e = hipStreamCreateWithFlags(&g_cc.streams[d], hipStreamNonBlocking);
+      if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&g_cc.bufs[d]), 128 * sizeof(double));
+      if (e != hipSuccess) {
+        cc_release_locked();
+        FAIL(e == hipErrorOutOfMemory ? NAGP_ENOMEM : NAGP_EHIP, "per-device resources of the nlZ all-reduce (device %d) -> %s", d, hipGetErrorString(e));
+      }
     }
+    g_cc.n = G;
   }
   for (int d = 0; d < G; ++d) {
     HIP_TRY(hipSetDevice(d));
@@ -1625,6 +1631,8 @@ extern "C" int nagp_batch_run(int32_t n_problems, const nagp_model* models, cons
                               int64_t T, const nagp_opts* opts, nagp_out* outs, int32_t n_gpus, double* nlZ_total) {
   if (n_problems < 1 || !models || !ys || !opts || !outs || n_gpus < 1) FAIL(NAGP_EINVAL, "null/empty argument");
   if (opts->kind == NAGP_KIND_IHGP && !tables) FAIL(NAGP_EINVAL, "IHGP tables missing");
+  if (opts->ttau0 || opts->tnu0)
+    FAIL(NAGP_EINVAL, "nagp_batch_run takes no warm-start sites (opts.ttau0 / tnu0 describe ONE problem): use nagp_plan_create + nagp_plan_upload_sites");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) FAIL(NAGP_ENODEVICE, "no HIP device visible");
   if (n_gpus > ndev) FAIL(NAGP_EINVAL, "n_gpus = %d but %d device(s) visible", n_gpus, ndev);

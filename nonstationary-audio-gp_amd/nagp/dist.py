@@ -22,10 +22,24 @@ def init(backend=None):
     import torch.distributed as dist
     rank, local_rank, world = env_world()
     if world > 1 and not dist.is_initialized():
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29500')
-        dist.init_process_group(backend=backend or 'nccl', rank=rank, world_size=world)
+        method = os.environ.get('NAGP_DIST_INIT_METHOD')       # e.g. file:///tmp/x/rdv -- no TCP port to race for
+        if method:
+            dist.init_process_group(backend=backend or 'nccl', init_method=method, rank=rank, world_size=world)
+        else:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29500')
+            dist.init_process_group(backend=backend or 'nccl', rank=rank, world_size=world)
     return rank, local_rank, world
+
+
+def file_rendezvous_env(dirpath, world):
+    """Environment entries for ranks started by hand (tests, `bench.py --gpus N` without a launcher): a file store in a
+    directory only these ranks know instead of a TCP port picked by bind-then-close, which two children can lose to
+    another process between the close and their own bind."""
+    path = os.path.join(os.path.abspath(dirpath), 'nagp_rendezvous')
+    if os.path.exists(path):
+        os.remove(path)
+    return {'NAGP_DIST_INIT_METHOD': 'file://' + path, 'WORLD_SIZE': str(world)}
 
 
 def allreduce_nlz(nlz_local, device=None):

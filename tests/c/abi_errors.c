@@ -54,7 +54,8 @@ int main(void) {
   for (i = 0; i < 8; ++i) if (dev[i] != i % 3) { fprintf(stderr, "partition[%d] = %d\n", i, dev[i]); ++bad; }
   EXPECT(nagp_batch_partition(4, 0, dev), NAGP_EINVAL);
   { const double* ys[1] = {y}; EXPECT(nagp_batch_run(0, &m, NULL, ys, T, &o, &out, 1, NULL), NAGP_EINVAL);
-    EXPECT(nagp_batch_run(1, &m, NULL, ys, T, &o, &out, 0, NULL), NAGP_EINVAL); }
+    EXPECT(nagp_batch_run(1, &m, NULL, ys, T, &o, &out, 0, NULL), NAGP_EINVAL);
+    { nagp_opts q = o; q.ttau0 = y; q.tnu0 = y; EXPECT(nagp_batch_run(1, &m, NULL, ys, T, &q, &out, 1, NULL), NAGP_EINVAL); } }   /* warm start: plans only */
   EXPECT(nagp_mom_eval(NULL, D, N, W, 0.0, 1, y, y, y, A, A, A), NAGP_EINVAL);
   EXPECT(nagp_iekf_update1(S, D, N, NULL, h, W, 0.1, 0.2, 1, A, P, NULL, NULL, NULL, 0), NAGP_EINVAL);
   EXPECT(nagp_fastfb_run(S, NULL, A, A, A, NULL, y, T, A, NULL, 0), NAGP_EINVAL);

@@ -15,7 +15,7 @@ int main(int argc, char** argv) {
   size_t n, T; double worst = 0.0, r;
   const int S = (int)dump_scalar(d, "S"), kind = (int)dump_scalar(d, "kind");
   mxArray *model = mock_struct(), *opts = mock_struct(), *tables = NULL, *y;
-  mxArray* plhs[12]; const mxArray* prhs[4];
+  mxArray **plhs, **plhs2; const mxArray* prhs[4];
   int32_t* bo = (int32_t*)dump_load(d, "block_offsets", 4, &n);
   mock_set(model, "A", dbl(d, "A", S)); mock_set(model, "Q", dbl(d, "Q", S)); mock_set(model, "Pinf", dbl(d, "Pinf", S));
   mock_set(model, "block_offsets", mock_numeric(mxINT32_CLASS, 1, n, bo));
@@ -45,7 +45,17 @@ int main(int argc, char** argv) {
     mock_set(tables, "pp_off", mock_numeric(mxINT64_CLASS, n, 1, po)); mock_set(tables, "pg_off", mock_numeric(mxINT64_CLASS, n, 1, pg));
     prhs[3] = tables;
   }
+  /* plhs has EXACTLY nlhs slots (heap, so that a sanitizer build sees a gateway that writes past them): MATLAB promises no more */
+  plhs = (mxArray**)malloc(11 * sizeof *plhs);
   mexFunction(11, plhs, kind == 1 ? 4 : 3, prhs);       /* ... counters, MS */
+  plhs2 = (mxArray**)malloc(2 * sizeof *plhs2);           /* the wrappers' predict call: [Eft, Varft] = nagp_mex(...) */
+  mexFunction(2, plhs2, kind == 1 ? 4 : 3, prhs);
+  {
+    size_t q; const size_t ne = mxGetNumberOfElements(plhs[0]);
+    if (mxGetNumberOfElements(plhs2[0]) != ne || mxGetNumberOfElements(plhs2[1]) != ne) { printf("nlhs=2 call: wrong output sizes\n"); return 1; }
+    q = ne * sizeof(double);
+    if (memcmp(mxGetPr(plhs2[0]), mxGetPr(plhs[0]), q) || memcmp(mxGetPr(plhs2[1]), mxGetPr(plhs[1]), q)) { printf("nlhs=2 call differs from the nlhs=11 call\n"); return 1; }
+  }
   {
     double* e = (double*)dump_load(d, "exp_Eft", 8, &n);
     r = rel_diff(mxGetPr(plhs[0]), e, n, "Eft"); if (r > worst) worst = r;

@@ -837,13 +837,12 @@ print('rank', rank, 'ok', tot)
 def test_two_ranks_with_real_plans_allreduce_nlz(tmp_path):
     """The N > 1 product path end to end on one card: every rank builds a Plan for its shard of the segments, executes it on
     the GPU and the per-sweep nlZ is all-reduced; equal to one rank running all segments."""
-    import socket, subprocess, sys
+    import subprocess, sys
+    from nagp import dist as nd
     script = tmp_path / 'rank_worker.py'
     script.write_text(_RANK_WORKER)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with socket.socket() as so:
-        so.bind(('127.0.0.1', 0)); port = so.getsockname()[1]
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE='2')
+    env = dict(os.environ, **nd.file_rendezvous_env(str(tmp_path), 2))      # file store: no port to race for
     procs = [subprocess.Popen([sys.executable, str(script), root], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=300)[0] for p in procs]

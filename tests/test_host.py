@@ -216,10 +216,8 @@ def test_two_rank_gloo_sharding_and_nlz_allreduce(tmp_path):
     gf_ep_modulator_nmf values, here produced by the oracle) all-reduced and compared with the serial sum (gloo stands in for RCCL)."""
     script = tmp_path / 'worker.py'
     script.write_text(_WORKER)
-    import socket
-    with socket.socket() as so:
-        so.bind(('127.0.0.1', 0)); port = so.getsockname()[1]
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE='2')
+    from nagp import dist as nd
+    env = dict(os.environ, **nd.file_rendezvous_env(str(tmp_path), 2))      # file store: no port to race for
     procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=180)[0] for p in procs]

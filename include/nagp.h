@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define NAGP_VERSION 200 /* 0.2.0 */
+#define NAGP_VERSION 300 /* 0.3.0 */
 
 typedef enum nagp_status {
   NAGP_OK = 0,
@@ -40,7 +40,8 @@ typedef enum nagp_status {
   NAGP_EHIP = -3,         /* HIP runtime error (see nagp_last_error) */
   NAGP_ENOMEM = -4,       /* device memory exhausted */
   NAGP_ENODEVICE = -5,    /* no gfx950 device visible */
-  NAGP_ENOTPD = -6,       /* Cholesky failed even after the jitter retry */
+  NAGP_ENOTPD = -6,       /* Cholesky failed even after the jitter retry (where MATLAB's chol throws, gf_ep_modulator_nmf.m:219-222);
+                             returned by the execute / run calls after the sweeps have finished: outputs can still be downloaded */
   NAGP_ERCCL = -7         /* RCCL failure in nagp_batch_run (see nagp_last_error) */
 } nagp_status;
 
@@ -133,6 +134,7 @@ typedef struct nagp_out {
   double* maxDiffM; /* ep_itts */
   double* maxDiffP; /* ep_itts */
   int64_t* counters; /* NAGP_N_COUNTERS: chol retries, clamped sites, NaN observations, not-PD */
+  double* MF;       /* S x T   filtered means of the last forward pass (the reference's out.MF, gf_ep_modulator_nmf.m:191-198) */
 } nagp_out;
 
 #define NAGP_N_COUNTERS 4

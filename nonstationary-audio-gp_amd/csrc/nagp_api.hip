@@ -1251,6 +1251,15 @@ extern "C" int nagp_plan_execute(nagp_plan* p) {
   float tot = 0.f;
   (void)hipEventElapsedTime(&tot, p->ev_t0, p->ev_t1);
   p->tim.total_ms = tot;
+  if (p->opts.kind != NAGP_KIND_IHGP) {
+    // a step whose PSkp failed the Cholesky even with the jitter: the reference stops there (chol throws inside the catch block,
+    // gf_ep_modulator_nmf.m:219-222).  The sweeps have run to the end (the outputs can be downloaded and will hold NaN).
+    std::vector<unsigned long long> c((size_t)p->B * 4);
+    HIP_TRY(hipMemcpy(c.data(), p->b.counters, c.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (int q = 0; q < p->B; ++q)
+      if (c[(size_t)q * 4 + NAGP_CNT_NOTPD])
+        FAIL(NAGP_ENOTPD, "problem %d: A*PS_k*A'+Q not positive definite at %llu smoother step(s) even with the jitter of the retry", q, c[(size_t)q * 4 + NAGP_CNT_NOTPD]);
+  }
   return NAGP_OK;
 }
 
@@ -1272,6 +1281,7 @@ extern "C" int nagp_plan_download(nagp_plan* p, nagp_out* outs) {
 #define D2H(dst, src, n) do { if (dst) HIP_TRY(hipMemcpyAsync(dst, src, (size_t)(n) * sizeof(double), hipMemcpyDeviceToHost, p->stream)); } while (0)
     D2H(o.Eft, p->b.sm + oM, T * M);
     D2H(o.MS, p->b.MS + oS, T * S);
+    D2H(o.MF, p->b.MF + oS, T * S);
     D2H(o.ttau, p->b.ttau + oM, T * M);
     D2H(o.tnu, p->b.tnu + oM, T * M);
     D2H(o.R, p->b.R + oM, T * M);

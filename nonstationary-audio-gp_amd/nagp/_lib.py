@@ -52,7 +52,7 @@ class Opts(C.Structure):
 class Out(C.Structure):
     _fields_ = [('Eft', c_dp), ('Varft', c_dp), ('MS', c_dp), ('PS', c_dp), ('ttau', c_dp), ('tnu', c_dp),
                 ('R', c_dp), ('lZ', c_dp), ('nlZ', c_dp), ('maxDiffM', c_dp), ('maxDiffP', c_dp),
-                ('counters', c_lp)]
+                ('counters', c_lp), ('MF', c_dp)]
 
 
 class Timings(C.Structure):

@@ -173,9 +173,11 @@ def _damping(ep_damping, ep_itts):
 class _Problem:
     """Everything the C ABI needs for one call, with the numpy arrays kept alive."""
 
-    def __init__(self, blk, Wnmf, lik_param, symmetrize_Q=False, stationary_Q=False):
+    def __init__(self, blk, Wnmf, lik_param, symmetrize_Q=False, stationary_Q=False, overrides=None):
         self.blk = blk
         A, Q, P = ssm.discretise(blk, symmetrize_Q, stationary_Q)
+        if overrides:      # the C ABI takes A, Q, Pinf as plain arrays: a caller (or a test) may hand over its own discrete model
+            A = overrides.get('A', A); Q = overrides.get('Q', Q); P = overrides.get('Pinf', P)
         self.A, self.Q, self.Pinf = L.f64(A), L.f64(Q), L.f64(P)
         self.h_val = L.f64(blk.h_val)
         self.offsets = np.ascontiguousarray(blk.offsets, dtype=np.int32)
@@ -187,7 +189,8 @@ class _Problem:
 
 
 class _Outputs:
-    def __init__(self, M, S, T, I, want_PS=False, want_MS=True):
+    def __init__(self, M, S, T, I, want_PS=False, want_MS=True, want_MF=False):
+        self.MF = np.zeros((S, T), order='F') if want_MF else None
         self.Eft = np.zeros((M, T), order='F'); self.Varft = np.zeros((M, T), order='F')
         self.MS = np.zeros((S, T), order='F') if want_MS else None
         self.PS = np.zeros((S, S, T), order='F') if want_PS else None
@@ -197,7 +200,7 @@ class _Outputs:
         self.c = L.Out(Eft=L.dptr(self.Eft), Varft=L.dptr(self.Varft), MS=L.dptr(self.MS), PS=L.dptr(self.PS),
                        ttau=L.dptr(self.ttau), tnu=L.dptr(self.tnu), R=L.dptr(self.R), lZ=L.dptr(self.lZ),
                        nlZ=L.dptr(self.nlZ), maxDiffM=L.dptr(self.maxDiffM), maxDiffP=L.dptr(self.maxDiffP),
-                       counters=self.counters.ctypes.data_as(L.c_lp))
+                       counters=self.counters.ctypes.data_as(L.c_lp), MF=L.dptr(self.MF))
 
     def as_dict(self):
         d = dict(tnu=self.tnu, ttau=self.ttau, lZ=self.lZ, R=self.R, MS=self.MS, PS=self.PS, nlZ=self.nlZ,

@@ -12,11 +12,12 @@ from . import ihgp_tables
 class Plan:
     def __init__(self, kind, problems, T, mom=None, ep_fraction=0.5, ep_damping=None, ep_itts=3, mode=L.MODE_PREDICT,
                  l_iter=1, predict_at_k1=0, flags=0, device=0, chunk=0):
-        """problems: list of (BlockSS, Wnmf, lik_param) -- already balanced if the variant balances."""
+        """problems: list of (BlockSS, Wnmf, lik_param[, overrides]) -- already balanced if the variant balances; `overrides` is an
+        optional dict of dense S x S arrays 'A', 'Q', 'Pinf' replacing the discretised blocks (block diagonal with the same blocks)."""
         self.kind, self.T, self.I = kind, int(T), int(ep_itts)
         sym = kind == L.KIND_IHGP
         statq = kind == L.KIND_GIEKF and mode == L.MODE_NLML        # Q = Pinf - A Pinf A' (gf_giekf_modulator_nmf_constraints.m:378)
-        self.probs = [_Problem(b, W, lp, symmetrize_Q=sym, stationary_Q=statq) for (b, W, lp) in problems]
+        self.probs = [_Problem(pr[0], pr[1], pr[2], symmetrize_Q=sym, stationary_Q=statq, overrides=(pr[3] if len(pr) > 3 else None)) for pr in problems]
         self.B = len(self.probs)
         blk0 = problems[0][0]
         self.M, self.S = blk0.M, blk0.S
@@ -66,8 +67,8 @@ class Plan:
         return dict(ms={k: t.ms[i] for i, k in enumerate(L.KERNEL_NAMES)},
                     launches={k: int(t.launches[i]) for i, k in enumerate(L.KERNEL_NAMES)}, total_ms=t.total_ms)
 
-    def download(self, want_PS=False, want_MS=True):
-        outs = [_Outputs(self.M, self.S, self.T, self.I, want_PS=want_PS, want_MS=want_MS) for _ in range(self.B)]
+    def download(self, want_PS=False, want_MS=True, want_MF=False):
+        outs = [_Outputs(self.M, self.S, self.T, self.I, want_PS=want_PS, want_MS=want_MS, want_MF=want_MF) for _ in range(self.B)]
         arr = (L.Out * self.B)(*[o.c for o in outs])
         L.check(L.lib().nagp_plan_download(self._h, arr))
         return outs

@@ -279,7 +279,13 @@ def _excused(name):
     import json
     with open(os.path.join(GOLD, name)) as fh:
         d = json.load(fh)
-    return d, {(e['draw'], e['family']) for e in d['excused']}
+    # value: can the oracle's NaN pattern be held against the device?  Yes for the mildly ill-conditioned draws (the oracle moves by
+    # < 1e-6 under the 1e-13 perturbation of y and no site passes 1e10); no when the oracle's own NaN pattern moves under the
+    # perturbation (self_sensitivity null) or sites of 1e14+ make inf - inf a matter of rounding.  Decided from the committed,
+    # oracle-derived list alone.
+    def pattern_holds(e):
+        return e['self_sensitivity'] is not None and e['self_sensitivity'] < 1e-6 and e['largest_site'] is not None and e['largest_site'] < 1e10
+    return d, {(e['draw'], e['family']): pattern_holds(e) for e in d['excused']}
 
 
 def test_randomised_configurations_against_oracle():
@@ -293,9 +299,12 @@ def test_randomised_configurations_against_oracle():
     assert meta['seed'] == 2024 and meta['n_draws'] == 30 and len(skip) <= 1
     rng = np.random.default_rng(2024)
     for i in range(30):
-        desc, res, _cfg = fz.one(rng, raw=True)
+        desc, res, cfg = fz.one(rng, raw=True)
         for fam, v in res.items():
             if (i, fam) in skip:
+                # excused from the tolerance, not from everything: clamped sites non-negative, and NaN exactly where the oracle has
+                # NaN -- unless the oracle's own NaN pattern moves under the 1e-13 perturbation (self_sensitivity null in the list)
+                assert cfg['weak'][fam]['ttau_nonneg'] and (cfg['weak'][fam]['same_nan_pattern'] or not skip[(i, fam)]), (i, fam, desc, cfg['weak'][fam])
                 continue
             assert v < TOL_MEAN, (i, fam, desc, res)
 
@@ -310,9 +319,11 @@ def test_randomised_mixtures_and_ekf_objective_against_oracle():
     assert meta['seed'] == 7 and meta['n_draws'] == 12 and len(skip) <= 6
     rng = np.random.default_rng(7)
     for i in range(12):
-        desc, res, _ = fz.one_widened(rng, raw=True)
+        desc, res, cfg = fz.one_widened(rng, raw=True)
         for fam, v in res.items():
             if (i, fam) in skip:
+                # excused from the tolerance, not from everything (see the main draw)
+                assert cfg['weak'][fam]['ttau_nonneg'] and (cfg['weak'][fam]['same_nan_pattern'] or not skip[(i, fam)]), (i, fam, desc, cfg['weak'][fam])
                 continue
             assert v < TOL_MEAN, (i, fam, desc, res)
 
@@ -1129,3 +1140,78 @@ def test_eight_segments_at_S146_equal_their_single_problem_plans():
     ref = ogf.run_predict(ogf.assemble(np.log(1e-4) * np.ones(1), *[harness.nmf_problem(D, N, T, 5003, 'constraints')[k] for k in ('param1', 'param2', 'W')],
                                        'matern32', 'matern52', True), ys[3], olik.Mom(olik.LIK_POWER_NMF, p=7), 0.5, d, 3)
     assert rel(outs[3].Eft, ref['Eft']) < TOL_MEAN and relz(outs[3].nlZ, ref['nlZ']) < TOL_LOGZ
+
+
+# ---------------------------------------------------------------------------------------------
+# the Cholesky jitter-retry branch (SURVEY C-7; gf_ep_modulator_nmf.m:216-223) and its failure
+def _indefinite_prior_problem(j, c, T=40):
+    """A 3-channel / 2-component model whose Pinf(j,j) is lowered by c: state j is the unobserved last state of a modulator or
+    sub-band block, the filter stays stable, and A*PS_k*A'+Q has a small negative eigenvalue -- the smoother's chol fails."""
+    D, N = 3, 2
+    pr = harness.nmf_problem(D, N, T, 11)
+    blk = pss.ss_blocks_nmf(pr['param1'], pr['param2'], 'matern32', 'matern52')
+    lik, p1, p2, W = ogf.ssm.unpack_log(pr['w'], 1, D, N)
+    model = ogf.assemble(lik, p1, p2, W, 'matern32', 'matern52', False)
+    assert np.allclose(model['Pinf'], np.asarray(pss.discretise(blk)[2]), rtol=1e-12, atol=0)   # same state ordering on both sides
+    P = np.array(model['Pinf']); P[j, j] -= c                 # one prior for both: the library takes Pinf as a plain array
+    model = dict(model); model['Pinf'] = P.copy()
+    return pr, (blk, pr['W'], np.log(pr['w_lik']), dict(Pinf=P)), model
+
+
+@pytest.mark.parametrize('j,c,every_step', [(17, 1e-8, True), (14, 1e-7, False), (3, 1e-6, False)])
+def test_cholesky_jitter_retry_branch_against_oracle(j, c, every_step):
+    """PSkp not positive definite -> second attempt with sqrt(1e-4)*0.5 on the diagonal (0.5 stands for the reference's unseeded
+    rand): the retry counter is positive and equals the oracle's, the outputs equal the oracle's jitter branch."""
+    T = 40
+    pr, prob, model = _indefinite_prior_problem(j, c, T)
+    mom = Mom('likModulatorNMFPower', p_cubature=5); d = 0.5 * np.ones(2)
+    ref = ogf.run_predict(model, pr['y'], olik.Mom(olik.LIK_POWER_NMF, p=5), 0.5, d, 2)
+    n_ref = ref['counters'].get('chol_retries', 0)
+    assert n_ref > 0 and (n_ref == 2 * (T - 1)) == every_step
+    plan = Plan(L.KIND_GF_EP, [prob], T, mom=mom, ep_fraction=0.5, ep_damping=d, ep_itts=2, flags=L.FLAG_WANT_PS)
+    plan.upload([pr['y']]); plan.execute(); o = plan.download(want_PS=True)[0]; plan.close()
+    assert o.counters[0] == n_ref and o.counters[3] == 0, (o.counters, n_ref)
+    assert rel(o.Eft, ref['Eft']) < TOL_MEAN and rel(o.Varft, ref['Varft']) < TOL_MEAN and relz(o.nlZ, ref['nlZ']) < TOL_LOGZ
+    assert rel(o.PS, np.transpose(ref['PS'], (1, 2, 0))) < TOL_MEAN and rel(o.ttau, ref['ttau']) < TOL_SITE
+
+
+def test_cholesky_failure_after_the_retry_is_reported_as_not_pd():
+    """Both attempts fail (negative eigenvalue far beyond the jitter): the oracle's chol throws as MATLAB's does inside the catch
+    block; the library finishes the sweeps, counts the steps and returns NAGP_ENOTPD from the execute call."""
+    T = 40
+    pr, prob, model = _indefinite_prior_problem(14, 1e-4, T)
+    mom = Mom('likModulatorNMFPower', p_cubature=5); d = 0.5 * np.ones(2)
+    with pytest.raises(np.linalg.LinAlgError):
+        ogf.run_predict(model, pr['y'], olik.Mom(olik.LIK_POWER_NMF, p=5), 0.5, d, 2)
+    plan = Plan(L.KIND_GF_EP, [prob], T, mom=mom, ep_fraction=0.5, ep_damping=d, ep_itts=2)
+    plan.upload([pr['y']])
+    with pytest.raises(nagp.NagpError, match='not positive definite'):
+        plan.execute()
+    o = plan.download()[0]; plan.close()                      # the plan stays usable: counters say what happened
+    assert o.counters[3] > 0 and o.counters[0] >= o.counters[3]
+
+
+def test_full_length_cfg4_predict_mode_filter_prefix_and_chunked_smoother():
+    """configs[3] in PREDICT mode at its native length (T = 88 200, 24 channels / 3 components, S = 105: 4 GB of filtered
+    covariances, chunked smoother).  One global iteration: the EKF filter is causal, so the filtered means MF of the first 799
+    steps equal those of the 800-step run bit for bit, and the 800-step run is compared with the oracle (filtered AND smoothed);
+    the smoothed output of the long run is finite with positive variances and does not depend on the chunking beyond rounding."""
+    g = gold('cfg4_gf_giekf_modulator_nmf'); Tg = g['y'].size; T = 88200
+    D, N = int(g['D']), int(g['N'])
+    blk, W, lik = _constrained_problem(g)
+    y = np.tile(g['y'], T // Tg + 1)[:T]
+    def run(yy, chunk=0):
+        plan = Plan(L.KIND_GIEKF, [(blk, W, lik)], yy.size, ep_itts=1, l_iter=1, flags=L.FLAG_EKF_RESET_P, chunk=chunk)
+        plan.upload([yy]); plan.execute(); o = plan.download(want_MS=False, want_MF=True)[0]; nb = plan.device_bytes(); plan.close()
+        return o, nb
+    (full, nbytes), (short, _) = run(y), run(g['y'])
+    assert blk.S == 105 and nbytes > 4e9
+    assert np.array_equal(full.MF[:, :Tg - 1], short.MF[:, :Tg - 1])
+    t = np.arange(1, Tg + 1.0)
+    ref = oek.gf_giekf_modulator_nmf_constraints(g['w'], t, g['y'], None, None, t, 'matern32', 'matern52', 1, D, N, 1, 1,
+                                                 g['constraints'], g['w_fixed'], list(g['tune_hypers']))[5]
+    assert rel(short.MF, ref['MF']) < TOL_MEAN and rel(short.Eft, ref['Eft']) < TOL_MEAN and rel(short.Varft, ref['Varft']) < TOL_MEAN
+    assert np.all(np.isfinite(full.Eft)) and np.all(full.Varft > 0) and full.counters[0] == 0 and full.counters[3] == 0
+    other, _ = run(y, chunk=20000)                             # another chunking / span partition of the same backward recursion
+    assert rel(other.Eft, full.Eft) < 1e-9 and rel(other.Varft, full.Varft) < 1e-9
+    assert np.array_equal(other.MF, full.MF)

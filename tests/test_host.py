@@ -128,7 +128,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     for sym in declared:
         assert hasattr(lib, sym), sym
     L = nagp.lib()
-    assert L.nagp_version() == 200
+    assert L.nagp_version() == 300
     assert 'ncclAllReduce' in subprocess.run(['nm', '-D', '--undefined-only', path], capture_output=True, text=True).stdout   # RCCL linked in
     assert L.nagp_strerror(-2).decode() == 'unsupported shape'
     out = subprocess.run(['nm', '-D', '--defined-only', path], capture_output=True, text=True).stdout

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the Kalman/RTS/Power-EP hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg4|cfg5] [--segments B] [--T T] [--extras ...]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg4|cfg5|cfg3_batch|cfg2_batch|cfg5_fill] [--segments B] [--T T] [--extras ...]
 
 A "step" is one full pass of the hot path (all EP sweeps: forward filter, smoother, site refresh) over one batch of
 synthetic audio segments already resident in HBM.
@@ -30,11 +30,16 @@ sys.path.insert(0, os.path.join(ROOT, 'nonstationary-audio-gp_amd'))
 import numpy as np  # noqa: E402
 
 WORKLOADS = {
-    # name: function, D, N, T, cubature order, parameter recipe, balance, segments IN TOTAL (None: one per GPU)
+    # name: function, D, N, T, cubature order, parameter recipe, balance, segments IN TOTAL (None: `per_gpu` segments on every GPU)
     'cfg2': dict(fn='gf_ep_modulator_nmf', D=16, N=3, T=84010, p=9, recipe='demo_nmf', balance=False, total_segments=None),
     'cfg3': dict(fn='ihgp_ep_modulator_nmf', D=32, N=6, T=200000, p=7, recipe='constraints', balance=True, total_segments=None),
     'cfg4': dict(fn='gf_giekf_modulator_nmf', D=24, N=3, T=88200, p=9, recipe='demo_nmf', balance=True, total_segments=None),
     'cfg5': dict(fn='gf_ep_modulator_nmf_constraints', D=32, N=6, T=100000, p=7, recipe='constraints', balance=True, total_segments=8),
+    # the fill-the-chip regime of the same three kernels families (the batch axes of the path: segments / hyper-parameter replicas):
+    # every GPU runs `per_gpu` independent segments, so the series is weak-scaling by construction
+    'cfg3_batch': dict(fn='ihgp_ep_modulator_nmf', D=32, N=6, T=4000, p=7, recipe='constraints', balance=True, total_segments=None, per_gpu=256),
+    'cfg2_batch': dict(fn='gf_ep_modulator_nmf', D=16, N=3, T=4000, p=9, recipe='demo_nmf', balance=False, total_segments=None, per_gpu=128),
+    'cfg5_fill': dict(fn='gf_ep_modulator_nmf_constraints', D=32, N=6, T=12500, p=7, recipe='constraints', balance=True, total_segments=None, per_gpu=32),
 }
 EP_ITTS = 3
 PEAK_FP64_TFLOPS = 78.6   # MI355X FP64 vector = matrix peak (MI355X_MICROARCH.md / SURVEY App. E)
@@ -55,40 +60,20 @@ def build_problems(wl, seeds):
     return probs, ys
 
 
-def _oracle_rate(args):
-    """One oracle run on the first Ts samples of the workload (NumPy restatement of the reference, dense as written).
-    Top-level so that a process pool can pickle it.  Returns (samples x sweeps per second, seconds)."""
-    wl, Ts, seed = args
-    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'nonstationary-audio-gp_amd'))
+def usable_cores():
+    """cores this process may use: the affinity mask, cut by the cgroup CPU quota when there is one"""
     try:
-        from threadpoolctl import threadpool_limits
-        ctx = threadpool_limits(limits=1)
-    except Exception:
-        import contextlib
-        ctx = contextlib.nullcontext()
-    from nagp import harness
-    from oracle import gf_ep as ogf, ihgp as oih, giekf as oek, lik as olik, ss as oss
-    D, N = wl['D'], wl['N']
-    om = olik.Mom(olik.LIK_POWER_NMF, p=wl['p'])
-    d = 0.5 * np.ones(EP_ITTS)
-    with ctx:
-        pr = harness.nmf_problem(D, N, Ts, seed, wl['recipe'])
-        lik_param, p1, p2, W = oss.unpack_log(pr['w'], 1, D, N)
-        if wl['fn'].startswith('ihgp'):
-            model = ogf.assemble(lik_param, p1, p2, W, 'matern32', 'matern52', True, True)
-            tabs = oih.build_tables(model)   # DARE tables are set-up, not the timed loop
-            t0 = time.perf_counter()
-            oih.run_predict(model, pr['y'], om, 0.5, d, EP_ITTS, tables=tabs)
-        elif wl['fn'].startswith('gf_giekf'):
-            model = ogf.assemble(lik_param, p1, p2, W, 'matern32', 'matern52', True)
-            t0 = time.perf_counter()
-            oek.run_predict(model, pr['y'], D, N, EP_ITTS, 1)
-        else:
-            model = ogf.assemble(lik_param, p1, p2, W, 'matern32', 'matern52', wl['balance'])
-            t0 = time.perf_counter()
-            ogf.run_predict(model, pr['y'], om, 0.5, d, EP_ITTS)
-        dt = time.perf_counter() - t0
-    return Ts * EP_ITTS / dt, dt
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as fh:
+            q, per = fh.read().split()
+        if q != 'max':
+            n = max(1, min(n, int(float(q) / float(per))))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 def host_cpu():
@@ -101,37 +86,85 @@ def host_cpu():
                     break
     except OSError:
         pass
-    try:
-        usable = len(os.sched_getaffinity(0))
-    except AttributeError:
-        usable = os.cpu_count() or 1
-    return model, os.cpu_count() or 1, usable
+    return model, os.cpu_count() or 1, usable_cores()
 
 
-def cpu_baseline(wl, budget_s=12.0):
-    """The oracle timed on this host: (i) one thread, (ii) one independent segment per core on min(usable cores, 16)
-    worker processes (the path's own parallel axis).  Bounded prefix of the same workload."""
-    Ts, rate1, dt = 100, None, 0.0
-    while True:
-        rate1, dt = _oracle_rate((wl, Ts, 1000))
-        if dt > budget_s / 3 or Ts >= 4000:
-            break
-        Ts = int(min(4000, max(Ts * 2, Ts * (budget_s / 1.5) / max(dt, 1e-3))))
-    model, nproc, usable = host_cpu()
-    cores = max(1, min(usable, 16))
-    rate_all, dt_all = rate1, dt
-    if cores > 1:
-        import multiprocessing as mp
+def cpu_baseline(wl, budget_s=4.0):
+    """The reference algorithm on this host's cores (MATLAB / Octave do not exist here: kind "port").  Timed, on a bounded prefix of the
+    same workload: the COMPILED restatement oracle/cpu/nagp_cpu.cpp (g++ -O3 -march=native, plain loops, checked against the oracle on
+    the golden vectors) -- (i) dense as written, one thread; (ii) structured (block-diagonal A, selection H: what a careful CPU port
+    does), one thread; (iii) structured, one independent segment per core on all usable cores (OpenMP; the path's own parallel axis) --
+    and (iv) the NumPy oracle, one thread, for continuity with the earlier rounds.  `value` is (iii), the strongest of them."""
+    from nagp import harness
+    from oracle import cpu as ocpu, gf_ep as ogf, ihgp as oih, giekf as oek, lik as olik, ss as oss
+    D, N = wl['D'], wl['N']
+    fam = 'ihgp' if wl['fn'].startswith('ihgp') else ('giekf' if wl['fn'].startswith('gf_giekf') else 'gf')
+    om = None if fam == 'giekf' else olik.Mom(olik.LIK_POWER_NMF, p=wl['p'])
+    d = 0.5 * np.ones(EP_ITTS)
+    model_name, nproc, usable = host_cpu()
+    Tmax = 20000 if fam == 'ihgp' else 4000
+    pr = harness.nmf_problem(D, N, Tmax, 1000, wl['recipe'])
+    lik_param, p1, p2, W = oss.unpack_log(pr['w'], 1, D, N)
+    model = ogf.assemble(lik_param, p1, p2, W, 'matern32', 'matern52', wl['balance'] or fam != 'gf', fam == 'ihgp')
+    tabs = oih.build_tables(model) if fam == 'ihgp' else None          # DARE tables are set-up, not the timed loop
+
+    def one(Ts, structured):
         t0 = time.perf_counter()
-        with mp.get_context('spawn').Pool(cores) as pool:      # fresh interpreters: nothing GPU-related is inherited
-            res = pool.map(_oracle_rate, [(wl, Ts, 1000 + q) for q in range(cores)])
-        wall = max(r[1] for r in res)                           # the slowest worker bounds the job
-        rate_all = cores * Ts * EP_ITTS / wall
+        if fam == 'ihgp':
+            r = ocpu.ihgp_predict(model, pr['y'][:Ts], om, 0.5, d, EP_ITTS, D, N, tabs, structured=structured)
+        elif fam == 'giekf':
+            r = ocpu.giekf_predict(model, pr['y'][:Ts], D, N, EP_ITTS, 1, structured=structured)
+        else:
+            r = ocpu.gf_predict(model, pr['y'][:Ts], om, 0.5, d, EP_ITTS, D, N, structured=structured)
+        dt = time.perf_counter() - t0
+        assert r['status'] == 0 and np.all(np.isfinite(r['Eft']))
+        return dt
+
+    def calibrated(structured, target_s):
+        Ts = 50
+        dt = one(Ts, structured)
+        Ts2 = int(min(Tmax, max(Ts, Ts * target_s / max(dt, 1e-4))))
+        if Ts2 > 2 * Ts:
+            Ts, dt = Ts2, one(Ts2, structured)
+        return Ts, dt, Ts * EP_ITTS / dt
+
+    ocpu.build()
+    Td, dtd, rate_dense = calibrated(False, budget_s * 0.5)
+    Tst, dts, rate_struct = calibrated(True, budget_s * 0.7)
+    threads = max(1, min(usable, 128))
+    rate_all, dt_all = rate_struct, dts
+    if threads > 1:
+        ys = [harness.nmf_problem(D, N, Tst, 1000 + q, wl['recipe'])['y'] for q in range(min(threads, 8))]
+        ys = [ys[q % len(ys)] for q in range(threads)]                   # the timing does not depend on the numbers
+        t0 = time.perf_counter()
+        _, st = ocpu.segments(fam, model, ys, om, 0.5, d, EP_ITTS, D, N, tables=tabs, threads=threads, structured=True)
         dt_all = time.perf_counter() - t0
-    return dict(value=rate_all, unit='samples/s', cores=cores, kind='port',
-                single_thread_value=rate1, host_cpu_model=model, host_nproc=nproc, host_usable_cores=usable,
-                sample='oracle (NumPy restatement of the reference loop, dense as written; MATLAB/Octave absent) on the first %d samples x %d sweeps '
-                       'of the same workload: 1 thread %.1f s; %d worker processes with one independent segment each %.1f s wall' % (Ts, EP_ITTS, dt, cores, dt_all))
+        assert st == 0
+        rate_all = threads * Tst * EP_ITTS / dt_all
+    # the NumPy oracle (interpreter + BLAS), one thread, ~2 s
+    try:
+        from threadpoolctl import threadpool_limits
+        ctx = threadpool_limits(limits=1)
+    except Exception:
+        import contextlib
+        ctx = contextlib.nullcontext()
+    Tn = int(max(50, min(Tmax, 1.0 * rate_dense / EP_ITTS)))            # a second or two of interpreter time
+    with ctx:
+        t0 = time.perf_counter()
+        if fam == 'ihgp':
+            oih.run_predict(model, pr['y'][:Tn], om, 0.5, d, EP_ITTS, tables=tabs)
+        elif fam == 'giekf':
+            oek.run_predict(model, pr['y'][:Tn], D, N, EP_ITTS, 1)
+        else:
+            ogf.run_predict(model, pr['y'][:Tn], om, 0.5, d, EP_ITTS)
+        dtn = time.perf_counter() - t0
+    return dict(value=rate_all, unit='samples/s', cores=threads, kind='port',
+                single_thread_value=rate_struct, dense_as_written_single_thread_value=rate_dense, numpy_oracle_single_thread_value=Tn * EP_ITTS / dtn,
+                host_cpu_model=model_name, host_nproc=nproc, host_usable_cores=usable,
+                sample='compiled restatement oracle/cpu/nagp_cpu.cpp (g++ -O3 -march=native, plain loops; MATLAB/Octave absent) on a prefix of the same '
+                       'workload x %d sweeps: dense as written, 1 thread: first %d samples %.1f s; structured, 1 thread: first %d samples %.1f s; structured, '
+                       '%d threads with one independent %d-sample segment each: %.1f s wall (= value); NumPy oracle, 1 thread: first %d samples %.1f s'
+                       % (EP_ITTS, Td, dtd, Tst, dts, threads, Tst, dt_all, Tn, dtn))
 
 
 def source_hash():
@@ -153,15 +186,18 @@ def run_workload(name, a, rank, local_rank, world, dev, with_cpu, steps, warmup)
     elif wl['total_segments']:               # a fixed set of segments sharded over the ranks (round robin)
         seeds = [5000 + q for q in nd.shard(wl['total_segments'], rank, world)]
         n_total = wl['total_segments']; scaling = 'strong'
-    else:                                    # one segment per GPU
-        seeds = [1000 + 100 * rank]
-        n_total = world; scaling = 'weak'
+    else:                                    # `per_gpu` segments on every GPU (1 for the BASELINE configurations)
+        per_gpu = wl.get('per_gpu', 1)
+        seeds = [1000 + 100 * rank + (q % 8) for q in range(per_gpu)]     # eight distinct prior samples, cycled: generating 256 on the host takes longer than the bench
+        n_total = per_gpu * world; scaling = 'weak'
     n_seg = len(seeds)
     kind = {'gf_ep': L.KIND_GF_EP, 'ihgp_': L.KIND_IHGP, 'gf_gi': L.KIND_GIEKF}[wl['fn'][:5]]
     mom = None if kind == L.KIND_GIEKF else Mom('likModulatorNMFPower', p_cubature=wl['p'])
     plan = None
     if n_seg:
-        probs, ys = build_problems(wl, seeds)
+        uniq = sorted(set(seeds))
+        up, uy = build_problems(wl, uniq)
+        probs = [up[uniq.index(sd)] for sd in seeds]; ys = [uy[uniq.index(sd)] for sd in seeds]
         plan = nagp.Plan(kind, probs, wl['T'], mom=mom, ep_fraction=0.5, ep_damping=0.5 * np.ones(EP_ITTS), ep_itts=EP_ITTS,
                          l_iter=1, device=local_rank)
         plan.upload(ys)                                           # inputs resident in HBM before timing
@@ -206,6 +242,10 @@ def run_workload(name, a, rank, local_rank, world, dev, with_cpu, steps, warmup)
                     achieved=achieved, peak=PEAK_HBM_GBS, unit='GB/s', frac=achieved / PEAK_HBM_GBS, traffic=None,
                     algorithmic_bytes_per_sample=per_sample, algorithmic_bytes_per_launch=per_launch,
                     valu_gflops=(8.0 * S * (S / M) + 8 * S + f_mom) * units / (kern[dom] * 1e-3) / 1e9,
+                    valu_peak_gflops=PEAK_FP64_TFLOPS * 1e3, valu_frac=(8.0 * S * (S / M) + 8 * S + f_mom) * units / (kern[dom] * 1e-3) / 1e9 / (PEAK_FP64_TFLOPS * 1e3),
+                    workgroups=n_seg, cus_occupied=min(n_seg, 256),
+                    # what the ADF launch itself moves (MF, five site / marginal arrays, y, lZ); SURVEY's figure above counts the whole sweep
+                    adf_kernel_bytes_per_sample=8.0 * (S + 5 * M + 2),
                     avg_launch_ms=kern[dom] / max(launches[dom], 1), us_per_sample=kern[dom] * 1e3 / units)
     elif plan is not None:
         # gf_ep: the ADF launches (sweep 1: all T steps, later sweeps: the step k = T-1) are one kernel
@@ -238,6 +278,16 @@ def run_workload(name, a, rank, local_rank, world, dev, with_cpu, steps, warmup)
                                              achieved=per_step * lin_steps / (kern['filter_lin'] * 1e-3) / 1e12, unit='TFLOP/s',
                                              avg_launch_ms=kern['filter_lin'] / max(launches['filter_lin'], 1),
                                              us_per_sample=kern['filter_lin'] * 1e3 / lin_steps)
+        # whole call against the FP64 peak with SURVEY 8(d)'s algorithmic flops per sample and sweep:
+        # F_gf = 19/3 S^3 (chol + 2 trsm + G dP G') + (10 b + 2M + 6) S^2 + c_mom F_mom   (giekf: no mom, 6 S^2 in place of 2M S^2)
+        if kind == L.KIND_GF_EP:
+            f_gf = 19.0 / 3.0 * S ** 3 + (10 * bbar + 2 * M + 6) * S * S + (4.0 / 3.0) * f_mom      # c_mom: 2 on sweep 1, 1 on sweep 2, 1 (filter only) on sweep 3
+        else:
+            f_gf = 19.0 / 3.0 * S ** 3 + (10 * bbar + 6 + 6) * S * S
+        roof['whole_call'] = dict(bound='fp64', algorithmic_flops_per_sample_per_sweep=f_gf,
+                                  achieved=f_gf * n_seg * T * EP_ITTS * steps / dt / 1e12, peak=PEAK_FP64_TFLOPS, unit='TFLOP/s',
+                                  frac=f_gf * n_seg * T * EP_ITTS * steps / dt / 1e12 / PEAK_FP64_TFLOPS,
+                                  note='this rank; wall time of the timed region (all kernels, both streams, host round trips)')
         roof['adf_us_per_sample'] = kern[dom] * 1e3 / adf_steps
         roof['algorithmic_bytes_per_launch'] = 8.0 * (8 * M * (M + 1) + S + 5 * M + 2) * adf_steps / max(launches[dom], 1)   # lower tiles + means + sites
     if roof is not None:
@@ -268,9 +318,14 @@ def run_workload(name, a, rank, local_rank, world, dev, with_cpu, steps, warmup)
     if plan is not None:
         plan.close()
     if rank == 0 and with_cpu:
-        res['cpu_baseline'] = cpu_baseline(wl)
-        res['speedup_vs_cpu_baseline'] = value / n_total / res['cpu_baseline']['value'] * 1.0          # one GPU segment stream vs ALL host cores
-        res['speedup_vs_cpu_single_thread'] = value / n_total / res['cpu_baseline']['single_thread_value']
+        cb = cpu_baseline(wl)
+        res['cpu_baseline'] = cb
+        # this rank's whole GPU (all its segments) against: every usable host core running independent segments (structured compiled
+        # port); one core, structured; one core, dense as written (the cost of the MATLAB text); one core, NumPy oracle
+        res['speedup_vs_cpu_all_cores_structured'] = value / world / cb['value']
+        res['speedup_vs_cpu_single_thread_structured'] = value / world / cb['single_thread_value']
+        res['speedup_vs_cpu_single_thread_dense_as_written'] = value / world / cb['dense_as_written_single_thread_value']
+        res['speedup_vs_cpu_single_thread_numpy_oracle'] = value / world / cb['numpy_oracle_single_thread_value']
     return res
 
 
@@ -341,15 +396,16 @@ def main():
     extras = []
     if a.extras == 'default':
         if a.workload == 'cfg3' and not a.T and not a.segments:
-            extras = ['cfg5'] + (['cfg2'] if world == 1 else [])
+            # configs[4] sharded (strong) and in the fill-the-chip form (weak), the full-chip batch lines of both kernel families,
+            # and at N = 1 the other single-GPU configurations
+            extras = ['cfg5', 'cfg5_fill', 'cfg3_batch', 'cfg2_batch'] + (['cfg2', 'cfg4'] if world == 1 else [])
     elif a.extras != 'none':
         extras = [e for e in a.extras.split(',') if e]
     for e in extras:
-        # extras: one warm-up + one timed step (the contract's K and W apply to the top-level line)
-        ex = run_workload(e, a, rank, local_rank, world, dev, with_cpu and e != 'cfg5', 1, 1)
+        # extras: one warm-up + two timed steps (the contract's K and W apply to the top-level line); CPU baseline for the BASELINE configurations
+        ex = run_workload(e, a, rank, local_rank, world, dev, with_cpu and e in ('cfg2', 'cfg4', 'cfg5'), 2, 1)
         key = 'cfg5_strong' if e == 'cfg5' else e
-        line[key] = {k: ex[k] for k in ('metric', 'value', 'unit', 'scaling', 'ms_per_step', 'steps', 'warmup', 'config', 'end_to_end_samples_per_s', 'kernel_ms_per_step',
-                                        'nlZ_allreduced', 'roofline', 'cpu_baseline', 'speedup_vs_cpu_baseline', 'speedup_vs_cpu_single_thread') if k in ex}
+        line[key] = {k: ex[k] for k in ex if k not in ('n_gpus', 'higher_is_better', 'vs_baseline', 'dtype', 'data')}
     if rank == 0:
         print(json.dumps(line))
         sys.stdout.flush()

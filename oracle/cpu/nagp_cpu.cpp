@@ -55,6 +55,7 @@ void gemm_nt(double* __restrict C, const double* __restrict A, const double* __r
       const double* a = A + (size_t)i * k;
       const double* b = B + (size_t)j * k;
       double s = 0.0;
+#pragma omp simd reduction(+ : s)
       for (int l = 0; l < k; ++l) s += a[l] * b[l];
       C[(size_t)i * m + j] = s;
     }
@@ -62,6 +63,7 @@ void gemm_nt(double* __restrict C, const double* __restrict A, const double* __r
 void gemv(double* __restrict y, const double* __restrict A, const double* __restrict x, int n, int k) {
   for (int i = 0; i < n; ++i) {
     double s = 0.0;
+#pragma omp simd reduction(+ : s)
     for (int l = 0; l < k; ++l) s += A[(size_t)i * k + l] * x[l];
     y[i] = s;
   }
@@ -108,12 +110,14 @@ bool chol_lower(double* L, const double* X, int n) {
     for (int j = 0; j < n; ++j) L[(size_t)i * n + j] = (j <= i) ? X[(size_t)i * n + j] : 0.0;
   for (int j = 0; j < n; ++j) {
     double d = L[(size_t)j * n + j];
+#pragma omp simd reduction(- : d)
     for (int l = 0; l < j; ++l) d -= L[(size_t)j * n + l] * L[(size_t)j * n + l];
     if (!(d > 0.0)) return false;
     d = std::sqrt(d);
     L[(size_t)j * n + j] = d;
     for (int i = j + 1; i < n; ++i) {
       double s = L[(size_t)i * n + j];
+#pragma omp simd reduction(- : s)
       for (int l = 0; l < j; ++l) s -= L[(size_t)i * n + l] * L[(size_t)j * n + l];
       L[(size_t)i * n + j] = s / d;
     }
@@ -192,8 +196,8 @@ struct Model { int S, M, D, N; const double *A, *Q, *H, *Pinf, *W; double lik_pa
 // One RTS step (gf_ep_modulator_nmf.m:210-230), dense as written.  Returns 0, 1 (retry taken) or -1 (both attempts failed).
 int rts_step(const Model& md, const double* PSk, const double* MSk, double* m, double* P, vec& w) {
   const int S = md.S; const size_t SS = (size_t)S * S;
-  w.resize(7 * SS + 2 * (size_t)S);
-  double *t1 = w.data(), *PSkp = t1 + SS, *L = PSkp + SS, *B = L + SS, *X = B + SS, *G = X + SS, *t2 = G + SS, *v = t2 + SS, *v2 = v + S;
+  w.resize(8 * SS + 2 * (size_t)S);
+  double *t1 = w.data(), *PSkp = t1 + SS, *L = PSkp + SS, *B = L + SS, *X = B + SS, *G = X + SS, *t2 = G + SS, *Lt = t2 + SS, *v = Lt + SS, *v2 = v + S;
   if (md.structured) { bd_left(t1, md.A, PSk, md.il, md.M, S); bd_right_t(PSkp, t1, md.A, md.il, md.M, S); }
   else { gemm_nn(t1, md.A, PSk, S, S, S); gemm_nt(PSkp, t1, md.A, S, S, S); }
   for (size_t i = 0; i < SS; ++i) PSkp[i] += md.Q[i];
@@ -207,17 +211,21 @@ int rts_step(const Model& md, const double* PSk, const double* MSk, double* m, d
   if (md.structured) bd_right_t(B, PSk, md.A, md.il, md.M, S);
   else gemm_nt(B, PSk, md.A, S, S, S);                             // PS_k * A'
   // X = B / L'  (X L' = B): row by row forward substitution; G = X / L (G L = X): backward
+  for (int i = 0; i < S; ++i) for (int j = 0; j < S; ++j) Lt[(size_t)j * S + i] = L[(size_t)i * S + j];
   for (int i = 0; i < S; ++i) {
     double* x = X + (size_t)i * S; const double* b = B + (size_t)i * S;
     for (int j = 0; j < S; ++j) {
       double s = b[j];
+#pragma omp simd reduction(- : s)
       for (int l = 0; l < j; ++l) s -= x[l] * L[(size_t)j * S + l];
       x[j] = s / L[(size_t)j * S + j];
     }
     double* g = G + (size_t)i * S;
     for (int j = S - 1; j >= 0; --j) {
       double s = x[j];
-      for (int l = j + 1; l < S; ++l) s -= g[l] * L[(size_t)l * S + j];
+      const double* lt = Lt + (size_t)j * S;             // row j of L' = column j of L, contiguous
+#pragma omp simd reduction(- : s)
+      for (int l = j + 1; l < S; ++l) s -= g[l] * lt[l];
       g[j] = s / L[(size_t)j * S + j];
     }
   }

@@ -15,6 +15,7 @@ NAGP_LIST_ALL(extern template __global__)
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -60,7 +61,6 @@ struct nagp_plan {
   int mfma_sp = 0;      // > 0: FP64-MFMA smoother passes on dense Sp x Sp matrices
   int big_sp = 0;       // 1: Sp > 96, the column-owner kernels of nagp_mfma_big.hpp
   int gain768 = 0;      // rts_gain_kernel<2, 768>: 1025..1536 tiles with a lower triangle of <= 768 tiles
-  bool gbuf_tiled = false;   // the chunk buffer last held tile-major matrices: zero it before the next dense use (padding rows)
   size_t gbuf_doubles = 0;
   MfmaPar mpar{};
   size_t lds_mfma = 0;
@@ -73,6 +73,26 @@ struct nagp_plan {
   int sp_ih = 0, sp_gf = 0, kb_sp = 16, hph_sp = 1; size_t lds_sp = 0;
   int sp_ih8 = 0, sp_pack = 0, sp_maxmem = 0; size_t lds_sp8 = 0;   // sp_maxmem: most points sharing one non-centre (dimension, coordinate)   // the role-specialised 512-thread form of the same sweep (ihgp_adf8_kernel)
   hipStream_t stream = nullptr;
+  // chunk-pipelined smoother (gf / giekf): while the sequential filter occupies one CU per problem, the parallel smoother kernels
+  // of the chunks it has finished (rts_gain + the compose pass) run on `stream2` on the rest of the chip
+  hipStream_t stream2 = nullptr;
+  bool pipeline = false;
+  int nc = 1;                                   // smoother chunks per sweep
+  std::vector<double*> slotG, slotD;            // (G, Delta) / delta chunk buffers; slot 0 doubles as the scratch of non-retained chunks
+  std::vector<char> slot_tiled;                 // the slot last held tile-major matrices: zero it before the next dense use (padding rows)
+  std::vector<int> slot_cap;                    // capacity of a slot in steps (= stride between its problems): `chunk`, except the small
+                                                // last slot that belongs to the short chunk of the latest steps
+  size_t mat_doubles = 0;                       // doubles of one dense / tile-major matrix in a slot
+  std::vector<double*> c_spanbuf, c_spanvec, c_mspanbuf, c_mspanvec;   // compose results per chunk (VALU / MFMA layouts)
+  std::vector<double*> c_bnd, c_mbnd;           // boundary values (E_top, e_top of every span) per chunk: the apply passes of several chunks
+                                                // run side by side on `s_apply` once the (sequential) boundary chain has passed them
+  std::vector<hipStream_t> s_apply;             // [0]: the merged apply launch of the chunks with their own (G, Delta) buffer
+  std::vector<hipEvent_t> ev_bnd, ev_app;       // [0]: boundary chain of those chunks done (main stream) / merged apply done (side stream)
+  ChunkTab* h_tab = nullptr;                    // pinned host memory [nc]: chunk table of the merged apply launch
+  std::vector<double*> c_xbuf;                  // per chunk as well: the VALU compose pass uses it as per-workgroup scratch, and the compose
+                                                // passes of two chunks may run at the same time (one on each stream)
+  unsigned long long* h_progress = nullptr;     // pinned host memory [B]: steps the filter has finished (FilterPar::progress)
+  hipEvent_t ev_filter = nullptr, ev_s2 = nullptr;
   Bufs b{};
   MomCfg mc{};
   IhgpTabs tb{};
@@ -261,13 +281,13 @@ static hipEvent_t next_event(nagp_plan* p) {
   return p->ev_pool[p->ev_next++];
 }
 struct Timed {
-  nagp_plan* p; int kid; hipEvent_t a, b;
-  Timed(nagp_plan* p_, int kid_) : p(p_), kid(kid_) {
+  nagp_plan* p; int kid; hipEvent_t a, b; hipStream_t st;
+  Timed(nagp_plan* p_, int kid_, hipStream_t st_ = nullptr) : p(p_), kid(kid_), st(st_ ? st_ : p_->stream) {
     a = next_event(p); b = next_event(p);
-    if (a) (void)hipEventRecord(a, p->stream);
+    if (a) (void)hipEventRecord(a, st);
   }
   ~Timed() {
-    if (b) (void)hipEventRecord(b, p->stream);
+    if (b) (void)hipEventRecord(b, st);
     if (a && b) p->evs.push_back({kid, a, b});
   }
 };
@@ -360,12 +380,12 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
   p->TPT = (nt + 511) / 512;   // <= 512 threads per workgroup: 256 VGPRs per lane for the register-resident tiles
   const bool ih = (o->kind == NAGP_KIND_IHGP);   // no covariance tiles: the tile-count limits below do not apply
   if (ih) p->TPT = std::min(p->TPT, 4);
-  if (!ih && (p->TPT > 4 || sh.S > 512)) { nagp_plan_destroy(p); FAIL(NAGP_EUNSUPPORTED, "M=%d / S=%d: more than 2048 tiles or 512 states", sh.M, sh.S); }
+  if (!ih && (p->TPT > 4 || sh.S > 512)) { const int Mx = sh.M, Sx = sh.S; nagp_plan_destroy(p); FAIL(NAGP_EUNSUPPORTED, "M=%d / S=%d: more than 2048 tiles or 512 states", Mx, Sx); }
   p->NT = std::max(roundup64((nt + p->TPT - 1) / p->TPT), std::max(roundup64(sh.S), 128));
   {   // filter: one thread per lower-triangular tile
     const int slots = sh.M * (sh.M + 1) / 2;
     p->TPT_f = (slots + 511) / 512;
-    if (p->TPT_f > 4 && !ih) { nagp_plan_destroy(p); FAIL(NAGP_EUNSUPPORTED, "M=%d too large for the filter kernel", sh.M); }
+    if (p->TPT_f > 4 && !ih) { const int Mx = sh.M; nagp_plan_destroy(p); FAIL(NAGP_EUNSUPPORTED, "M=%d too large for the filter kernel", Mx); }
     if (ih) p->TPT_f = std::min(p->TPT_f, 4);
     if (p->TPT_f == 3) p->TPT_f = 4;   // instantiated: 1, 2, 4 tiles per thread
     p->NT_f = std::max(roundup64((slots + p->TPT_f - 1) / p->TPT_f), std::max(roundup64(sh.S), ekf ? 128 : 384));
@@ -499,36 +519,36 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
   PLAN_TRY(dalloc(p, &b.state, (size_t)B * ((size_t)nt * 16 + sh.S)));
   PLAN_TRY(dalloc(p, &b.red, (size_t)B * 8));
   { double* c = nullptr; PLAN_TRY(dalloc(p, &c, (size_t)B * 4)); b.counters = reinterpret_cast<unsigned long long*>(c); }
-  p->chunk = (o->chunk > 0) ? o->chunk : (int)std::min<int64_t>(T, 1 << 20);
+  // smoother chunk: the unit of the (G, Delta) buffers and of the filter -> smoother pipeline.  About a dozen chunks per sweep
+  // (the tail the pipeline cannot hide is one chunk's gain + compose), at least 2048 steps each, at most what one buffer may take.
+  p->chunk = (o->chunk > 0) ? o->chunk : (int)std::min<int64_t>(T, std::max<int64_t>(2048, (T + 11) / 12));
   if (p->chunk > T) p->chunk = (int)T;
   PLAN_TRY(dalloc(p, &p->d_stamps, 8));
   if (o->kind != NAGP_KIND_IHGP) {
-    // the (G, Delta) chunk buffer: at most 24 GiB and at most a quarter of the device memory that is free once the
-    // per-step arrays (filtered covariances, means, sites) of this plan are counted
-    const int Sp_dense = ((4 * sh.M + 15) / 16) * 16;
-    const double per_step = (double)B * 2.0 * std::max<double>(std::max<double>(nt * 16.0, 96.0 * 96.0), (Sp_dense <= 160) ? (double)Sp_dense * Sp_dense : 0.0) * 8.0;
-    double cap_bytes = 24.0 * 1073741824.0;
+    {   // FP64 MFMA smoother for padded dimensions up to 96 (set NAGP_NO_MFMA=1 to force the VALU passes)
+      const int Sp = ((4 * sh.M + 15) / 16) * 16;
+      if (Sp <= 96 && !getenv("NAGP_NO_MFMA")) p->mfma_sp = Sp;
+      // 96 < Sp <= 160: state and G no longer fit LDS side by side; column-owner kernels
+      // (a sweep that stores the smoothed covariances runs the VALU passes instead: see run_smoother)
+      else if (Sp <= 160 && !getenv("NAGP_NO_MFMA") && !getenv("NAGP_NO_MFMA_BIG")) { p->mfma_sp = Sp; p->big_sp = 1; }
+    }
+    const size_t mat = p->mfma_sp ? (size_t)p->mfma_sp * p->mfma_sp : (size_t)nt * 16;     // (4M)^2 <= Sp^2: the tile-major form fits the dense slot
+    const double per_step = (double)B * (2.0 * (double)mat + sh.S) * 8.0;                  // one step of a (G, Delta, delta) chunk buffer
     {
+      // one chunk buffer: at most 24 GiB and at most a quarter of the device memory that is free once the per-step arrays
+      // (filtered covariances, means, sites) of this plan are counted
+      double cap_bytes = 24.0 * 1073741824.0;
       size_t free_b = 0, total_b = 0;
       if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
         const double fixed = (double)BT * ((p->need_PF ? pf_ntiles(sh) * 16.0 : 0.0) + (p->want_PS ? nt * 16.0 : 0.0) + 2.0 * sh.S) * 8.0;
         cap_bytes = std::min(cap_bytes, std::max(0.25 * ((double)free_b - fixed), 64.0 * per_step));
       }
+      while (p->chunk > 64 && per_step * p->chunk > cap_bytes) p->chunk = (p->chunk + 1) / 2;
     }
-    while (p->chunk > 64 && per_step * p->chunk > cap_bytes) p->chunk = (p->chunk + 1) / 2;
+    p->nc = (int)std::max<int64_t>(1, (T - 1 + p->chunk - 1) / p->chunk);
+    if (p->nc >= 2) p->nc += 1;      // the chunk of the latest steps is cut short (chunk0_len): one chunk more
     if (p->need_PF) PLAN_TRY(dalloc(p, &b.PF, BT * pf_ntiles(sh) * 16, false));   // lower-triangular tiles only
     if (p->want_PS) PLAN_TRY(dalloc(p, &b.PSs, BT * nt * 16, false));
-    {   // FP64 MFMA smoother for padded dimensions up to 96 (set NAGP_NO_MFMA=1 to force the VALU passes)
-      const int Sp = ((4 * sh.M + 15) / 16) * 16;
-      if (Sp <= 96 && !getenv("NAGP_NO_MFMA")) p->mfma_sp = Sp;
-      // 96 < Sp <= 160: state and G no longer fit LDS side by side; column-owner kernels
-      // (a sweep that stores the smoothed covariances runs the VALU passes instead: see launch_smoother)
-      else if (Sp <= 160 && !getenv("NAGP_NO_MFMA") && !getenv("NAGP_NO_MFMA_BIG")) { p->mfma_sp = Sp; p->big_sp = 1; }
-    }
-    const size_t mat = p->mfma_sp ? (size_t)p->mfma_sp * p->mfma_sp : (size_t)nt * 16;
-    PLAN_TRY(dalloc(p, &b.Gbuf, (size_t)B * p->chunk * 2 * mat, true));
-    p->gbuf_doubles = (size_t)B * p->chunk * 2 * mat;
-    PLAN_TRY(dalloc(p, &b.dbuf, (size_t)B * p->chunk * sh.S, false));
     // panel widths: one tile per thread per operand panel, panels (double buffered) within 72 KiB of LDS
     const double cap = 72.0 * 1024.0;
     p->LP1 = std::max(1, std::min(std::min(sh.M, p->NT / (3 * sh.M)), (int)(cap / (2.0 * 3 * sh.M * TS * 8))));
@@ -540,18 +560,75 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
       ns = std::max(1, std::min(std::min(ns, per_prob), (p->chunk + 7) / 8));
       p->ns_max = ns;
     }
-    PLAN_TRY(dalloc(p, &p->spar.spanbuf, (size_t)B * p->ns_max * 2 * nt * 16, false));
-    PLAN_TRY(dalloc(p, &p->spar.spanvec, (size_t)B * p->ns_max * sh.S, false));
-    PLAN_TRY(dalloc(p, &p->spar.bnd, (size_t)B * p->ns_max * ((size_t)nt * 16 + sh.S), false));
-    PLAN_TRY(dalloc(p, &p->spar.xbuf, (size_t)B * p->ns_max * nt * 16, false));
+    const bool need_valu = !p->mfma_sp || (p->big_sp && p->want_PS);   // the column-owner kernels have no smoothed-covariance output
+    const size_t SS = (size_t)p->mfma_sp * p->mfma_sp;
+    // boundary values / scratch of the span passes: one set (boundary and apply of a chunk run back to back on the main stream)
     if (p->mfma_sp) {
-      const size_t SS = (size_t)p->mfma_sp * p->mfma_sp;
-      PLAN_TRY(dalloc(p, &p->mpar.spanbuf, (size_t)B * p->ns_max * 2 * SS, false));
-      PLAN_TRY(dalloc(p, &p->mpar.spanvec, (size_t)B * p->ns_max * sh.S, false));
-      PLAN_TRY(dalloc(p, &p->mpar.bnd, (size_t)B * p->ns_max * (SS + sh.S), false));
       PLAN_TRY(dalloc(p, &p->mpar.stateD, (size_t)B * (SS + sh.S), true));
       p->lds_mfma = (p->big_sp ? big_lds_doubles(p->mfma_sp / 16) : mfma_lds_doubles(p->mfma_sp)) * sizeof(double);
     }
+    // Chunk-pipelined schedule: needs >= 2 chunks and >= 2 chunk buffers.  The compose results (Phi, C, c of every span) are kept
+    // per chunk; the (G, Delta, delta) buffers are kept for as many chunks as the free memory holds, the rest recompute their
+    // gains after the filter (slot 0 is the scratch).
+    p->pipeline = p->need_PF && p->nc >= 2 && !getenv("NAGP_NO_PIPELINE");
+    const int n_sets = p->pipeline ? p->nc : 1;
+    for (int c = 0; c < n_sets; ++c) {
+      double *a1 = nullptr, *a2 = nullptr, *a3 = nullptr, *a4 = nullptr, *a5 = nullptr;
+      if (need_valu) {
+        PLAN_TRY(dalloc(p, &a1, (size_t)B * p->ns_max * 2 * nt * 16, false));
+        PLAN_TRY(dalloc(p, &a2, (size_t)B * p->ns_max * sh.S, false));
+        PLAN_TRY(dalloc(p, &a5, (size_t)B * p->ns_max * nt * 16, false));
+      }
+      p->c_xbuf.push_back(a5);
+      {
+        double *b1 = nullptr, *b2 = nullptr;
+        if (need_valu) PLAN_TRY(dalloc(p, &b1, (size_t)B * p->ns_max * ((size_t)nt * 16 + sh.S), false));
+        if (p->mfma_sp) PLAN_TRY(dalloc(p, &b2, (size_t)B * p->ns_max * (SS + sh.S), false));
+        p->c_bnd.push_back(b1); p->c_mbnd.push_back(b2);
+      }
+      if (p->mfma_sp) {
+        PLAN_TRY(dalloc(p, &a3, (size_t)B * p->ns_max * 2 * SS, false));
+        PLAN_TRY(dalloc(p, &a4, (size_t)B * p->ns_max * sh.S, false));
+      }
+      p->c_spanbuf.push_back(a1); p->c_spanvec.push_back(a2); p->c_mspanbuf.push_back(a3); p->c_mspanvec.push_back(a4);
+    }
+    int n_slots = 1;
+    if (p->pipeline) {
+      size_t free_b = 0, total_b = 0;
+      const double slot_bytes = per_step * p->chunk;
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        const double avail = (double)free_b - 2.0 * 1073741824.0 - 0.03 * (double)total_b;     // head-room for the runtime, RCCL, other plans
+        n_slots = (int)std::max(1.0, std::min((double)(p->nc - 1), std::floor((avail - slot_bytes / 8.0) / slot_bytes)));   // full chunks: nc - 1
+      }
+      if (const char* e = getenv("NAGP_PIPELINE_SLOTS")) n_slots = std::max(1, std::min(p->nc - 1, atoi(e)));   // developer switch (tests: partial retention)
+      if (n_slots < 2) { p->pipeline = false; n_slots = 1; }
+    }
+    p->mat_doubles = mat;
+    auto add_slot = [&](int cap_steps) -> int {
+      double *g = nullptr, *d = nullptr;
+      int st = dalloc(p, &g, (size_t)B * cap_steps * 2 * mat, true);
+      if (st == NAGP_OK) st = dalloc(p, &d, (size_t)B * cap_steps * sh.S, false);
+      if (st == NAGP_OK) { p->slotG.push_back(g); p->slotD.push_back(d); p->slot_tiled.push_back(0); p->slot_cap.push_back(cap_steps); }
+      return st;
+    };
+    for (int q = 0; q < n_slots; ++q) PLAN_TRY(add_slot(p->chunk));
+    if (p->pipeline) PLAN_TRY(add_slot(std::min(p->chunk, std::max(64, p->chunk / 8))));   // the short chunk of the latest steps has its own
+    p->gbuf_doubles = (size_t)B * p->chunk * 2 * mat;
+    if (p->pipeline) {
+      PLAN_HIP(hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking));
+      { hipStream_t st = nullptr; PLAN_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); p->s_apply.push_back(st); }
+      {
+        hipEvent_t e1 = nullptr, e2 = nullptr;
+        PLAN_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming)); p->ev_bnd.push_back(e1);
+        PLAN_HIP(hipEventCreateWithFlags(&e2, hipEventDisableTiming)); p->ev_app.push_back(e2);
+      }
+      PLAN_HIP(hipHostMalloc(reinterpret_cast<void**>(&p->h_tab), (size_t)(p->nc + 1) * sizeof(ChunkTab), hipHostMallocMapped | hipHostMallocCoherent));
+      PLAN_HIP(hipEventCreateWithFlags(&p->ev_filter, hipEventDisableTiming));
+      PLAN_HIP(hipEventCreateWithFlags(&p->ev_s2, hipEventDisableTiming));
+      PLAN_HIP(hipHostMalloc(reinterpret_cast<void**>(&p->h_progress), (size_t)B * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent));
+      std::memset(p->h_progress, 0, (size_t)B * sizeof(unsigned long long));
+    }
+    if (getenv("NAGP_STAMPS")) fprintf(stderr, "[nagp plan] smoother: chunk %d, %d chunk(s) per sweep, %d (G,Delta) buffer(s) of %.2f GiB, pipelined %d\n", p->chunk, p->nc, n_slots, per_step * p->chunk / 1073741824.0, (int)p->pipeline);
   } else {
     PLAN_TRY(dalloc(p, &p->d_lZs, BT));
     PLAN_TRY(dalloc(p, &p->d_vprev, (size_t)B * sh.M));
@@ -674,6 +751,9 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     if (filter_lds_doubles(sh, t, ekf ? 1 : 0, p->kb_f) * sizeof(double) > cap) t.cache_tabs = 0;
     p->cache_f = t.cache_tabs; p->sta_f = t.store_a;
     p->lds_filter = filter_lds_doubles(sh, t, ekf ? 1 : 0, p->kb_f) * sizeof(double);
+    // pipelined plans: the filter's workgroup asks for the whole LDS of its CU, so that no workgroup of the smoother kernels running
+    // beside it on the second stream is placed on the same CU (the filter is the critical path; its time is latency, not occupancy)
+    if (p->pipeline) p->lds_filter = 160 * 1024;
     if (getenv("NAGP_STAMPS")) fprintf(stderr, "[nagp plan] gf filter: LDS %zu B, ring %d steps, cubature tables in LDS %d, mom LDS %zu B, sparse-point ADF %d\n", p->lds_filter, p->kb_f, p->cache_f, ekf ? (size_t)0 : mom_lds_doubles(t) * sizeof(double), p->sp_gf);
     p->lds_gain = gain_lds_doubles(sh) * sizeof(double);
     p->lds_scan = span_lds_doubles(sh, p->LP1, p->LP2) * sizeof(double);
@@ -767,6 +847,14 @@ extern "C" void nagp_plan_destroy(nagp_plan* p) {
   for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
   if (p->ev_t0) (void)hipEventDestroy(p->ev_t0);
   if (p->ev_t1) (void)hipEventDestroy(p->ev_t1);
+  for (hipStream_t st : p->s_apply) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+  for (hipEvent_t e : p->ev_bnd) (void)hipEventDestroy(e);
+  for (hipEvent_t e : p->ev_app) (void)hipEventDestroy(e);
+  if (p->ev_filter) (void)hipEventDestroy(p->ev_filter);
+  if (p->ev_s2) (void)hipEventDestroy(p->ev_s2);
+  if (p->h_progress) (void)hipHostFree(p->h_progress);
+  if (p->h_tab) (void)hipHostFree(p->h_tab);
+  if (p->stream2) { (void)hipStreamSynchronize(p->stream2); (void)hipStreamDestroy(p->stream2); }
   if (p->stream) (void)hipStreamDestroy(p->stream);
   delete p;
 }
@@ -810,6 +898,7 @@ extern "C" int nagp_plan_upload_y(nagp_plan* p, const double* const* ys) {
 static int launch_filter(nagp_plan* p, const FilterPar& fp_in) {
   FilterPar fp = fp_in;
   fp.kb = p->kb_f;
+  if (p->pipeline && fp.store_PF) { fp.progress = p->h_progress; fp.progress_every = 256; }
   const bool ekf = p->opts.kind == NAGP_KIND_GIEKF;
   MomCfg mc = p->mc; mc.DG = p->DG_f; mc.cache_tabs = p->cache_f; mc.store_a = p->sta_f;
   mc.sp = p->sp_gf ? p->sp : MomSp{};
@@ -863,92 +952,343 @@ static int launch_filter(nagp_plan* p, const FilterPar& fp_in) {
   return NAGP_OK;
 }
 
-static int launch_smoother(nagp_plan* p, bool write_PSs) {
+#define RUN(expr) do { int _s = (expr); if (_s != NAGP_OK) return _s; } while (0)
+
+// ---- smoother of one sweep, chunk by chunk (chunks are cut from the END of the sequence: chunk 0 holds the latest steps)
+struct ChunkGeom { int64_t k0; int nk; int L, ns; };
+enum SmMode { SM_VALU = 0, SM_MFMA = 1, SM_BIG = 2 };
+
+struct SweepCtx {
+  bool write_PSs = false;
+  SmMode mode = SM_VALU;
+  std::vector<ChunkGeom> ch;     // [0] = latest steps
+  std::vector<int> slot_of;      // chunk -> its own (G, Delta) buffer, or -1: not retained (slot 0 = scratch, gains recomputed)
+  std::vector<char> composed;    // gain + compose of the chunk were enqueued on the second stream while the filter ran
+  int next = -1;                 // next chunk the pump may start (counts down to 1; chunk 0 needs the complete filter)
+  bool s2_used = false;
+};
+
+static void sweep_begin(nagp_plan* p, SweepCtx& sc, bool write_PSs) {
   const Shape& sh = p->sh;
-  const int64_t nsm = sh.T - 1;   // smoothing steps k = 0 .. T-2
-  bool first = true;
-  for (int64_t k1 = nsm; k1 > 0;) {
-    const int nk = (int)std::min<int64_t>(p->chunk, k1);
-    const int64_t k0 = k1 - nk;
-    const bool use_big = p->big_sp && !write_PSs;            // the column-owner kernels have no smoothed-covariance output
-    const bool use_mfma = p->mfma_sp && !p->big_sp;
-    GainPar gp{k0, nk, p->chunk, (use_big || use_mfma) ? p->mfma_sp : 0};
-    if (gp.dense_sp && p->gbuf_tiled) { HIP_TRY(hipMemsetAsync(p->b.Gbuf, 0, p->gbuf_doubles * sizeof(double), p->stream)); p->gbuf_tiled = false; }
-    if (!gp.dense_sp && p->mfma_sp) p->gbuf_tiled = true;
-    {
-      Timed t(p, NAGP_K_GAIN);
-      dim3 g(nk, p->B), bl(p->NT);
-      if (p->gain768) hipLaunchKernelGGL((rts_gain_kernel<2, 768>), g, dim3(768), p->lds_gain, p->stream, sh, p->b, gp);
-      else switch (p->TPT) {
-        case 1: hipLaunchKernelGGL((rts_gain_kernel<1>), g, bl, p->lds_gain, p->stream, sh, p->b, gp); break;
-        case 2: hipLaunchKernelGGL((rts_gain_kernel<2>), g, bl, p->lds_gain, p->stream, sh, p->b, gp); break;
-        case 3: hipLaunchKernelGGL((rts_gain_kernel<3>), g, bl, p->lds_gain, p->stream, sh, p->b, gp); break;
-        default: hipLaunchKernelGGL((rts_gain_kernel<4>), g, bl, p->lds_gain, p->stream, sh, p->b, gp); break;
+  sc.write_PSs = write_PSs;
+  sc.mode = (p->big_sp && !write_PSs) ? SM_BIG : ((p->mfma_sp && !p->big_sp) ? SM_MFMA : SM_VALU);
+  sc.ch.clear();
+  // Chunk 0 (the latest steps) is all the pipeline cannot hide: its gains and compose pass need the complete filter.  It is cut
+  // short (an eighth of a chunk, spans a quarter as long) whenever there is more than one chunk.
+  const bool many = (sh.T - 1) > p->chunk;
+  for (int64_t k1 = sh.T - 1; k1 > 0;) {
+    const bool c0 = many && sc.ch.empty();
+    const int nk = (int)std::min<int64_t>(c0 ? std::min(p->chunk, std::max(64, p->chunk / 8)) : p->chunk, k1);   // never beyond the buffer's capacity
+    ChunkGeom g{k1 - nk, nk, 1, 1};
+    // Spans.  The boundary pass is one sequential chain over ALL spans of the sweep (one workgroup per problem, a step per span); a
+    // compose / apply launch costs a span LENGTH of latency, and the apply passes of the chunks run as one merged grid.
+    //  * few workgroups (B * spans of the whole sweep <= 512: single sequences): latency decides -- one span length for the whole
+    //    backward recursion, L* = sqrt((T-1)/r) with r = boundary step : apply step (2.5 VALU passes, ~1 MFMA passes;
+    //    profiles/r03_pipeline_timeline_*); per-chunk sqrt rules would multiply the boundary chain by sqrt(#chunks);
+    //  * many workgroups (segments x spans fill the chip): throughput decides -- a chunk's launch should be whole rounds of the CUs the
+    //    filter leaves free, spans as long as that allows (column-owner kernels: ~90 us per step of the three span passes, ~47 us
+    //    per boundary span, measured at Sp = 160); the other kernels keep the sqrt(2.5 nk) rule under the workgroup cap.
+    double Lstar = std::max(8.0, std::sqrt((double)(sh.T - 1) / (sc.mode == SM_VALU ? 2.5 : 1.0)));
+    const bool latency_regime = (double)p->B * (double)(sh.T - 1) / Lstar <= 512.0;
+    int ns;
+    if (latency_regime) {
+      // one span length for the sweep: the boundary chain costs (T/L) r, the merged apply grid ceil(B (T/L) / 256) rounds of L steps
+      const double r = (sc.mode == SM_VALU) ? 2.5 : 1.0;
+      double best = 1e300;
+      for (int L = 8; L <= std::max<int64_t>(8, sh.T - 1); L += std::max(1, L / 64)) {
+        const double spans = std::ceil((double)(sh.T - 1) / L);
+        const double cost = spans * r + std::ceil(spans * p->B / 256.0) * L;
+        if (cost < best) { best = cost; Lstar = L; }
       }
-    }
-    HIP_TRY(hipGetLastError());
-    SpanPar sp = p->spar;
-    sp.k0 = k0; sp.nk = nk; sp.chunk = p->chunk; sp.ns_max = p->ns_max; sp.LP1 = p->LP1; sp.LP2 = p->LP2;
-    sp.first = first ? 1 : 0; sp.write_PSs = write_PSs ? 1 : 0;
-    {
-      int ns = (int)std::lround(std::sqrt(2.5 * (double)nk));
+      // the two chunks of the latest steps are what the pipeline cannot hide (chunk 0 needs the complete filter, chunk 1's compose
+      // pass is still running when the filter ends): shorter spans there -- a few more steps of the boundary chain for a quarter
+      // of the compose latency
+      if (many && sc.ch.size() <= 1) Lstar = std::max(8.0, Lstar / 4.0);
+      ns = (int)std::lround((double)nk / Lstar);
       ns = std::max(1, std::min(std::min(ns, p->ns_max), (nk + 7) / 8));
-      if (use_big) {
-        // column-owner kernels: a step of the three span passes costs ~90 us of one CU (Phi 19, C 34, apply 37; measured at
-        // Sp = 160), a span of the sequential boundary pass ~47 us.  Spans run in rounds of one workgroup per CU.
-        const int n_cu = 256;
-        double best = 1e300;
-        for (int c = 1; c <= std::max(1, std::min(p->ns_max, (nk + 7) / 8)); ++c) {
-          const int L = (nk + c - 1) / c, cc = (nk + L - 1) / L;
-          const double rounds = std::ceil((double)cc * p->B / n_cu);
-          const double cost = rounds * L * 90.0 + cc * 47.0;
-          if (cost < best) { best = cost; ns = cc; }
-        }
+    } else if (sc.mode == SM_BIG) {
+      const int n_cu = std::max(32, 256 - p->B);
+      double best = 1e300; ns = 1;
+      for (int c = 1; c <= std::max(1, std::min(p->ns_max, (nk + 7) / 8)); ++c) {
+        const int L = (nk + c - 1) / c, cc = (nk + L - 1) / L;
+        const double rounds = std::ceil((double)cc * p->B / n_cu);
+        const double cost = rounds * L * 90.0 + cc * 47.0;
+        if (cost < best) { best = cost; ns = cc; }
       }
-      sp.L = (nk + ns - 1) / ns;
-      sp.ns = (nk + sp.L - 1) / sp.L;
+    } else {
+      ns = (int)std::lround(std::sqrt(2.5 * (double)nk));
+      ns = std::max(1, std::min(std::min(ns, p->ns_max), (nk + 7) / 8));
     }
-    if (use_big) {
-      MfmaPar mp = p->mpar;
-      mp.k0 = k0; mp.nk = nk; mp.chunk = p->chunk; mp.L = sp.L; mp.ns = sp.ns; mp.ns_max = p->ns_max; mp.Sp = p->mfma_sp;
-      mp.first = first ? 1 : 0; mp.write_PSs = 0;
-      Timed t(p, NAGP_K_SCAN);
-      const int ntl = p->mfma_sp / 16;
-      dim3 g(mp.ns, p->B), g2(p->B), bl(64 * ntl);
-#define LB(N) do { \
-        hipLaunchKernelGGL((rts_big_phi_kernel<N>), g, bl, p->lds_mfma, p->stream, sh, p->b, mp); \
-        hipLaunchKernelGGL((rts_big_kernel<N, 0>), g, bl, p->lds_mfma, p->stream, sh, p->b, mp); \
-        hipLaunchKernelGGL((rts_big_kernel<N, 1>), g2, bl, p->lds_mfma, p->stream, sh, p->b, mp); \
-        hipLaunchKernelGGL((rts_big_kernel<N, 2>), g, bl, p->lds_mfma, p->stream, sh, p->b, mp); } while (0)
-      switch (ntl) { case 7: LB(7); break; case 8: LB(8); break; case 9: LB(9); break; default: LB(10); break; }
-#undef LB
-    } else if (use_mfma) {
-      MfmaPar mp = p->mpar;
-      mp.k0 = k0; mp.nk = nk; mp.chunk = p->chunk; mp.L = sp.L; mp.ns = sp.ns; mp.ns_max = p->ns_max; mp.Sp = p->mfma_sp;
-      mp.first = first ? 1 : 0; mp.write_PSs = write_PSs ? 1 : 0;
-      Timed t(p, NAGP_K_SCAN);
-      dim3 g(mp.ns, p->B), g2(p->B), bl(256);
-#define LM(N) do { \
-        hipLaunchKernelGGL((rts_compose_mfma_kernel<N>), g, bl, p->lds_mfma, p->stream, sh, p->b, mp); \
-        hipLaunchKernelGGL((rts_boundary_mfma_kernel<N>), g2, bl, p->lds_mfma, p->stream, sh, p->b, mp); \
-        hipLaunchKernelGGL((rts_apply_mfma_kernel<N>), g, bl, p->lds_mfma, p->stream, sh, p->b, mp); } while (0)
-      switch (p->mfma_sp / 16) { case 1: LM(1); break; case 2: LM(2); break; case 3: LM(3); break; case 4: LM(4); break; case 5: LM(5); break; default: LM(6); break; }
-#undef LM
-    } else
-    {
-      Timed t(p, NAGP_K_SCAN);
-      dim3 g(sp.ns, p->B), g2(p->B), bl(p->NT);
-#define LS(TP) do { \
-        hipLaunchKernelGGL((rts_compose_kernel<TP>), g, bl, p->lds_scan, p->stream, sh, p->b, sp); \
-        hipLaunchKernelGGL((rts_boundary_kernel<TP>), g2, bl, p->lds_scan, p->stream, sh, p->b, sp); \
-        hipLaunchKernelGGL((rts_apply_kernel<TP>), g, bl, p->lds_scan, p->stream, sh, p->b, sp); } while (0)
-      switch (p->TPT) { case 1: LS(1); break; case 2: LS(2); break; case 3: LS(3); break; default: LS(4); break; }
-#undef LS
-    }
-    HIP_TRY(hipGetLastError());
-    first = false;
-    k1 = k0;
+    g.L = (nk + ns - 1) / ns;
+    g.ns = (nk + g.L - 1) / g.L;
+    sc.ch.push_back(g);
+    k1 = g.k0;
   }
+  const int nc = (int)sc.ch.size();
+  sc.slot_of.assign(nc, -1);
+  sc.composed.assign(nc, 0);
+  if (p->pipeline) {
+    // the short chunk 0 owns the small last slot; full slots 1 .. n_full-1 belong to the chunks the filter finishes last (slot 0 is
+    // the scratch of the others) -- or, with a full slot for every other chunk, slot c-1 to chunk c
+    const int n_full = (int)p->slotG.size() - 1;
+    sc.slot_of[0] = n_full;
+    if (n_full >= nc - 1) for (int c = 1; c < nc; ++c) sc.slot_of[c] = c - 1;
+    else for (int c = 1; c < n_full; ++c) sc.slot_of[c] = c;
+    sc.next = nc - 1;
+    std::memset(p->h_progress, 0, (size_t)p->B * sizeof(unsigned long long));
+  } else {
+    sc.next = 0;
+  }
+  sc.s2_used = false;
+}
+
+static int launch_gain_chunk(nagp_plan* p, const SweepCtx& sc, int c, int slot, hipStream_t st) {
+  const Shape& sh = p->sh; const ChunkGeom& g = sc.ch[c];
+  GainPar gp{g.k0, g.nk, p->slot_cap[slot], (sc.mode != SM_VALU) ? p->mfma_sp : 0};
+  if (gp.dense_sp && p->slot_tiled[slot]) {
+    HIP_TRY(hipMemsetAsync(p->slotG[slot], 0, (size_t)p->B * p->slot_cap[slot] * 2 * p->mat_doubles * sizeof(double), st)); p->slot_tiled[slot] = 0;
+  }
+  if (!gp.dense_sp && p->mfma_sp) p->slot_tiled[slot] = 1;
+  Bufs b = p->b; b.Gbuf = p->slotG[slot]; b.dbuf = p->slotD[slot];
+  Timed t(p, NAGP_K_GAIN, st);
+  dim3 gr(g.nk, p->B), bl(p->NT);
+  if (p->gain768) hipLaunchKernelGGL((rts_gain_kernel<2, 768>), gr, dim3(768), p->lds_gain, st, sh, b, gp);
+  else switch (p->TPT) {
+    case 1: hipLaunchKernelGGL((rts_gain_kernel<1>), gr, bl, p->lds_gain, st, sh, b, gp); break;
+    case 2: hipLaunchKernelGGL((rts_gain_kernel<2>), gr, bl, p->lds_gain, st, sh, b, gp); break;
+    case 3: hipLaunchKernelGGL((rts_gain_kernel<3>), gr, bl, p->lds_gain, st, sh, b, gp); break;
+    default: hipLaunchKernelGGL((rts_gain_kernel<4>), gr, bl, p->lds_gain, st, sh, b, gp); break;
+  }
+  HIP_TRY(hipGetLastError());
+  return NAGP_OK;
+}
+
+static SpanPar span_par(nagp_plan* p, const SweepCtx& sc, int c, int slot) {
+  const ChunkGeom& g = sc.ch[c];
+  const int set = p->pipeline ? c : 0;
+  SpanPar sp = p->spar;
+  sp.k0 = g.k0; sp.nk = g.nk; sp.chunk = p->slot_cap[slot]; sp.ns_max = p->ns_max; sp.LP1 = p->LP1; sp.LP2 = p->LP2;
+  sp.first = (c == 0) ? 1 : 0; sp.write_PSs = sc.write_PSs ? 1 : 0; sp.L = g.L; sp.ns = g.ns;
+  sp.spanbuf = p->c_spanbuf[set]; sp.spanvec = p->c_spanvec[set]; sp.xbuf = p->c_xbuf[set]; sp.bnd = p->c_bnd[set];
+  sp.tab = nullptr; sp.ntab = 0;
+  return sp;
+}
+static MfmaPar mfma_par(nagp_plan* p, const SweepCtx& sc, int c, int slot) {
+  const ChunkGeom& g = sc.ch[c];
+  const int set = p->pipeline ? c : 0;
+  MfmaPar mp = p->mpar;
+  mp.k0 = g.k0; mp.nk = g.nk; mp.chunk = p->slot_cap[slot]; mp.L = g.L; mp.ns = g.ns; mp.ns_max = p->ns_max; mp.Sp = p->mfma_sp;
+  mp.first = (c == 0) ? 1 : 0; mp.write_PSs = (sc.mode == SM_MFMA && sc.write_PSs) ? 1 : 0;
+  mp.spanbuf = p->c_mspanbuf[set]; mp.spanvec = p->c_mspanvec[set]; mp.bnd = p->c_mbnd[set];
+  mp.tab = nullptr; mp.ntab = 0; mp.xbuf = nullptr;
+  return mp;
+}
+
+// pass 1 of the span scheme (one workgroup per span): reads the chunk's (G, Delta, delta), writes its (Phi, C, c)
+static int launch_compose_chunk(nagp_plan* p, const SweepCtx& sc, int c, int slot, hipStream_t st) {
+  const Shape& sh = p->sh; const ChunkGeom& g = sc.ch[c];
+  Bufs b = p->b; b.Gbuf = p->slotG[slot]; b.dbuf = p->slotD[slot];
+  Timed t(p, NAGP_K_SCAN, st);
+  if (sc.mode == SM_BIG) {
+    MfmaPar mp = mfma_par(p, sc, c, slot);
+    const int ntl = p->mfma_sp / 16;
+    dim3 gr(g.ns, p->B), bl(64 * ntl);
+#define LB(N) do { \
+      hipLaunchKernelGGL((rts_big_phi_kernel<N>), gr, bl, p->lds_mfma, st, sh, b, mp); \
+      hipLaunchKernelGGL((rts_big_kernel<N, 0>), gr, bl, p->lds_mfma, st, sh, b, mp); } while (0)
+    switch (ntl) { case 7: LB(7); break; case 8: LB(8); break; case 9: LB(9); break; default: LB(10); break; }
+#undef LB
+  } else if (sc.mode == SM_MFMA) {
+    MfmaPar mp = mfma_par(p, sc, c, slot);
+    dim3 gr(g.ns, p->B), bl(256);
+#define LM(N) hipLaunchKernelGGL((rts_compose_mfma_kernel<N>), gr, bl, p->lds_mfma, st, sh, b, mp)
+    switch (p->mfma_sp / 16) { case 1: LM(1); break; case 2: LM(2); break; case 3: LM(3); break; case 4: LM(4); break; case 5: LM(5); break; default: LM(6); break; }
+#undef LM
+  } else {
+    SpanPar sp = span_par(p, sc, c, slot);
+    dim3 gr(g.ns, p->B), bl(p->NT);
+#define LS(TP) hipLaunchKernelGGL((rts_compose_kernel<TP>), gr, bl, p->lds_scan, st, sh, b, sp)
+    switch (p->TPT) { case 1: LS(1); break; case 2: LS(2); break; case 3: LS(3); break; default: LS(4); break; }
+#undef LS
+  }
+  HIP_TRY(hipGetLastError());
+  return NAGP_OK;
+}
+
+// pass 2: boundary values over the spans of the chunk (sequential; continues from the chunk behind it in time through the carry
+// state), pass 3: the reference recursion inside every span from its boundary value
+static int launch_boundary_chunk(nagp_plan* p, const SweepCtx& sc, int c, int slot, hipStream_t st) {
+  const Shape& sh = p->sh;
+  Bufs b = p->b; b.Gbuf = p->slotG[slot]; b.dbuf = p->slotD[slot];
+  Timed t(p, NAGP_K_SCAN, st);
+  dim3 g2(p->B);
+  if (sc.mode == SM_BIG) {
+    MfmaPar mp = mfma_par(p, sc, c, slot);
+    const int ntl = p->mfma_sp / 16;
+    dim3 bl(64 * ntl);
+#define LB(N) hipLaunchKernelGGL((rts_big_kernel<N, 1>), g2, bl, p->lds_mfma, st, sh, b, mp)
+    switch (ntl) { case 7: LB(7); break; case 8: LB(8); break; case 9: LB(9); break; default: LB(10); break; }
+#undef LB
+  } else if (sc.mode == SM_MFMA) {
+    MfmaPar mp = mfma_par(p, sc, c, slot);
+    dim3 bl(256);
+#define LM(N) hipLaunchKernelGGL((rts_boundary_mfma_kernel<N>), g2, bl, p->lds_mfma, st, sh, b, mp)
+    switch (p->mfma_sp / 16) { case 1: LM(1); break; case 2: LM(2); break; case 3: LM(3); break; case 4: LM(4); break; case 5: LM(5); break; default: LM(6); break; }
+#undef LM
+  } else {
+    SpanPar sp = span_par(p, sc, c, slot);
+    dim3 bl(p->NT);
+#define LS(TP) hipLaunchKernelGGL((rts_boundary_kernel<TP>), g2, bl, p->lds_scan, st, sh, b, sp)
+    switch (p->TPT) { case 1: LS(1); break; case 2: LS(2); break; case 3: LS(3); break; default: LS(4); break; }
+#undef LS
+  }
+  HIP_TRY(hipGetLastError());
+  return NAGP_OK;
+}
+
+static int launch_apply_chunk(nagp_plan* p, const SweepCtx& sc, int c, int slot, hipStream_t st) {
+  const Shape& sh = p->sh; const ChunkGeom& g = sc.ch[c];
+  Bufs b = p->b; b.Gbuf = p->slotG[slot]; b.dbuf = p->slotD[slot];
+  Timed t(p, NAGP_K_SCAN, st);
+  if (sc.mode == SM_BIG) {
+    MfmaPar mp = mfma_par(p, sc, c, slot);
+    const int ntl = p->mfma_sp / 16;
+    dim3 gr(g.ns, p->B), bl(64 * ntl);
+#define LB(N) hipLaunchKernelGGL((rts_big_kernel<N, 2>), gr, bl, p->lds_mfma, st, sh, b, mp)
+    switch (ntl) { case 7: LB(7); break; case 8: LB(8); break; case 9: LB(9); break; default: LB(10); break; }
+#undef LB
+  } else if (sc.mode == SM_MFMA) {
+    MfmaPar mp = mfma_par(p, sc, c, slot);
+    dim3 gr(g.ns, p->B), bl(256);
+#define LM(N) hipLaunchKernelGGL((rts_apply_mfma_kernel<N>), gr, bl, p->lds_mfma, st, sh, b, mp)
+    switch (p->mfma_sp / 16) { case 1: LM(1); break; case 2: LM(2); break; case 3: LM(3); break; case 4: LM(4); break; case 5: LM(5); break; default: LM(6); break; }
+#undef LM
+  } else {
+    SpanPar sp = span_par(p, sc, c, slot);
+    dim3 gr(g.ns, p->B), bl(p->NT);
+#define LS(TP) hipLaunchKernelGGL((rts_apply_kernel<TP>), gr, bl, p->lds_scan, st, sh, b, sp)
+    switch (p->TPT) { case 1: LS(1); break; case 2: LS(2); break; case 3: LS(3); break; default: LS(4); break; }
+#undef LS
+  }
+  HIP_TRY(hipGetLastError());
+  return NAGP_OK;
+}
+
+// While the filter launches of this sweep run on the main stream: start gain + compose of every chunk whose steps (and the one
+// behind them, for Delta_k = PS_{k+1} - ...) the filter has published, on the second stream.  Returns when the filter has finished.
+static int sweep_pump(nagp_plan* p, SweepCtx& sc) {
+  if (!p->pipeline) return NAGP_OK;
+  HIP_TRY(hipEventRecord(p->ev_filter, p->stream));
+  auto try_start = [&]() -> int {
+    unsigned long long done = ~0ull;
+    for (int q = 0; q < p->B; ++q) {
+      const unsigned long long v = __atomic_load_n(&p->h_progress[q], __ATOMIC_ACQUIRE);
+      done = std::min(done, v);
+    }
+    while (sc.next >= 1) {
+      const ChunkGeom& g = sc.ch[sc.next];
+      if (done < (unsigned long long)(g.k0 + g.nk + 1)) break;       // steps k0 .. k0+nk (inclusive) are needed
+      const int c = sc.next;
+      const int slot = sc.slot_of[c] >= 0 ? sc.slot_of[c] : 0;
+      RUN(launch_gain_chunk(p, sc, c, slot, p->stream2));
+      RUN(launch_compose_chunk(p, sc, c, slot, p->stream2));
+      sc.composed[c] = 1; sc.s2_used = true;
+      --sc.next;
+    }
+    return NAGP_OK;
+  };
+  for (;;) {
+    const hipError_t e = hipEventQuery(p->ev_filter);
+    if (e == hipSuccess) break;
+    if (e != hipErrorNotReady) HIP_TRY(e);
+    RUN(try_start());
+    std::this_thread::sleep_for(std::chrono::microseconds(50));
+  }
+  RUN(try_start());      // whatever the last poll missed (chunk 0 stays with the main stream)
+  if (sc.s2_used) HIP_TRY(hipEventRecord(p->ev_s2, p->stream2));
+  return NAGP_OK;
+}
+
+// The apply passes of chunks [0, n_own) -- those with their own (G, Delta) buffer -- as ONE grid on the side stream.
+static int launch_apply_merged(nagp_plan* p, const SweepCtx& sc, int n_own, hipStream_t st) {
+  const Shape& sh = p->sh;
+  int tot = 0;
+  for (int c = 0; c < n_own; ++c) {
+    const ChunkGeom& g = sc.ch[c];
+    ChunkTab& t = p->h_tab[c];
+    const int slot = sc.slot_of[c];
+    t.k0 = g.k0; t.nk = g.nk; t.L = g.L; t.ns = g.ns; t.first = (c == 0) ? 1 : 0; t.span0 = tot; t.cap = p->slot_cap[slot];
+    t.G = p->slotG[slot]; t.d = p->slotD[slot];
+    if (sc.mode == SM_VALU) { t.spanbuf = p->c_spanbuf[c]; t.spanvec = p->c_spanvec[c]; t.bnd = p->c_bnd[c]; t.xbuf = p->c_xbuf[c]; }
+    else { t.spanbuf = p->c_mspanbuf[c]; t.spanvec = p->c_mspanvec[c]; t.bnd = p->c_mbnd[c]; t.xbuf = nullptr; }
+    tot += g.ns;
+  }
+  Bufs b = p->b; b.Gbuf = p->slotG[sc.slot_of[0]]; b.dbuf = p->slotD[sc.slot_of[0]];
+  Timed t(p, NAGP_K_SCAN, st);
+  dim3 gr(tot, p->B);
+  if (sc.mode == SM_BIG) {
+    MfmaPar mp = mfma_par(p, sc, 0, sc.slot_of[0]); mp.tab = p->h_tab; mp.ntab = n_own;
+    const int ntl = p->mfma_sp / 16;
+    dim3 bl(64 * ntl);
+#define LB(N) hipLaunchKernelGGL((rts_big_kernel<N, 2>), gr, bl, p->lds_mfma, st, sh, b, mp)
+    switch (ntl) { case 7: LB(7); break; case 8: LB(8); break; case 9: LB(9); break; default: LB(10); break; }
+#undef LB
+  } else if (sc.mode == SM_MFMA) {
+    MfmaPar mp = mfma_par(p, sc, 0, sc.slot_of[0]); mp.tab = p->h_tab; mp.ntab = n_own;
+    dim3 bl(256);
+#define LM(N) hipLaunchKernelGGL((rts_apply_mfma_kernel<N>), gr, bl, p->lds_mfma, st, sh, b, mp)
+    switch (p->mfma_sp / 16) { case 1: LM(1); break; case 2: LM(2); break; case 3: LM(3); break; case 4: LM(4); break; case 5: LM(5); break; default: LM(6); break; }
+#undef LM
+  } else {
+    SpanPar sp = span_par(p, sc, 0, sc.slot_of[0]); sp.tab = p->h_tab; sp.ntab = n_own;
+    dim3 bl(p->NT);
+#define LS(TP) hipLaunchKernelGGL((rts_apply_kernel<TP>), gr, bl, p->lds_scan, st, sh, b, sp)
+    switch (p->TPT) { case 1: LS(1); break; case 2: LS(2); break; case 3: LS(3); break; default: LS(4); break; }
+#undef LS
+  }
+  HIP_TRY(hipGetLastError());
+  return NAGP_OK;
+}
+
+// After the filter: chunk by chunk from the end of the sequence -- (gain, compose unless they ran beside the filter,) boundary pass on
+// the main stream (the carry between chunks is its order).  The apply passes of the chunks that own a (G, Delta) buffer run as ONE
+// merged grid on a side stream once the boundary chain has passed them (a span length of latency instead of one per chunk);
+// the chunks without a buffer follow on the main stream: gains again into the scratch buffer, boundary, apply.
+static int sweep_finish(nagp_plan* p, SweepCtx& sc) {
+  const int nc = (int)sc.ch.size();
+  bool waited = !sc.s2_used;       // the main stream has to wait ONCE for the second stream's work (one event behind all of it)
+  auto wait_s2 = [&]() -> int {
+    if (!waited) { HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_s2, 0)); waited = true; }
+    return NAGP_OK;
+  };
+  int n_own = 0;                   // chunks 0 .. n_own-1 own a buffer (pipelined plans; slot_of is a prefix by construction)
+  if (p->pipeline) while (n_own < nc && sc.slot_of[n_own] >= 0) ++n_own;
+  for (int c = 0; c < nc; ++c) {
+    const int slot = sc.slot_of[c] >= 0 ? sc.slot_of[c] : 0;
+    if (!sc.composed[c]) {
+      // chunk 0 (it needs the complete filter), and every chunk of a serial plan
+      if (sc.slot_of[c] < 0) RUN(wait_s2());                 // slot 0 may still be the second stream's scratch
+      RUN(launch_gain_chunk(p, sc, c, slot, p->stream));
+      RUN(launch_compose_chunk(p, sc, c, slot, p->stream));
+    } else {
+      RUN(wait_s2());                                        // its compose results (and gains) come from the second stream
+      if (sc.slot_of[c] < 0) RUN(launch_gain_chunk(p, sc, c, slot, p->stream));   // gains dropped after the compose pass: recompute
+    }
+    RUN(launch_boundary_chunk(p, sc, c, slot, p->stream));
+    if (c < n_own) {
+      if (c == n_own - 1) {
+        hipStream_t st = p->s_apply[0];
+        HIP_TRY(hipEventRecord(p->ev_bnd[0], p->stream));
+        HIP_TRY(hipStreamWaitEvent(st, p->ev_bnd[0], 0));
+        RUN(launch_apply_merged(p, sc, n_own, st));
+        HIP_TRY(hipEventRecord(p->ev_app[0], st));
+      }
+    } else {
+      RUN(launch_apply_chunk(p, sc, c, slot, p->stream));    // (scratch buffer: the next chunk's gains overwrite it)
+    }
+  }
+  RUN(wait_s2());
+  if (n_own > 0) HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_app[0], 0));
   return NAGP_OK;
 }
 
@@ -1002,8 +1342,6 @@ static int seed_last_step(nagp_plan* p) {
   return NAGP_OK;
 }
 
-#define RUN(expr) do { int _s = (expr); if (_s != NAGP_OK) return _s; } while (0)
-
 static int zero_async(nagp_plan* p, void* ptr, size_t bytes) {
   HIP_TRY(hipMemsetAsync(ptr, 0, bytes, p->stream));
   return NAGP_OK;
@@ -1015,6 +1353,10 @@ static int exec_gf(nagp_plan* p) {
   std::vector<double> red;
   for (int itt = 1; itt <= I; ++itt) {
     const bool run_filter = !nlml || itt == 1 || itt < I;
+    const bool run_smoother = !nlml || itt < I;
+    SweepCtx sc;
+    const bool smooth = run_smoother && run_filter && sh.T > 1;
+    if (smooth) sweep_begin(p, sc, p->want_PS && itt == I);
     if (run_filter) {
       FilterPar fp{};
       fp.itt = itt; fp.ep_damp = p->damping[itt - 1]; fp.mom_all = (itt == 1);
@@ -1030,17 +1372,17 @@ static int exec_gf(nagp_plan* p) {
         fp.k_begin = sh.T - 1; fp.k_end = sh.T;
       }
       RUN(launch_filter(p, fp));
+      if (smooth) RUN(sweep_pump(p, sc));      // gain + compose of the finished chunks on the second stream while the filter runs
     }
     if (itt == 1 && !nlml) {
       RUN(reduce_sum(p, p->b.lZ, 0, sh.T, 0));
       RUN(fetch_red(p, red));
       for (int q = 0; q < B; ++q) p->nlZ[(size_t)q * I] = -red[(size_t)q * 8];
     }
-    const bool run_smoother = !nlml || itt < I;
     if (run_smoother && run_filter) {
       RUN(zero_async(p, p->b.red, (size_t)B * 8 * sizeof(double)));
       RUN(seed_last_step(p));
-      RUN(launch_smoother(p, p->want_PS && itt == I));
+      if (smooth) RUN(sweep_finish(p, sc));
       if (itt < I) {
         // the mixture variant leaves the clamp to the next filter pass (gf_ep_mods_nmf_mixture.m:195, 280-284)
         RUN(launch_ep(p, o.ep_fraction, p->damping[itt], (nlml || mixture_rule(p)) ? 0 : 1, nlml ? 0 : 1, mixture_rule(p) ? nullptr : p->b.lZ));
@@ -1082,7 +1424,10 @@ static int exec_giekf(nagp_plan* p) {
     fp.itt = itt; fp.store_PF = 1; fp.l_iter = o.l_iter;
     fp.init_from_state = (itt > 1); fp.reset_P = (o.flags & NAGP_FLAG_EKF_RESET_P) ? 1 : 0;
     fp.k_begin = 0; fp.k_end = sh.T;
+    SweepCtx sc;
+    if (sh.T > 1) sweep_begin(p, sc, p->want_PS && itt == I);
     RUN(launch_filter(p, fp));
+    if (sh.T > 1) RUN(sweep_pump(p, sc));
     RUN(zero_async(p, p->b.red, (size_t)B * 8 * sizeof(double)));
     RUN(seed_last_step(p));
     if (sh.T == 1) {   // no smoothing step: the restart state is the filtered one
@@ -1102,7 +1447,7 @@ static int exec_giekf(nagp_plan* p) {
         HIP_TRY(hipMemcpyAsync(st + (size_t)sh.ntiles * 16, p->b.MF + (size_t)q * sh.S, sh.S * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
       }
     }
-    RUN(launch_smoother(p, p->want_PS && itt == I));
+    if (sh.T > 1) RUN(sweep_finish(p, sc));
     RUN(fetch_red(p, red));
     for (int q = 0; q < B; ++q) {
       p->mdM[(size_t)q * I + itt - 1] = red[(size_t)q * 8 + 1];

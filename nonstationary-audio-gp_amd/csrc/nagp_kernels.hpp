@@ -76,6 +76,11 @@ struct FilterPar {
   int R_raw;               // mixture variant: R = 1/ttau before the clamp (gf_ep_mods_nmf_mixture.m:190,195)
   int ekf_energy;          // EKF nlml pass (gf_giekf_modulator_nmf_constraints.m:385-472): lZ_k = -(log(2pi)/2 + log sqrt(S) + v^2/(2S)),
                            // no isnan guard on y (a NaN observation poisons the energy, as in the reference)
+  // chunk-pipelined smoother: progress[pb] = number of leading steps whose filter outputs (MF, PF, marginals) are in HBM and visible
+  // to the rest of the device -- host-pinned memory the host polls to start the gain / compose launches of finished chunks on a
+  // second stream while this workgroup filters on.  nullptr: nothing published.
+  unsigned long long* progress;
+  int progress_every;      // publish when the step count crosses a multiple of this (and at the end of the launch)
 };
 
 // The filtered covariance is symmetric: PF holds only the lower-triangular tiles, tile (I,J), I >= J, at
@@ -617,7 +622,11 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
       g_fm[(size_t)k0 * M + i] = rfm[i]; g_fv[(size_t)k0 * M + i] = rfv[i];
     }
     for (int i = tid; i < nb * S; i += NT) g_MF[(size_t)k0 * S + i] = rMF[i];
+    const bool publish = fp.progress && ((k0 + nb) / fp.progress_every != k0 / fp.progress_every || k0 + nb == fp.k_end);
+    if (publish) __threadfence_system();      // this thread's stores (its PF tiles, its share of the flush) before the flag
     __syncthreads();
+    if (publish && tid == 0)
+      __hip_atomic_store(&fp.progress[pb], (unsigned long long)(k0 + nb), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   if (tid < M && n_clamped) atomicAdd(&b.counters[(size_t)pb * 4 + 1], n_clamped);
   if (tid == 0 && n_nan) atomicAdd(&b.counters[(size_t)pb * 4 + 2], n_nan);
@@ -1014,6 +1023,15 @@ __global__ void __launch_bounds__(LB) __attribute__((amdgpu_waves_per_eu(LB > 51
 // All three are panel GEMMs on 4x4 register tiles: operands stream global(L2) -> registers -> LDS panels
 // (double buffered, padded tiles, one LDS barrier per panel); every thread loads at most one tile per
 // operand panel, one panel ahead of the arithmetic.
+// One smoother chunk of a MERGED apply launch (the apply passes of all chunks whose boundary values exist run as one grid: every
+// workgroup finds its chunk from its span index and takes the chunk's geometry and buffers from this table, which lives in
+// host-pinned memory).
+struct ChunkTab {
+  long long k0;
+  int nk, L, ns, first, span0, cap;    // span0: index of the chunk's first span in the merged grid; cap: stride of the chunk's buffer
+  double *G, *d, *spanbuf, *spanvec, *bnd, *xbuf;
+};
+
 struct SpanPar {
   int64_t k0;       // first step of the chunk
   int nk;           // steps in the chunk
@@ -1028,7 +1046,22 @@ struct SpanPar {
   double* spanvec;  // [B][ns_max][S]             c
   double* bnd;      // [B][ns_max][ntiles*16 + S] E_top, e_top
   double* xbuf;     // [B][ns_max][ntiles*16]     per-workgroup scratch for X
+  const ChunkTab* tab;  // merged apply launch: chunk table (nullptr: the fields above describe the one chunk of the launch)
+  int ntab;
 };
+
+// merged launch: span index of the grid -> (chunk, span inside the chunk); the chunk's geometry and buffers replace those of the
+// by-value parameter copies (all uniform over the workgroup)
+template <class Par>
+__device__ __forceinline__ int chunk_select(Par& sp, Bufs& b, int j) {
+  int c = 0;
+  while (c + 1 < sp.ntab && j >= sp.tab[c + 1].span0) ++c;
+  const ChunkTab t = sp.tab[c];
+  sp.k0 = t.k0; sp.nk = t.nk; sp.L = t.L; sp.ns = t.ns; sp.first = t.first; sp.chunk = t.cap;
+  sp.spanbuf = t.spanbuf; sp.spanvec = t.spanvec; sp.bnd = t.bnd; sp.xbuf = t.xbuf;
+  b.Gbuf = t.G; b.dbuf = t.d;
+  return j - t.span0;
+}
 
 template <int TPT>
 struct GemmCtx {
@@ -1321,7 +1354,8 @@ __global__ void __launch_bounds__(512) rts_boundary_kernel(Shape sh, Bufs b, Spa
 template <int TPT>
 __global__ void __launch_bounds__(512) rts_apply_kernel(Shape sh, Bufs b, SpanPar sp) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  const int j = blockIdx.x, pb = blockIdx.y;
+  int j = blockIdx.x; const int pb = blockIdx.y;
+  if (sp.tab) j = chunk_select(sp, b, j);
   const int ntl = sh.ntiles, S = sh.S, M = sh.M;
   const int64_t T = sh.T;
   const double* mdl = b.model + (size_t)pb * mdl_size(sh);

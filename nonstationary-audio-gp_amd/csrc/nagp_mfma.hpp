@@ -23,6 +23,9 @@ struct MfmaPar {
   double* spanvec;  // [B][ns_max][S]
   double* bnd;      // [B][ns_max][Sp*Sp + S]  E_top (dense), e_top
   double* stateD;   // [B][Sp*Sp + S]          dense carry between chunks
+  const ChunkTab* tab;  // merged apply launch (see SpanPar)
+  int ntab;
+  double* xbuf;         // (unused by the MFMA passes; keeps chunk_select one template)
 };
 
 __host__ __device__ inline size_t mfma_lds_doubles(int Sp) { return 2 * (size_t)Sp * (Sp + 1) + 3 * (size_t)Sp + MAXM + 8; }
@@ -106,7 +109,9 @@ template <int NTL>
 __global__ void __launch_bounds__(256) rts_apply_mfma_kernel(Shape sh, Bufs b, MfmaPar sp) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   using C = MfmaCtx<NTL>;
-  const int tid = threadIdx.x, j = blockIdx.x, pb = blockIdx.y;
+  const int tid = threadIdx.x, pb = blockIdx.y;
+  int j = blockIdx.x;
+  if (sp.tab) j = chunk_select(sp, b, j);
   constexpr int Sp = 16 * NTL, LD = Sp + 1;     // == sp.Sp: the host instantiates NTL = Sp / 16; compile-time strides
   const int S = sh.S, M = sh.M;
   const int64_t T = sh.T;

@@ -194,7 +194,8 @@ __global__ void __launch_bounds__(64 * NTL) rts_big_kernel(Shape sh, Bufs b, Mfm
   BigCtx<NTL> c;
   big_ctx_init<NTL>(c, lds);
   const int tid = c.tid, J = c.wave;
-  const int j = (MODE == 1) ? 0 : blockIdx.x, pb = (MODE == 1) ? blockIdx.x : blockIdx.y;
+  int j = (MODE == 1) ? 0 : blockIdx.x; const int pb = (MODE == 1) ? blockIdx.x : blockIdx.y;
+  if (MODE == 2 && sp.tab) j = chunk_select(sp, b, j);      // merged apply launch of several chunks
   const int S = sh.S, M = sh.M;
   const int64_t T = sh.T;
   const size_t SS = (size_t)Sp * Sp;

@@ -423,7 +423,7 @@ def test_large_batch_of_replicas_equals_single_problem_plans():
     probs = [probs2[q % 2] for q in range(B)]; ys = [ys2[q % 2] for q in range(B)]
     mom = Mom('likModulatorNMFPower', p_cubature=5); kw = dict(mom=mom, ep_fraction=0.5, ep_damping=[0.5, 0.5], ep_itts=2)
     big = Plan(L.KIND_GF_EP, probs, T, **kw); big.upload(ys); big.execute(); a = big.download()
-    t = big.timings(); assert t['launches']['scan'] == 2
+    t = big.timings(); assert t['launches']['scan'] == 6      # one chunk per sweep: compose, boundary and apply passes
     for q in (0, 1):
         one = Plan(L.KIND_GF_EP, probs2[q:q + 1], T, **kw); one.upload(ys2[q:q + 1]); one.execute(); o = one.download()[0]
         for qq in (q, q + 2, B - 2 + q):
@@ -1215,3 +1215,67 @@ def test_full_length_cfg4_predict_mode_filter_prefix_and_chunked_smoother():
     other, _ = run(y, chunk=20000)                             # another chunking / span partition of the same backward recursion
     assert rel(other.Eft, full.Eft) < 1e-9 and rel(other.Varft, full.Varft) < 1e-9
     assert np.array_equal(other.MF, full.MF)
+
+
+# ---------------------------------------------------------------------------------------------
+# chunk-pipelined smoother: same kernels, same operands, another schedule -> bit-equal outputs
+def _run_schedules(kind, probs, ys, T, chunk, **kw):
+    """the same plan under the pipelined schedule (gain + compose of finished chunks on a second stream beside the filter), the
+    pipelined schedule with only two (G, Delta) buffers (gains of the other chunks recomputed after the filter) and the serial one"""
+    res = {}
+    for name, env in (('pipelined', {}), ('two_buffers', {'NAGP_PIPELINE_SLOTS': '2'}), ('serial', {'NAGP_NO_PIPELINE': '1'})):
+        os.environ.update(env)
+        try:
+            plan = Plan(kind, probs, T, chunk=chunk, **kw)
+            plan.upload(ys); plan.execute(); res[name] = plan.download(want_PS=bool(kw.get('flags', 0) & L.FLAG_WANT_PS), want_MF=True); plan.close()
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+    return res
+
+
+@pytest.mark.parametrize('D,N,want_ps', [(32, 6, False), (32, 6, True), (16, 3, False), (16, 3, True), (36, 8, False)])
+def test_pipelined_smoother_is_bit_equal_to_the_serial_schedule(D, N, want_ps):
+    """Eight (four) segments, several chunks per sweep, three sweeps: 32 channels / 6 components (S = 146, column-owner MFMA passes;
+    with smoothed covariances requested the last sweep runs the VALU passes), 16 / 3 (S = 73, dense MFMA passes), 36 / 8 (44 sites: VALU
+    passes only).  Every output of the pipelined schedules equals the serial schedule's bit for bit."""
+    T = 150; B = 8 if D == 32 else 4
+    probs, ys = [], []
+    for q in range(B):
+        pr = harness.nmf_problem(D, N, T, 6100 + q, 'constraints')
+        blk = pss.balance_blocks(pss.ss_blocks_nmf(pr['param1'], pr['param2'], 'matern32', 'matern52'))
+        y = pr['y'].copy(); y[7 * q + 5] = np.nan
+        probs.append((blk, pr['W'], np.log(pr['w_lik']))); ys.append(y)
+    mom = Mom('likModulatorNMFPower', p_cubature=3 if D == 36 else 5); d = 0.5 * np.ones(3)
+    res = _run_schedules(L.KIND_GF_EP, probs, ys, T, 24, mom=mom, ep_fraction=0.5, ep_damping=d, ep_itts=3, flags=L.FLAG_WANT_PS if want_ps else 0)
+    for q in range(B):
+        for other in ('pipelined', 'two_buffers'):
+            for f in ('Eft', 'Varft', 'MS', 'MF', 'ttau', 'tnu', 'R', 'lZ', 'nlZ', 'maxDiffM', 'maxDiffP') + (('PS',) if want_ps else ()):
+                assert np.array_equal(getattr(res[other][q], f), getattr(res['serial'][q], f), equal_nan=True), (other, q, f)
+            assert np.array_equal(res[other][q].counters, res['serial'][q].counters)
+    if D == 32 and not want_ps:       # and the serial schedule is the one the oracle pins
+        ref = ogf.run_predict(ogf.assemble(np.log(1e-4) * np.ones(1), *[harness.nmf_problem(D, N, T, 6102, 'constraints')[k] for k in ('param1', 'param2', 'W')],
+                                           'matern32', 'matern52', True), ys[2], olik.Mom(olik.LIK_POWER_NMF, p=5), 0.5, d, 3)
+        assert rel(res['pipelined'][2].Eft, ref['Eft']) < TOL_MEAN and relz(res['pipelined'][2].nlZ, ref['nlZ']) < TOL_LOGZ
+
+
+def test_pipelined_smoother_ekf_bit_equal_and_long_sequence_against_serial():
+    """The EKF family under the three schedules (restart from the smoothed state between global iterations), and a sequence long
+    enough for the default chunking to pipeline (T = 9000: five chunks): pipelined == serial bit for bit."""
+    D, N, T = 12, 3, 130
+    pr = harness.nmf_problem(D, N, T, 6200)
+    blk = pss.balance_blocks(pss.ss_blocks_nmf(pr['param1'], pr['param2'], 'matern32', 'matern52'))
+    res = _run_schedules(L.KIND_GIEKF, [(blk, pr['W'], np.log(pr['w_lik']))] * 2, [pr['y'], pr['y'][::-1].copy()], T, 16, ep_itts=3, l_iter=2)
+    for q in range(2):
+        for other in ('pipelined', 'two_buffers'):
+            for f in ('Eft', 'Varft', 'MS', 'MF', 'maxDiffP'):
+                assert np.array_equal(getattr(res[other][q], f), getattr(res['serial'][q], f)), (other, q, f)
+    D, N, T = 16, 3, 9000
+    pr = harness.nmf_problem(D, N, T, 6300)
+    blk = pss.ss_blocks_nmf(pr['param1'], pr['param2'], 'matern32', 'matern52')
+    mom = Mom('likModulatorNMFPower', p_cubature=9); d = 0.5 * np.ones(2)
+    res = _run_schedules(L.KIND_GF_EP, [(blk, pr['W'], np.log(pr['w_lik']))], [pr['y']], T, 0, mom=mom, ep_fraction=0.5, ep_damping=d, ep_itts=2)
+    for other in ('pipelined', 'two_buffers'):
+        for f in ('Eft', 'Varft', 'MS', 'ttau', 'tnu', 'lZ', 'nlZ'):
+            assert np.array_equal(getattr(res[other][0], f), getattr(res['serial'][0], f)), (other, f)
+    assert np.all(np.isfinite(res['pipelined'][0].Eft)) and np.all(res['pipelined'][0].Varft > 0)

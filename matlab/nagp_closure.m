@@ -32,24 +32,7 @@ function c = nagp_closure(mom, cub_dim)
   end
 
   % --- link: log(1+exp(g)), log(1+exp(g-1)), log(1+exp(g-<captured variable>)), exp(g)
-  s = regexprep(func2str(ws.link),'\s','');
-  c.link_kind = 0; c.link_shift = 0;
-  tok = regexp(s,'^@\((\w+)\)log\(1\+exp\(\1(?:-([\w\.]+))?\)\)$','tokens','once');
-  if ~isempty(tok)
-    if numel(tok) > 1 && ~isempty(tok{2})
-      v = str2double(tok{2});
-      if isnan(v)                              % a captured variable, e.g. mod_sparsity
-        lw = functions(ws.link); lw = lw.workspace{1};
-        if ~isfield(lw,tok{2}), error('nagp:closure','cannot resolve %s in the link function',tok{2}); end
-        v = lw.(tok{2});
-      end
-      c.link_shift = double(v);
-    end
-  elseif ~isempty(regexp(s,'^@\((\w+)\)exp\(\1\)$','once'))
-    c.link_kind = 1;
-  else
-    error('nagp:closure','link %s has no GPU implementation',s);
-  end
+  [c.link_kind,c.link_shift] = nagp_link(ws.link);
 
   % --- sigma points (unit scale; the kernels apply mean and standard deviation)
   if isfield(ws,'wn') && isfield(ws,'xn_unscaled')

@@ -8,7 +8,7 @@
 extern "C" {
 #endif
 typedef size_t mwSize;
-typedef enum { mxDOUBLE_CLASS = 1, mxINT32_CLASS, mxINT64_CLASS, mxSTRUCT_CLASS } mxClassID;
+typedef enum { mxDOUBLE_CLASS = 1, mxINT32_CLASS, mxINT64_CLASS, mxSTRUCT_CLASS, mxCHAR_CLASS, mxCELL_CLASS } mxClassID;
 typedef enum { mxREAL = 0 } mxComplexity;
 typedef struct mxArray_tag mxArray;
 
@@ -18,6 +18,13 @@ int mxIsComplex(const mxArray* a);
 int mxIsInt32(const mxArray* a);
 int mxIsInt64(const mxArray* a);
 int mxIsEmpty(const mxArray* a);
+int mxIsChar(const mxArray* a);
+int mxIsCell(const mxArray* a);
+int mxGetString(const mxArray* a, char* buf, mwSize buflen); /* 0 = ok, 1 = truncated (as MATLAB's) */
+mxArray* mxGetCell(const mxArray* a, mwSize index);
+void mxSetCell(mxArray* a, mwSize index, mxArray* value);
+mxArray* mxCreateCellMatrix(mwSize m, mwSize n);
+size_t mxGetN(const mxArray* a);
 mxArray* mxGetField(const mxArray* a, size_t index, const char* name);
 double mxGetScalar(const mxArray* a);
 double* mxGetPr(const mxArray* a);
@@ -37,6 +44,7 @@ mxArray* mock_numeric(mxClassID cls, size_t m, size_t n, const void* data); /* c
 mxArray* mock_struct(void);
 void mock_set(mxArray* s, const char* name, mxArray* v);
 mxArray* mock_scalar(double v);
+mxArray* mock_string(const char* s);
 #ifdef __cplusplus
 }
 #endif

@@ -68,6 +68,43 @@ int main(int argc, char** argv) {
       r = 0.1 * rel_diff(mxGetPr(plhs[3]), e, n, "tnu"); if (r > worst) worst = r;
     }
   }
+  if (kind == 0) {
+    /* the command forms of the gateway on the same fixture:
+       'batch' = nagp_batch_run over two copies of the problem (one GPU): every copy equals the single call, nlZ_total = 2 x nlZ;
+       'reconstruct' on the marginals just computed (moments form): finite outputs of the right sizes;
+       'iekf_update1' with iters = 1 on a small state: K = P J'/S, M moves along K */
+    mxArray *models = mxCreateCellMatrix(1, 2), *ysc = mxCreateCellMatrix(1, 2), *o4[4]; const mxArray* a5[5]; size_t q; const size_t ne = mxGetNumberOfElements(plhs[0]);
+    mxSetCell(models, 0, model); mxSetCell(models, 1, model); mxSetCell(ysc, 0, y); mxSetCell(ysc, 1, y);
+    a5[0] = mock_string("batch"); a5[1] = models; a5[2] = ysc; a5[3] = opts; a5[4] = mock_scalar(1);
+    mexFunction(4, o4, 5, a5);
+    for (q = 0; q < 2; ++q)
+      if (memcmp(mxGetPr(mxGetCell(o4[1], q)), mxGetPr(plhs[0]), ne * sizeof(double)) || memcmp(mxGetPr(mxGetCell(o4[2], q)), mxGetPr(plhs[1]), ne * sizeof(double))) {
+        printf("batch call: problem %zu differs from the single call\n", q); return 1; }
+    for (q = 0; q < mxGetNumberOfElements(o4[0]); ++q)
+      if (fabs(mxGetPr(o4[0])[q] - 2.0 * mxGetPr(plhs[6])[q]) > 1e-12 * fabs(mxGetPr(plhs[6])[q])) { printf("batch call: nlZ_total is not the sum over the problems\n"); return 1; }
+    {
+      const mxArray* r[10]; mxArray* ro[4]; const double gx[3] = {-1.7320508075688772, 0.0, 1.7320508075688772}, gw[3] = {1.0 / 6, 2.0 / 3, 1.0 / 6};
+      const size_t Dn = (size_t)dump_scalar(d, "D"), Nn = (size_t)dump_scalar(d, "N");
+      r[0] = mock_string("reconstruct"); r[1] = plhs[0]; r[2] = plhs[1]; r[3] = mxGetField(model, 0, "Wnmf"); r[4] = mock_scalar(0); r[5] = mock_scalar(0);
+      r[6] = mock_numeric(mxDOUBLE_CLASS, 1, 3, gx); r[7] = mock_numeric(mxDOUBLE_CLASS, 1, 3, gw); r[8] = mock_scalar(0); r[9] = mock_scalar(1);
+      mexFunction(4, ro, 10, r);
+      if (mxGetNumberOfElements(ro[0]) != T || mxGetNumberOfElements(ro[2]) != Nn * T || mxGetM(ro[2]) != Nn || Dn + Nn != mxGetM(plhs[0])) { printf("reconstruct: wrong output sizes\n"); return 1; }
+      for (q = 0; q < T; ++q) if (!isfinite(mxGetPr(ro[0])[q]) || !(mxGetPr(ro[1])[q] >= 0)) { printf("reconstruct: bad value at %zu\n", q); return 1; }
+    }
+    {
+      const double m0[3] = {0.3, -0.2, 0.1}, P0[9] = {1, 0, 0, 0, 2, 0, 0, 0, 0.5}, hv[2] = {1.0, 1.0}, W1[1] = {0.7}; const int32_t hc[2] = {0, 2};
+      const mxArray* r[9]; mxArray* ro[5]; double e0, J0, J2, Sx, K0;
+      r[0] = mock_string("iekf_update1"); r[1] = mock_numeric(mxDOUBLE_CLASS, 3, 1, m0); r[2] = mock_numeric(mxDOUBLE_CLASS, 3, 3, P0); r[3] = mock_scalar(0.4);
+      r[4] = mock_numeric(mxINT32_CLASS, 1, 2, hc); r[5] = mock_numeric(mxDOUBLE_CLASS, 2, 1, hv); r[6] = mock_numeric(mxDOUBLE_CLASS, 1, 1, W1); r[7] = mock_scalar(0.05); r[8] = mock_scalar(1);
+      mexFunction(5, ro, 9, r);
+      /* h = z W softplus(g), z = m(1), g = m(3):  J = [W softplus(g), 0, z W sigmoid(g)] */
+      e0 = exp(m0[2]); J0 = 0.7 * log(1.0 + e0); J2 = m0[0] * 0.7 * e0 / (1.0 + e0);
+      Sx = 0.05 + J0 * J0 * 1.0 + J2 * J2 * 0.5; K0 = 1.0 * J0 / Sx;
+      if (fabs(mxGetPr(ro[4])[0] - Sx) > 1e-13 || fabs(mxGetPr(ro[2])[0] - K0) > 1e-13 || fabs(mxGetPr(ro[3])[0] - m0[0] * J0) > 1e-13) {
+        printf("iekf_update1: S %.15g (%.15g) K1 %.15g (%.15g) MU %.15g\n", mxGetPr(ro[4])[0], Sx, mxGetPr(ro[2])[0], K0, mxGetPr(ro[3])[0]); return 1; }
+    }
+    printf("command forms ok: batch, reconstruct, iekf_update1\n");
+  }
   printf("counters: %lld %lld %lld %lld; MS is %zu x %zu; T = %zu\n", (long long)((int64_t*)mxGetData(plhs[9]))[0], (long long)((int64_t*)mxGetData(plhs[9]))[1],
          (long long)((int64_t*)mxGetData(plhs[9]))[2], (long long)((int64_t*)mxGetData(plhs[9]))[3], mxGetM(plhs[10]), mxGetNumberOfElements(plhs[10]) / mxGetM(plhs[10]), T);
   printf("worst %.3e\n", worst);

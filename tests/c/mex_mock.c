@@ -16,13 +16,24 @@ struct mxArray_tag {
   mxArray* fval[MAXF];
 };
 
-static size_t esize(mxClassID c) { return c == mxINT32_CLASS ? 4 : 8; }
+static size_t esize(mxClassID c) { return c == mxINT32_CLASS ? 4 : (c == mxCHAR_CLASS ? 1 : 8); }   /* cells: 8 = a pointer */
 int mxIsStruct(const mxArray* a) { return a && a->cls == mxSTRUCT_CLASS; }
 int mxIsDouble(const mxArray* a) { return a && a->cls == mxDOUBLE_CLASS; }
 int mxIsComplex(const mxArray* a) { (void)a; return 0; }
 int mxIsInt32(const mxArray* a) { return a && a->cls == mxINT32_CLASS; }
 int mxIsInt64(const mxArray* a) { return a && a->cls == mxINT64_CLASS; }
 int mxIsEmpty(const mxArray* a) { return !a || a->m * a->n == 0; }
+int mxIsChar(const mxArray* a) { return a && a->cls == mxCHAR_CLASS; }
+int mxIsCell(const mxArray* a) { return a && a->cls == mxCELL_CLASS; }
+int mxGetString(const mxArray* a, char* buf, mwSize buflen) {
+  const size_t n = a->m * a->n;
+  if (a->cls != mxCHAR_CLASS || buflen == 0) return 1;
+  if (n + 1 > buflen) { memcpy(buf, a->data, buflen - 1); buf[buflen - 1] = 0; return 1; }
+  memcpy(buf, a->data, n); buf[n] = 0; return 0;
+}
+mxArray* mxGetCell(const mxArray* a, mwSize index) { return (a && a->cls == mxCELL_CLASS && index < a->m * a->n) ? ((mxArray**)a->data)[index] : NULL; }
+void mxSetCell(mxArray* a, mwSize index, mxArray* value) { if (a && a->cls == mxCELL_CLASS && index < a->m * a->n) ((mxArray**)a->data)[index] = value; }
+size_t mxGetN(const mxArray* a) { return a->n; }
 mxArray* mxGetField(const mxArray* a, size_t index, const char* name) {
   int i;
   if (!a || a->cls != mxSTRUCT_CLASS || index != 0) return NULL;
@@ -60,6 +71,8 @@ void mock_set(mxArray* s, const char* name, mxArray* v) {
   strncpy(s->fname[s->nf], name, 31); s->fval[s->nf++] = v;
 }
 mxArray* mock_scalar(double v) { return mock_numeric(mxDOUBLE_CLASS, 1, 1, &v); }
+mxArray* mock_string(const char* s) { return mock_numeric(mxCHAR_CLASS, 1, strlen(s), s); }
+mxArray* mxCreateCellMatrix(mwSize m, mwSize n) { return mock_numeric(mxCELL_CLASS, m, n, NULL); }
 void mexErrMsgIdAndTxt(const char* id, const char* fmt, ...) {
   va_list ap;
   fprintf(stderr, "MEX error %s: ", id);

@@ -255,10 +255,23 @@ def test_c_callers_and_the_mex_gateway_compile_and_link():
             'ihgp_ep_modulator_nmf_constraints': 'w,x,y,ss,mom,xt,kernel1,kernel2,num_lik_params,D,N,ep_fraction,ep_damping,ep_itts,constraints,w_fixed,tune_hypers',
             'gf_giekf_modulator_nmf': 'w,x,y,ss,mom,xt,kernel1,kernel2,num_lik_params,D,N,g_iter,l_iter,GradObj',
             'gf_giekf_modulator_nmf_constraints': 'w,x,y,ss,mom,xt,kernel1,kernel2,num_lik_params,D,N,g_iter,l_iter,constraints,w_fixed,tune_hypers,GradObj'}
+    sigs.update({'gf_ep_mods_nmf_mixture': 'w,x,y,ss,mom,xt,kernel1,kernel2,J,ep_fraction,ep_damping,ep_itts',
+                 'ihgp_ep_mods_nmf_mixture': 'w,x,y,ss,mom,xt,kernel1,kernel2,J,ep_fraction,ep_damping,ep_itts'})
     for fn, args in sigs.items():
         src = open(os.path.join(ROOT, 'matlab', fn + '.m')).read()
         m = re.match(r'function \[varargout\] = (\w+)\(([^)]*)\)', re.sub(r'\.\.\.\s*', '', src))
         assert m and m.group(1) == fn and re.sub(r'\s', '', m.group(2)) == args, fn
+    # the entry points with named outputs: first lines equal to the reference's (ekf_update1.m:48, iekf_update1.m:48, kernel_ss_kalmanFastFB.m:1)
+    for fn, line in (('ekf_update1', 'function [M,P,K,MU,S,LH] = ekf_update1(M,P,y,H,R,h,V,param)'),
+                     ('iekf_update1', 'function [M,P,K,MU,S,LH] = iekf_update1(M,P,y,H,R,h,V,param,iters)'),
+                     ('kernel_ss_kalmanFastFB', 'function [lik,Xfin,Pfin,varargout] = kernel_ss_kalmanFastFB(A,Q,C,P0,K,vary,y,varargin)')):
+        assert open(os.path.join(ROOT, 'matlab', fn + '.m')).readline().strip() == line, fn
+    # every command string the wrappers send exists in the gateway
+    gw = open(os.path.join(ROOT, 'matlab', 'nagp_mex.c')).read()
+    for f in os.listdir(os.path.join(ROOT, 'matlab')):
+        if f.endswith('.m'):
+            for cmd in re.findall(r"nagp_mex\('(\w+)'", open(os.path.join(ROOT, 'matlab', f)).read()):
+                assert '!strcmp(cmd, "%s")' % cmd in gw, (f, cmd)
 
 
 def test_abi_error_paths_under_asan():

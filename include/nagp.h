@@ -194,6 +194,23 @@ int nagp_iekf_update1(int32_t S, int32_t D, int32_t N, const int32_t* h_col, con
                       double R, double y, int32_t iters, double* m, double* P, double* K, double* MU, double* Sinn,
                       int32_t device);
 
+/* The EKF training objective WITH its gradient recursion -- matlab/gf_giekf_modulator_nmf_constraints.m:332-480 with GradObj = 'on'
+ * (gf_giekf_modulator_nmf.m:296-439): one plain EKF pass (as NAGP_MODE_NLML of the GIEKF kind: prediction at the first step too,
+ * one update per step, no isnan guard) and, per parameter slice j, the sensitivity recursion of (m, P) (:387-401, :437-466).
+ * models[q].A = expm(F), models[q].Q = Pinf - A*Pinf*A' (:377-378).  Per problem and slice, S x S column-major, block diagonal with
+ * the blocks of the model (only those blocks are read): dA[q][j] = lower-left block of expm([F 0; dF_j F]) (:355-366),
+ * dQ[q][j] = dPinf_j - dA_j*Pinf*A' - A*dPinf_j*A' - (dA_j*Pinf*A')' (:392-394), dPinf[q][j]; dR[j] (:124).
+ * What the Jacobian derivative `dmdJH` of slice j is made of is data: hess[j] != 0 adds dm_j' * d2h (:439), w_index[j] >= 0 adds
+ * dh(.; W_) with W_ the unit matrix at column-major position w_index[j] of Wnmf (:441-443), w_direct[j] != 0 adds h(.; W_) to the
+ * derivative of the predicted measurement (a term the reference's statements leave out).  The reference as written:
+ * hess = 1, w_index = -1 for j < n_param - D*N and hess = 0, w_index = j - (n_param - D*N) for the last D*N slices, w_direct = 0.
+ * edata[q], gdata[q * n_param + j]; NaN for a problem whose innovation variance is not positive even with the jitter (:423-426).
+ * Shapes: M = D + N <= 32 sites, blocks of <= 4 states. */
+int nagp_giekf_nlml_grad(int32_t n_problems, const nagp_model* models, const double* const* ys, int64_t T, int32_t n_param,
+                         const double* const* dA, const double* const* dQ, const double* const* dPinf, const double* dR,
+                         const int32_t* hess, const int32_t* w_index, const int32_t* w_direct, double* edata, double* gdata,
+                         int32_t device);
+
 /* Stationary filterbank (the step before the hot path in every real-audio script, e.g. train_GTFNMF.m:56-65):
  * the two loops of unifying_prob_tf/kernel_ss_kalmanFastFB.m -- infinite-horizon Kalman filter (:83-110)
  *     if ~isnan(y_k): v = y_k - HA*m; m = AKHA*m + K*y_k; else m = A*m;   MS(:,k) = m

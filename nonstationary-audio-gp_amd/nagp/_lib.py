@@ -62,7 +62,8 @@ class Timings(C.Structure):
 EXPORTS = ['nagp_version', 'nagp_device_count', 'nagp_strerror', 'nagp_last_error', 'nagp_ep_run',
            'nagp_ihgp_run', 'nagp_giekf_run', 'nagp_plan_create', 'nagp_plan_upload_y', 'nagp_plan_execute',
            'nagp_plan_timings', 'nagp_plan_download', 'nagp_plan_device_bytes', 'nagp_plan_destroy', 'nagp_plan_upload_sites',
-           'nagp_batch_partition', 'nagp_batch_run', 'nagp_shutdown', 'nagp_reconstruct', 'nagp_mom_eval', 'nagp_iekf_update1', 'nagp_fastfb_run']
+           'nagp_batch_partition', 'nagp_batch_run', 'nagp_shutdown', 'nagp_reconstruct', 'nagp_mom_eval', 'nagp_iekf_update1', 'nagp_fastfb_run',
+           'nagp_giekf_nlml_grad']
 
 
 class NagpError(RuntimeError):
@@ -188,6 +189,9 @@ def lib():
     L.nagp_iekf_update1.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), c_dp, c_dp, C.c_double, C.c_double, C.c_int32,
                                     c_dp, c_dp, c_dp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32]
     L.nagp_fastfb_run.argtypes = [C.c_int32, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, C.c_int64, c_dp, C.POINTER(C.c_double), C.c_int32]
+    L.nagp_giekf_nlml_grad.argtypes = [C.c_int32, C.POINTER(Model), C.POINTER(c_dp), C.c_int64, C.c_int32, C.POINTER(c_dp), C.POINTER(c_dp), C.POINTER(c_dp),
+                                       c_dp, c_ip, c_ip, c_ip, c_dp, c_dp, C.c_int32]
+    L.nagp_giekf_nlml_grad.restype = C.c_int
     L.nagp_plan_upload_y.argtypes = [C.c_void_p, C.POINTER(c_dp)]
     L.nagp_plan_upload_sites.argtypes = [C.c_void_p, C.POINTER(c_dp), C.POINTER(c_dp)]
     L.nagp_batch_partition.argtypes = [C.c_int32, C.c_int32, c_ip]

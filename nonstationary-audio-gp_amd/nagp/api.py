@@ -16,6 +16,7 @@ The two function handles of the reference become:
 import ctypes as C
 
 import numpy as np
+import scipy.linalg as sla
 
 from . import _lib as L
 from . import cubature, ihgp_tables
@@ -438,6 +439,76 @@ def gf_giekf_modulator_nmf(w, x, y, ss, mom, xt, kernel1, kernel2, num_lik_param
     return _returns(out, return_ind, nargout)
 
 
+def _giekf_grad_slices(blk, p1, p2, kernel1, kernel2, consistent):
+    """Per-slice inputs of nagp_giekf_nlml_grad for the balanced block model `blk`: the slices the reference builds
+    (gf_giekf_modulator_nmf_constraints.m:121-125: noise variance, then [sig1, len1, omega, sig2, len2] of ss_modulators_nmf.m:88, 130)
+    -- dA_j from expm([F 0; dF_j F]) (:355-366), dQ_j (:392-394), dPinf_j -- block by block (every slice touches one block).
+    consistent=False: dF_j, dPinf_j UNBALANCED beside the balanced F, Pinf, as the reference has them (:117-119 commented out);
+    True: carried through the balancing (T\\dF*T, T\\dPinf/T')."""
+    D, N, S = blk.D, blk.N, blk.S
+    n_par = 1 + 3 * D + 2 * N
+    dA = np.zeros((n_par, S, S)); dQ = np.zeros((n_par, S, S)); dPi = np.zeros((n_par, S, S))
+    tb = getattr(blk, 'tbal', [np.ones(k) for k in blk.sizes])
+    p1 = np.asarray(p1, float).ravel(); p2 = np.asarray(p2, float).ravel()
+
+    def put(j, n, dF, dP):
+        o, e = blk.offsets[n], blk.offsets[n + 1]; b = e - o
+        if consistent:
+            t = tb[n]; dF = dF * np.outer(1.0 / t, t); dP = dP / np.outer(t, t)
+        Fn, Pn = blk.F[n], blk.Pinf[n]
+        A = sla.expm(Fn)
+        E = sla.expm(np.block([[Fn, np.zeros((b, b))], [dF, Fn]]))
+        dAn = E[b:, :b]
+        X = dAn @ Pn @ A.T
+        dA[j, o:e, o:e] = dAn; dPi[j, o:e, o:e] = dP
+        dQ[j, o:e, o:e] = dP - X - A @ dP @ A.T - X.T
+
+    I2 = np.eye(2)
+    for d in range(D):
+        (dFs, dPs), (dFl, dPl) = ssm.kernel_block_derivs(kernel1, p1[d], p1[D + d])
+        t1 = dFs.shape[0]
+        put(1 + d, d, np.kron(dFs, I2), np.kron(dPs, I2))
+        put(1 + D + d, d, np.kron(dFl, I2), np.kron(dPl, I2))
+        put(1 + 2 * D + d, d, np.kron(np.eye(t1), np.array([[0.0, -1.0], [1.0, 0.0]])), np.zeros((2 * t1, 2 * t1)))
+    for n in range(N):
+        (dFs, dPs), (dFl, dPl) = ssm.kernel_block_derivs(kernel2, p2[n], p2[N + n])
+        put(1 + 3 * D + n, D + n, dFs, dPs)
+        put(1 + 3 * D + N + n, D + n, dFl, dPl)
+    return dA, dQ, dPi
+
+
+def giekf_nlml_grad(blk, Wnmf, lik_param, p1, p2, kernel1, kernel2, yall, consistent=False, device=0):
+    """(edata, gdata) of the EKF energy and its gradient recursion on the GPU (nagp_giekf_nlml_grad).
+    consistent=False: the reference's statements as written -- 1+3D+2N slices, the last D*N of them with the Jacobian derivative
+    taken w.r.t. an entry of W while dm, dP carry the kernel parameter of the same index (:438-444), unbalanced dF / dPinf.
+    consistent=True: the gradient of the energy w.r.t. [sigma2, sig1, len1, omega, sig2, len2, W(:)] (1+3D+2N+D*N entries)."""
+    D, N, S = blk.D, blk.N, blk.S
+    dA, dQ, dPi = _giekf_grad_slices(blk, p1, p2, kernel1, kernel2, consistent)
+    n_k = 1 + 3 * D + 2 * N
+    if consistent:
+        z = np.zeros((D * N, S, S))
+        dA = np.concatenate([dA, z]); dQ = np.concatenate([dQ, z]); dPi = np.concatenate([dPi, z])
+        hess = np.ones(n_k + D * N, np.int32); widx = np.concatenate([-np.ones(n_k, np.int32), np.arange(D * N, dtype=np.int32)])
+        wdir = (widx >= 0).astype(np.int32)
+    else:
+        nk = n_k - D * N
+        idx = np.arange(n_k)
+        hess = (idx < nk).astype(np.int32); widx = np.where(idx < nk, -1, idx - nk).astype(np.int32); wdir = np.zeros(n_k, np.int32)
+    n_par = dA.shape[0]
+    dR = np.zeros(n_par); dR[0] = 1.0
+    prob = _Problem(blk, Wnmf, lik_param, stationary_Q=True)
+    cm = lambda a: L.f64(np.ascontiguousarray(np.transpose(a, (0, 2, 1))), 'C')       # every slice column-major
+    dAc, dQc, dPc = cm(dA), cm(dQ), cm(dPi)
+    y = L.f64(np.asarray(yall, float).ravel(), 'C')
+    models = (L.Model * 1)(prob.model)
+    arr = lambda a: (L.c_dp * 1)(L.dptr(a))
+    e = np.zeros(1); g = np.zeros(n_par)
+    L.check(L.lib().nagp_giekf_nlml_grad(1, models, arr(y), y.size, n_par, arr(dAc), arr(dQc), arr(dPc), L.dptr(L.f64(dR, 'C')),
+                                         hess.ctypes.data_as(L.c_ip), widx.ctypes.data_as(L.c_ip), wdir.ctypes.data_as(L.c_ip),
+                                         L.dptr(e), L.dptr(g), int(device)))
+    return float(e[0]), g
+
+
 def gf_giekf_modulator_nmf_constraints(w, x, y, ss, mom, xt, kernel1, kernel2, num_lik_params, D, N, g_iter, l_iter,
                                        constraints, w_fixed, tune_hypers, GradObj='off', nargout=2, device=0):
     """matlab/gf_giekf_modulator_nmf_constraints.m:1-2.  xt empty: [e, eg] of :332-480 with GradObj='off' (what
@@ -448,8 +519,22 @@ def gf_giekf_modulator_nmf_constraints(w, x, y, ss, mom, xt, kernel1, kernel2, n
     lik_param, p1, p2, Wnmf = _unpack_constraints(w, w_fixed, tune_hypers, constraints, num_lik_params, D, N)
     blk = ssm.balance_blocks(_blocks_from_dense(*ss(x, p1, p2, kernel1, kernel2), D, N))
     if xt is None or np.size(xt) == 0:
+        if GradObj == 'on':
+            # :332-480 as written: gdata = zeros(1,length(w)) is indexed with j = 1..size(dF,3) = 1+3D+2N (:336-342, :453-457) --
+            # MATLAB stops with an index error when fewer parameters than that are tuned; with all groups tuned it runs
+            n_par = 1 + 3 * D + 2 * N
+            if np.size(w) < n_par:
+                raise IndexError('Index exceeds the number of array elements (%d): gdata(j) is read for j up to size(dF,3) = %d '
+                                 '(gf_giekf_modulator_nmf_constraints.m:453-457)' % (np.size(w), n_par))
+            e, g = giekf_nlml_grad(blk, Wnmf, lik_param, p1, p2, kernel1, kernel2, yall, consistent=False, device=device)
+            eg = np.zeros(np.size(w)); eg[:n_par] = g
+            return e, eg
+        if GradObj == 'consistent':
+            # not in the reference: the same recursion as the true gradient of the energy w.r.t. the NATURAL parameters
+            # [sigma2, sig1, len1, omega, sig2, len2, W(:)] (central differences of the energy confirm it, tests/test_gpu_parity.py)
+            return giekf_nlml_grad(blk, Wnmf, lik_param, p1, p2, kernel1, kernel2, yall, consistent=True, device=device)
         if GradObj != 'off':
-            raise NotImplementedError("GradObj='on': the reference's gradient recursion indexes numel(w) outputs with size(dF,3) slices")
+            raise ValueError("GradObj must be 'off', 'on' or 'consistent'")
         out = _run_giekf(blk, Wnmf, lik_param, yall, 1, 1, True, 2, device, nlml=True)
         return float(out.nlZ[0]), np.zeros(np.size(w))
     out = _run_giekf(blk, Wnmf, lik_param, yall, g_iter, l_iter, True, nargout, device)

@@ -48,6 +48,29 @@ def kernel_block(kernel, sigma2, ell):
     return F, L, Qc, Pinf
 
 
+def kernel_block_derivs(kernel, sigma2, ell):
+    """Derivatives of kernel_block's (F, Pinf) w.r.t. (sigma2, ell) -- the dF / dPinf outputs of cf_<kernel>_to_ss
+    (cf_exp_to_ss.m:116-146, cf_matern32_to_ss.m:121-157, cf_matern52_to_ss.m:127-166), obtained through lam = c / ell:
+    d/d ell = (-lam / ell) d/d lam.  Returns ((dF_sigma2, dPinf_sigma2), (dF_ell, dPinf_ell))."""
+    F, _, _, Pinf = kernel_block(kernel, sigma2, ell)
+    n = F.shape[0]
+    if kernel == 'exp':
+        return (np.zeros((1, 1)), np.ones((1, 1))), (np.array([[1.0 / ell ** 2]]), np.zeros((1, 1)))
+    lam = _SQ[kernel] / ell
+    binom = {'matern32': [1.0, 2.0], 'matern52': [1.0, 3.0, 3.0]}.get(kernel)
+    if binom is None:
+        raise ValueError('kernel derivatives exist for exp, matern32, matern52 (the kernels of the drivers)')
+    # last row of the companion matrix: -C(n,i) lam^(n-i), i = 0..n-1
+    dF_lam = np.zeros((n, n))
+    for i in range(n):
+        dF_lam[n - 1, i] = -binom[i] * (n - i) * lam ** (n - i - 1)
+    dF_ell = dF_lam * (-lam / ell)
+    # Pinf entries are sigma2 * c_ik * lam^(i+k) (i + k even, 0-based): linear in sigma2, power i+k of lam
+    pw = np.add.outer(np.arange(n), np.arange(n)).astype(float)
+    dP_ell = Pinf * pw * (-1.0 / ell)
+    return (np.zeros((n, n)), Pinf / sigma2), (dF_ell, dP_ell)
+
+
 class BlockSS:
     """Block-diagonal continuous-time model: lists of per-block (F, LQL', Pinf) and the H pattern."""
 
@@ -124,6 +147,9 @@ def balance_blocks(blk):
         if not np.allclose(T, np.diag(t)):
             raise ValueError('balance() permuted block %d; the single-nonzero-per-row structure of H is lost' % n)
         blk.F[n] = Fb
+        if not hasattr(blk, 'tbal'):
+            blk.tbal = [np.ones(k) for k in blk.sizes]           # the diagonal of T per block (what the derivative stacks need)
+        blk.tbal[n] = blk.tbal[n] * t
         blk.LQL[n] = blk.LQL[n] / np.outer(t, t)
         LL = np.linalg.cholesky(blk.Pinf[n]) / t[:, None]
         blk.Pinf[n] = LL @ LL.T

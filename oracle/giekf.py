@@ -167,3 +167,101 @@ def gf_giekf_modulator_nmf_constraints_nlml(w, x, y, kernel1, kernel2, num_lik_p
     lik_param, param1, param2, Wnmf = ssm.unpack_constraints(w, w_fixed, tune_hypers, constraints, num_lik_params, D, N)
     model = assemble(lik_param, param1, param2, Wnmf, kernel1, kernel2, balance=True)
     return run_nlml(model, yall, D, N), np.zeros(np.size(w))
+
+
+# ---------------------------------------------------------------------------------------------
+# EKF energy WITH its gradient recursion: gf_giekf_modulator_nmf_constraints.m:332-480, GradObj='on'
+def d2linkf(x):
+    return dlinkf(x) * (1.0 - dlinkf(x))
+
+
+def funhd2(x, H, D, N, W):
+    """gf_giekf_modulator_nmf_constraints.m:505-514 (Hessian of h)."""
+    z = H[:D] @ x; g = H[D:D + N] @ x
+    Wd = W * dlinkf(g)[None, :]
+    partials = np.block([[np.zeros((D, D)), Wd], [Wd.T, np.diag((z @ W) * d2linkf(g))]])
+    return H.T @ partials @ H
+
+
+def grad_setup(model, param1, param2, kernel1, kernel2, consistent=False):
+    """The derivative inputs of the recursion: AA_j = expm([F 0; dF_j F]) (:355-366), dPinf_j, dR_j for the nparam = 1+3D+2N slices
+    the reference builds (:121-125: a zero slice for the noise parameter in front).
+    consistent=False -- as the reference: the UNBALANCED dF, dPinf of ss_modulators_nmf beside the balanced F, Pinf (:117-119 commented out).
+    consistent=True  -- the derivative stacks carried through the balancing transformation (T\\dF*T, T\\dPinf/T'): the recursion then
+                        differentiates the energy it runs beside, which central differences can confirm (test pin, not reference behaviour)."""
+    F, Pinf = model['F'], model['Pinf']
+    S = F.shape[0]
+    dF0, dP0 = ssm.ss_modulators_nmf_derivs(param1, param2, kernel1, kernel2)
+    if consistent and model.get('Tbal') is not None:
+        T = model['Tbal']; Ti = np.linalg.inv(T)
+        dF0 = np.stack([Ti @ a @ T for a in dF0]); dP0 = np.stack([Ti @ a @ Ti.T for a in dP0])
+    dF = np.concatenate([np.zeros((1, S, S)), dF0]); dP = np.concatenate([np.zeros((1, S, S)), dP0])
+    nparam = dF.shape[0]
+    AA = np.stack([sla.expm(np.block([[F, np.zeros((S, S))], [dF[j], F]])) for j in range(nparam)])
+    dR = np.zeros(nparam); dR[0] = 1.0
+    return dict(AA=AA, dPinf=dP, dR=dR)
+
+
+def run_nlml_grad(model, gs, yall, D, N, n_w, consistent=False):
+    """gf_giekf_modulator_nmf_constraints.m:332-480 with GradObj='on' -> (edata, gdata[n_w]).
+    consistent=False: the statements as written -- gdata has length(w) = n_w entries while the loop runs over nparam = size(dF,3)
+    (:336-342): MATLAB stops with an index error when n_w < nparam (IndexError here); for j > nparam - D*N the Jacobian derivative
+    is taken w.r.t. entry j-nparam+D*N of W (:440-444) while dm, dP still carry kernel parameter j; derivatives are w.r.t. the
+    natural parameters (sigma2 itself for j = 1), the chain rule to w is commented out (:480).
+    consistent=True: the same recursion as the true gradient of the energy w.r.t. [sigma2, kernel parameters (3D+2N), W(:) (D*N)]:
+    kernel parameters take the Hessian term only, W entries their own slices (dF = dPinf = 0) with the direct terms d mu/dW, dJH/dW."""
+    F, H, Pinf, Wnmf, lik_param = (model[k] for k in ('F', 'H', 'Pinf', 'Wnmf', 'lik_param'))
+    R = math.exp(float(np.ravel(lik_param)[0]))
+    AA, dPinf, dR = gs['AA'], gs['dPinf'], gs['dR']
+    d = F.shape[0]; nparam = AA.shape[0]
+    if consistent:
+        AW = np.block([[sla.expm(F), np.zeros((d, d))], [np.zeros((d, d)), sla.expm(F)]])
+        AA = np.concatenate([AA, np.repeat(AW[None], D * N, axis=0)])
+        dPinf = np.concatenate([dPinf, np.zeros((D * N, d, d))]); dR = np.concatenate([dR, np.zeros(D * N)])
+        nparam += D * N
+    if n_w < nparam:
+        raise IndexError('gdata(j) read past length(w) = %d (nparam = %d): Index exceeds the number of array elements' % (n_w, nparam))
+    gdata = np.zeros(n_w); edata = 0.0
+    m = np.zeros(d); P = Pinf.copy()
+    dm = np.zeros((d, nparam)); dP = dPinf.copy()
+    A = sla.expm(F); Q = Pinf - A @ Pinf @ A.T
+    nk = nparam - D * N                                           # j <= nparam - D*N (1-based): Hessian branch (:438)
+    for k in range(yall.size):
+        for j in range(nparam):
+            dm[:, j] = AA[j][d:, :] @ np.concatenate([m, dm[:, j]])
+            dA = AA[j][d:, :d]
+            dAPinfAt = dA @ Pinf @ A.T
+            dQ = dPinf[j] - dAPinfAt - A @ dPinf[j] @ A.T - dAPinfAt.T
+            dAPAt = dA @ P @ A.T
+            dP[j] = dAPAt + A @ dP[j] @ A.T + dAPAt.T + dQ
+        m = A @ m; P = A @ P @ A.T + Q
+        mu = funh(m, H, D, N, Wnmf); JH = funhd(m, H, D, N, Wnmf); dJH = funhd2(m, H, D, N, Wnmf)
+        S = JH @ P @ JH + R
+        if not S > 0:
+            S = S + 0.5e-4
+            if not S > 0:
+                return float('nan'), np.full(n_w, np.nan)
+        HtiS = JH / S; K = P @ HtiS; v = yall[k] - mu; vtiS = v / S
+        for j in range(nparam):
+            dmu_dir = 0.0
+            if consistent:
+                dmdJH = dm[:, j] @ dJH
+                if j >= nk:
+                    W_ = np.zeros(D * N); W_[j - nk] = 1.0; W_ = W_.reshape((D, N), order='F')
+                    dmdJH = dmdJH + funhd(m, H, D, N, W_)
+                    dmu_dir = funh(m, H, D, N, W_)
+            elif j < nk:
+                dmdJH = dm[:, j] @ dJH
+            else:
+                W_ = np.zeros(D * N); W_[j - nk] = 1.0; W_ = W_.reshape((D, N), order='F')
+                dmdJH = funhd(m, H, D, N, W_)
+            dmu = JH @ dm[:, j] + dmu_dir
+            dS = dmdJH @ P @ JH + JH @ dP[j] @ JH + JH @ P @ dmdJH + dR[j]
+            gdata[j] += 0.5 * dS / S - 0.5 * dmu * vtiS - 0.5 * vtiS * dS * vtiS - 0.5 * vtiS * dmu
+            dK = dP[j] @ HtiS + P @ dmdJH / S - P @ HtiS * dS / S
+            dm[:, j] = dm[:, j] + dK * v - K * dmu
+            dKSKt = np.outer(dK, K) * S
+            dP[j] = dP[j] - dKSKt - np.outer(K, K) * dS - dKSKt.T
+        edata += 0.5 * math.log(2 * math.pi) + math.log(math.sqrt(S)) + 0.5 * vtiS * v
+        m = m + K * v; P = P - np.outer(K, K) * S
+    return edata, gdata

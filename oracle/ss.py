@@ -196,3 +196,55 @@ def block_starts(H):
     """ihgp_ep_modulator_nmf.m:104  ilist = [find(sum(H,1)) size(H,2)+1]  (0-based here)."""
     cols = np.nonzero(np.sum(H, axis=0))[0]
     return np.concatenate([cols, [H.shape[1]]]).astype(int)
+
+
+# ---------------------------------------------------------------------------------------------
+# Derivative stacks (dF, dQc, dPinf) -- used only by the EKF nlml gradient (gf_giekf_modulator_nmf_constraints.m:332-480)
+def cf_derivs(kernel, magnSigma2, lengthScale):
+    """[dF, dPinf] of cf_<kernel>_to_ss w.r.t. (magnSigma2, lengthScale): cf_exp_to_ss.m:116-146, cf_matern32_to_ss.m:121-157,
+    cf_matern52_to_ss.m:127-166.  (dQc is not read by the gradient recursion, which uses Q = Pinf - A Pinf A'.)"""
+    s2, ell = float(magnSigma2), float(lengthScale)
+    if kernel == 'exp':
+        dF = [np.array([[0.0]]), np.array([[1.0 / ell ** 2]])]
+        dP = [np.array([[1.0]]), np.array([[0.0]])]
+    elif kernel == 'matern32':
+        dF = [np.zeros((2, 2)), np.array([[0.0, 0.0], [6.0 / ell ** 3, 2.0 * math.sqrt(3.0) / ell ** 2]])]
+        dP = [np.array([[1.0, 0.0], [0.0, 3.0 / ell ** 2]]), np.array([[0.0, 0.0], [0.0, -6.0 * s2 / ell ** 3]])]
+    elif kernel == 'matern52':
+        dF = [np.zeros((3, 3)), np.array([[0.0, 0.0, 0.0], [0.0, 0.0, 0.0],
+                                          [15.0 * math.sqrt(5.0) / ell ** 4, 30.0 / ell ** 3, 3.0 * math.sqrt(5.0) / ell ** 2]])]
+        Pinf = cf_matern52_to_ss(s2, ell)[4]
+        kappa = 5.0 / 3.0 * s2 / ell ** 2; kappa2 = -2.0 * kappa / ell
+        dP = [Pinf / s2, np.array([[0.0, 0.0, -kappa2], [0.0, kappa2, 0.0], [-kappa2, 0.0, -100.0 * s2 / ell ** 5]])]
+    else:
+        raise ValueError('derivatives restated for exp / matern32 / matern52 (the kernels the drivers use)')
+    return dF, dP
+
+
+def ss_modulators_nmf_derivs(w_subband, w_modulator, kernel1, kernel2):
+    """ss_modulators_nmf.m:24-132, derivative outputs: dF, dPinf of shape (3D+2N, S, S), parameter order
+    [sig1 (D), len1 (D), omega (D), sig2 (N), len2 (N)] -- the order of `cat(3, dF_sm_1, dF_sm_2, dF_cos_kron)` (:88) and
+    `cat(3, dF_sm, dF2_blk)` (:130).  UNBALANCED, as the reference uses them (the balancing lines
+    gf_giekf_modulator_nmf_constraints.m:117-119 are commented out)."""
+    w_subband = np.asarray(w_subband, float).ravel(); w_modulator = np.asarray(w_modulator, float).ravel()
+    D = len(w_subband) // 3; N = len(w_modulator) // 2
+    sig1, len1 = w_subband[:D], w_subband[D:2 * D]
+    sig2, len2 = w_modulator[:N], w_modulator[N:2 * N]
+    tau1 = _CF[kernel1](1.0, 1.0)[0].shape[0]; tau3 = _CF[kernel2](1.0, 1.0)[0].shape[0]
+    zt = 2 * tau1; S = zt * D + tau3 * N
+    dF = np.zeros((3 * D + 2 * N, S, S)); dP = np.zeros_like(dF)
+    I2 = np.eye(2)
+    for d in range(D):
+        dFd, dPd = cf_derivs(kernel1, sig1[d], len1[d])
+        sl = slice(zt * d, zt * (d + 1))
+        for q in range(2):                                   # :83-86  kron(dF1, eye(tau2))
+            dF[q * D + d, sl, sl] = np.kron(dFd[q], I2)
+            dP[q * D + d, sl, sl] = np.kron(dPd[q], I2)
+        dF[2 * D + d, sl, sl] = np.kron(np.eye(tau1), np.array([[0.0, -1.0], [1.0, 0.0]]))     # :56, 70-72  d/d omega
+    for n in range(N):
+        dFn, dPn = cf_derivs(kernel2, sig2[n], len2[n])
+        sl = slice(zt * D + tau3 * n, zt * D + tau3 * (n + 1))
+        for q in range(2):                                   # :108-124
+            dF[3 * D + q * N + n, sl, sl] = dFn[q]
+            dP[3 * D + q * N + n, sl, sl] = dPn[q]
+    return dF, dP

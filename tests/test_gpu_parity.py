@@ -1279,3 +1279,76 @@ def test_pipelined_smoother_ekf_bit_equal_and_long_sequence_against_serial():
         for f in ('Eft', 'Varft', 'MS', 'ttau', 'tnu', 'lZ', 'nlZ'):
             assert np.array_equal(getattr(res[other][0], f), getattr(res['serial'][0], f)), (other, f)
     assert np.all(np.isfinite(res['pipelined'][0].Eft)) and np.all(res['pipelined'][0].Varft > 0)
+
+
+# ---------------------------------------------------------------------------------------------
+# rows a11 / f-4: the EKF energy with its gradient recursion (gf_giekf_modulator_nmf_constraints.m:332-480, GradObj = 'on')
+def _grad_problem(D, N, T, seed):
+    pr = harness.nmf_problem(D, N, T, seed, 'constraints')
+    cons = harness.CONSTRAINTS_DEMO(D); tune = [1] * 7                       # every group tuned: the only case the reference statement runs in
+    w, wf = harness.constrained_vectors(pr, cons, tune)
+    return pr, cons, tune, w, wf
+
+
+@pytest.mark.parametrize('D,N,T', [(3, 2, 60), (8, 3, 80), (24, 3, 120)])
+def test_ekf_gradient_recursion_as_written_against_oracle(D, N, T):
+    """GradObj = 'on' as the reference has it (1+3D+2N slices; the last D*N with the Jacobian derivative w.r.t. an entry of W while
+    dm, dP carry the kernel parameter of the same index; unbalanced dF, dPinf beside the balanced F, Pinf): energy and every
+    gradient entry against the oracle's literal restatement.  (24, 3) is the configs[3] shape: 27 sites, three tiles per thread."""
+    pr, cons, tune, w, wf = _grad_problem(D, N, T, 900 + D)
+    t = np.arange(1, T + 1.0)
+    e, eg = nagp.gf_giekf_modulator_nmf_constraints(w, t, pr['y'], SSHandle(), None, None, 'matern32', 'matern52', 1, D, N, 3, 2, cons, wf, tune, 'on')
+    lik, p1, p2, W = ogf.ssm.unpack_constraints(w, wf, tune, cons, 1, D, N)
+    model = ogf.assemble(lik, p1, p2, W, 'matern32', 'matern52', True)
+    gs = oek.grad_setup(model, p1, p2, 'matern32', 'matern52', consistent=False)
+    eo, go = oek.run_nlml_grad(model, gs, pr['y'], D, N, w.size, consistent=False)
+    n_par = 1 + 3 * D + 2 * N
+    assert eg.shape == (w.size,) and not np.any(eg[n_par:])
+    assert abs(e - eo) < TOL_LOGZ * abs(eo)
+    assert rel(eg[:n_par], go[:n_par]) < 1e-7, np.c_[eg[:n_par], go[:n_par]]
+    # the energy is the one the GradObj = 'off' call returns
+    e_off, _ = nagp.gf_giekf_modulator_nmf_constraints(w, t, pr['y'], SSHandle(), None, None, 'matern32', 'matern52', 1, D, N, 3, 2, cons, wf, tune, 'off')
+    assert abs(e - e_off) < 1e-11 * abs(e_off)
+
+
+def test_ekf_gradient_index_error_when_fewer_groups_are_tuned():
+    """tune_hypers = [0 0 1 0 1 1 0] (demo_toy_modulators_nmf_constraints.m:40): numel(w) = D + 2N < size(dF,3) -- MATLAB stops at
+    gdata(j) with an index error (:453-457); so does the wrapper, before anything runs."""
+    D, N, T = 3, 2, 30
+    pr = harness.nmf_problem(D, N, T, 5, 'constraints'); cons = harness.CONSTRAINTS_DEMO(D)
+    w, wf = harness.constrained_vectors(pr, cons, harness.TUNE_DEMO)
+    t = np.arange(1, T + 1.0)
+    with pytest.raises(IndexError):
+        nagp.gf_giekf_modulator_nmf_constraints(w, t, pr['y'], SSHandle(), None, None, 'matern32', 'matern52', 1, D, N, 3, 2, cons, wf, harness.TUNE_DEMO, 'on')
+
+
+def test_ekf_gradient_consistent_form_equals_central_differences_of_the_energy():
+    """The same recursion with consistent inputs (derivatives carried through the balancing, W entries as slices of their own with
+    the direct terms): the gradient of the energy w.r.t. the natural parameters [sigma2, sig1, len1, omega, sig2, len2, W(:)].
+    Pinned twice: against the oracle's consistent form, and against central differences of the DEVICE's own energy (GradObj 'off'),
+    which the oracle and the golden fixture already pin."""
+    from nagp import api as napi
+    D, N, T = 4, 2, 70
+    pr = harness.nmf_problem(D, N, T, 31)
+    p1, p2, W = pr['param1'], pr['param2'], pr['W']; lik = np.array([np.log(pr['w_lik'])])
+    theta = np.concatenate([[pr['w_lik']], p1, p2, W.ravel(order='F')])
+
+    def energy(th):
+        q1 = th[1:1 + 3 * D]; q2 = th[1 + 3 * D:1 + 3 * D + 2 * N]; Wm = th[1 + 3 * D + 2 * N:].reshape((D, N), order='F')
+        blk = pss.balance_blocks(pss.ss_blocks_nmf(q1, q2, 'matern32', 'matern52'))
+        plan = Plan(L.KIND_GIEKF, [(blk, Wm, np.array([np.log(th[0])]))], T, ep_itts=1, mode=L.MODE_NLML, l_iter=1)
+        plan.upload([pr['y']]); plan.execute(); e = float(plan.download_nlz()[0, 0]); plan.close()
+        return e
+
+    blk = pss.balance_blocks(pss.ss_blocks_nmf(p1, p2, 'matern32', 'matern52'))
+    e, g = napi.giekf_nlml_grad(blk, W, lik, p1, p2, 'matern32', 'matern52', pr['y'], consistent=True)
+    assert abs(e - energy(theta)) < 1e-11 * abs(e) and g.size == theta.size
+    model = ogf.assemble(lik, p1, p2, W, 'matern32', 'matern52', True)
+    eo, go = oek.run_nlml_grad(model, oek.grad_setup(model, p1, p2, 'matern32', 'matern52', consistent=True), pr['y'], D, N, theta.size, consistent=True)
+    assert abs(e - eo) < TOL_LOGZ * abs(eo) and rel(g, go) < 1e-7
+    fd = np.zeros_like(theta)
+    for j in range(theta.size):
+        h = 1e-5 * max(abs(theta[j]), 1e-3); tp = theta.copy(); tp[j] += h; tm = theta.copy(); tm[j] -= h
+        fd[j] = (energy(tp) - energy(tm)) / (2 * h)
+    scale = np.maximum(np.abs(fd), 1e-6 * np.max(np.abs(fd)))
+    assert np.max(np.abs(g - fd) / scale) < 1e-4, np.c_[g, fd]

@@ -23,6 +23,7 @@
  *                                                                                                              nagp_reconstruct
  *   [nlZ_total, Eft, Varft, nlZ] = nagp_mex('batch', models {cell of model structs}, ys {cell}, opts, n_gpus [, tables {cell}])
  *                                    Eft, Varft, nlZ: cells, one entry per problem                             nagp_batch_run
+ *   [e, g] = nagp_mex('giekf_grad', model, y, dA, dQ, dPinf, dR, hess, w_index, w_direct [,device])            nagp_giekf_nlml_grad
  *
  * The kernels replace the loops of matlab/gf_ep_modulator_nmf.m:113-283 / :384-522 (and the other functions listed in
  * include/nagp.h); everything before those loops stays in the .m wrappers.
@@ -132,6 +133,30 @@ static void read_tables(const mxArray* stb, nagp_ihgp_tables* tb, int M) {
 }
 
 /* ---- the command forms (first argument a string) */
+static void cmd_giekf_grad(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+  /* ('giekf_grad', model, y, dA, dQ, dPinf (S x S x n_param each), dR, hess, w_index, w_direct (int32, n_param each) [,device]) -> [e, g]
+     the EKF energy with its gradient recursion, gf_giekf_modulator_nmf_constraints.m:332-480 with GradObj = 'on' */
+  nagp_model m; size_t T, n, np_; const double *y, *dA, *dQ, *dP, *dR; const double* ys[1]; const double* a1[1]; const double* a2[1]; const double* a3[1];
+  double e = 0; int32_t dev;
+  if (nrhs < 10 || nrhs > 11) mexErrMsgIdAndTxt("nagp:arg", "usage: [e,g] = nagp_mex('giekf_grad',model,y,dA,dQ,dPinf,dR,hess,w_index,w_direct[,device])");
+  read_model(prhs[1], &m);
+  y = dvec(prhs[2], "y", &T);
+  dR = dvec(prhs[6], "dR", &np_);
+  dA = dvec(prhs[3], "dA", &n); if (n != (size_t)m.S * m.S * np_) mexErrMsgIdAndTxt("nagp:arg", "dA must be S x S x numel(dR)");
+  dQ = dvec(prhs[4], "dQ", &n); if (n != (size_t)m.S * m.S * np_) mexErrMsgIdAndTxt("nagp:arg", "dQ must be S x S x numel(dR)");
+  dP = dvec(prhs[5], "dPinf", &n); if (n != (size_t)m.S * m.S * np_) mexErrMsgIdAndTxt("nagp:arg", "dPinf must be S x S x numel(dR)");
+  if (!mxIsInt32(prhs[7]) || !mxIsInt32(prhs[8]) || !mxIsInt32(prhs[9]) || mxGetNumberOfElements(prhs[7]) != np_ ||
+      mxGetNumberOfElements(prhs[8]) != np_ || mxGetNumberOfElements(prhs[9]) != np_) mexErrMsgIdAndTxt("nagp:arg", "hess, w_index, w_direct must be int32 with numel(dR) entries");
+  dev = nrhs > 10 ? (int32_t)mxGetScalar(prhs[10]) : 0;
+  plhs[0] = mxCreateDoubleMatrix(1, 1, mxREAL);
+  { mxArray* g = mxCreateDoubleMatrix(1, np_, mxREAL);
+    ys[0] = y; a1[0] = dA; a2[0] = dQ; a3[0] = dP;
+    fail_if(nagp_giekf_nlml_grad(1, &m, ys, (int64_t)T, (int32_t)np_, a1, a2, a3, dR, (const int32_t*)mxGetData(prhs[7]), (const int32_t*)mxGetData(prhs[8]),
+                                 (const int32_t*)mxGetData(prhs[9]), &e, mxGetPr(g), dev));
+    mxGetPr(plhs[0])[0] = e;
+    if (nlhs > 1) plhs[1] = g; }
+}
+
 static void cmd_iekf_update1(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
   /* ('iekf_update1', M, P, y, h_col, h_val, Wnmf, R, iters [,device]) -> [M,P,K,MU,S]  (iekf_update1.m:48, :110-117) */
   size_t S, n, nm; int32_t D, N, iters, dev; const double *m0, *P0, *hv, *W; double *m, *P, *K, MU = 0, Sx = 0;
@@ -242,6 +267,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     else if (!strcmp(cmd, "fastfb")) cmd_fastfb(nlhs, plhs, nrhs, prhs);
     else if (!strcmp(cmd, "reconstruct")) cmd_reconstruct(nlhs, plhs, nrhs, prhs);
     else if (!strcmp(cmd, "batch")) cmd_batch(nlhs, plhs, nrhs, prhs);
+    else if (!strcmp(cmd, "giekf_grad")) cmd_giekf_grad(nlhs, plhs, nrhs, prhs);
     else mexErrMsgIdAndTxt("nagp:arg", "unknown command '%s'", cmd);
     return;
   }

@@ -118,7 +118,7 @@ extern "C" int nagp_device_count(void) {
 }
 extern "C" const char* nagp_last_error(void) { return g_last_error.c_str(); }
 // (other translation units of the library record their error text here; not part of the ABI)
-extern "C" __attribute__((visibility("default"))) void nagp_internal_set_error(const char* msg) { g_last_error = msg ? msg : ""; }
+extern "C" __attribute__((visibility("hidden"))) void nagp_internal_set_error(const char* msg) { g_last_error = msg ? msg : ""; }
 extern "C" const char* nagp_strerror(int s) {
   switch (s) {
     case NAGP_OK: return "ok";

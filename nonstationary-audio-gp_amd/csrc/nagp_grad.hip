@@ -12,7 +12,7 @@
 // selection), so the update needs two LDS panels -- those columns of P and of dP_j -- and a handful of vectors.
 // Which terms a parameter takes is data (three flags per parameter), so that the host can ask for the reference's statements as
 // written (kernel parameters: dmdJH = dm' d2h; the last D*N slices: dmdJH = dh(.; W_) with the kernel parameter's dm, dP --
-// :438-444) or for the consistent gradient of the energy (see nagp/api.py and oracle/giekf.py).
+// :438-444) or for the consistent gradient of the energy (see nagp/api.py: giekf_nlml_grad).
 #include "nagp_dev.hpp"
 #include "../../include/nagp.h"
 
@@ -20,7 +20,7 @@
 #include <cstdio>
 #include <vector>
 
-extern "C" void nagp_internal_set_error(const char* msg);   // nagp_api.hip: the text nagp_last_error() returns on this thread
+extern "C" __attribute__((visibility("hidden"))) void nagp_internal_set_error(const char* msg);   // nagp_api.hip: the text nagp_last_error() returns on this thread
 
 namespace nagp {
 

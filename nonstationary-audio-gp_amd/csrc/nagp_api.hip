@@ -61,6 +61,7 @@ struct nagp_plan {
   int mfma_sp = 0;      // > 0: FP64-MFMA smoother passes on dense Sp x Sp matrices
   int big_sp = 0;       // 1: Sp > 96, the column-owner kernels of nagp_mfma_big.hpp
   int gain768 = 0;      // rts_gain_kernel<2, 768>: 1025..1536 tiles with a lower triangle of <= 768 tiles
+  int gain_mfma = 0;    // dense (G, Delta) output through rts_gain_mfma_kernel<Sp/16> (nagp_gain_mfma.hpp)
   size_t gbuf_doubles = 0;
   MfmaPar mpar{};
   size_t lds_mfma = 0;
@@ -809,6 +810,16 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
       default: PLAN_TRY(set_lds(rts_gain_kernel<4>, p->lds_gain)); PLAN_TRY(set_lds(rts_compose_kernel<4>, p->lds_scan)); PLAN_TRY(set_lds(rts_boundary_kernel<4>, p->lds_scan)); PLAN_TRY(set_lds(rts_apply_kernel<4>, p->lds_scan)); break;
     }
   }
+  // rts_gain_mfma_kernel (16x16 tiles on the matrix cores) is opt-in: measured on MI355X it is still behind the 4x4-tile VALU kernel
+  // (32 x 12 500 steps at Sp = 160: 1 195 ms against 972 ms; phase table in profiles/r03_gain_mfma_phases.txt)
+  if (p->mfma_sp && getenv("NAGP_GAIN_MFMA")) {
+    p->gain_mfma = 1;
+    const size_t lg = gainm_lds_doubles(p->mfma_sp / 16) * sizeof(double);
+#define SETG(N) PLAN_TRY(set_lds(rts_gain_mfma_kernel<N>, lg))
+    switch (p->mfma_sp / 16) { case 1: SETG(1); break; case 2: SETG(2); break; case 3: SETG(3); break; case 4: SETG(4); break; case 5: SETG(5); break;
+                               case 6: SETG(6); break; case 7: SETG(7); break; case 8: SETG(8); break; case 9: SETG(9); break; default: SETG(10); break; }
+#undef SETG
+  }
   if (p->big_sp) {
 #define SETB(N) PLAN_TRY(set_lds(rts_big_kernel<N, 0>, p->lds_mfma)); PLAN_TRY(set_lds(rts_big_kernel<N, 1>, p->lds_mfma)); \
     PLAN_TRY(set_lds(rts_big_kernel<N, 2>, p->lds_mfma)); PLAN_TRY(set_lds(rts_big_phi_kernel<N>, p->lds_mfma))
@@ -1046,7 +1057,7 @@ static void sweep_begin(nagp_plan* p, SweepCtx& sc, bool write_PSs) {
 
 static int launch_gain_chunk(nagp_plan* p, const SweepCtx& sc, int c, int slot, hipStream_t st) {
   const Shape& sh = p->sh; const ChunkGeom& g = sc.ch[c];
-  GainPar gp{g.k0, g.nk, p->slot_cap[slot], (sc.mode != SM_VALU) ? p->mfma_sp : 0};
+  GainPar gp{g.k0, g.nk, p->slot_cap[slot], (sc.mode != SM_VALU) ? p->mfma_sp : 0, getenv("NAGP_GAINM_DBG") ? atoi(getenv("NAGP_GAINM_DBG")) : 0};
   if (gp.dense_sp && p->slot_tiled[slot]) {
     HIP_TRY(hipMemsetAsync(p->slotG[slot], 0, (size_t)p->B * p->slot_cap[slot] * 2 * p->mat_doubles * sizeof(double), st)); p->slot_tiled[slot] = 0;
   }
@@ -1054,6 +1065,14 @@ static int launch_gain_chunk(nagp_plan* p, const SweepCtx& sc, int c, int slot, 
   Bufs b = p->b; b.Gbuf = p->slotG[slot]; b.dbuf = p->slotD[slot];
   Timed t(p, NAGP_K_GAIN, st);
   dim3 gr(g.nk, p->B), bl(p->NT);
+  if (gp.dense_sp && p->gain_mfma) {
+    const int ntl = p->mfma_sp / 16;
+    const size_t lg = gainm_lds_doubles(ntl) * sizeof(double);
+#define LG(N) hipLaunchKernelGGL((rts_gain_mfma_kernel<N>), gr, dim3(64 * N), lg, st, sh, b, gp)
+    switch (ntl) { case 1: LG(1); break; case 2: LG(2); break; case 3: LG(3); break; case 4: LG(4); break; case 5: LG(5); break;
+                   case 6: LG(6); break; case 7: LG(7); break; case 8: LG(8); break; case 9: LG(9); break; default: LG(10); break; }
+#undef LG
+  } else
   if (p->gain768) hipLaunchKernelGGL((rts_gain_kernel<2, 768>), gr, dim3(768), p->lds_gain, st, sh, b, gp);
   else switch (p->TPT) {
     case 1: hipLaunchKernelGGL((rts_gain_kernel<1>), gr, bl, p->lds_gain, st, sh, b, gp); break;

@@ -5,6 +5,7 @@
 #include "nagp_ihgp.hpp"
 #include "nagp_mfma.hpp"
 #include "nagp_mfma_big.hpp"
+#include "nagp_gain_mfma.hpp"
 
 #define NAGP_SIG_GF (nagp::Shape, nagp::Bufs, nagp::MomCfg, nagp::FilterPar)
 #define NAGP_LIST_GF_ADF(P, TPT, LB)                                                                                       \
@@ -48,6 +49,14 @@
   NAGP_LIST_SMOOTH_T(P, 1) NAGP_LIST_SMOOTH_T(P, 2) NAGP_LIST_SMOOTH_T(P, 3) NAGP_LIST_SMOOTH_T(P, 4)                    \
   NAGP_LIST_SMOOTH_M(P, 1) NAGP_LIST_SMOOTH_M(P, 2) NAGP_LIST_SMOOTH_M(P, 3) NAGP_LIST_SMOOTH_M(P, 4)                    \
   NAGP_LIST_SMOOTH_M(P, 5) NAGP_LIST_SMOOTH_M(P, 6)
+
+// RTS gain on the matrix cores (dense output), Sp = 16 .. 160
+#define NAGP_LIST_GAINM(P)                                                                                                 \
+  P void nagp::rts_gain_mfma_kernel<1>(nagp::Shape, nagp::Bufs, nagp::GainPar); P void nagp::rts_gain_mfma_kernel<2>(nagp::Shape, nagp::Bufs, nagp::GainPar);   \
+  P void nagp::rts_gain_mfma_kernel<3>(nagp::Shape, nagp::Bufs, nagp::GainPar); P void nagp::rts_gain_mfma_kernel<4>(nagp::Shape, nagp::Bufs, nagp::GainPar);   \
+  P void nagp::rts_gain_mfma_kernel<5>(nagp::Shape, nagp::Bufs, nagp::GainPar); P void nagp::rts_gain_mfma_kernel<6>(nagp::Shape, nagp::Bufs, nagp::GainPar);   \
+  P void nagp::rts_gain_mfma_kernel<7>(nagp::Shape, nagp::Bufs, nagp::GainPar); P void nagp::rts_gain_mfma_kernel<8>(nagp::Shape, nagp::Bufs, nagp::GainPar);   \
+  P void nagp::rts_gain_mfma_kernel<9>(nagp::Shape, nagp::Bufs, nagp::GainPar); P void nagp::rts_gain_mfma_kernel<10>(nagp::Shape, nagp::Bufs, nagp::GainPar);
 
 // MFMA smoother passes for 96 < Sp <= 160
 #define NAGP_LIST_BIG_N(P, NTL)                                                                                            \
@@ -93,4 +102,4 @@
 
 #define NAGP_LIST_ALL(P)                                                                                                   \
   NAGP_LIST_GF_ADF1(P) NAGP_LIST_GF_ADF2(P) NAGP_LIST_GF_ADF3(P) NAGP_LIST_GF_ADF4(P) NAGP_LIST_GF_ADF5(P)               \
-  NAGP_LIST_GF_SP12(P) NAGP_LIST_GF_SP34(P) NAGP_LIST_GF_REST(P) NAGP_LIST_SMOOTH(P) NAGP_LIST_BIG(P) NAGP_LIST_EP(P) NAGP_LIST_IH0(P) NAGP_LIST_IH1(P) NAGP_LIST_IHA(P) NAGP_LIST_IHA8(P)
+  NAGP_LIST_GF_SP12(P) NAGP_LIST_GF_SP34(P) NAGP_LIST_GF_REST(P) NAGP_LIST_SMOOTH(P) NAGP_LIST_BIG(P) NAGP_LIST_GAINM(P) NAGP_LIST_EP(P) NAGP_LIST_IH0(P) NAGP_LIST_IH1(P) NAGP_LIST_IHA(P) NAGP_LIST_IHA8(P)

@@ -645,6 +645,7 @@ struct GainPar {
   int nk;       // steps in the chunk
   int chunk;    // chunk capacity (buffer stride)
   int dense_sp; // 0: (G, Delta) tile-major ; > 0: dense row-major Sp x Sp (input layout of the MFMA smoother passes)
+  int dbg;      // developer switch of rts_gain_mfma_kernel (NAGP_GAINM_DBG): skip phases to time the others (results are garbage)
 };
 
 __host__ __device__ inline size_t gain_lds_doubles(const Shape& s) {

@@ -1352,3 +1352,31 @@ def test_ekf_gradient_consistent_form_equals_central_differences_of_the_energy()
         fd[j] = (energy(tp) - energy(tm)) / (2 * h)
     scale = np.maximum(np.abs(fd), 1e-6 * np.max(np.abs(fd)))
     assert np.max(np.abs(g - fd) / scale) < 1e-4, np.c_[g, fd]
+
+
+@pytest.mark.parametrize('D,N', [(3, 2), (16, 3), (22, 4), (32, 6)])
+def test_mfma_gain_kernel_equals_the_valu_gain_kernel(D, N):
+    """rts_gain_mfma_kernel (16x16 tiles on the matrix cores, opt-in: NAGP_GAIN_MFMA=1) against the default 4x4-tile kernel on the
+    same plans: Sp = 32, 80, 112, 160 (2, 5, 7, 10 waves), two problems, chunks of 24 steps, a missing observation -- every output
+    to rounding, the jitter counters identical."""
+    T = 60
+    probs, ys = [], []
+    for q in range(2):
+        pr = harness.nmf_problem(D, N, T, 8700 + q, 'constraints')
+        blk = pss.balance_blocks(pss.ss_blocks_nmf(pr['param1'], pr['param2'], 'matern32', 'matern52'))
+        y = pr['y'].copy(); y[9 + q] = np.nan
+        probs.append((blk, pr['W'], np.log(pr['w_lik']))); ys.append(y)
+    mom = Mom('likModulatorNMFPower', p_cubature=3); d = np.array([0.6, 0.5])
+    res = {}
+    for mode in ('mfma', 'valu'):
+        if mode == 'mfma': os.environ['NAGP_GAIN_MFMA'] = '1'
+        try:
+            plan = Plan(L.KIND_GF_EP, probs, T, mom=mom, ep_fraction=0.5, ep_damping=d, ep_itts=2, chunk=24)
+            plan.upload(ys); plan.execute(); res[mode] = plan.download(); plan.close()
+        finally:
+            os.environ.pop('NAGP_GAIN_MFMA', None)
+    for q in range(2):
+        a, v = res['mfma'][q], res['valu'][q]
+        for f, tol in (('Eft', 1e-9), ('Varft', 1e-9), ('MS', 1e-9), ('lZ', 1e-9), ('ttau', 1e-7), ('tnu', 1e-7)):
+            assert rel(getattr(a, f), getattr(v, f)) < tol, (q, f)
+        assert relz(a.nlZ, v.nlZ) < 1e-10 and np.array_equal(a.counters, v.counters)

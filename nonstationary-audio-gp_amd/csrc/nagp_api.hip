@@ -62,6 +62,8 @@ struct nagp_plan {
   int big_sp = 0;       // 1: Sp > 96, the column-owner kernels of nagp_mfma_big.hpp
   int gain768 = 0;      // rts_gain_kernel<2, 768>: 1025..1536 tiles with a lower triangle of <= 768 tiles
   int gain_mfma = 0;    // dense (G, Delta) output through rts_gain_mfma_kernel<Sp/16> (nagp_gain_mfma.hpp)
+  int lin_mfma = 0;     // fixed-site filter launches through gf_filter_lin_mfma_kernel<NTL> (nagp_filter_mfma.hpp); = NTL
+  size_t lds_lin = 0;
   size_t gbuf_doubles = 0;
   MfmaPar mpar{};
   size_t lds_mfma = 0;
@@ -810,6 +812,18 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
       default: PLAN_TRY(set_lds(rts_gain_kernel<4>, p->lds_gain)); PLAN_TRY(set_lds(rts_compose_kernel<4>, p->lds_scan)); PLAN_TRY(set_lds(rts_boundary_kernel<4>, p->lds_scan)); PLAN_TRY(set_lds(rts_apply_kernel<4>, p->lds_scan)); break;
     }
   }
+  if (!ekf && o->kind == NAGP_KIND_GF_EP && o->mode == NAGP_MODE_PREDICT && !(o->flags & NAGP_FLAG_MIXTURE_RULE) && 4 * sh.M <= 160 && getenv("NAGP_LIN_MFMA")) {
+    // fixed-site steps (sweeps >= 2) on the matrix cores: the plain predict-mode rule only.  Opt-in: measured on MI355X the step is
+    // 13.7 us against 10.4 us of the 4x4-tile VALU kernel at S = 146 (6.2 against 3.85 at S = 73) -- DESIGN section 8
+    const int ntl = (4 * sh.M + 15) / 16;
+    p->lin_mfma = ntl;
+    p->lds_lin = flm_lds_doubles(sh, ntl, 16) * sizeof(double);
+    if (p->pipeline) p->lds_lin = 160 * 1024;      // (the CU to itself, as for the other filter launches)
+#define SETF(N, W) PLAN_TRY(set_lds((gf_filter_lin_mfma_kernel<N, W>), p->lds_lin))
+    switch (ntl) { case 1: SETF(1, 4); break; case 2: SETF(2, 4); break; case 3: SETF(3, 4); break; case 4: SETF(4, 4); break; case 5: SETF(5, 4); break;
+                   case 6: SETF(6, 8); break; case 7: SETF(7, 8); break; case 8: SETF(8, 8); break; case 9: SETF(9, 8); break; default: SETF(10, 8); break; }
+#undef SETF
+  }
   // rts_gain_mfma_kernel (16x16 tiles on the matrix cores) is opt-in: measured on MI355X it is still behind the 4x4-tile VALU kernel
   // (32 x 12 500 steps at Sp = 160: 1 195 ms against 972 ms; phase table in profiles/r03_gain_mfma_phases.txt)
   if (p->mfma_sp && getenv("NAGP_GAIN_MFMA")) {
@@ -950,6 +964,12 @@ static int launch_filter(nagp_plan* p, const FilterPar& fp_in) {
 #undef LF3
 #undef LF4
 #undef LF5
+    } else if (p->lin_mfma && !fp.legacy_update && !fp.clamp_always && !fp.R_raw) {
+      FilterPar fl = fp; fl.kb = 16;
+#define LFM(N, W) hipLaunchKernelGGL((gf_filter_lin_mfma_kernel<N, W>), g, dim3(64 * W), p->lds_lin, p->stream, p->sh, p->b, fl)
+      switch (p->lin_mfma) { case 1: LFM(1, 4); break; case 2: LFM(2, 4); break; case 3: LFM(3, 4); break; case 4: LFM(4, 4); break; case 5: LFM(5, 4); break;
+                             case 6: LFM(6, 8); break; case 7: LFM(7, 8); break; case 8: LFM(8, 8); break; case 9: LFM(9, 8); break; default: LFM(10, 8); break; }
+#undef LFM
     } else if (p->wide_l) {
       if (p->NT_l <= 768) hipLaunchKernelGGL((gf_filter_kernel<1, 0, -1, 768>), g, dim3(p->NT_l), p->lds_filter, p->stream, p->sh, p->b, mc, fp);
       else hipLaunchKernelGGL((gf_filter_kernel<1, 0, -1, 1024>), g, dim3(p->NT_l), p->lds_filter, p->stream, p->sh, p->b, mc, fp);

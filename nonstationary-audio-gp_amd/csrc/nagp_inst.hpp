@@ -6,6 +6,7 @@
 #include "nagp_mfma.hpp"
 #include "nagp_mfma_big.hpp"
 #include "nagp_gain_mfma.hpp"
+#include "nagp_filter_mfma.hpp"
 
 #define NAGP_SIG_GF (nagp::Shape, nagp::Bufs, nagp::MomCfg, nagp::FilterPar)
 #define NAGP_LIST_GF_ADF(P, TPT, LB)                                                                                       \
@@ -49,6 +50,15 @@
   NAGP_LIST_SMOOTH_T(P, 1) NAGP_LIST_SMOOTH_T(P, 2) NAGP_LIST_SMOOTH_T(P, 3) NAGP_LIST_SMOOTH_T(P, 4)                    \
   NAGP_LIST_SMOOTH_M(P, 1) NAGP_LIST_SMOOTH_M(P, 2) NAGP_LIST_SMOOTH_M(P, 3) NAGP_LIST_SMOOTH_M(P, 4)                    \
   NAGP_LIST_SMOOTH_M(P, 5) NAGP_LIST_SMOOTH_M(P, 6)
+
+// fixed-site filter step on the matrix cores
+#define NAGP_SIG_FLM (nagp::Shape, nagp::Bufs, nagp::FilterPar)
+#define NAGP_LIST_FLM(P)                                                                                                   \
+  P void nagp::gf_filter_lin_mfma_kernel<1, 4> NAGP_SIG_FLM; P void nagp::gf_filter_lin_mfma_kernel<2, 4> NAGP_SIG_FLM;   \
+  P void nagp::gf_filter_lin_mfma_kernel<3, 4> NAGP_SIG_FLM; P void nagp::gf_filter_lin_mfma_kernel<4, 4> NAGP_SIG_FLM;   \
+  P void nagp::gf_filter_lin_mfma_kernel<5, 4> NAGP_SIG_FLM; P void nagp::gf_filter_lin_mfma_kernel<6, 8> NAGP_SIG_FLM;   \
+  P void nagp::gf_filter_lin_mfma_kernel<7, 8> NAGP_SIG_FLM; P void nagp::gf_filter_lin_mfma_kernel<8, 8> NAGP_SIG_FLM;   \
+  P void nagp::gf_filter_lin_mfma_kernel<9, 8> NAGP_SIG_FLM; P void nagp::gf_filter_lin_mfma_kernel<10, 8> NAGP_SIG_FLM;
 
 // RTS gain on the matrix cores (dense output), Sp = 16 .. 160
 #define NAGP_LIST_GAINM(P)                                                                                                 \
@@ -102,4 +112,4 @@
 
 #define NAGP_LIST_ALL(P)                                                                                                   \
   NAGP_LIST_GF_ADF1(P) NAGP_LIST_GF_ADF2(P) NAGP_LIST_GF_ADF3(P) NAGP_LIST_GF_ADF4(P) NAGP_LIST_GF_ADF5(P)               \
-  NAGP_LIST_GF_SP12(P) NAGP_LIST_GF_SP34(P) NAGP_LIST_GF_REST(P) NAGP_LIST_SMOOTH(P) NAGP_LIST_BIG(P) NAGP_LIST_GAINM(P) NAGP_LIST_EP(P) NAGP_LIST_IH0(P) NAGP_LIST_IH1(P) NAGP_LIST_IHA(P) NAGP_LIST_IHA8(P)
+  NAGP_LIST_GF_SP12(P) NAGP_LIST_GF_SP34(P) NAGP_LIST_GF_REST(P) NAGP_LIST_SMOOTH(P) NAGP_LIST_BIG(P) NAGP_LIST_GAINM(P) NAGP_LIST_FLM(P) NAGP_LIST_EP(P) NAGP_LIST_IH0(P) NAGP_LIST_IH1(P) NAGP_LIST_IHA(P) NAGP_LIST_IHA8(P)

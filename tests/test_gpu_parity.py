@@ -1380,3 +1380,32 @@ def test_mfma_gain_kernel_equals_the_valu_gain_kernel(D, N):
         for f, tol in (('Eft', 1e-9), ('Varft', 1e-9), ('MS', 1e-9), ('lZ', 1e-9), ('ttau', 1e-7), ('tnu', 1e-7)):
             assert rel(getattr(a, f), getattr(v, f)) < tol, (q, f)
         assert relz(a.nlZ, v.nlZ) < 1e-10 and np.array_equal(a.counters, v.counters)
+
+
+@pytest.mark.parametrize('D,N,k1', [(3, 2, 'matern32'), (16, 3, 'matern32'), (22, 4, 'exp'), (32, 6, 'matern32')])
+def test_mfma_fixed_site_filter_equals_the_valu_filter(D, N, k1):
+    """gf_filter_lin_mfma_kernel (covariance in the MFMA accumulator layout, rank-M update on the matrix cores; opt-in:
+    NAGP_LIN_MFMA=1) against the default 4x4-tile kernel: the sweeps >= 2 of the same plans -- 5, 19, 26, 38 sites (1, 4, 8 waves'
+    worth of tiles; 2-state sub-band blocks in the third case), missing observations, a continuation chunk -- to rounding."""
+    T = 70
+    probs, ys = [], []
+    for q in range(2):
+        pr = harness.nmf_problem(D, N, T, 8800 + q, 'constraints')
+        blk = pss.balance_blocks(pss.ss_blocks_nmf(pr['param1'], pr['param2'], k1, 'matern52'))
+        y = pr['y'].copy(); y[13 + q] = np.nan; y[T - 2] = np.nan
+        probs.append((blk, pr['W'], np.log(pr['w_lik']))); ys.append(y)
+    mom = Mom('likModulatorNMFPower', p_cubature=3); d = np.array([0.6, 0.5, 0.5])
+    res = {}
+    for mode in ('mfma', 'valu'):
+        if mode == 'mfma': os.environ['NAGP_LIN_MFMA'] = '1'
+        try:
+            plan = Plan(L.KIND_GF_EP, probs, T, mom=mom, ep_fraction=0.5, ep_damping=d, ep_itts=3, chunk=24)
+            plan.upload(ys); plan.execute(); res[mode] = plan.download(want_MF=True); tm = plan.timings(); plan.close()
+            assert tm['launches']['filter_lin'] == 2                      # sweeps 2 and 3 ran the fixed-site kernel
+        finally:
+            os.environ.pop('NAGP_LIN_MFMA', None)
+    for q in range(2):
+        a, v = res['mfma'][q], res['valu'][q]
+        for f, tol in (('Eft', 1e-9), ('Varft', 1e-9), ('MS', 1e-9), ('MF', 1e-9), ('lZ', 1e-9), ('ttau', 1e-7), ('tnu', 1e-7)):
+            assert rel(getattr(a, f), getattr(v, f)) < tol, (q, f)
+        assert relz(a.nlZ, v.nlZ) < 1e-10 and np.array_equal(a.counters, v.counters)

@@ -926,6 +926,7 @@ static int launch_filter(nagp_plan* p, const FilterPar& fp_in) {
   FilterPar fp = fp_in;
   fp.kb = p->kb_f;
   if (p->pipeline && fp.store_PF) { fp.progress = p->h_progress; fp.progress_every = 256; }
+  if (const char* e = getenv("NAGP_FILTER_DBG")) fp.dbg = atoi(e);   // developer switch: see FilterPar::dbg
   const bool ekf = p->opts.kind == NAGP_KIND_GIEKF;
   MomCfg mc = p->mc; mc.DG = p->DG_f; mc.cache_tabs = p->cache_f; mc.store_a = p->sta_f;
   mc.sp = p->sp_gf ? p->sp : MomSp{};

@@ -81,6 +81,8 @@ struct FilterPar {
   // second stream while this workgroup filters on.  nullptr: nothing published.
   unsigned long long* progress;
   int progress_every;      // publish when the step count crosses a multiple of this (and at the end of the launch)
+  int dbg;                 // developer switch (NAGP_FILTER_DBG): skip phases to time the others -- results are garbage.
+                           // 1: rank-M covariance update, 2: PF stores, 4: prediction congruence, 8: W panel writes, 16: mean update
 };
 
 // The filtered covariance is symmetric: PF holds only the lower-triangular tiles, tile (I,J), I >= J, at
@@ -325,7 +327,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
       for (int q = 0; q < TPT; ++q) {
         if (own.ok[q]) {
           const int I = own.I[q], J = own.J[q];
-          if (pred) {
+          if (pred && !(fp.dbg & 4)) {
             tile_congruence(P[q], sA + (size_t)I * TS, sA + (size_t)J * TS);
             if (I == J) {
               const double* Qb = sQ + (size_t)I * TS;
@@ -335,6 +337,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
           }
           const double hJ = shv[J], hI = shv[I];
           // P(rows of I, c_J)
+          if (!(fp.dbg & 8))
 #pragma unroll
           for (int i = 0; i < 4; ++i) Wl[(((size_t)J * 2 + (i >> 1)) * M + I) * 2 + (i & 1)] = hJ * P[q][4 * i];
           if (I == J) {
@@ -365,7 +368,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
               if (formA) { const double z = t * hp + 1.0; cA[I] = t / z; cm[I] = -(t * f - n_) / z; }
               else { const double s = 1.0 / (hp + 1.0 / t); cA[I] = s; cm[I] = s * (n_ / t - f); }
             }
-          } else {             // P(rows of J, c_I) = P(c_I, cols of J) by symmetry
+          } else if (!(fp.dbg & 8)) {             // P(rows of J, c_I) = P(c_I, cols of J) by symmetry
 #pragma unroll
             for (int j = 0; j < 4; ++j) Wl[(((size_t)I * 2 + (j >> 1)) * M + J) * 2 + (j & 1)] = hI * P[q][j];
           }
@@ -438,7 +441,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
             if (tid == 0) misc[1] = formA ? 1.0 : 0.0;
           }
           if (do_mom) lds_barrier();  // B4
-          if (tid < S) {
+          if (tid < S && !(fp.dbg & 16)) {
             double a0 = rm, a1 = 0.0, a2 = 0.0, a3 = 0.0;
             const double* wp = Wl + ((size_t)(myrow >> 1) * M + myblk) * 2 + (myrow & 1);
             int n = 0;
@@ -455,7 +458,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
           // P -= sum_n cA[n] W[:,n] W[:,n]'   (K*H*P and K*W' coincide for the symmetric P)
 #pragma unroll
           for (int q = 0; q < TPT; ++q) {
-            if (own.ok[q]) {
+            if (own.ok[q] && !(fp.dbg & 1)) {
               const double* wbase = Wl + (size_t)own.I[q] * 2;
               const double* rbase = Wl + (size_t)own.J[q] * 2;
               int n0 = 0;
@@ -598,7 +601,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
       for (int q = 0; q < TPT; ++q)
         if (own.ok[q] && own.I[q] == own.J[q])
           rfv[kk * M + own.I[q]] = shv[own.I[q]] * shv[own.I[q]] * P[q][0];
-      if (g_PF) {
+      if (g_PF && !(fp.dbg & 2)) {
 #pragma unroll
         for (int q = 0; q < TPT; ++q)
           if (own.ok[q]) {

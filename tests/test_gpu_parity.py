@@ -1409,3 +1409,18 @@ def test_mfma_fixed_site_filter_equals_the_valu_filter(D, N, k1):
         for f, tol in (('Eft', 1e-9), ('Varft', 1e-9), ('MS', 1e-9), ('MF', 1e-9), ('lZ', 1e-9), ('ttau', 1e-7), ('tnu', 1e-7)):
             assert rel(getattr(a, f), getattr(v, f)) < tol, (q, f)
         assert relz(a.nlZ, v.nlZ) < 1e-10 and np.array_equal(a.counters, v.counters)
+
+
+def test_plan_that_cannot_fit_returns_enomem_and_the_device_stays_usable():
+    """A plan whose filtered-covariance history alone exceeds the HBM of the card (64 segments x 400 000 steps at 38 sites = 2.4 TB):
+    nagp_plan_create fails with NAGP_ENOMEM (hipMalloc says so before anything is touched), frees what it had allocated, and the
+    next plan on the same device works."""
+    D, N = 32, 6
+    pr = harness.nmf_problem(D, N, 8, 1, 'constraints')
+    blk = pss.balance_blocks(pss.ss_blocks_nmf(pr['param1'], pr['param2'], 'matern32', 'matern52'))
+    mom = Mom('likModulatorNMFPower', p_cubature=3)
+    with pytest.raises(nagp.NagpError, match='out of device memory'):
+        Plan(L.KIND_GF_EP, [(blk, pr['W'], np.log(pr['w_lik']))] * 64, 400000, mom=mom, ep_fraction=0.5, ep_damping=[0.5, 0.5], ep_itts=2)
+    plan = Plan(L.KIND_GF_EP, [(blk, pr['W'], np.log(pr['w_lik']))], 8, mom=mom, ep_fraction=0.5, ep_damping=[0.5, 0.5], ep_itts=2)
+    plan.upload([pr['y']]); plan.execute(); o = plan.download()[0]; plan.close()
+    assert np.all(np.isfinite(o.Eft)) and np.all(o.Varft > 0)

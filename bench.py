@@ -300,6 +300,8 @@ def run_workload(name, a, rank, local_rank, world, dev, with_cpu, steps, warmup)
                 per_exec = max(launches[dom] / steps, 1.0)            # launches of the dominant kernel in one execute
                 roof['traffic'] = (pm['fetch_bytes_per_execute'] + pm['write_bytes_per_execute']) / per_exec
                 roof['traffic_source'] = pm['source'] + ' (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, this build)'
+                if roof['bound'] == 'hbm':   # the same launch priced with the bytes it really moved instead of SURVEY's per-sample figure
+                    roof['achieved_from_traffic'] = roof['traffic'] / (roof['avg_launch_ms'] * 1e-3) / 1e9
         except (OSError, ValueError, KeyError):
             pass
     res = {

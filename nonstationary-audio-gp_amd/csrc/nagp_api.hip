@@ -34,6 +34,7 @@ static thread_local std::string g_last_error;
       char _b[512];                                                                           \
       snprintf(_b, sizeof _b, "%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
       g_last_error = _b;                                                                      \
+      (void)hipGetLastError();   /* the runtime's last-error slot is sticky: a later hipGetLastError() after a launch must not see this one */ \
       return (_e == hipErrorOutOfMemory) ? NAGP_ENOMEM : NAGP_EHIP;                           \
     }                                                                                         \
   } while (0)
@@ -367,7 +368,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
   p->want_PS = true;   // smoothed covariances are cheap to keep only if asked; decided at download (see below)
 
 #define PLAN_TRY(expr) do { int _s = (expr); if (_s != NAGP_OK) { nagp_plan_destroy(p); return _s; } } while (0)
-#define PLAN_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { char _b[512]; snprintf(_b, sizeof _b, "%s -> %s", #expr, hipGetErrorString(_e)); g_last_error = _b; nagp_plan_destroy(p); return _e == hipErrorOutOfMemory ? NAGP_ENOMEM : NAGP_EHIP; } } while (0)
+#define PLAN_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { char _b[512]; snprintf(_b, sizeof _b, "%s -> %s", #expr, hipGetErrorString(_e)); g_last_error = _b; (void)hipGetLastError(); nagp_plan_destroy(p); return _e == hipErrorOutOfMemory ? NAGP_ENOMEM : NAGP_EHIP; } } while (0)
 
   // the device is looked at only after every pure-host check has passed (those run under ASan on GPU-less machines)
   {
@@ -1017,17 +1018,19 @@ static void sweep_begin(nagp_plan* p, SweepCtx& sc, bool write_PSs) {
     // Spans.  The boundary pass is one sequential chain over ALL spans of the sweep (one workgroup per problem, a step per span); a
     // compose / apply launch costs a span LENGTH of latency, and the apply passes of the chunks run as one merged grid.
     //  * few workgroups (B * spans of the whole sweep <= 512: single sequences): latency decides -- one span length for the whole
-    //    backward recursion, L* = sqrt((T-1)/r) with r = boundary step : apply step (2.5 VALU passes, ~1 MFMA passes;
-    //    profiles/r03_pipeline_timeline_*); per-chunk sqrt rules would multiply the boundary chain by sqrt(#chunks);
+    //    backward recursion, L* = sqrt((T-1) r) with r = boundary step : apply step (2.5 VALU passes; MFMA passes 0.5: 54 us per
+    //    span against 109 us per step at Sp = 160, 13 against 31 at Sp = 80, profiles/r03_pipeline_timeline_*); per-chunk sqrt
+    //    rules would multiply the boundary chain by sqrt(#chunks);
     //  * many workgroups (segments x spans fill the chip): throughput decides -- a chunk's launch should be whole rounds of the CUs the
     //    filter leaves free, spans as long as that allows (column-owner kernels: ~90 us per step of the three span passes, ~47 us
     //    per boundary span, measured at Sp = 160); the other kernels keep the sqrt(2.5 nk) rule under the workgroup cap.
-    double Lstar = std::max(8.0, std::sqrt((double)(sh.T - 1) / (sc.mode == SM_VALU ? 2.5 : 1.0)));
+    const double r_ba = (sc.mode == SM_VALU) ? 2.5 : 0.5;
+    double Lstar = std::max(8.0, std::sqrt((double)(sh.T - 1) / (sc.mode == SM_VALU ? 2.5 : 1.0)));   // (regime test only)
     const bool latency_regime = (double)p->B * (double)(sh.T - 1) / Lstar <= 512.0;
     int ns;
     if (latency_regime) {
       // one span length for the sweep: the boundary chain costs (T/L) r, the merged apply grid ceil(B (T/L) / 256) rounds of L steps
-      const double r = (sc.mode == SM_VALU) ? 2.5 : 1.0;
+      const double r = r_ba;
       double best = 1e300;
       for (int L = 8; L <= std::max<int64_t>(8, sh.T - 1); L += std::max(1, L / 64)) {
         const double spans = std::ceil((double)(sh.T - 1) / L);
@@ -1794,7 +1797,7 @@ extern "C" int nagp_mom_eval(const nagp_opts* o, int32_t D, int32_t N, const dou
                o_mu = o_y + n, o_s2 = o_mu + (size_t)n * M, o_lZ = o_s2 + (size_t)n * M, o_dl = o_lZ + n, o_d2 = o_dl + (size_t)n * M,
                total = o_d2 + (size_t)n * M;
   double* dev = nullptr;
-  if (hipMalloc(&dev, total * sizeof(double)) != hipSuccess) FAIL(NAGP_ENOMEM, "hipMalloc(%zu)", total * sizeof(double));
+  if (hipMalloc(&dev, total * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); FAIL(NAGP_ENOMEM, "hipMalloc(%zu)", total * sizeof(double)); }
   std::vector<double> Wr(nW);
   for (int dd = 0; dd < (power ? 0 : D); ++dd)
     for (int j = 0; j < N; ++j) Wr[(size_t)dd * N + j] = Wnmf[dd + (size_t)D * j];
@@ -1849,7 +1852,7 @@ extern "C" int nagp_iekf_update1(int32_t S, int32_t D, int32_t N, const int32_t*
   const size_t o_m = 0, o_P = o_m + S, o_K = o_P + (size_t)S * S, o_ms = o_K + S, o_hv = o_ms + 2, o_W = o_hv + M,
                o_hc = o_W + (size_t)D * N, total = o_hc + (M + 1) / 2 + 1;
   double* dev = nullptr;
-  if (hipMalloc(&dev, total * sizeof(double)) != hipSuccess) FAIL(NAGP_ENOMEM, "hipMalloc(%zu)", total * sizeof(double));
+  if (hipMalloc(&dev, total * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); FAIL(NAGP_ENOMEM, "hipMalloc(%zu)", total * sizeof(double)); }
   std::vector<double> Wr((size_t)D * N);
   for (int dd = 0; dd < D; ++dd)
     for (int j = 0; j < N; ++j) Wr[(size_t)dd * N + j] = Wnmf[dd + (size_t)D * j];
@@ -1896,7 +1899,7 @@ extern "C" int nagp_fastfb_run(int32_t S, const double* A, const double* AKHA, c
   const size_t o_A = 0, o_B = o_A + SS, o_G = o_B + SS, o_ha = o_G + SS, o_k = o_ha + S, o_y = o_k + S, o_ms = o_y + T,
                o_sv = o_ms + (size_t)T * S, o_phi = o_sv + ns + 1, o_st = o_phi + (size_t)ns * S * SP, total = o_st + (size_t)ns * S + 2;
   double* dev = nullptr;
-  if (hipMalloc(&dev, total * sizeof(double)) != hipSuccess) FAIL(NAGP_ENOMEM, "hipMalloc(%zu)", total * sizeof(double));
+  if (hipMalloc(&dev, total * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); FAIL(NAGP_ENOMEM, "hipMalloc(%zu)", total * sizeof(double)); }
   int st = NAGP_OK;
 #define FB_HIP(x) do { if (st == NAGP_OK) { hipError_t _e = (x); if (_e != hipSuccess) { g_last_error = std::string("nagp_fastfb_run: " #x " -> ") + hipGetErrorString(_e); st = NAGP_EHIP; } } } while (0)
   FB_HIP(hipMemcpy(dev + o_A, A, SS * 8, hipMemcpyHostToDevice));
@@ -2108,7 +2111,7 @@ extern "C" int nagp_reconstruct(int32_t D, int32_t N, int64_t T, const double* E
   const size_t o_W = 0, o_E = o_W + nW, o_V = o_E + nMT, o_gx = o_V + nMT, o_gw = o_gx + ngh, o_es = o_gw + ngh, o_vs = o_es + T,
                o_em = o_vs + T, o_vm = o_em + (size_t)N * T, total = o_vm + (size_t)N * T;
   double* dev = nullptr;
-  if (hipMalloc(&dev, total * sizeof(double)) != hipSuccess) FAIL(NAGP_ENOMEM, "hipMalloc(%zu)", total * sizeof(double));
+  if (hipMalloc(&dev, total * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); FAIL(NAGP_ENOMEM, "hipMalloc(%zu)", total * sizeof(double)); }
   std::vector<double> Wr(nW);
   for (int d = 0; d < D; ++d)
     for (int j = 0; j < N; ++j) Wr[(size_t)d * N + j] = Wnmf[d + (size_t)D * j];

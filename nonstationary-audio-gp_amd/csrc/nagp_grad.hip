@@ -215,7 +215,7 @@ __host__ inline size_t grad_lds_bytes(int M, int D, int N) {
 using namespace nagp;
 
 #define GFAIL(code, ...) do { char _b[512]; snprintf(_b, sizeof _b, __VA_ARGS__); nagp_internal_set_error(_b); return (code); } while (0)
-#define GHIP(x) do { hipError_t _e = (x); if (_e != hipSuccess) { for (void* v : allocs) (void)hipFree(v); GFAIL(_e == hipErrorOutOfMemory ? NAGP_ENOMEM : NAGP_EHIP, "nagp_giekf_nlml_grad: %s -> %s", #x, hipGetErrorString(_e)); } } while (0)
+#define GHIP(x) do { hipError_t _e = (x); if (_e != hipSuccess) { for (void* v : allocs) (void)hipFree(v); (void)hipGetLastError(); GFAIL(_e == hipErrorOutOfMemory ? NAGP_ENOMEM : NAGP_EHIP, "nagp_giekf_nlml_grad: %s -> %s", #x, hipGetErrorString(_e)); } } while (0)
 
 extern "C" int nagp_giekf_nlml_grad(int32_t B, const nagp_model* models, const double* const* ys, int64_t T, int32_t n_param,
                                     const double* const* dA, const double* const* dQ, const double* const* dPinf, const double* dR,

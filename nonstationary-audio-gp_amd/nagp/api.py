@@ -513,8 +513,10 @@ def gf_giekf_modulator_nmf_constraints(w, x, y, ss, mom, xt, kernel1, kernel2, n
                                        constraints, w_fixed, tune_hypers, GradObj='off', nargout=2, device=0):
     """matlab/gf_giekf_modulator_nmf_constraints.m:1-2.  xt empty: [e, eg] of :332-480 with GradObj='off' (what
     train_GTFNMF.m:199 / train_model.m:239 pass): one plain EKF pass, e = sum_k log(2pi)/2 + log sqrt(S_k) + v_k^2/(2 S_k),
-    eg = zeros(1,numel(w)).  GradObj='on' mixes size(dF,3) hyper-parameter slices with numel(w) tuned entries
-    (:339-341, :432-441) and is not reproduced."""
+    eg = zeros(1,numel(w)).  GradObj='on': the dm/dP recursion of :355-402, 437-466 as written (nagp_giekf_nlml_grad; it indexes
+    gdata(1..size(dF,3)) in a vector of numel(w) entries, so it runs only when at least 1+3D+2N parameters are tuned -- an
+    IndexError otherwise, as MATLAB's).  GradObj='consistent' (not in the reference): the gradient of the energy with respect to
+    the natural parameters, which central differences of the energy confirm."""
     yall, return_ind = _merge_inputs(x, y, xt)
     lik_param, p1, p2, Wnmf = _unpack_constraints(w, w_fixed, tune_hypers, constraints, num_lik_params, D, N)
     blk = ssm.balance_blocks(_blocks_from_dense(*ss(x, p1, p2, kernel1, kernel2), D, N))

@@ -1425,3 +1425,12 @@ def test_plan_that_cannot_fit_returns_enomem_and_the_device_stays_usable():
     plan = Plan(L.KIND_GF_EP, [(blk, pr['W'], np.log(pr['w_lik']))], 8, mom=mom, ep_fraction=0.5, ep_damping=[0.5, 0.5], ep_itts=2)
     plan.upload([pr['y']]); plan.execute(); o = plan.download()[0]; plan.close()
     assert np.all(np.isfinite(o.Eft)) and np.all(o.Varft > 0)
+
+
+def test_randomised_schedules_pipelined_equals_serial():
+    """tools/gpu_fuzz_schedules.py, fixed seed: 16 random draws of shape / family (EP, EKF) / segments / chunk length / number of
+    (G, Delta) buffers / sweeps / missing data / smoothed covariances -- the pipelined plan equals the serial plan bit for bit in all."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('gpu_fuzz_schedules', os.path.join(os.path.dirname(__file__), '..', 'tools', 'gpu_fuzz_schedules.py'))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    assert mod.run_cases(16, 31, verbose=False) == 0

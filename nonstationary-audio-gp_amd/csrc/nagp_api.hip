@@ -870,7 +870,10 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
 
 extern "C" void nagp_plan_destroy(nagp_plan* p) {
   if (!p) return;
+  // every stream of the plan is drained BEFORE its memory goes (an execute that failed half way may have left launches on the side streams)
   if (p->stream) (void)hipStreamSynchronize(p->stream);
+  if (p->stream2) (void)hipStreamSynchronize(p->stream2);
+  for (hipStream_t st : p->s_apply) (void)hipStreamSynchronize(st);
   for (void* v : p->allocs) (void)hipFree(v);
   for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
   if (p->ev_t0) (void)hipEventDestroy(p->ev_t0);
@@ -1623,7 +1626,15 @@ extern "C" int nagp_plan_execute(nagp_plan* p) {
     case NAGP_KIND_IHGP: st = exec_ihgp(p); break;
     default: st = exec_giekf(p); break;
   }
-  if (st != NAGP_OK) return st;
+  if (st != NAGP_OK) {   // leave no launch of the failed call behind: the next upload / execute / destroy starts from idle streams
+    const std::string keep = g_last_error;
+    if (p->stream) (void)hipStreamSynchronize(p->stream);
+    if (p->stream2) (void)hipStreamSynchronize(p->stream2);
+    for (hipStream_t s2 : p->s_apply) (void)hipStreamSynchronize(s2);
+    (void)hipGetLastError();
+    g_last_error = keep;
+    return st;
+  }
   HIP_TRY(hipEventRecord(p->ev_t1, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
   if (getenv("NAGP_STAMPS") && p->d_stamps) {

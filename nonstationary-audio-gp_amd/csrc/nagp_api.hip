@@ -529,7 +529,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
   // (the tail the pipeline cannot hide is one chunk's gain + compose), at least 2048 steps each, at most what one buffer may take.
   p->chunk = (o->chunk > 0) ? o->chunk : (int)std::min<int64_t>(T, std::max<int64_t>(2048, (T + 11) / 12));
   if (p->chunk > T) p->chunk = (int)T;
-  PLAN_TRY(dalloc(p, &p->d_stamps, 8));
+  PLAN_TRY(dalloc(p, &p->d_stamps, 24));
   if (o->kind != NAGP_KIND_IHGP) {
     {   // FP64 MFMA smoother for padded dimensions up to 96 (set NAGP_NO_MFMA=1 to force the VALU passes)
       const int Sp = ((4 * sh.M + 15) / 16) * 16;
@@ -1552,6 +1552,7 @@ static int exec_ihgp(nagp_plan* p) {
     if (itt > 1) RUN(affine(0, sh.T - 1, itt));
     IhgpPar ip{itt, p->damping[itt - 1], itt == 1 ? 1 : 0, (itt == 1) ? (int64_t)0 : (int64_t)(sh.T - 1)};
     ip.hph_lds = p->hph_lds; ip.kb = p->kb_ih;
+    if (const char* e = getenv("NAGP_STAMP_WORKER")) ip.dbg_wave = atoi(e);
     ip.w_old = 1.0 - ip.ep_damp; ip.w_new = mix ? ip.ep_damp / o.ep_fraction : ip.ep_damp; ip.mom_alpha = mix ? o.ep_fraction : 1.0;
     {
       Timed t(p, itt == 1 ? NAGP_K_FILTER : NAGP_K_FILTER_LIN);
@@ -1616,7 +1617,7 @@ extern "C" int nagp_plan_execute(nagp_plan* p) {
   RUN(zero_async(p, p->b.MS, BT * sh.S * 8)); RUN(zero_async(p, p->b.red, (size_t)p->B * 64));
   RUN(zero_async(p, p->b.counters, (size_t)p->B * 32));
   RUN(zero_async(p, p->b.state, (size_t)p->B * ((size_t)sh.ntiles * 16 + sh.S) * 8));
-  if (p->d_stamps) RUN(zero_async(p, p->d_stamps, 64));
+  if (p->d_stamps) RUN(zero_async(p, p->d_stamps, 24 * 8));
   std::fill(p->nlZ.begin(), p->nlZ.end(), 0.0);
   std::fill(p->mdM.begin(), p->mdM.end(), 0.0);
   std::fill(p->mdP.begin(), p->mdP.end(), 0.0);
@@ -1638,8 +1639,14 @@ extern "C" int nagp_plan_execute(nagp_plan* p) {
   HIP_TRY(hipEventRecord(p->ev_t1, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
   if (getenv("NAGP_STAMPS") && p->d_stamps) {
-    unsigned long long st[8];
-    if (hipMemcpy(st, p->d_stamps, sizeof st, hipMemcpyDeviceToHost) == hipSuccess)
+    unsigned long long st[24];
+    if (hipMemcpy(st, p->d_stamps, sizeof st, hipMemcpyDeviceToHost) == hipSuccess) {
+      if (p->opts.kind == NAGP_KIND_IHGP)
+        for (int w = 0; w < 2; ++w)
+          fprintf(stderr, "[nagp stamps] %s: wait at B1 %llu | Q/v %llu | B2..B3 %llu | weights %llu | wait at B4 %llu | marginal sums %llu | MFMA steps %llu | wait at B5 %llu\n",
+                  w ? "last worker wave " : "first worker wave", st[8 + 8 * w], st[9 + 8 * w], st[10 + 8 * w], st[11 + 8 * w], st[12 + 8 * w], st[13 + 8 * w], st[14 + 8 * w], st[15 + 8 * w]);
+    }
+    if (hipMemcpy(st, p->d_stamps, 64, hipMemcpyDeviceToHost) == hipSuccess)
       fprintf(stderr, "[nagp stamps] mom: p1a %llu p1b %llu p2 %llu p3 %llu | pre-mom %llu post-mom %llu | aux %llu %llu  (sparse-point IHGP sweep: p1a..p3 = A, B+1b, 2, wait at B1 ; pre..aux = reduce+outputs, site+state+ring, look-up, A m)\n", st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7]);
   }
 

@@ -67,6 +67,7 @@ struct IhgpPar {
   double R_init;     // exp(lik) (or 0 for the constraints variant): initial content of R(:,k)
   int hph_lds;       // filter: keep the H PP H' look-up table [M][NG] in LDS
   int kb;            // steps per I/O block of the filter (LDS ring), <= IH_KB
+  int dbg_wave;      // developer diagnostics (NAGP_STAMPS): which worker's time line goes to stamps[8..15] (NAGP_STAMP_WORKER, default 0)
   double w_old, w_new, mom_alpha;   // as FilterPar: (1-d, d, 1) ihgp_ep_modulator_nmf.m:210-211 ; (1-d, d/alpha, alpha) experiments/ihgp_ep_mods_nmf_mixture.m:291-297
 };
 
@@ -591,6 +592,13 @@ __global__ void __launch_bounds__(MSR_NT) ihgp_adf8_kernel(Shape sh, Bufs b, Mom
     const MspLay lay = msp_layout(CD, D, 1);
     MsrW<CD, PACK> xw;
     msr_setup_W<CD, PACK>(xw, mc, sp, sW, fmu, HPH, ws);
+    // developer diagnostics (NAGP_STAMPS): time lines of worker 0 (an MFMA worker) in stamps[8..15] and of the last worker (marginal
+    // sums in the packed form) in stamps[16..23]
+    const int wk_slot = (wave == MSR_W0 + (ip.dbg_wave & 7)) ? 8 : ((wave == MSR_W0 + MSR_NWK - 1) ? 16 : -1);
+    const bool wk_stamp = mc.stamps && wk_slot >= 0 && (tid & 63) == 0;
+    unsigned long long wk_a = 0, wk_b = 0, wk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (wk_stamp) wk_a = __builtin_readcyclecounter();
+#define WK_STAMP(slot) do { if (wk_stamp) { wk_b = __builtin_readcyclecounter(); wk[slot] += wk_b - wk_a; wk_a = wk_b; } } while (0)
   for (int64_t k0 = ip.k_start; k0 < T; k0 += KB) {
     const int nb = (T - k0 < KB) ? (int)(T - k0) : KB;
     // ---- fill the ring for steps k0 .. k0+nb-1
@@ -599,15 +607,23 @@ __global__ void __launch_bounds__(MSR_NT) ihgp_adf8_kernel(Shape sh, Bufs b, Mom
     __syncthreads();
     for (int kk = 0; kk < nb; ++kk) {
       lds_barrier();                 // B1
+      WK_STAMP(0);                   // (wait at B1: the serial waves' tail and head)
       msp_qv<CD>(xw, mc);            // workers 0..2
+      WK_STAMP(1);
       lds_barrier();                 // B2
       if (wave == MSR_W0 + 3) msp_q0s0(xw, ws + lay.q0, ws + lay.s0);
       lds_barrier();                 // B3
+      WK_STAMP(2);                   // (B2 .. B3: tables on wave 1, q0 / s0 on worker 3)
       msp_stage1b<CD>(xw, mc, sp, sn2a, ry[kk], ws);
+      WK_STAMP(3);
       lds_barrier();                 // B4
+      WK_STAMP(4);
       if constexpr (PACK) { if (wave >= MSR_W0 + MSR_NWK - 2) msr_marginals<CD>(xw); }
+      WK_STAMP(5);
       msp_stage2<CD>(xw, mc, ws);
+      WK_STAMP(6);
       lds_barrier();                 // B5
+      WK_STAMP(7);
     }
     // ---- flush the ring
     __syncthreads();
@@ -619,6 +635,9 @@ __global__ void __launch_bounds__(MSR_NT) ihgp_adf8_kernel(Shape sh, Bufs b, Mom
     for (int i = tid; i < nb * S; i += NT) { const int q = i / S, e = i - q * S; g_MF[(size_t)k0 * S + i] = rMF[(size_t)q * M * 4 + smap[e]]; }
     __syncthreads();
   }
+    if (wk_stamp)
+      for (int i = 0; i < 8; ++i) mc.stamps[wk_slot + i] += wk[i];
+#undef WK_STAMP
     return;
   }
   // ================= serial role (waves 0 and 1)

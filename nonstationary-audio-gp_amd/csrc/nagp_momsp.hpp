@@ -524,6 +524,7 @@ __device__ __forceinline__ void msr_init(int CD, int D, double* ws) {
   for (int i = threadIdx.x; i < 6 * MSP_TS; i += MSR_NT) ws[i] = 0.0;
   if (threadIdx.x == 0) ws[l.one] = 1.0;
   for (int i = threadIdx.x; i < 3 * MSR_CS; i += MSR_NT) ws[l.c0 + i] = 0.0;
+  for (int i = threadIdx.x; i < MSR_NWK * 256; i += MSR_NT) ws[l.part + i] = 0.0;   // partial blocks of workers without MFMA steps stay zero
 }
 
 template <int CD, bool PACK>
@@ -661,8 +662,8 @@ __device__ __forceinline__ void msr_setup_W(MsrW<CD, PACK>& x, const MomCfg& c, 
     else { sl0 = (wr <= 2) ? ((wr == 2) ? 2 : wr) : ((wr == 3) ? 4 : wr + 2); sl1 = (wr == 2 || wr == 3) ? sl0 + 2 : sl0 + 1; }
     const bool mf = on && (!PACK || wr < 4);
     const int st0 = mf ? slot_start(sl0) : 0, st1 = mf ? slot_start(sl1) : 0;
-    x.m_on = on ? 1 : 0;            // a worker without steps still writes its (zero) partial block
     x.nst = st1 - st0;
+    x.m_on = (on && x.nst > 0) ? 1 : 0;   // a worker without steps skips the stage: its partial block was zeroed by msr_init
     int wbase = l.c0;
     if (PACK) { if (f < CD) wbase = l.c2; else if (f == CD) wbase = l.c1; }
     else { if (i < CD) wbase = l.c2; else if (i == CD) wbase = l.c1; }

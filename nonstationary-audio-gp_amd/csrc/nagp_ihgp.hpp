@@ -592,6 +592,7 @@ __global__ void __launch_bounds__(MSR_NT) ihgp_adf8_kernel(Shape sh, Bufs b, Mom
     const MspLay lay = msp_layout(CD, D, 1);
     MsrW<CD, PACK> xw;
     msr_setup_W<CD, PACK>(xw, mc, sp, sW, fmu, HPH, ws);
+    if (ip.dbg_wave & 8) xw.m_on = (wave - MSR_W0 < MSR_NWK) ? 1 : 0;   // developer A/B (NAGP_STAMP_WORKER=8): every worker runs the accumulation stage
     // developer diagnostics (NAGP_STAMPS): time lines of worker 0 (an MFMA worker) in stamps[8..15] and of the last worker (marginal
     // sums in the packed form) in stamps[16..23]
     const int wk_slot = (wave == MSR_W0 + (ip.dbg_wave & 7)) ? 8 : ((wave == MSR_W0 + MSR_NWK - 1) ? 16 : -1);
@@ -611,7 +612,7 @@ __global__ void __launch_bounds__(MSR_NT) ihgp_adf8_kernel(Shape sh, Bufs b, Mom
       msp_qv<CD>(xw, mc);            // workers 0..2
       WK_STAMP(1);
       lds_barrier();                 // B2
-      if (wave == MSR_W0 + 3) msp_q0s0(xw, ws + lay.q0, ws + lay.s0);
+      if (wave == MSR_W0 + 3 || wave == MSR_W0 + 4) msr_q0_or_s0(xw, wave == MSR_W0 + 3, ws + lay.q0, ws + lay.s0);
       lds_barrier();                 // B3
       WK_STAMP(2);                   // (B2 .. B3: tables on wave 1, q0 / s0 on worker 3)
       msp_stage1b<CD>(xw, mc, sp, sn2a, ry[kk], ws);
@@ -718,7 +719,11 @@ __global__ void __launch_bounds__(MSR_NT) ihgp_adf8_kernel(Shape sh, Bufs b, Mom
     }
   };
   if (wave <= 1) head(ip.k_start);
-  if (wave == 1) { msp_wave_fence(); msp_link<CD>(x, mc); }      // link tables of the first step
+  // link tables of a step (the exp / log chain of the modulators' sigma-point coordinates, ~1 000 cycles on wave 1): evaluated BEHIND
+  // barrier B1, beside the worker waves' Q / 2Q / v stage -- nothing reads them before wave 1's own msp_tables behind B2.  (Evaluated
+  // ahead of B1 they were the tail of the serial chain: wave 0 waited ~800 cycles at B1 for them.)  ip.dbg_wave & 16: the old placement.
+  const bool link_early = (ip.dbg_wave & 16) != 0;
+  if (wave == 1 && link_early) { msp_wave_fence(); msp_link<CD>(x, mc); }      // link tables of the first step
   if (stamp) st_a = __builtin_readcyclecounter();
 
   for (int64_t k0 = ip.k_start; k0 < T; k0 += KB) {
@@ -732,6 +737,7 @@ __global__ void __launch_bounds__(MSR_NT) ihgp_adf8_kernel(Shape sh, Bufs b, Mom
       lds_barrier();                 // B1: fmu, HPH of step k; its link tables (written by wave 1 on its way here)
       IH_STAMP(3);
       // (Q / 2Q / v: worker waves)
+      if (wave == 1 && !link_early) msp_link<CD>(x, mc);
       lds_barrier();                 // B2
       IH_STAMP(0);
       if (wave == 1) msp_tables<CD>(x, mc);
@@ -778,7 +784,7 @@ __global__ void __launch_bounds__(MSR_NT) ihgp_adf8_kernel(Shape sh, Bufs b, Mom
         }
         if (k + 1 < T) {
           head(k + 1);
-          if (wave == 1) { msp_wave_fence(); msp_link<CD>(x, mc); }     // fmu / HPH of the modulators just written by this wave
+          if (wave == 1 && link_early) { msp_wave_fence(); msp_link<CD>(x, mc); }     // fmu / HPH of the modulators just written by this wave
         }
       }
     }

@@ -336,6 +336,13 @@ __device__ __forceinline__ void msp_q0s0(const X& x, double* q0, double* s0) {
   tsv = wave_sum(tsv);
   if (((int)threadIdx.x & 63) == 0) { *q0 = tq; *s0 = tsv; }
 }
+// the same, one sum per wave (role layout): the wave holding the Q terms writes q0, the wave holding the v terms writes s0
+template <class X>
+__device__ __forceinline__ void msr_q0_or_s0(const X& x, bool is_q0, double* q0, double* s0) {
+  const double t = (*x.b_p0) * (*x.b_p1) * (*x.b_p2);      // unused lanes: zero * ...
+  const double sum = wave_sum(t);
+  if (((int)threadIdx.x & 63) == 0) { if (is_q0) *q0 = sum; else *s0 = sum; }
+}
 // stage B.  After a barrier behind stage A; ends without a barrier.
 template <int CD>
 __device__ __forceinline__ void msp_stageB(const MspCtx<CD>& x, const MomCfg& c, double* ws) {
@@ -573,15 +580,15 @@ __device__ __forceinline__ void msr_setup_W(MsrW<CD, PACK>& x, const MomCfg& c, 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave - MSR_W0;     // wr = 0 .. 5
   const int nd = c.nd, D = c.D, npt = c.n_pts;
   const MspLay l = msp_layout(CD, D, 1);
-  // ---- q0, s0 on worker 3
+  // ---- q0 on worker 3, s0 on worker 4 (one wave sum each, side by side between barriers B2 and B3)
   {
-    const int L = tid - 64 * (MSR_W0 + 3);
+    const int L = tid - 64 * (MSR_W0 + 3), L2 = tid - 64 * (MSR_W0 + 4);
     x.b_kind = 0; x.b_p0 = x.b_p1 = x.b_p2 = (msp_rp)(ws + l.zero);
     if (L >= 0 && L < CD * CD) {
       const int j = L / CD, j2 = L - j * CD;
       x.b_kind = 1; x.b_p0 = (msp_rp)(ws + l.Q + L); x.b_p1 = (msp_rp)(ws + l.lk + j * nd + sp.c0); x.b_p2 = (msp_rp)(ws + l.lk + j2 * nd + sp.c0);
-    } else if (L >= CD * CD && L < CD * CD + CD) {
-      const int j = L - CD * CD;
+    } else if (L2 >= 0 && L2 < CD) {
+      const int j = L2;
       x.b_kind = 2; x.b_p0 = (msp_rp)(ws + l.v + j); x.b_p1 = (msp_rp)(ws + l.lk + j * nd + sp.c0); x.b_p2 = (msp_rp)(ws + l.one);
     }
   }

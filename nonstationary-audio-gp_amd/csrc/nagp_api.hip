@@ -704,6 +704,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     // the ADF sweep in the sparse-point form (ihgp_adf_kernel): plain NMF likelihood, <= 320 sigma points, unstructured Wnmf
     if (p->sp.enabled && !p->src_f && sh.M <= 64 && sh.D <= 4 * MSP_DT && o->n_pts <= MSP_NT + 64 && (o->n_pts + 3) / 4 <= MSP_NW * MSP_NST) {
       p->kb_sp = IH_KB; p->hph_sp = 1;
+      if (const char* e = getenv("NAGP_IH_KB")) p->kb_sp = std::max(1, std::min(IH_KB, atoi(e)));   // developer switch: steps per I/O block
       auto need = [&]() { return ihgp_adf_lds_doubles(sh, o->cub_dim, p->tb.NG, p->hph_sp, p->kb_sp) * sizeof(double) + 16; };
       if (need() > 156 * 1024) p->kb_sp = 8;
       if (need() > 156 * 1024) p->hph_sp = 0;

@@ -687,7 +687,7 @@ __global__ void __launch_bounds__(MSR_NT) ihgp_adf8_kernel(Shape sh, Bufs b, Mom
   double Rprev = (act && ip.k_start > 0) ? b.R[((size_t)pb * T + (ip.k_start - 1)) * M + n] : 0.0;
   unsigned int n_clamped = 0;
   unsigned long long st_a = 0, st_b = 0, st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const bool stamp = mc.stamps && tid == 0;      // wave 0's time line
+  const bool stamp = mc.stamps && tid == ((ip.dbg_wave & 32) ? 64 : 0);      // time line of wave 0 (NAGP_STAMP_WORKER & 32: of wave 1)
 #define IH_STAMP(slot) do { if (stamp) { st_b = __builtin_readcyclecounter(); st[slot] += st_b - st_a; st_a = st_b; } } while (0)
 
   // head of step k: table look-up, A m, the cubature's inputs (wave 0, no barrier)

@@ -546,14 +546,14 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
       double cap_bytes = 24.0 * 1073741824.0;
       size_t free_b = 0, total_b = 0;
       if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-        const double fixed = (double)BT * ((p->need_PF ? pf_ntiles(sh) * 16.0 : 0.0) + (p->want_PS ? nt * 16.0 : 0.0) + 2.0 * sh.S) * 8.0;
+        const double fixed = (double)BT * ((p->need_PF ? (double)pf_step_doubles(sh) : 0.0) + (p->want_PS ? nt * 16.0 : 0.0) + 2.0 * sh.S) * 8.0;
         cap_bytes = std::min(cap_bytes, std::max(0.25 * ((double)free_b - fixed), 64.0 * per_step));
       }
       while (p->chunk > 64 && per_step * p->chunk > cap_bytes) p->chunk = (p->chunk + 1) / 2;
     }
     p->nc = (int)std::max<int64_t>(1, (T - 1 + p->chunk - 1) / p->chunk);
     if (p->nc >= 2) p->nc += 1;      // the chunk of the latest steps is cut short (chunk0_len): one chunk more
-    if (p->need_PF) PLAN_TRY(dalloc(p, &b.PF, BT * pf_ntiles(sh) * 16, false));   // lower-triangular tiles only
+    if (p->need_PF) PLAN_TRY(dalloc(p, &b.PF, BT * pf_step_doubles(sh), false));   // lower-triangular tiles only (layout: pf_off)
     if (p->want_PS) PLAN_TRY(dalloc(p, &b.PSs, BT * nt * 16, false));
     // panel widths: one tile per thread per operand panel, panels (double buffered) within 72 KiB of LDS
     const double cap = 72.0 * 1024.0;
@@ -1482,15 +1482,15 @@ static int exec_giekf(nagp_plan* p) {
     if (sh.T == 1) {   // no smoothing step: the restart state is the filtered one
       for (int q = 0; q < B; ++q) {
         double* st = p->b.state + (size_t)q * ((size_t)sh.ntiles * 16 + sh.S);
-        std::vector<double> lo((size_t)pf_ntiles(sh) * 16), full((size_t)sh.ntiles * 16);
-        HIP_TRY(hipMemcpyAsync(lo.data(), p->b.PF + (size_t)q * pf_ntiles(sh) * 16, lo.size() * 8, hipMemcpyDeviceToHost, p->stream));
+        std::vector<double> lo(pf_step_doubles(sh)), full((size_t)sh.ntiles * 16);
+        HIP_TRY(hipMemcpyAsync(lo.data(), p->b.PF + (size_t)q * pf_step_doubles(sh), lo.size() * 8, hipMemcpyDeviceToHost, p->stream));
         HIP_TRY(hipStreamSynchronize(p->stream));
         for (int Ib = 0; Ib < sh.M; ++Ib)
           for (int Jb = 0; Jb < sh.M; ++Jb)
             for (int i = 0; i < 4; ++i)
               for (int j = 0; j < 4; ++j)
-                full[((size_t)Ib * sh.M + Jb) * 16 + 4 * i + j] = (Ib >= Jb) ? lo[((size_t)Ib * (Ib + 1) / 2 + Jb) * 16 + 4 * i + j]
-                                                                            : lo[((size_t)Jb * (Jb + 1) / 2 + Ib) * 16 + 4 * j + i];
+                full[((size_t)Ib * sh.M + Jb) * 16 + 4 * i + j] = (Ib >= Jb) ? lo[pf_off(Ib * (Ib + 1) / 2 + Jb, 4 * i + j)]
+                                                                            : lo[pf_off(Jb * (Jb + 1) / 2 + Ib, 4 * j + i)];
         HIP_TRY(hipMemcpyAsync(st, full.data(), full.size() * 8, hipMemcpyHostToDevice, p->stream));
         HIP_TRY(hipStreamSynchronize(p->stream));
         HIP_TRY(hipMemcpyAsync(st + (size_t)sh.ntiles * 16, p->b.MF + (size_t)q * sh.S, sh.S * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
@@ -1716,15 +1716,15 @@ extern "C" int nagp_plan_download(nagp_plan* p, nagp_out* outs) {
         const int64_t nsm = std::min<int64_t>(nk, std::max<int64_t>(0, (T - 1) - k0));
         if (nsm > 0) HIP_TRY(hipMemcpy(tmp.data(), p->b.PSs + ((size_t)q * T + k0) * tl, (size_t)nsm * tl * 8, hipMemcpyDeviceToHost));
         if (nsm < nk) {
-          std::vector<double> lo((size_t)pf_ntiles(sh) * 16);
-          HIP_TRY(hipMemcpy(lo.data(), p->b.PF + ((size_t)q * T + (T - 1)) * pf_ntiles(sh) * 16, lo.size() * 8, hipMemcpyDeviceToHost));
+          std::vector<double> lo(pf_step_doubles(sh));
+          HIP_TRY(hipMemcpy(lo.data(), p->b.PF + ((size_t)q * T + (T - 1)) * pf_step_doubles(sh), lo.size() * 8, hipMemcpyDeviceToHost));
           double* full = tmp.data() + (size_t)nsm * tl;
           for (int Ib = 0; Ib < M; ++Ib)
             for (int Jb = 0; Jb < M; ++Jb)
               for (int i = 0; i < 4; ++i)
                 for (int j = 0; j < 4; ++j)
-                  full[((size_t)Ib * M + Jb) * 16 + 4 * i + j] = (Ib >= Jb) ? lo[((size_t)Ib * (Ib + 1) / 2 + Jb) * 16 + 4 * i + j]
-                                                                           : lo[((size_t)Jb * (Jb + 1) / 2 + Ib) * 16 + 4 * j + i];
+                  full[((size_t)Ib * M + Jb) * 16 + 4 * i + j] = (Ib >= Jb) ? lo[pf_off(Ib * (Ib + 1) / 2 + Jb, 4 * i + j)]
+                                                                           : lo[pf_off(Jb * (Jb + 1) / 2 + Ib, 4 * j + i)];
         }
         for (int64_t kk = 0; kk < nk; ++kk) {
           double* dst = o.PS + (size_t)(k0 + kk) * S * S;

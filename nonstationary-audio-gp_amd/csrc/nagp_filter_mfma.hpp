@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(64 * NW) gf_filter_lin_mfma_kernel(Shape sh, B
   // ---- initial state
   v4d P[TPW];
   const int64_t kb0 = fp.k_begin;
-  const double* PF0 = (kb0 > 0) ? b.PF + ((size_t)pb * T + (kb0 - 1)) * pf_ntiles(sh) * 16 : nullptr;
+  const double* PF0 = (kb0 > 0) ? b.PF + ((size_t)pb * T + (kb0 - 1)) * pf_step_doubles(sh) : nullptr;
 #pragma unroll
   for (int q = 0; q < TPW; ++q) {
     const int br = 4 * TI[q] + kq, bc = 4 * TJ[q] + (i & 3);
@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(64 * NW) gf_filter_lin_mfma_kernel(Shape sh, B
   double* g_MF = b.MF + (size_t)pb * T * S;
   double* g_fm = b.fm + (size_t)pb * T * M;
   double* g_fv = b.fv + (size_t)pb * T * M;
-  double* g_PF = (b.PF && fp.store_PF) ? b.PF + (size_t)pb * T * pf_ntiles(sh) * 16 : nullptr;
+  double* g_PF = (b.PF && fp.store_PF) ? b.PF + (size_t)pb * T * pf_step_doubles(sh) : nullptr;
   unsigned long long n_nan = 0;
 
   for (int64_t k0 = fp.k_begin; k0 < fp.k_end; k0 += KB) {
@@ -246,9 +246,10 @@ __global__ void __launch_bounds__(64 * NW) gf_filter_lin_mfma_kernel(Shape sh, B
         const int br = 4 * TI[q] + kq, bc = 4 * TJ[q] + (i & 3);
         if (br < M && bc < M && br >= bc) {
           if (g_PF) {
-            double* dst = g_PF + ((size_t)k * pf_ntiles(sh) + (size_t)br * (br + 1) / 2 + bc) * 16 + rc;
+            double* dst = g_PF + (size_t)k * pf_step_doubles(sh);      // element x of tile (br, bc) at pf_off(tile, x)
+            const int pft = br * (br + 1) / 2 + bc;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) dst[4 * t] = P[q][t];
+            for (int t = 0; t < 4; ++t) dst[pf_off(pft, rc + 4 * t)] = P[q][t];
           }
           if (br == bc && rc == 0) rfv[kk * M + br] = shv[br] * shv[br] * P[q][0];
         }

@@ -194,8 +194,8 @@ __global__ void __launch_bounds__(64 * NTL) rts_gain_mfma_kernel(Shape sh, Bufs 
   if (tid == 0) { flag[0] = 0; flag[1] = 0; }
   __syncthreads();
 
-  const double* PFk = b.PF + ((size_t)pb * T + k) * pf_ntiles(sh) * 16;
-  const double* PFk1 = PFk + (size_t)pf_ntiles(sh) * 16;
+  const double* PFk = b.PF + ((size_t)pb * T + k) * pf_step_doubles(sh);
+  const double* PFk1 = PFk + pf_step_doubles(sh);
   const size_t SS = (size_t)Sp * Sp;
   double* Gout = b.Gbuf + (((size_t)pb * gp.chunk + kk) * 2) * SS;
   double* Dout = Gout + SS;

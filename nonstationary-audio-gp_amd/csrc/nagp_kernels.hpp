@@ -85,15 +85,34 @@ struct FilterPar {
                            // 1: rank-M covariance update, 2: PF stores, 4: prediction congruence, 8: W panel writes, 16: mean update
 };
 
-// The filtered covariance is symmetric: PF holds only the lower-triangular tiles, tile (I,J), I >= J, at
-// index I(I+1)/2 + J.  pf_load returns tile (I,J) of the full matrix (transposing the stored tile for I < J).
+// The filtered covariance is symmetric: PF holds only the lower-triangular tiles, tile (I,J), I >= J, at tile index I(I+1)/2 + J.
+// Layout of ONE step (pf_step_doubles): groups of 64 consecutive tile indices, and inside a group the eight 16-byte pieces of the
+// tiles piece-major -- [group][piece e = 0..7][tile in group = 0..63][2 doubles], element x = 4i+j of a tile in piece x/2.  The filter
+// thread that owns tile t is lane t % 64 of its wave, so each of its eight stores writes 1 KB of contiguous memory per wave (with the
+// tiles contiguous, a 16-byte store per lane touched 64 different 128-byte lines: 1.2 of the 6.0 us EKF step, 2.1 of the 20.6 us ADF
+// step at S = 146 -- profiles/r03_filter_phase_costs.txt).  pf_load returns tile (I,J) of the full matrix (transposing for I < J).
 __host__ __device__ inline int pf_ntiles(const Shape& s) { return s.M * (s.M + 1) / 2; }
+__host__ __device__ inline size_t pf_step_doubles(const Shape& s) { return (size_t)((pf_ntiles(s) + 63) / 64) * 64 * 16; }
+__host__ __device__ inline size_t pf_off(int t, int x) { return ((((size_t)(t >> 6) * 8 + (x >> 1)) * 64) + (t & 63)) * 2 + (x & 1); }
+// (32-bit index arithmetic on purpose: a step holds < 2^16 tiles, and the sequential filters have no scalar registers to spare)
+__device__ __forceinline__ void pf_tile_load(double* t, const double* PFk, int tile) {
+  const double2* q = reinterpret_cast<const double2*>(PFk);
+  const int i0 = (tile >> 6) * 512 + (tile & 63);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { const double2 v = q[i0 + e * 64]; t[2 * e] = v.x; t[2 * e + 1] = v.y; }
+}
+__device__ __forceinline__ void pf_tile_store(double* PFk, int tile, const double* t) {
+  double2* q = reinterpret_cast<double2*>(PFk);
+  const int i0 = (tile >> 6) * 512 + (tile & 63);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) q[i0 + e * 64] = make_double2(t[2 * e], t[2 * e + 1]);
+}
 __device__ __forceinline__ void pf_load(double* t, const double* PFk, int I, int J) {
   if (I >= J) {
-    tile_load(t, PFk + ((size_t)I * (I + 1) / 2 + J) * 16);
+    pf_tile_load(t, PFk, I * (I + 1) / 2 + J);
   } else {
     double u[16];
-    tile_load(u, PFk + ((size_t)J * (J + 1) / 2 + I) * 16);
+    pf_tile_load(u, PFk, J * (J + 1) / 2 + I);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -101,7 +120,7 @@ __device__ __forceinline__ void pf_load(double* t, const double* PFk, int I, int
   }
 }
 __device__ __forceinline__ double pf_elem(const double* PFk, int I, int J, int i, int j) {
-  return (I >= J) ? PFk[((size_t)I * (I + 1) / 2 + J) * 16 + 4 * i + j] : PFk[((size_t)J * (J + 1) / 2 + I) * 16 + 4 * j + i];
+  return (I >= J) ? PFk[pf_off(I * (I + 1) / 2 + J, 4 * i + j)] : PFk[pf_off(J * (J + 1) / 2 + I, 4 * j + i)];
 }
 
 // thread tid owns tiles t = tid + q*NT (q < TPT)
@@ -237,7 +256,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
     tile_zero(P[q]);
     if (own.ok[q]) {
       if (fp.k_begin > 0)
-        tile_load(P[q], b.PF + ((size_t)pb * T + (fp.k_begin - 1)) * nlow * 16 + (size_t)(tid + q * NT) * 16);
+        pf_tile_load(P[q], b.PF + ((size_t)pb * T + (fp.k_begin - 1)) * (size_t)(((nlow + 63) & ~63) * 16), tid + q * NT);
       else if (fp.init_from_state && !fp.reset_P)
         tile_load(P[q], st + (size_t)(own.I[q] * M + own.J[q]) * 16);
       else if (own.I[q] == own.J[q])
@@ -263,7 +282,8 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
   double* g_MF = b.MF + (size_t)pb * T * S;
   double* g_fm = b.fm + (size_t)pb * T * M;
   double* g_fv = b.fv + (size_t)pb * T * M;
-  double* g_PF = (b.PF && fp.store_PF) ? b.PF + (size_t)pb * T * pf_ntiles(sh) * 16 : nullptr;
+  const int pf_tiles = (nlow + 63) & ~63;       // tiles per step of PF, padded to whole groups of 64 (pf_step_doubles = 16 * pf_tiles)
+  double* g_PF = (b.PF && fp.store_PF) ? b.PF + (size_t)pb * T * pf_tiles * 16 : nullptr;
   unsigned long long n_clamped = 0, n_nan = 0;
   unsigned long long stp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_a = 0, st_b = 0;   // developer diagnostics (mc.stamps)
   if (mc.stamps && tid == 0) st_a = __builtin_readcyclecounter();
@@ -578,7 +598,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
           // P -= K S K'
 #pragma unroll
           for (int q = 0; q < TPT; ++q) {
-            if (own.ok[q]) {
+            if (own.ok[q] && !(fp.dbg & 1)) {
               const int oI = ioff[own.I[q]], oJ = ioff[own.J[q]];
               const int bI = ibsz[own.I[q]], bJ = ibsz[own.J[q]];
 #pragma unroll
@@ -604,9 +624,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
       if (g_PF && !(fp.dbg & 2)) {
 #pragma unroll
         for (int q = 0; q < TPT; ++q)
-          if (own.ok[q]) {
-            tile_store(g_PF + ((size_t)k * nlow + tid + q * NT) * 16, P[q]);   // lower tile index == ownership index
-          }
+          if (own.ok[q]) pf_tile_store(g_PF + (size_t)k * pf_tiles * 16, tid + q * NT, P[q]);   // lower tile index == ownership index
       }
       lds_barrier();  // B5
       if (mc.stamps && tid == 0 && do_mom) { st_b = __builtin_readcyclecounter(); stp[5] += st_b - st_a; st_a = st_b; }
@@ -775,8 +793,8 @@ __global__ void __launch_bounds__(LB) __attribute__((amdgpu_waves_per_eu(LB > 51
       low.I[q] = own.I[q]; low.J[q] = own.J[q]; low.ok[q] = own.ok[q] && own.I[q] >= own.J[q];
     }
   }
-  const double* PFk = b.PF + ((size_t)pb * T + k) * pf_ntiles(sh) * 16;
-  const double* PFk1 = PFk + (size_t)pf_ntiles(sh) * 16;
+  const double* PFk = b.PF + ((size_t)pb * T + k) * pf_step_doubles(sh);
+  const double* PFk1 = PFk + pf_step_doubles(sh);
   const size_t mstride = gp.dense_sp ? (size_t)gp.dense_sp * gp.dense_sp : (size_t)sh.ntiles * 16;
   double* Gout = b.Gbuf + (((size_t)pb * gp.chunk + kk) * 2) * mstride;
   double* Dout = Gout + mstride;
@@ -1394,7 +1412,7 @@ __global__ void __launch_bounds__(512) rts_apply_kernel(Shape sh, Bufs b, SpanPa
     for (int q = 0; q < TPT; ++q) tile_zero(acc[q]);
     gemm_nt<TPT>(c, sp.LP2, acc, Xb, Gk);
     // ---- store E_k, outputs
-    const double* PFk = b.PF + ((size_t)pb * T + k) * pf_ntiles(sh) * 16;
+    const double* PFk = b.PF + ((size_t)pb * T + k) * pf_step_doubles(sh);
 #pragma unroll
     for (int q = 0; q < TPT; ++q)
       if (c.own.ok[q]) {

@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(256) rts_apply_mfma_kernel(Shape sh, Bufs b, M
           for (int r = 0; r < 4; ++r) { int row, col; acc_rc(NTL, c.tile(q), r, row, col); Bs[(size_t)row * LD + col] = E[q][r]; }
         }
       __syncthreads();
-      const double* PFk = b.PF + ((size_t)pb * T + k) * pf_ntiles(sh) * 16;
+      const double* PFk = b.PF + ((size_t)pb * T + k) * pf_step_doubles(sh);
       for (int i = tid; i < Sp * Sp; i += 256) {
         const int row = i / Sp, col = i - row * Sp;
         const int I = row >> 2, J = col >> 2;

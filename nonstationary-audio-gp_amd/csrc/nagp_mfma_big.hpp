@@ -323,7 +323,7 @@ __global__ void __launch_bounds__(64 * NTL) rts_big_kernel(Shape sh, Bufs b, Mfm
     }
     if (MODE == 2 && k == 0) {
       // restart state of the next sweep: P^s_0 = P_0 + E_0 in tile-major layout (last step of the bottom span; Y = E_0)
-      const double* PFk = b.PF + ((size_t)pb * T + k) * pf_ntiles(sh) * 16;
+      const double* PFk = b.PF + ((size_t)pb * T + k) * pf_step_doubles(sh);
       for (int q = tid; q < Sp * Sp; q += NT) {
         const int row = q / Sp, col = q - row * Sp;
         const int Ib = row >> 2, Jb = col >> 2;

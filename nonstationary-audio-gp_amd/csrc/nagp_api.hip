@@ -75,6 +75,7 @@ struct nagp_plan {
   int src_f = 0, src_ep = 0, kb_ih = 16;
   MomSp sp{};           // sparse-point form of likModulatorNMFPower (nagp_momsp.hpp); sp_ih: the IHGP ADF sweep uses it
   int sp_ih = 0, sp_gf = 0, kb_sp = 16, hph_sp = 1; size_t lds_sp = 0;
+  int sp_ep = 0; size_t lds_ep_sp = 0;      // site refresh (ep_site_sp_kernel) in the sparse-point form
   int sp_ih8 = 0, sp_pack = 0, sp_maxmem = 0; size_t lds_sp8 = 0;   // sp_maxmem: most points sharing one non-centre (dimension, coordinate)   // the role-specialised 512-thread form of the same sweep (ihgp_adf8_kernel)
   hipStream_t stream = nullptr;
   // chunk-pipelined smoother (gf / giekf): while the sequential filter occupies one CU per problem, the parallel smoother kernels
@@ -860,6 +861,15 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
 #define SL(V) PLAN_TRY(set_lds(ep_site_kernel<V>, p->lds_ep))
     NAGP_MV_SWITCH9(mom_variant(mc), SL)
 #undef SL
+    // site refresh in the staged sparse-point form (the conditions of the ADF launches: likModulatorNMFPower on a fully symmetric rule)
+    if (p->sp.enabled && !p->src_ep && sh.M <= 64 && sh.D <= 4 * MSP_DT && o->cub_dim <= MSP_MAXCD && o->n_pts <= MSP_NT + 64 &&
+        (o->n_pts + 3) / 4 <= MSP_NW * MSP_NST && !getenv("NAGP_NO_SPARSE_EP")) {
+      p->sp_ep = 1;
+      p->lds_ep_sp = ep_sp_lds_doubles(sh, o->cub_dim) * sizeof(double);
+#define SLS(V) PLAN_TRY(set_lds(ep_site_sp_kernel<V>, p->lds_ep_sp))
+      switch (o->cub_dim) { case 1: SLS(1); break; case 2: SLS(2); break; case 3: SLS(3); break; case 4: SLS(4); break; case 5: SLS(5); break; case 6: SLS(6); break; default: SLS(7); break; }
+#undef SLS
+    }
   }
   p->nlZ.assign((size_t)B * o->ep_itts, 0.0);
   p->mdM.assign((size_t)B * o->ep_itts, 0.0);
@@ -1350,12 +1360,22 @@ static int launch_ep(nagp_plan* p, double alpha, double damp, int clamp, int wri
   if (p->src_ep) mc.src = p->src_all;
   EpPar ep{};
   ep.k_end = sh.T - 1;
-  ep.steps_per_wg = (int)std::max<int64_t>(1, (ep.k_end + 4095) / 4096);
+  // ~8192 workgroups over all problems (32 per CU): enough to fill the chip, and the per-workgroup set-up (cubature tables, the static
+  // addresses of the sparse-point stages) is amortised over the steps of a workgroup when many problems share the launch
+  ep.steps_per_wg = (int)std::max<int64_t>(1, ((int64_t)p->B * ep.k_end + 8191) / 8192);
   ep.alpha = alpha; ep.clamp = clamp; ep.write_R = write_R; ep.lZ_out = lZ_out;
   if (mixture_rule(p)) { ep.w_old = 1.0 - damp; ep.w_new = damp / alpha; }
   else { ep.w_old = 1.0 - damp * alpha; ep.w_new = damp; }
   Timed t(p, NAGP_K_EPSITE);
   dim3 g((unsigned)((ep.k_end + ep.steps_per_wg - 1) / ep.steps_per_wg), p->B), bl(256);
+  if (p->sp_ep) {
+    MomCfg ms = mc; ms.sp = p->sp; ms.src = MomSrc{};
+#define LES(V) hipLaunchKernelGGL(ep_site_sp_kernel<V>, g, dim3(MSP_NT), p->lds_ep_sp, p->stream, sh, p->b, ms, ep)
+    switch (ms.cdim) { case 1: LES(1); break; case 2: LES(2); break; case 3: LES(3); break; case 4: LES(4); break; case 5: LES(5); break; case 6: LES(6); break; default: LES(7); break; }
+#undef LES
+    HIP_TRY(hipGetLastError());
+    return NAGP_OK;
+  }
 #define LE(V) hipLaunchKernelGGL(ep_site_kernel<V>, g, bl, p->lds_ep, p->stream, sh, p->b, mc, ep)
   NAGP_MV_SWITCH9(mom_variant(mc), LE)
 #undef LE

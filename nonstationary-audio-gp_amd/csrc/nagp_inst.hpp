@@ -84,6 +84,13 @@
   NAGP_LIST_EP_V(P, 0) NAGP_LIST_EP_V(P, 1) NAGP_LIST_EP_V(P, 2) NAGP_LIST_EP_V(P, 3) NAGP_LIST_EP_V(P, 4)               \
   NAGP_LIST_EP_V(P, 5) NAGP_LIST_EP_V(P, 6) NAGP_LIST_EP_V(P, 7) NAGP_LIST_EP_V(P, 8) NAGP_LIST_EP_V(P, 9)
 
+// site refresh in the sparse-point form
+#define NAGP_SIG_EPS (nagp::Shape, nagp::Bufs, nagp::MomCfg, nagp::EpPar)
+#define NAGP_LIST_EPS(P)                                                                                                   \
+  P void nagp::ep_site_sp_kernel<1> NAGP_SIG_EPS; P void nagp::ep_site_sp_kernel<2> NAGP_SIG_EPS; P void nagp::ep_site_sp_kernel<3> NAGP_SIG_EPS;   \
+  P void nagp::ep_site_sp_kernel<4> NAGP_SIG_EPS; P void nagp::ep_site_sp_kernel<5> NAGP_SIG_EPS; P void nagp::ep_site_sp_kernel<6> NAGP_SIG_EPS;   \
+  P void nagp::ep_site_sp_kernel<7> NAGP_SIG_EPS;
+
 // infinite-horizon filters
 #define NAGP_SIG_IH (nagp::Shape, nagp::Bufs, nagp::MomCfg, nagp::IhgpTabs, nagp::IhgpPar)
 #define NAGP_LIST_IH_S(P, SRC)                                                                                             \
@@ -112,4 +119,4 @@
 
 #define NAGP_LIST_ALL(P)                                                                                                   \
   NAGP_LIST_GF_ADF1(P) NAGP_LIST_GF_ADF2(P) NAGP_LIST_GF_ADF3(P) NAGP_LIST_GF_ADF4(P) NAGP_LIST_GF_ADF5(P)               \
-  NAGP_LIST_GF_SP12(P) NAGP_LIST_GF_SP34(P) NAGP_LIST_GF_REST(P) NAGP_LIST_SMOOTH(P) NAGP_LIST_BIG(P) NAGP_LIST_GAINM(P) NAGP_LIST_FLM(P) NAGP_LIST_EP(P) NAGP_LIST_IH0(P) NAGP_LIST_IH1(P) NAGP_LIST_IHA(P) NAGP_LIST_IHA8(P)
+  NAGP_LIST_GF_SP12(P) NAGP_LIST_GF_SP34(P) NAGP_LIST_GF_REST(P) NAGP_LIST_SMOOTH(P) NAGP_LIST_BIG(P) NAGP_LIST_GAINM(P) NAGP_LIST_FLM(P) NAGP_LIST_EP(P) NAGP_LIST_EPS(P) NAGP_LIST_IH0(P) NAGP_LIST_IH1(P) NAGP_LIST_IHA(P) NAGP_LIST_IHA8(P)

@@ -1528,6 +1528,79 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) e
   if (tid < M && n_clamped) atomicAdd(&b.counters[(size_t)pb * 4 + 1], n_clamped);
 }
 
+// The same refresh with likModulatorNMFPower in the staged sparse-point form of nagp_momsp.hpp (fully symmetric sigma-point sets,
+// <= 7 components, <= 320 points: what the ADF launches of the filters use): the cavity marginals go where the stages read the
+// predicted ones, the sites live in wave 0.  Four times fewer instructions per evaluation than the generic mom_eval.
+__host__ __device__ inline size_t ep_sp_lds_doubles(const Shape& s, int CD) { return (size_t)s.D * CD + 2 * 68 + msp_lds_doubles(CD, s.D); }
+template <int CD>
+__global__ void __launch_bounds__(MSP_NT) __attribute__((amdgpu_waves_per_eu(2))) ep_site_sp_kernel(Shape sh, Bufs b, MomCfg mc, EpPar ep) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int tid = threadIdx.x, NT = blockDim.x;
+  const int M = sh.M, D = sh.D;
+  const int64_t T = sh.T;
+  const int pb = blockIdx.y;
+  const double* mdl = b.model + (size_t)pb * mdl_size(sh);
+  double* sW = lds;                          // [D][CD]
+  double* fmu = sW + (size_t)D * CD;         // cavity means, 68 entries (zero beyond the M sites: stage A reads 4*K of them)
+  double* HPH = fmu + 68;                    // cavity variances
+  double* ws = HPH + 68;
+  for (int i = tid; i < D * CD; i += NT) sW[i] = mdl[mdl_W(sh) + i];
+  for (int i = tid; i < 68; i += NT) { fmu[i] = 0.0; HPH[i] = 0.0; }
+  const double sn2 = mdl[mdl_sn2(sh)];
+  const double pEPa = mom_pEP(mc, sn2, ep.alpha), sn2a = sn2 / ep.alpha;
+  __syncthreads();
+  MspCtx<CD> xsp;
+  msp_setup<CD>(xsp, mc, mc.sp, sW, fmu, HPH, ws);
+  double wrow[CD];
+#pragma unroll
+  for (int j = 0; j < CD; ++j) wrow[j] = (tid < D) ? sW[tid * CD + j] : 0.0;
+  __syncthreads();
+  const int64_t kb = (int64_t)blockIdx.x * ep.steps_per_wg;
+  unsigned long long n_clamped = 0;
+  for (int64_t k = kb; k < kb + ep.steps_per_wg && k < ep.k_end; ++k) {
+    const double yk = b.y[(size_t)pb * T + k];
+    if (yk != yk) continue;   // isnan(y_k): no EP update (uniform)
+    const size_t ix = ((size_t)pb * T + k) * M + tid;
+    double t_old = 0.0, n_old = 0.0, vcav = 0.0, mcav = 0.0;
+    if (tid < M) {
+      t_old = b.ttau[ix]; n_old = b.tnu[ix];
+      const double vm = b.sv[ix], mm = b.sm[ix];
+      vcav = 1.0 / (1.0 / vm - ep.alpha * t_old);
+      mcav = vcav * (mm / vm - ep.alpha * n_old);
+      fmu[tid] = mcav; HPH[tid] = vcav;
+    }
+    lds_barrier();
+    msp_stageA<CD>(xsp, mc);
+    lds_barrier();
+    msp_stageB<CD>(xsp, mc, ws);
+    lds_barrier();
+    msp_stage1b<CD>(xsp, mc, mc.sp, sn2a, yk, ws);
+    lds_barrier();
+    msp_stage2<CD>(xsp, mc, ws);
+    lds_barrier();
+    if (tid < 64) {       // the sites live in wave 0: partial sums and outputs without another workgroup barrier
+      msp_reduce<CD>(xsp);
+      msp_wave_fence();
+      if (tid < M) {
+        double Zv, d1, d2;
+        msp_outputs<CD>(xsp.accp, tid < D, tid - D, wrow, pEPa, mc.jitter, Zv, d1, d2);
+        const bool upd = vcav > 0.0;
+        double tnew = t_old, nnew = n_old;
+        if (upd) {
+          tnew = ep.w_old * t_old + ep.w_new * (-d2 / (1.0 + d2 * vcav));
+          nnew = ep.w_old * n_old + ep.w_new * ((d1 - mcav * d2) / (1.0 + d2 * vcav));
+        }
+        if (ep.clamp) { if (!(tnew > 0.0)) ++n_clamped; tnew = max0(tnew); }
+        b.ttau[ix] = tnew; b.tnu[ix] = nnew;
+        if (ep.write_R == 1 || (ep.write_R == 2 && upd)) b.R[ix] = 1.0 / tnew;
+        if (tid == 0 && ep.lZ_out) ep.lZ_out[(size_t)pb * T + k] = log(Zv);
+      }
+    }
+    lds_barrier();        // fmu / HPH and the tables are rewritten by the next step
+  }
+  if (tid < M && n_clamped) atomicAdd(&b.counters[(size_t)pb * 4 + 1], n_clamped);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Deterministic reductions: out[pb*8 + slot] = sum_{k in [k_lo,k_hi)} v[pb][k]   (skipping nothing:
 // entries that were never written are zero, like the reference's zeros(1,T) initialisation).

@@ -1399,16 +1399,22 @@ static int fetch_red(nagp_plan* p, std::vector<double>& h) {
 
 // copy the filtered marginals / mean of the last step into the smoothed arrays (the smoother never
 // visits k = T-1: gf_ep_modulator_nmf.m:207)
-static int seed_last_step(nagp_plan* p) {
+static __global__ void seed_last_kernel(Bufs b, int64_t T, int M, int S, int with_sv) {
+  const size_t o = (size_t)blockIdx.x * T + (T - 1);
+  for (int i = threadIdx.x; i < M; i += blockDim.x) { b.sm[o * M + i] = b.fm[o * M + i]; if (with_sv) b.sv[o * M + i] = b.fv[o * M + i]; }
+  for (int i = threadIdx.x; i < S; i += blockDim.x) b.MS[o * S + i] = b.MF[o * S + i];
+}
+static int seed_last_step(nagp_plan* p) {      // one launch for all problems (a batch of 256 segments made 768 small copies of it)
   const Shape& sh = p->sh;
-  for (int q = 0; q < p->B; ++q) {
-    const size_t o = ((size_t)q * sh.T + (sh.T - 1));
-    HIP_TRY(hipMemcpyAsync(p->b.sm + o * sh.M, p->b.fm + o * sh.M, sh.M * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
-    if (p->opts.kind != NAGP_KIND_IHGP)
-      HIP_TRY(hipMemcpyAsync(p->b.sv + o * sh.M, p->b.fv + o * sh.M, sh.M * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
-    HIP_TRY(hipMemcpyAsync(p->b.MS + o * sh.S, p->b.MF + o * sh.S, sh.S * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
-  }
+  hipLaunchKernelGGL(seed_last_kernel, dim3(p->B), dim3(256), 0, p->stream, p->b, sh.T, sh.M, sh.S, p->opts.kind != NAGP_KIND_IHGP ? 1 : 0);
+  HIP_TRY(hipGetLastError());
   return NAGP_OK;
+}
+
+// red[q][1], red[q][2] (maxDiffM, maxDiffP) <- 0 for every problem
+static __global__ void zero_maxdiff_kernel(double* red, int B) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < B) { red[(size_t)q * 8 + 1] = 0.0; red[(size_t)q * 8 + 2] = 0.0; }
 }
 
 static int zero_async(nagp_plan* p, void* ptr, size_t bytes) {
@@ -1526,8 +1532,15 @@ static int exec_giekf(nagp_plan* p) {
   return NAGP_OK;
 }
 
-static __global__ void fill_kernel(double* p, size_t n, double v) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+
+static __global__ void ihgp_init_kernel(double* R, size_t n_per, const double* model, size_t msz, size_t sn2_off, int zero_R,
+                                        double* vprev, const double* tab, size_t tab_sz, size_t hph0_off, int M) {
+  const int q = blockIdx.y;
+  const double v = zero_R ? 0.0 : model[(size_t)q * msz + sn2_off];
+  double* r = R + (size_t)q * n_per;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_per; i += (size_t)gridDim.x * blockDim.x) r[i] = v;
+  if (blockIdx.x == 0)
+    for (int i = threadIdx.x; i < M; i += blockDim.x) vprev[(size_t)q * M + i] = tab[(size_t)q * tab_sz + hph0_off + i];
 }
 
 static int exec_ihgp(nagp_plan* p) {
@@ -1535,15 +1548,14 @@ static int exec_ihgp(nagp_plan* p) {
   std::vector<double> red;
   const bool mix = mixture_rule(p);
   const bool cv = (o.flags & NAGP_FLAG_IHGP_CONSTRAINTS) != 0 || mix;   // the mixture variant also starts from R = 0 (:248)
-  // R = exp(lik) .* ones (ihgp_ep_modulator_nmf.m:209) or zeros (constraints variant :243); problem-wise value
-  for (int q = 0; q < B; ++q) {
-    double sn2 = 0.0;
-    if (!cv) HIP_TRY(hipMemcpyAsync(&sn2, p->d_model + (size_t)q * mdl_size(sh) + mdl_sn2(sh), sizeof(double), hipMemcpyDeviceToHost, p->stream));
-    HIP_TRY(hipStreamSynchronize(p->stream));
-    hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, p->stream, p->b.R + (size_t)q * sh.T * sh.M, (size_t)sh.T * sh.M, cv ? 0.0 : sn2);
-    // PSP of sweep 1 = Pinf  ->  vprev = h^2 Pinf(c,c)
-    HIP_TRY(hipMemcpyAsync(p->d_vprev + (size_t)q * sh.M, p->d_tab + (size_t)q * itab_size(sh, p->tb.NG) + itab_hph0(sh, p->tb.NG),
-                           sh.M * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
+  // R = exp(lik) .* ones (ihgp_ep_modulator_nmf.m:209) or zeros (constraints variant :243), problem-wise value; PSP of sweep 1 = Pinf
+  // -> vprev = h^2 Pinf(c,c).  One launch for all problems (the values are read from the packed models and tables on the device).
+  {
+    const size_t n_per = (size_t)sh.T * sh.M;
+    const unsigned gx = (unsigned)std::max<size_t>(1, std::min<size_t>(64, (n_per + 4095) / 4096));
+    hipLaunchKernelGGL(ihgp_init_kernel, dim3(gx, B), dim3(256), 0, p->stream, p->b.R, n_per, p->d_model, mdl_size(sh), mdl_sn2(sh), cv ? 1 : 0,
+                       p->d_vprev, p->d_tab, itab_size(sh, p->tb.NG), itab_hph0(sh, p->tb.NG), sh.M);
+    HIP_TRY(hipGetLastError());
   }
   MomCfg mcf = p->mc; mcf.DG = p->DG_f; mcf.cache_tabs = p->cache_f; mcf.store_a = p->sta_f;
   if (p->src_f) mcf.src = p->src_all;
@@ -1596,8 +1608,7 @@ static int exec_ihgp(nagp_plan* p) {
     RUN(reduce_sum(p, p->b.lZ, itt == 1 ? 0 : sh.T - 1, sh.T, 0));
     RUN(seed_last_step(p));
     // backward mean recursion (parallel in time); red[1], red[2] = maxDiffM, maxDiffP
-    RUN(zero_async(p, p->b.red + 1, 2 * sizeof(double)));
-    if (B > 1) for (int q = 1; q < B; ++q) RUN(zero_async(p, p->b.red + (size_t)q * 8 + 1, 2 * sizeof(double)));
+    hipLaunchKernelGGL(zero_maxdiff_kernel, dim3((B + 255) / 256), dim3(256), 0, p->stream, p->b.red, B);
     if (sh.T > 1) RUN(affine(1, sh.T - 1, itt));
     else {   // no smoothing step: P = zeros (ihgp_ep_modulator_nmf.m:364) -> maxDiffP = |H PSP H'|
       Timed t(p, NAGP_K_SCAN);

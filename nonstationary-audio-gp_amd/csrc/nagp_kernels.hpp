@@ -267,11 +267,19 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
     m[i] = (fp.k_begin > 0) ? b.MF[((size_t)pb * T + (fp.k_begin - 1)) * S + i]
                             : (fp.init_from_state ? st[(size_t)sh.ntiles * 16 + i] : 0.0);
   __syncthreads();
-  // which block / row-in-block does state i (= tid) belong to
+  // State lanes.  The vector work of a step (mean prediction, mean update, the filtered mean's way to the ring) belongs to thread
+  // soff + i for state i.  One-tile-per-thread launches of the EP filters whose workgroup has whole waves beyond the tile threads
+  // (the fixed-site kernel of small models: 190 tiles on a 384-thread launch at 19 sites) put it on those waves, beside the tile
+  // waves instead of in front of them; otherwise soff = 0.
+  const int tile_threads = (nlow + 63) & ~63;
+  const int soff = (MEAS == 0 && TPT == 1 && NT >= tile_threads + ((S + 63) & ~63)) ? tile_threads : 0;
+  const int sid = tid - soff;
+  const bool slane = sid >= 0 && sid < S;
+  // which block / row-in-block does state sid belong to
   int myblk = 0, myrow = 0;
-  if (tid < S) {
-    while (ioff[myblk + 1] <= tid) ++myblk;
-    myrow = tid - ioff[myblk];
+  if (slane) {
+    while (ioff[myblk + 1] <= sid) ++myblk;
+    myrow = sid - ioff[myblk];
   }
 
   const double* yv = b.y + (size_t)pb * T;
@@ -308,7 +316,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
       const bool early = (MEAS == 0) && !do_mom && !(yk != yk);
       // ---- S0: prediction (registers), publish W = P H', H P, diag(H P H'), fmu = H m
       double rm = 0.0;
-      if (tid < S) {
+      if (slane) {
         if (pred) {
           const double* a = sA + (size_t)myblk * TS + 4 * myrow;
           const double* mb = m + ioff[myblk];
@@ -317,7 +325,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
           for (int l = 0; l < 4; ++l)
             if (l < bs) rm = fma(a[l], mb[l], rm);
         } else {
-          rm = m[tid];
+          rm = m[sid];
         }
         if (myrow == 0) fmu[myblk] = shv[myblk] * rm;
       }
@@ -395,7 +403,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
         }
       }
       lds_barrier();  // B1
-      if (tid < S) m[tid] = rm;
+      if (slane) m[sid] = rm;
 
       if (upd) {
         if (MEAS == 0) {
@@ -461,7 +469,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
             if (tid == 0) misc[1] = formA ? 1.0 : 0.0;
           }
           if (do_mom) lds_barrier();  // B4
-          if (tid < S && !(fp.dbg & 16)) {
+          if (slane && !(fp.dbg & 16)) {
             double a0 = rm, a1 = 0.0, a2 = 0.0, a3 = 0.0;
             const double* wp = Wl + ((size_t)(myrow >> 1) * M + myblk) * 2 + (myrow & 1);
             int n = 0;
@@ -473,7 +481,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
             }
             for (; n < M; ++n) a0 = fma(wp[(size_t)n * 4 * M], cm[n], a0);
             rm = (a0 + a1) + (a2 + a3);
-            m[tid] = rm;
+            m[sid] = rm;
           }
           // P -= sum_n cA[n] W[:,n] W[:,n]'   (K*H*P and K*W' coincide for the symmetric P)
 #pragma unroll
@@ -554,7 +562,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
               mp[tid] = (tid < D) ? fmu[tid] * pv : 0.0;
             }
             lds_barrier();
-            if (tid < S) {
+            if (slane) {
               double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
               const double* wp = Wl + ((size_t)(myrow >> 1) * M + myblk) * 2 + (myrow & 1);
               int n = 0;
@@ -563,7 +571,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
                 a2 = fma(wp[(size_t)(n + 2) * 4 * M], part[n + 2], a2); a3 = fma(wp[(size_t)(n + 3) * 4 * M], part[n + 3], a3);
               }
               for (; n < M; ++n) a0 = fma(wp[(size_t)n * 4 * M], part[n], a0);
-              PJ[tid] = (a0 + a1) + (a2 + a3);
+              PJ[sid] = (a0 + a1) + (a2 + a3);
             }
             lds_barrier();
             {
@@ -580,8 +588,8 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
                 rlZ[kk] = -(0.9189385332046727 + log(LS) + 0.5 * ((v / LS) / LS) * v);
               }
             }
-            if (tid < S) {
-              const double Kt = PJ[tid] / Sx; Kv[tid] = Kt; rm = rm + Kt * (yk - MU);     // K = P J' / S, once per state
+            if (slane) {
+              const double Kt = PJ[sid] / Sx; Kv[sid] = Kt; rm = rm + Kt * (yk - MU);     // K = P J' / S, once per state
               if (it + 1 < fp.l_iter && myrow == 0) {
                 const double f = shv[myblk] * rm;
                 fmu[myblk] = f;
@@ -591,7 +599,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
                   spl[N + myblk - D] = eg / (eg + 1.0);
                 }
               }
-              if (it + 1 == fp.l_iter) m[tid] = rm;
+              if (it + 1 == fp.l_iter) m[sid] = rm;
             }
             lds_barrier();   // Kv (and fmu, spl of the next iteration) visible
           }
@@ -613,8 +621,8 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
         ++n_nan;
       }
       // ---- per-step outputs -> ring ; covariance tiles -> HBM
-      if (tid < S) {
-        rMF[(size_t)kk * S + tid] = rm;
+      if (slane) {
+        rMF[(size_t)kk * S + sid] = rm;
         if (myrow == 0) rfm[kk * M + myblk] = shv[myblk] * rm;
       }
 #pragma unroll

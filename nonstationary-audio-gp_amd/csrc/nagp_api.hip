@@ -56,6 +56,7 @@ struct nagp_plan {
   int B = 0;
   int TPT = 1, TPT_f = 1, NT = 256, NT_f = 256, NT_ih = 256;
   int TPT_a = 1, NT_a = 256, LB_a = 256;   // ADF (mom) launches of the gf filter
+  int NT_fl = 256;                         // threads of the (not wide) fixed-site launches
   int wide_l = 0, NT_l = 256;              // fixed-site launches of models with 512 < tiles <= 1024: one tile per thread, 1024-thread bound
   int chunk = 2048, LP1 = 1, LP2 = 1, ns_max = 1;
   SpanPar spar{};
@@ -401,6 +402,9 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     else { p->TPT_a = 4; p->NT_a = std::max(roundup64((slots + 3) / 4), roundup64(sh.S)); p->LB_a = 512; }
     p->wide_l = (!ekf && slots > 512 && slots <= 1024 && !getenv("NAGP_NO_WIDE")) ? 1 : 0;
     p->NT_l = p->wide_l ? roundup64(slots) : p->NT_f;
+    // fixed-site launches with one tile per thread: whole waves beyond the tile threads for the state lanes (gf_filter_kernel: soff)
+    p->NT_fl = p->NT_f;
+    if (!ekf && p->TPT_f == 1 && roundup64(slots) + roundup64(sh.S) <= 512) p->NT_fl = std::max(p->NT_f, roundup64(slots) + roundup64(sh.S));
   }
   p->want_PS = (o->flags & 0x4u) != 0;
   p->need_PF = (o->kind != NAGP_KIND_IHGP) && !(o->mode == NAGP_MODE_NLML && (o->ep_itts == 1 || ekf));
@@ -991,7 +995,7 @@ static int launch_filter(nagp_plan* p, const FilterPar& fp_in) {
       else hipLaunchKernelGGL((gf_filter_kernel<1, 0, -1, 1024>), g, dim3(p->NT_l), p->lds_filter, p->stream, p->sh, p->b, mc, fp);
     } else {   // no step of this launch calls mom
       switch (p->TPT_f) {
-        case 1: hipLaunchKernelGGL((gf_filter_kernel<1, 0, -1>), g, bl, p->lds_filter, p->stream, p->sh, p->b, mc, fp); break;
+        case 1: hipLaunchKernelGGL((gf_filter_kernel<1, 0, -1>), g, dim3(p->NT_fl), p->lds_filter, p->stream, p->sh, p->b, mc, fp); break;
         case 2: hipLaunchKernelGGL((gf_filter_kernel<2, 0, -1>), g, bl, p->lds_filter, p->stream, p->sh, p->b, mc, fp); break;
         default: hipLaunchKernelGGL((gf_filter_kernel<4, 0, -1>), g, bl, p->lds_filter, p->stream, p->sh, p->b, mc, fp); break;
       }

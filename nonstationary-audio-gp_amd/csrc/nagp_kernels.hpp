@@ -294,6 +294,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
   double* g_PF = (b.PF && fp.store_PF) ? b.PF + (size_t)pb * T * pf_tiles * 16 : nullptr;
   unsigned long long n_clamped = 0, n_nan = 0;
   unsigned long long stp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_a = 0, st_b = 0;   // developer diagnostics (mc.stamps)
+#define EKF_STAMP(slot) do { if (MEAS == 1 && mc.stamps && tid == 0) { st_b = __builtin_readcyclecounter(); stp[slot] += st_b - st_a; st_a = st_b; } } while (0)
   if (mc.stamps && tid == 0) st_a = __builtin_readcyclecounter();
 
   for (int64_t k0 = fp.k_begin; k0 < fp.k_end; k0 += KB) {
@@ -403,6 +404,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
         }
       }
       lds_barrier();  // B1
+      EKF_STAMP(0);   // (prediction, panel, mean prediction, softplus wave)
       if (slane) m[sid] = rm;
 
       if (upd) {
@@ -473,6 +475,13 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
             double a0 = rm, a1 = 0.0, a2 = 0.0, a3 = 0.0;
             const double* wp = Wl + ((size_t)(myrow >> 1) * M + myblk) * 2 + (myrow & 1);
             int n = 0;
+            for (; n + 8 <= M; n += 8) {   // sixteen LDS reads in flight per trip (the four-term trips waited for their reads one by one)
+              double w8[8], c8[8];
+#pragma unroll
+              for (int u = 0; u < 8; ++u) { w8[u] = wp[(size_t)(n + u) * 4 * M]; c8[u] = cm[n + u]; }
+              a0 = fma(w8[0], c8[0], a0); a1 = fma(w8[1], c8[1], a1); a2 = fma(w8[2], c8[2], a2); a3 = fma(w8[3], c8[3], a3);
+              a0 = fma(w8[4], c8[4], a0); a1 = fma(w8[5], c8[5], a1); a2 = fma(w8[6], c8[6], a2); a3 = fma(w8[7], c8[7], a3);
+            }
             for (; n + 4 <= M; n += 4) {
               a0 = fma(wp[(size_t)(n + 0) * 4 * M], cm[n + 0], a0);
               a1 = fma(wp[(size_t)(n + 1) * 4 * M], cm[n + 1], a1);
@@ -551,6 +560,13 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
                 const int j = tid - D;
                 double z0 = 0.0, z1 = 0.0, z2 = 0.0, z3 = 0.0;   // four independent chains (same terms, fixed order)
                 int d = 0;
+                for (; d + 8 <= D; d += 8) {   // sixteen LDS reads in flight per trip
+                  double f8[8], w8[8];
+#pragma unroll
+                  for (int u = 0; u < 8; ++u) { f8[u] = fmu[d + u]; w8[u] = sW[(d + u) * N + j]; }
+                  z0 = fma(f8[0], w8[0], z0); z1 = fma(f8[1], w8[1], z1); z2 = fma(f8[2], w8[2], z2); z3 = fma(f8[3], w8[3], z3);
+                  z0 = fma(f8[4], w8[4], z0); z1 = fma(f8[5], w8[5], z1); z2 = fma(f8[6], w8[6], z2); z3 = fma(f8[7], w8[7], z3);
+                }
                 for (; d + 4 <= D; d += 4) {
                   z0 = fma(fmu[d], sW[d * N + j], z0); z1 = fma(fmu[d + 1], sW[(d + 1) * N + j], z1);
                   z2 = fma(fmu[d + 2], sW[(d + 2) * N + j], z2); z3 = fma(fmu[d + 3], sW[(d + 3) * N + j], z3);
@@ -562,10 +578,18 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
               mp[tid] = (tid < D) ? fmu[tid] * pv : 0.0;
             }
             lds_barrier();
+            EKF_STAMP(1);   // (partials of the Jacobian row)
             if (slane) {
               double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
               const double* wp = Wl + ((size_t)(myrow >> 1) * M + myblk) * 2 + (myrow & 1);
               int n = 0;
+              for (; n + 8 <= M; n += 8) {   // sixteen LDS reads in flight per trip
+                double w8[8], c8[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { w8[u] = wp[(size_t)(n + u) * 4 * M]; c8[u] = part[n + u]; }
+                a0 = fma(w8[0], c8[0], a0); a1 = fma(w8[1], c8[1], a1); a2 = fma(w8[2], c8[2], a2); a3 = fma(w8[3], c8[3], a3);
+                a0 = fma(w8[4], c8[4], a0); a1 = fma(w8[5], c8[5], a1); a2 = fma(w8[6], c8[6], a2); a3 = fma(w8[7], c8[7], a3);
+              }
               for (; n + 4 <= M; n += 4) {
                 a0 = fma(wp[(size_t)(n + 0) * 4 * M], part[n + 0], a0); a1 = fma(wp[(size_t)(n + 1) * 4 * M], part[n + 1], a1);
                 a2 = fma(wp[(size_t)(n + 2) * 4 * M], part[n + 2], a2); a3 = fma(wp[(size_t)(n + 3) * 4 * M], part[n + 3], a3);
@@ -574,6 +598,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
               PJ[sid] = (a0 + a1) + (a2 + a3);
             }
             lds_barrier();
+            EKF_STAMP(2);   // (P J')
             {
               double tj = 0.0, tm = 0.0;
               for (int n = tid & 63; n < M; n += 64) { tj = fma(part[n] * shv[n], PJ[ioff[n]], tj); tm += mp[n]; }
@@ -602,6 +627,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
               if (it + 1 == fp.l_iter) m[sid] = rm;
             }
             lds_barrier();   // Kv (and fmu, spl of the next iteration) visible
+            EKF_STAMP(3);   // (wave sums, gain, mean)
           }
           // P -= K S K'
 #pragma unroll
@@ -609,17 +635,25 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
             if (own.ok[q] && !(fp.dbg & 1)) {
               const int oI = ioff[own.I[q]], oJ = ioff[own.J[q]];
               const int bI = ibsz[own.I[q]], bJ = ibsz[own.J[q]];
+              // the gain entries of the two blocks, zero on the padding rows: eight selects in place of sixteen guarded updates
+              double ki[4], kj[4];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const double a = Kv[oI + ((i < bI) ? i : 0)], c = Kv[oJ + ((i < bJ) ? i : 0)];
+                ki[i] = (i < bI) ? a * Sx : 0.0;
+                kj[i] = (i < bJ) ? c : 0.0;
+              }
 #pragma unroll
               for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                  if (i < bI && j < bJ) P[q][4 * i + j] -= (Kv[oI + i] * Sx) * Kv[oJ + j];
+                for (int j = 0; j < 4; ++j) P[q][4 * i + j] -= ki[i] * kj[j];
             }
           }
         }
       } else {
         ++n_nan;
       }
+      EKF_STAMP(6);   // (P -= K S K')
       // ---- per-step outputs -> ring ; covariance tiles -> HBM
       if (slane) {
         rMF[(size_t)kk * S + sid] = rm;
@@ -635,6 +669,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
           if (own.ok[q]) pf_tile_store(g_PF + (size_t)k * pf_tiles * 16, tid + q * NT, P[q]);   // lower tile index == ownership index
       }
       lds_barrier();  // B5
+      EKF_STAMP(7);   // (outputs, PF stores, B5)
       if (mc.stamps && tid == 0 && do_mom) { st_b = __builtin_readcyclecounter(); stp[5] += st_b - st_a; st_a = st_b; }
     }
     // ---- flush the ring

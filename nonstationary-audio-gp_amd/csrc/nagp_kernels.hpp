@@ -488,7 +488,13 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
               a2 = fma(wp[(size_t)(n + 2) * 4 * M], cm[n + 2], a2);
               a3 = fma(wp[(size_t)(n + 3) * 4 * M], cm[n + 3], a3);
             }
-            for (; n < M; ++n) a0 = fma(wp[(size_t)n * 4 * M], cm[n], a0);
+            if (n < M) {      // tail (< 4 terms, all on chain a0 as before): its reads together, then the same fused multiply-adds
+              double wt[3], ct[3];
+#pragma unroll
+              for (int u = 0; u < 3; ++u) { const int nn = (n + u < M) ? n + u : M - 1; wt[u] = wp[(size_t)nn * 4 * M]; ct[u] = cm[nn]; }
+#pragma unroll
+              for (int u = 0; u < 3; ++u) if (n + u < M) a0 = fma(wt[u], ct[u], a0);
+            }
             rm = (a0 + a1) + (a2 + a3);
             m[sid] = rm;
           }
@@ -555,7 +561,13 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
             if (tid < M) {
               double pv = 0.0;
               if (tid < D) {
-                for (int j = 0; j < N; ++j) pv = fma(sW[tid * N + j], spl[j], pv);
+                for (int j0 = 0; j0 < N; j0 += 4) {      // (reads of four terms together; same order of the fused multiply-adds)
+                  double w4[4], s4[4];
+#pragma unroll
+                  for (int u = 0; u < 4; ++u) { const int jj = (j0 + u < N) ? j0 + u : N - 1; w4[u] = sW[tid * N + jj]; s4[u] = spl[jj]; }
+#pragma unroll
+                  for (int u = 0; u < 4; ++u) if (j0 + u < N) pv = fma(w4[u], s4[u], pv);
+                }
               } else {
                 const int j = tid - D;
                 double z0 = 0.0, z1 = 0.0, z2 = 0.0, z3 = 0.0;   // four independent chains (same terms, fixed order)
@@ -571,7 +583,13 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
                   z0 = fma(fmu[d], sW[d * N + j], z0); z1 = fma(fmu[d + 1], sW[(d + 1) * N + j], z1);
                   z2 = fma(fmu[d + 2], sW[(d + 2) * N + j], z2); z3 = fma(fmu[d + 3], sW[(d + 3) * N + j], z3);
                 }
-                for (; d < D; ++d) z0 = fma(fmu[d], sW[d * N + j], z0);
+                if (d < D) {      // tail: reads together, then the same fused multiply-adds on chain z0
+                  double ft[3], wt[3];
+#pragma unroll
+                  for (int u = 0; u < 3; ++u) { const int dd = (d + u < D) ? d + u : D - 1; ft[u] = fmu[dd]; wt[u] = sW[dd * N + j]; }
+#pragma unroll
+                  for (int u = 0; u < 3; ++u) if (d + u < D) z0 = fma(ft[u], wt[u], z0);
+                }
                 pv = ((z0 + z1) + (z2 + z3)) * spl[N + j];
               }
               part[tid] = pv;
@@ -594,7 +612,13 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
                 a0 = fma(wp[(size_t)(n + 0) * 4 * M], part[n + 0], a0); a1 = fma(wp[(size_t)(n + 1) * 4 * M], part[n + 1], a1);
                 a2 = fma(wp[(size_t)(n + 2) * 4 * M], part[n + 2], a2); a3 = fma(wp[(size_t)(n + 3) * 4 * M], part[n + 3], a3);
               }
-              for (; n < M; ++n) a0 = fma(wp[(size_t)n * 4 * M], part[n], a0);
+              if (n < M) {      // tail: reads together, then the same fused multiply-adds on chain a0
+                double wt[3], ct[3];
+#pragma unroll
+                for (int u = 0; u < 3; ++u) { const int nn = (n + u < M) ? n + u : M - 1; wt[u] = wp[(size_t)nn * 4 * M]; ct[u] = part[nn]; }
+#pragma unroll
+                for (int u = 0; u < 3; ++u) if (n + u < M) a0 = fma(wt[u], ct[u], a0);
+              }
               PJ[sid] = (a0 + a1) + (a2 + a3);
             }
             lds_barrier();

@@ -277,8 +277,11 @@ __device__ __forceinline__ void msp_link(const X& x, const MomCfg& c) {
   const int tl = (int)threadIdx.x - 64 * x.lw, TN = CD * c.nd;
   if (tl >= 0 && tl < TN) {
     const double mu = *x.a_mu, s2 = *x.a_s2;
-    const double rs = rsqrt_nr(s2);
-    const double sg = s2 * rs, inv = rs * rs;
+    // sqrt(s2) and 1/s2 through one reciprocal square root -- inside the range where its Newton steps are exact to an ulp; a cavity
+    // variance of 1e200 or 1e-200 (the site refresh of an ill-conditioned sweep produces them) takes the square root and the division
+    double sg, inv;
+    if (s2 > 1e-150 && s2 < 1e150) { const double rs = rsqrt_nr(s2); sg = s2 * rs; inv = rs * rs; }
+    else { sg = sqrt(s2); inv = 1.0 / s2; }
     const double xn = mu + sg * x.xdc;                                   // likModulatorNMFPower.m:34
     const double lk = link_eval(c.link_kind, c.link_shift, xn);
     const double xg = (xn - mu) * inv;                                   // (xn - mu_g)./s2_g  (:72)

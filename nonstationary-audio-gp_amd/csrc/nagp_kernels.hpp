@@ -277,9 +277,11 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
   const bool slane = sid >= 0 && sid < S;
   // which block / row-in-block does state sid belong to
   int myblk = 0, myrow = 0;
+  int my_o = 0, my_bs = 0;      // offset and size of that block (registers: the step loop does not go back to the LDS tables for them)
   if (slane) {
     while (ioff[myblk + 1] <= sid) ++myblk;
     myrow = sid - ioff[myblk];
+    my_o = ioff[myblk]; my_bs = ibsz[myblk];
   }
 
   const double* yv = b.y + (size_t)pb * T;
@@ -320,8 +322,8 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
       if (slane) {
         if (pred) {
           const double* a = sA + (size_t)myblk * TS + 4 * myrow;
-          const double* mb = m + ioff[myblk];
-          const int bs = ibsz[myblk];
+          const double* mb = m + my_o;
+          const int bs = my_bs;
 #pragma unroll
           for (int l = 0; l < 4; ++l)
             if (l < bs) rm = fma(a[l], mb[l], rm);
@@ -330,6 +332,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
         }
         if (myrow == 0) fmu[myblk] = shv[myblk] * rm;
       }
+      EKF_STAMP(4);   // (loop top, ring, mean prediction of the state lanes)
       const bool upd = !(yk != yk) || (MEAS == 1 && fp.ekf_energy);   // ~isnan(y_k), or the guard-less nlml loop
       if (MEAS == 1 && fp.spl_wave && tid >= NT - 64 && upd) {
         // EKF: the launch carries one extra wave without tiles; it evaluates softplus(g_j) and its derivative of the first
@@ -403,6 +406,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
           }
         }
       }
+      EKF_STAMP(5);   // (congruence, panel: this wave's tiles)
       lds_barrier();  // B1
       EKF_STAMP(0);   // (prediction, panel, mean prediction, softplus wave)
       if (slane) m[sid] = rm;
@@ -558,7 +562,25 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
               }
               lds_barrier();
             }
-            if (tid < M) {
+            // The modulators' partials are D-term sums: eight lanes of wave 1 per modulator (fixed tree over the lanes) beside the
+            // sub-band lanes of wave 0, instead of one lane each behind them in the same wave (<= 8 modulators; otherwise as before)
+            const bool mod_w1 = (N <= 8) && (NT >= 128);
+            if (mod_w1 && tid >= 64 && tid < 128) {
+              const int g = (tid - 64) >> 3, sub = tid & 7;
+              double f8[8], w8[8];
+#pragma unroll
+              for (int u = 0; u < 8; ++u) {
+                const int d = sub + 8 * u;
+                const bool ok = (g < N) && (d < D);
+                f8[u] = ok ? fmu[d] : 0.0; w8[u] = ok ? sW[d * N + g] : 0.0;
+              }
+              double z = 0.0;
+#pragma unroll
+              for (int u = 0; u < 8; ++u) z = fma(f8[u], w8[u], z);
+              z = group_sum(z, 8);
+              if (sub == 0 && g < N) { part[D + g] = z * spl[N + g]; mp[D + g] = 0.0; }
+            }
+            if (tid < (mod_w1 ? D : M)) {
               double pv = 0.0;
               if (tid < D) {
                 for (int j0 = 0; j0 < N; j0 += 4) {      // (reads of four terms together; same order of the fused multiply-adds)

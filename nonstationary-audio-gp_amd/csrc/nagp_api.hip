@@ -1682,6 +1682,8 @@ extern "C" int nagp_plan_execute(nagp_plan* p) {
           fprintf(stderr, "[nagp stamps] %s: wait at B1 %llu | Q/v %llu | B2..B3 %llu | weights %llu | wait at B4 %llu | marginal sums %llu | MFMA steps %llu | wait at B5 %llu\n",
                   w ? "last worker wave " : "first worker wave", st[8 + 8 * w], st[9 + 8 * w], st[10 + 8 * w], st[11 + 8 * w], st[12 + 8 * w], st[13 + 8 * w], st[14 + 8 * w], st[15 + 8 * w]);
     }
+    if (p->opts.kind == NAGP_KIND_GF_EP && hipMemcpy(st, p->d_stamps, 64, hipMemcpyDeviceToHost) == hipSuccess)
+      fprintf(stderr, "[nagp stamps] fixed-site step (thread 0; the ADF launches add their cubature stamps to the same slots): loop top + mean prediction %llu | congruence + panel %llu | wait at B1 %llu | mean update %llu | rank-M update %llu | outputs, PF stores, B5 %llu\n", st[4], st[5], st[0], st[1], st[6], st[7]);
     if (p->opts.kind == NAGP_KIND_GIEKF && hipMemcpy(st, p->d_stamps, 64, hipMemcpyDeviceToHost) == hipSuccess)
       fprintf(stderr, "[nagp stamps] EKF step: loop top + mean prediction %llu | congruence + panel of wave 0 %llu | wait at B1 %llu | Jacobian partials %llu | P J' %llu | wave sums, gain, mean %llu | P -= K S K' %llu | outputs, PF stores, B5 %llu\n", st[4], st[5], st[0], st[1], st[2], st[3], st[6], st[7]);
     else if (hipMemcpy(st, p->d_stamps, 64, hipMemcpyDeviceToHost) == hipSuccess)

@@ -296,7 +296,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
   double* g_PF = (b.PF && fp.store_PF) ? b.PF + (size_t)pb * T * pf_tiles * 16 : nullptr;
   unsigned long long n_clamped = 0, n_nan = 0;
   unsigned long long stp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_a = 0, st_b = 0;   // developer diagnostics (mc.stamps)
-#define EKF_STAMP(slot) do { if (MEAS == 1 && mc.stamps && tid == 0) { st_b = __builtin_readcyclecounter(); stp[slot] += st_b - st_a; st_a = st_b; } } while (0)
+#define EKF_STAMP(slot) do { if ((MEAS == 1 || MV == -1) && mc.stamps && tid == 0) { st_b = __builtin_readcyclecounter(); stp[slot] += st_b - st_a; st_a = st_b; } } while (0)
   if (mc.stamps && tid == 0) st_a = __builtin_readcyclecounter();
 
   for (int64_t k0 = fp.k_begin; k0 < fp.k_end; k0 += KB) {
@@ -502,6 +502,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
             rm = (a0 + a1) + (a2 + a3);
             m[sid] = rm;
           }
+          EKF_STAMP(1);   // (fixed-site kernel: mean update)
           // P -= sum_n cA[n] W[:,n] W[:,n]'   (K*H*P and K*W' coincide for the symmetric P)
 #pragma unroll
           for (int q = 0; q < TPT; ++q) {

@@ -1434,3 +1434,33 @@ def test_randomised_schedules_pipelined_equals_serial():
     spec = importlib.util.spec_from_file_location('gpu_fuzz_schedules', os.path.join(os.path.dirname(__file__), '..', 'tools', 'gpu_fuzz_schedules.py'))
     mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
     assert mod.run_cases(16, 31, verbose=False) == 0
+
+
+@pytest.mark.parametrize('family', ['gf', 'ihgp'])
+def test_sparse_point_site_refresh_equals_the_generic_one(family):
+    """ep_site_sp_kernel (likModulatorNMFPower in the staged sparse-point form) against ep_site_kernel (generic mom_eval,
+    NAGP_NO_SPARSE_EP=1) on the same plans -- three problems in one launch, three sweeps, so that two refreshes feed the later
+    sweeps: sites, marginals and nlZ agree to rounding (1e-9 of the scale; the two forms order their sums differently)."""
+    D, N, T = 12, 4, 160
+    probs, ys = [], []
+    for q in range(3):
+        pr = harness.nmf_problem(D, N, T, 9400 + q, 'constraints')
+        blk = pss.balance_blocks(pss.ss_blocks_nmf(pr['param1'], pr['param2'], 'matern32', 'matern52'))
+        probs.append((blk, pr['W'], np.log(pr['w_lik']))); ys.append(pr['y'])
+    mom = Mom('likModulatorNMFPower', p_cubature=7); d = 0.5 * np.ones(3)
+    res = {}
+    for mode in ('sparse', 'generic'):
+        if mode == 'generic': os.environ['NAGP_NO_SPARSE_EP'] = '1'
+        try:
+            if family == 'gf':
+                plan = Plan(L.KIND_GF_EP, probs, T, mom=mom, ep_fraction=0.5, ep_damping=d, ep_itts=3)
+            else:
+                plan = Plan(L.KIND_IHGP, probs, T, mom=mom, ep_fraction=0.5, ep_damping=d, ep_itts=3)
+            plan.upload(ys); plan.execute(); res[mode] = plan.download(); plan.close()
+        finally:
+            os.environ.pop('NAGP_NO_SPARSE_EP', None)
+    for q in range(3):
+        a, b = res['sparse'][q], res['generic'][q]
+        for f in ('Eft', 'Varft', 'ttau', 'tnu'):
+            assert rel(getattr(a, f), getattr(b, f)) < 1e-9, (q, f)
+        assert relz(a.nlZ, b.nlZ) < 1e-10

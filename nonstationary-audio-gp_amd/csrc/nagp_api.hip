@@ -150,12 +150,13 @@ static int dalloc(nagp_plan* p, double** ptr, size_t n_doubles, bool zero = true
   return NAGP_OK;
 }
 
-// run CALL(MV) for the mom variant mv (0 = POWER, 1..8 = NMF cubature dimension)
+// run CALL(MV) for the mom variant mv (0 = POWER, 1..9 = NMF cubature dimension; 9 = three sources x three components of the
+// source-separation mixtures, experiments/source_sep_piano.m:78-90)
 #define NAGP_MV_SWITCH(mv, CALL)                                                                         \
   switch (mv) {                                                                                          \
     case 0: CALL(0); break; case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break;      \
     case 4: CALL(4); break; case 5: CALL(5); break; case 6: CALL(6); break; case 7: CALL(7); break;      \
-    default: CALL(8); break;                                                                             \
+    case 8: CALL(8); break; default: CALL(9); break;                                                     \
   }
 
 // the kernels without covariance tiles (IHGP filter, site refresh, mom) also exist for N = 9 (three sources x three

@@ -1109,7 +1109,7 @@ __device__ __forceinline__ void mom_eval(const MomCfg& c, const double* Wl, doub
   }
 }
 constexpr int MOM_MAXCD = 9;      // IHGP filter, site refresh, mom on its own
-constexpr int MOM_MAXCD_GF = 8;   // kernels with register-resident covariance tiles
+constexpr int MOM_MAXCD_GF = 9;   // kernels with register-resident covariance tiles
 __host__ __device__ inline int mom_variant(const MomCfg& c) { return c.lik_kind == 0 ? 0 : c.cdim; }
 
 }  // namespace nagp

@@ -14,7 +14,7 @@
   P void nagp::gf_filter_kernel<TPT, 0, 2, LB> NAGP_SIG_GF; P void nagp::gf_filter_kernel<TPT, 0, 3, LB> NAGP_SIG_GF;    \
   P void nagp::gf_filter_kernel<TPT, 0, 4, LB> NAGP_SIG_GF; P void nagp::gf_filter_kernel<TPT, 0, 5, LB> NAGP_SIG_GF;    \
   P void nagp::gf_filter_kernel<TPT, 0, 6, LB> NAGP_SIG_GF; P void nagp::gf_filter_kernel<TPT, 0, 7, LB> NAGP_SIG_GF;    \
-  P void nagp::gf_filter_kernel<TPT, 0, 8, LB> NAGP_SIG_GF;
+  P void nagp::gf_filter_kernel<TPT, 0, 8, LB> NAGP_SIG_GF; P void nagp::gf_filter_kernel<TPT, 0, 9, LB> NAGP_SIG_GF;
 #define NAGP_LIST_GF_ADF1(P) NAGP_LIST_GF_ADF(P, 1, 256)
 #define NAGP_LIST_GF_ADF2(P) NAGP_LIST_GF_ADF(P, 2, 256)
 #define NAGP_LIST_GF_ADF3(P) NAGP_LIST_GF_ADF(P, 3, 256)

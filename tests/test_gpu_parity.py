@@ -565,8 +565,8 @@ def test_source_separation_mixtures_against_oracle(shapes, k1, k2, lik, p):
 
 def test_three_sources_with_nine_modulators_ihgp_mixture():
     """The shape family of source_sep_piano.m:78-90 (three sources x three NMF components, exp sub-band kernels,
-    likModulatorPreCalcwn with the shifted softplus): cubature dimension 9 exists for the kernels without covariance
-    tiles (IHGP filter, site refresh, mom); the full-covariance path refuses it."""
+    likModulatorPreCalcwn with the shifted softplus): cubature dimension 9 on the infinite-horizon path AND, since round 3, in the
+    ADF launches of the full-covariance filter (gf_ep_mods_nmf_mixture with nine components runs while the 21 sites fit)."""
     shapes = [(4, 3)] * 3; k1 = ['exp'] * 3; k2 = ['matern52'] * 3
     T = 28; t = np.arange(1, T + 1.0)
     mp = harness.mixture_problem(shapes, T, 5, k1, k2)
@@ -576,8 +576,23 @@ def test_three_sources_with_nine_modulators_ihgp_mixture():
     assert c[0].shape == (21, T)
     assert rel(c[0], d[0]) < TOL_MEAN and rel(c[1], d[1]) < TOL_MEAN
     assert rel(c[5]['ttau'], d[5]['ttau']) < TOL_SITE and rel(c[5]['tnu'], d[5]['tnu']) < TOL_SITE
-    with pytest.raises(nagp.NagpError):
-        nagp.gf_ep_mods_nmf_mixture(mp['w'], t, mp['y'], SSHandle(), mom, t, k1, k2, 3, 0.75, 0.2, 3)
+    a = nagp.gf_ep_mods_nmf_mixture(mp['w'], t, mp['y'], SSHandle(), mom, t, k1, k2, 3, 0.75, 0.2, 3, nargout=6)
+    b = omx.gf_ep_mods_nmf_mixture(mp['w'], t, mp['y'], None, omom, t, k1, k2, 3, 0.75, 0.2, 3)
+    assert rel(a[0], b[0]) < TOL_MEAN and rel(a[1], b[1]) < TOL_MEAN
+    assert rel(a[5]['ttau'], b[5]['ttau']) < TOL_SITE and rel(a[5]['tnu'], b[5]['tnu']) < TOL_SITE and rel(a[5]['MS'], b[5]['MS']) < TOL_MEAN
+
+
+def test_nine_nmf_components_full_covariance_against_oracle():
+    """gf_ep_modulator_nmf with nine components (cubature dimension 9, ut3: 19 points): the ADF kernels with covariance tiles."""
+    D, N, T = 8, 9, 48
+    pr = harness.nmf_problem(D, N, T, 9901); t = np.arange(1, T + 1.0)
+    y = pr['y'].copy(); y[11] = np.nan
+    d = 0.5 * np.ones(3)
+    Eft, Varft, _, _, _, out = nagp.gf_ep_modulator_nmf(pr['w'], t, y, SSHandle(), Mom('likModulatorNMFPower', p_cubature=3), t, 'matern32', 'matern52', 1, D, N,
+                                                        0.5, d, 3, nargout=6)
+    o = ogf.gf_ep_modulator_nmf(pr['w'], t, y, None, olik.Mom(olik.LIK_POWER_NMF, p=3), t, 'matern32', 'matern52', 1, D, N, 0.5, d, 3)
+    assert rel(Eft, o[0]) < TOL_MEAN and rel(Varft, o[1]) < TOL_MEAN and relz(out['nlZ'], o[5]['nlZ']) < TOL_LOGZ
+    assert rel(out['ttau'], o[5]['ttau']) < TOL_SITE and rel(out['tnu'], o[5]['tnu']) < TOL_SITE
 
 
 def test_block_structured_cubature_equals_per_point_evaluation(monkeypatch):

@@ -89,6 +89,7 @@ struct nagp_plan {
   std::vector<int> slot_cap;                    // capacity of a slot in steps (= stride between its problems): `chunk`, except the small
                                                 // last slot that belongs to the short chunk of the latest steps
   size_t mat_doubles = 0;                       // doubles of one dense / tile-major matrix in a slot
+  size_t gstep = 0; int dpacked = 0;            // doubles of (G, Delta) of one step in a slot; Delta as packed lower 16x16 tiles (GainPar::dpacked)
   std::vector<double*> c_spanbuf, c_spanvec, c_mspanbuf, c_mspanvec;   // compose results per chunk (VALU / MFMA layouts)
   std::vector<double*> c_bnd, c_mbnd;           // boundary values (E_top, e_top of every span) per chunk: the apply passes of several chunks
                                                 // run side by side on `s_apply` once the (sequential) boundary chain has passed them
@@ -545,7 +546,12 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
       else if (Sp <= 160 && !getenv("NAGP_NO_MFMA") && !getenv("NAGP_NO_MFMA_BIG")) { p->mfma_sp = Sp; p->big_sp = 1; }
     }
     const size_t mat = p->mfma_sp ? (size_t)p->mfma_sp * p->mfma_sp : (size_t)nt * 16;     // (4M)^2 <= Sp^2: the tile-major form fits the dense slot
-    const double per_step = (double)B * (2.0 * (double)mat + sh.S) * 8.0;                  // one step of a (G, Delta, delta) chunk buffer
+    // column-owner passes (96 < Sp <= 160) read the symmetric Delta through its lower 16x16 tiles only: the slots hold it packed
+    // (Sp = 160: 315 KB per step instead of 410 -- eight chunks of the 8-segment cfg5 plan keep their slot where six did).  Not when a
+    // sweep stores smoothed covariances (its VALU passes use the tile-major layout of the same slots) or with the opt-in MFMA gain kernel.
+    p->dpacked = (p->big_sp && !p->want_PS && !getenv("NAGP_GAIN_MFMA") && !getenv("NAGP_DENSE_DELTA")) ? 1 : 0;
+    p->gstep = p->mfma_sp ? gd_step_doubles(p->mfma_sp, p->dpacked) : 2 * mat;
+    const double per_step = (double)B * ((double)p->gstep + sh.S) * 8.0;                   // one step of a (G, Delta, delta) chunk buffer
     {
       // one chunk buffer: at most 24 GiB and at most a quarter of the device memory that is free once the per-step arrays
       // (filtered covariances, means, sites) of this plan are counted
@@ -618,14 +624,14 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     p->mat_doubles = mat;
     auto add_slot = [&](int cap_steps) -> int {
       double *g = nullptr, *d = nullptr;
-      int st = dalloc(p, &g, (size_t)B * cap_steps * 2 * mat, true);
+      int st = dalloc(p, &g, (size_t)B * cap_steps * p->gstep, true);
       if (st == NAGP_OK) st = dalloc(p, &d, (size_t)B * cap_steps * sh.S, false);
       if (st == NAGP_OK) { p->slotG.push_back(g); p->slotD.push_back(d); p->slot_tiled.push_back(0); p->slot_cap.push_back(cap_steps); }
       return st;
     };
     for (int q = 0; q < n_slots; ++q) PLAN_TRY(add_slot(p->chunk));
     if (p->pipeline) PLAN_TRY(add_slot(std::min(p->chunk, std::max(64, p->chunk / 8))));   // the short chunk of the latest steps has its own
-    p->gbuf_doubles = (size_t)B * p->chunk * 2 * mat;
+    p->gbuf_doubles = (size_t)B * p->chunk * p->gstep;
     if (p->pipeline) {
       PLAN_HIP(hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking));
       { hipStream_t st = nullptr; PLAN_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); p->s_apply.push_back(st); }
@@ -1100,9 +1106,10 @@ static void sweep_begin(nagp_plan* p, SweepCtx& sc, bool write_PSs) {
 
 static int launch_gain_chunk(nagp_plan* p, const SweepCtx& sc, int c, int slot, hipStream_t st) {
   const Shape& sh = p->sh; const ChunkGeom& g = sc.ch[c];
-  GainPar gp{g.k0, g.nk, p->slot_cap[slot], (sc.mode != SM_VALU) ? p->mfma_sp : 0, getenv("NAGP_GAINM_DBG") ? atoi(getenv("NAGP_GAINM_DBG")) : 0};
+  GainPar gp{g.k0, g.nk, p->slot_cap[slot], (sc.mode != SM_VALU) ? p->mfma_sp : 0, getenv("NAGP_GAINM_DBG") ? atoi(getenv("NAGP_GAINM_DBG")) : 0, 0};
+  gp.dpacked = (sc.mode == SM_BIG) ? p->dpacked : 0;
   if (gp.dense_sp && p->slot_tiled[slot]) {
-    HIP_TRY(hipMemsetAsync(p->slotG[slot], 0, (size_t)p->B * p->slot_cap[slot] * 2 * p->mat_doubles * sizeof(double), st)); p->slot_tiled[slot] = 0;
+    HIP_TRY(hipMemsetAsync(p->slotG[slot], 0, (size_t)p->B * p->slot_cap[slot] * p->gstep * sizeof(double), st)); p->slot_tiled[slot] = 0;
   }
   if (!gp.dense_sp && p->mfma_sp) p->slot_tiled[slot] = 1;
   Bufs b = p->b; b.Gbuf = p->slotG[slot]; b.dbuf = p->slotD[slot];
@@ -1145,6 +1152,7 @@ static MfmaPar mfma_par(nagp_plan* p, const SweepCtx& sc, int c, int slot) {
   mp.first = (c == 0) ? 1 : 0; mp.write_PSs = (sc.mode == SM_MFMA && sc.write_PSs) ? 1 : 0;
   mp.spanbuf = p->c_mspanbuf[set]; mp.spanvec = p->c_mspanvec[set]; mp.bnd = p->c_mbnd[set];
   mp.tab = nullptr; mp.ntab = 0; mp.xbuf = nullptr;
+  mp.dpacked = (sc.mode == SM_BIG) ? p->dpacked : 0;
   return mp;
 }
 

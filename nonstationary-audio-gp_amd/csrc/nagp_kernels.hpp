@@ -757,7 +757,13 @@ struct GainPar {
   int chunk;    // chunk capacity (buffer stride)
   int dense_sp; // 0: (G, Delta) tile-major ; > 0: dense row-major Sp x Sp (input layout of the MFMA smoother passes)
   int dbg;      // developer switch of rts_gain_mfma_kernel (NAGP_GAINM_DBG): skip phases to time the others (results are garbage)
+  int dpacked;  // dense_sp > 0: Delta is stored as its lower-triangular 16x16 tiles, tile (TI,TJ), TI >= TJ, at [TI(TI+1)/2+TJ][16][16]
+                // (all the column-owner smoother passes read of it): a step of the slot is Sp^2 + NTL(NTL+1)/2*256 doubles instead of 2 Sp^2
 };
+__host__ __device__ inline size_t gd_step_doubles(int Sp, int dpacked) {      // doubles of (G, Delta) of one step in a dense slot
+  const size_t ntl = (size_t)Sp / 16;
+  return dpacked ? (size_t)Sp * Sp + ntl * (ntl + 1) / 2 * 256 : 2 * (size_t)Sp * Sp;
+}
 
 __host__ __device__ inline size_t gain_lds_doubles(const Shape& s) {
   return LDS_INT_DOUBLES + (size_t)s.M * 16 * 2 + 4 * (size_t)s.M * TS + 8;
@@ -886,10 +892,23 @@ __global__ void __launch_bounds__(LB) __attribute__((amdgpu_waves_per_eu(LB > 51
   const double* PFk = b.PF + ((size_t)pb * T + k) * pf_step_doubles(sh);
   const double* PFk1 = PFk + pf_step_doubles(sh);
   const size_t mstride = gp.dense_sp ? (size_t)gp.dense_sp * gp.dense_sp : (size_t)sh.ntiles * 16;
-  double* Gout = b.Gbuf + (((size_t)pb * gp.chunk + kk) * 2) * mstride;
+  const size_t gstep = gp.dense_sp ? gd_step_doubles(gp.dense_sp, gp.dpacked) : 2 * mstride;
+  double* Gout = b.Gbuf + ((size_t)pb * gp.chunk + kk) * gstep;
   double* Dout = Gout + mstride;
   // tile (I,J) -> output location (tile-major: 16 contiguous doubles; dense: 4 rows of 4 at row stride Sp)
   auto put_tile = [&](double* base, int I, int J, const double* t16) {
+    if (gp.dense_sp && gp.dpacked && base == Dout) {
+      // packed Delta: 4x4 tile (I,J) sits in 16x16 tile (I/4, J/4); only the lower 16x16 tiles exist (both halves of a diagonal one)
+      const int TI = I >> 2, TJ = J >> 2;
+      if (TI < TJ) return;
+      double2* d0 = reinterpret_cast<double2*>(base + (size_t)(TI * (TI + 1) / 2 + TJ) * 256 + (size_t)(4 * (I & 3)) * 16 + 4 * (J & 3));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        d0[i * 8] = make_double2(t16[4 * i], t16[4 * i + 1]);
+        d0[i * 8 + 1] = make_double2(t16[4 * i + 2], t16[4 * i + 3]);
+      }
+      return;
+    }
     if (gp.dense_sp) {
       double2* d0 = reinterpret_cast<double2*>(base + ((size_t)(4 * I) * gp.dense_sp + 4 * J));
 #pragma unroll

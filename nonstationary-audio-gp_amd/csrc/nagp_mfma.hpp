@@ -26,6 +26,7 @@ struct MfmaPar {
   const ChunkTab* tab;  // merged apply launch (see SpanPar)
   int ntab;
   double* xbuf;         // (unused by the MFMA passes; keeps chunk_select one template)
+  int dpacked;          // column-owner passes: Delta of the chunk's slot as packed lower 16x16 tiles (GainPar::dpacked)
 };
 
 __host__ __device__ inline size_t mfma_lds_doubles(int Sp) { return 2 * (size_t)Sp * (Sp + 1) + 3 * (size_t)Sp + MAXM + 8; }

@@ -89,6 +89,21 @@ __device__ __forceinline__ v4d big_tile_load(const double* __restrict__ A, int I
   return v;
 }
 
+// tile (I,J) of the symmetric Delta stored as its lower 16x16 tiles (GainPar::dpacked), in the accumulator layout
+__device__ __forceinline__ v4d big_delta_load(const double* __restrict__ Dp, int I, int J, int i, int kq) {
+  v4d v;
+  if (I >= J) {
+    const double* t = Dp + (size_t)(I * (I + 1) / 2 + J) * 256;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = t[(4 * r + kq) * 16 + i];
+  } else {      // the mirror tile, transposed
+    const double* t = Dp + (size_t)(J * (J + 1) / 2 + I) * 256;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = t[i * 16 + 4 * r + kq];
+  }
+  return v;
+}
+
 // value of tile (I,J) -> state Y (mirrored across the diagonal when I < J), optionally dense global (both triangles)
 template <int NTL>
 __device__ __forceinline__ void big_emit(const BigCtx<NTL>& c, int I, int J, v4d v, double* __restrict__ gout) {
@@ -215,7 +230,7 @@ __global__ void __launch_bounds__(64 * NTL) rts_big_kernel(Shape sh, Bufs b, Mfm
   if (MODE == 1) { n_lo = 0; n_hi = sp.ns; }
   else { n_lo = j * sp.L; n_hi = (n_lo + sp.L < sp.nk) ? n_lo + sp.L : sp.nk; }
   auto Gmat = [&](int n) -> const double* {
-    return (MODE == 1) ? sp.spanbuf + (((size_t)pb * sp.ns_max + n) * 2) * SS : b.Gbuf + (((size_t)pb * sp.chunk + n) * 2) * SS;
+    return (MODE == 1) ? sp.spanbuf + (((size_t)pb * sp.ns_max + n) * 2) * SS : b.Gbuf + ((size_t)pb * sp.chunk + n) * gd_step_doubles(Sp, sp.dpacked);
   };
   auto Dvec = [&](int n) -> double {     // vector term of index n (delta_n, or c of span n), dense row tid
     if (sidx < 0) return 0.0;
@@ -234,7 +249,7 @@ __global__ void __launch_bounds__(64 * NTL) rts_big_kernel(Shape sh, Bufs b, Mfm
       if (big_active<NTL>(I, J)) {
         v4d v = {0.0, 0.0, 0.0, 0.0};
         if (E0) v = big_tile_load<NTL>(E0, I, J, c.i, c.kq);
-        if (A0) v += big_tile_load<NTL>(A0, I, J, c.i, c.kq);
+        if (A0) v += (MODE != 1 && sp.dpacked) ? big_delta_load(A0, I, J, c.i, c.kq) : big_tile_load<NTL>(A0, I, J, c.i, c.kq);
         big_emit<NTL>(c, I, J, v, g0);
       }
     if (tid < Sp) {
@@ -277,7 +292,7 @@ __global__ void __launch_bounds__(64 * NTL) rts_big_kernel(Shape sh, Bufs b, Mfm
       if (I + 1 < NTL) big_panel_fetch<NTL>(Gk, I + 1, tid, st);
       if (big_active<NTL>(I, J)) {
         v4d addv = {0.0, 0.0, 0.0, 0.0};
-        if (Add) addv = big_tile_load<NTL>(Add, I, J, c.i, c.kq);
+        if (Add) addv = (MODE != 1 && sp.dpacked) ? big_delta_load(Add, I, J, c.i, c.kq) : big_tile_load<NTL>(Add, I, J, c.i, c.kq);
         const v4d e = big_panel_tile<NTL>(c, Pc, Z);
         if (MODE == 2 && I == J) {
           // smoothed marginal variances: E(4m,4m) of the diagonal tile sits in register m of lane 4m
@@ -364,7 +379,7 @@ __global__ void __launch_bounds__(64 * NTL) rts_big_phi_kernel(Shape sh, Bufs b,
     for (int r = 0; r < 4; ++r) Ph[K][r] = (K == J && 4 * r + c.kq == c.i) ? 1.0 : 0.0;
   const int n_lo = j * sp.L, n_hi = (n_lo + sp.L < sp.nk) ? n_lo + sp.L : sp.nk;
   for (int n = n_hi - 1; n >= n_lo; --n) {
-    const double* Gk = b.Gbuf + (((size_t)pb * sp.chunk + n) * 2) * SS;
+    const double* Gk = b.Gbuf + ((size_t)pb * sp.chunk + n) * gd_step_doubles(Sp, sp.dpacked);
     double st[4];
     big_panel_fetch<NTL>(Gk, 0, tid, st);
     big_panel_store<NTL>(c.P, tid, st);

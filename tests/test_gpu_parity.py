@@ -1479,3 +1479,24 @@ def test_sparse_point_site_refresh_equals_the_generic_one(family):
         for f in ('Eft', 'Varft', 'ttau', 'tnu'):
             assert rel(getattr(a, f), getattr(b, f)) < 1e-9, (q, f)
         assert relz(a.nlZ, b.nlZ) < 1e-10
+
+
+def test_packed_delta_slots_equal_the_dense_ones_bit_for_bit(monkeypatch):
+    """Column-owner smoother plans keep Delta as its lower 16x16 tiles (GainPar::dpacked); NAGP_DENSE_DELTA=1 keeps the dense matrix.
+    Same values through a different layout: every output of an 8-segment S = 146 plan (several chunks, three sweeps) is bit-equal."""
+    D, N, T, B = 32, 6, 120, 4
+    probs, ys = [], []
+    for q in range(B):
+        pr = harness.nmf_problem(D, N, T, 9600 + q, 'constraints')
+        blk = pss.balance_blocks(pss.ss_blocks_nmf(pr['param1'], pr['param2'], 'matern32', 'matern52'))
+        probs.append((blk, pr['W'], np.log(pr['w_lik']))); ys.append(pr['y'])
+    mom = Mom('likModulatorNMFPower', p_cubature=5); d = 0.5 * np.ones(3)
+    res = {}
+    for mode in ('packed', 'dense'):
+        if mode == 'dense': monkeypatch.setenv('NAGP_DENSE_DELTA', '1')
+        plan = Plan(L.KIND_GF_EP, probs, T, mom=mom, ep_fraction=0.5, ep_damping=d, ep_itts=3, chunk=32)
+        plan.upload(ys); plan.execute(); res[mode] = plan.download(); plan.close()
+        monkeypatch.delenv('NAGP_DENSE_DELTA', raising=False)
+    for q in range(B):
+        for f in ('Eft', 'Varft', 'MS', 'ttau', 'tnu', 'R', 'lZ', 'nlZ', 'maxDiffM', 'maxDiffP'):
+            assert np.array_equal(getattr(res['packed'][q], f), getattr(res['dense'][q], f), equal_nan=True), (q, f)

@@ -88,6 +88,8 @@ struct nagp_plan {
   std::vector<char> slot_tiled;                 // the slot last held tile-major matrices: zero it before the next dense use (padding rows)
   std::vector<int> slot_cap;                    // capacity of a slot in steps (= stride between its problems): `chunk`, except the small
                                                 // last slot that belongs to the short chunk of the latest steps
+  std::vector<size_t> slot_gps;                 // Bufs::gpstride of the slot: 0, or the PF stride of a slot recycled from PF
+  int n_full_slots = 0, n_recycled = 0;         // full-size slots of their own; slots inside PF (behind the small slot in the vectors)
   size_t mat_doubles = 0;                       // doubles of one dense / tile-major matrix in a slot
   size_t gstep = 0; int dpacked = 0;            // doubles of (G, Delta) of one step in a slot; Delta as packed lower 16x16 tiles (GainPar::dpacked)
   std::vector<double*> c_spanbuf, c_spanvec, c_mspanbuf, c_mspanvec;   // compose results per chunk (VALU / MFMA layouts)
@@ -138,6 +140,12 @@ extern "C" const char* nagp_strerror(int s) {
     case NAGP_ERCCL: return "RCCL error";
     default: return "unknown";
   }
+}
+
+// length of the smoother chunk that ends at step k1 (exclusive); `latest`: the chunk of the latest steps, cut short (see sweep_begin)
+static int chunk_len(const nagp_plan* p, int64_t k1, bool latest) {
+  const bool c0 = latest && (p->sh.T - 1) > p->chunk;
+  return (int)std::min<int64_t>(c0 ? std::min(p->chunk, std::max(64, p->chunk / 8)) : p->chunk, k1);
 }
 
 static int dalloc(nagp_plan* p, double** ptr, size_t n_doubles, bool zero = true) {
@@ -626,11 +634,39 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
       double *g = nullptr, *d = nullptr;
       int st = dalloc(p, &g, (size_t)B * cap_steps * p->gstep, true);
       if (st == NAGP_OK) st = dalloc(p, &d, (size_t)B * cap_steps * sh.S, false);
-      if (st == NAGP_OK) { p->slotG.push_back(g); p->slotD.push_back(d); p->slot_tiled.push_back(0); p->slot_cap.push_back(cap_steps); }
+      if (st == NAGP_OK) { p->slotG.push_back(g); p->slotD.push_back(d); p->slot_tiled.push_back(0); p->slot_cap.push_back(cap_steps); p->slot_gps.push_back(0); }
       return st;
     };
     for (int q = 0; q < n_slots; ++q) PLAN_TRY(add_slot(p->chunk));
+    p->n_full_slots = n_slots;
     if (p->pipeline) PLAN_TRY(add_slot(std::min(p->chunk, std::max(64, p->chunk / 8))));   // the short chunk of the latest steps has its own
+    // Recycled slots.  The column-owner passes read PF_k for k = 0 only (the restart state), the gain kernel of a chunk reads the PF of
+    // its own steps and of the step behind them, and the gains of the chunks are enqueued in time order on one stream: once the gains
+    // of the earliest chunks exist, their part of PF is free until the next sweep's filter.  When the free memory does not hold a slot
+    // per chunk, the chunks the filter finishes LAST take theirs from there -- recycled slot j (the chunk with n_slots + j full chunks
+    // before it in time) occupies doubles [pf_step + j * chunk * gstep, pf_step + (j+1) * chunk * gstep) of every problem's PF; all of
+    // it must lie below the first step of that chunk.  All-or-nothing: a chunk left without a slot would read PF again.
+    if (p->pipeline && p->dpacked && n_slots < p->nc - 1 && !getenv("NAGP_NO_RECYCLE")) {
+      std::vector<int64_t> k0s;      // first step of the chunks, latest first (the cuts of sweep_begin)
+      for (int64_t k1 = T - 1; k1 > 0;) { const int nk = chunk_len(p, k1, k0s.empty()); k0s.push_back(k1 - nk); k1 -= nk; }
+      const int ncs = (int)k0s.size(), need = (ncs - 1) - n_slots;
+      const size_t pfs = pf_step_doubles(sh);
+      bool ok = need > 0;
+      for (int j = 0; ok && j < need; ++j) {
+        const size_t end = pfs + (size_t)(j + 1) * p->chunk * p->gstep;
+        const int c = ncs - 1 - (n_slots + j);               // time-chunk n_slots + j
+        ok = (end + pfs - 1) / pfs <= (size_t)k0s[c];
+      }
+      if (ok) {
+        for (int j = 0; j < need; ++j) {
+          double* d = nullptr;
+          PLAN_TRY(dalloc(p, &d, (size_t)B * p->chunk * sh.S, false));
+          p->slotG.push_back(b.PF + pfs + (size_t)j * p->chunk * p->gstep); p->slotD.push_back(d);
+          p->slot_tiled.push_back(0); p->slot_cap.push_back(p->chunk); p->slot_gps.push_back((size_t)T * pfs);
+        }
+        p->n_recycled = need;
+      }
+    }
     p->gbuf_doubles = (size_t)B * p->chunk * p->gstep;
     if (p->pipeline) {
       PLAN_HIP(hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking));
@@ -646,7 +682,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
       PLAN_HIP(hipHostMalloc(reinterpret_cast<void**>(&p->h_progress), (size_t)B * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent));
       std::memset(p->h_progress, 0, (size_t)B * sizeof(unsigned long long));
     }
-    if (getenv("NAGP_STAMPS")) fprintf(stderr, "[nagp plan] smoother: chunk %d, %d chunk(s) per sweep, %d (G,Delta) buffer(s) of %.2f GiB, pipelined %d\n", p->chunk, p->nc, n_slots, per_step * p->chunk / 1073741824.0, (int)p->pipeline);
+    if (getenv("NAGP_STAMPS")) fprintf(stderr, "[nagp plan] smoother: chunk %d, %d chunk(s) per sweep, %d (G,Delta) buffer(s) of %.2f GiB (+ %d recycled from PF), pipelined %d\n", p->chunk, p->nc, n_slots, per_step * p->chunk / 1073741824.0, p->n_recycled, (int)p->pipeline);
   } else {
     PLAN_TRY(dalloc(p, &p->d_lZs, BT));
     PLAN_TRY(dalloc(p, &p->d_vprev, (size_t)B * sh.M));
@@ -1037,8 +1073,7 @@ static void sweep_begin(nagp_plan* p, SweepCtx& sc, bool write_PSs) {
   // short (an eighth of a chunk, spans a quarter as long) whenever there is more than one chunk.
   const bool many = (sh.T - 1) > p->chunk;
   for (int64_t k1 = sh.T - 1; k1 > 0;) {
-    const bool c0 = many && sc.ch.empty();
-    const int nk = (int)std::min<int64_t>(c0 ? std::min(p->chunk, std::max(64, p->chunk / 8)) : p->chunk, k1);   // never beyond the buffer's capacity
+    const int nk = chunk_len(p, k1, sc.ch.empty());   // never beyond the buffer's capacity
     ChunkGeom g{k1 - nk, nk, 1, 1};
     // Spans.  The boundary pass is one sequential chain over ALL spans of the sweep (one workgroup per problem, a step per span); a
     // compose / apply launch costs a span LENGTH of latency, and the apply passes of the chunks run as one merged grid.
@@ -1092,8 +1127,12 @@ static void sweep_begin(nagp_plan* p, SweepCtx& sc, bool write_PSs) {
   if (p->pipeline) {
     // the short chunk 0 owns the small last slot; full slots 1 .. n_full-1 belong to the chunks the filter finishes last (slot 0 is
     // the scratch of the others) -- or, with a full slot for every other chunk, slot c-1 to chunk c
-    const int n_full = (int)p->slotG.size() - 1;
+    const int n_full = p->n_full_slots;
     sc.slot_of[0] = n_full;
+    if (p->n_recycled > 0) {
+      // every chunk owns a slot: the earliest n_full chunks the full ones, the later ones the slots recycled from PF (plan creation)
+      for (int c = 1; c < nc; ++c) { const int tau = nc - 1 - c; sc.slot_of[c] = tau < n_full ? tau : n_full + 1 + (tau - n_full); }
+    } else
     if (n_full >= nc - 1) for (int c = 1; c < nc; ++c) sc.slot_of[c] = c - 1;
     else for (int c = 1; c < n_full; ++c) sc.slot_of[c] = c;
     sc.next = nc - 1;
@@ -1112,7 +1151,7 @@ static int launch_gain_chunk(nagp_plan* p, const SweepCtx& sc, int c, int slot, 
     HIP_TRY(hipMemsetAsync(p->slotG[slot], 0, (size_t)p->B * p->slot_cap[slot] * p->gstep * sizeof(double), st)); p->slot_tiled[slot] = 0;
   }
   if (!gp.dense_sp && p->mfma_sp) p->slot_tiled[slot] = 1;
-  Bufs b = p->b; b.Gbuf = p->slotG[slot]; b.dbuf = p->slotD[slot];
+  Bufs b = p->b; b.Gbuf = p->slotG[slot]; b.dbuf = p->slotD[slot]; b.gpstride = p->slot_gps[slot];
   Timed t(p, NAGP_K_GAIN, st);
   dim3 gr(g.nk, p->B), bl(p->NT);
   if (gp.dense_sp && p->gain_mfma) {
@@ -1159,7 +1198,7 @@ static MfmaPar mfma_par(nagp_plan* p, const SweepCtx& sc, int c, int slot) {
 // pass 1 of the span scheme (one workgroup per span): reads the chunk's (G, Delta, delta), writes its (Phi, C, c)
 static int launch_compose_chunk(nagp_plan* p, const SweepCtx& sc, int c, int slot, hipStream_t st) {
   const Shape& sh = p->sh; const ChunkGeom& g = sc.ch[c];
-  Bufs b = p->b; b.Gbuf = p->slotG[slot]; b.dbuf = p->slotD[slot];
+  Bufs b = p->b; b.Gbuf = p->slotG[slot]; b.dbuf = p->slotD[slot]; b.gpstride = p->slot_gps[slot];
   Timed t(p, NAGP_K_SCAN, st);
   if (sc.mode == SM_BIG) {
     MfmaPar mp = mfma_par(p, sc, c, slot);
@@ -1191,7 +1230,7 @@ static int launch_compose_chunk(nagp_plan* p, const SweepCtx& sc, int c, int slo
 // state), pass 3: the reference recursion inside every span from its boundary value
 static int launch_boundary_chunk(nagp_plan* p, const SweepCtx& sc, int c, int slot, hipStream_t st) {
   const Shape& sh = p->sh;
-  Bufs b = p->b; b.Gbuf = p->slotG[slot]; b.dbuf = p->slotD[slot];
+  Bufs b = p->b; b.Gbuf = p->slotG[slot]; b.dbuf = p->slotD[slot]; b.gpstride = p->slot_gps[slot];
   Timed t(p, NAGP_K_SCAN, st);
   dim3 g2(p->B);
   if (sc.mode == SM_BIG) {
@@ -1220,7 +1259,7 @@ static int launch_boundary_chunk(nagp_plan* p, const SweepCtx& sc, int c, int sl
 
 static int launch_apply_chunk(nagp_plan* p, const SweepCtx& sc, int c, int slot, hipStream_t st) {
   const Shape& sh = p->sh; const ChunkGeom& g = sc.ch[c];
-  Bufs b = p->b; b.Gbuf = p->slotG[slot]; b.dbuf = p->slotD[slot];
+  Bufs b = p->b; b.Gbuf = p->slotG[slot]; b.dbuf = p->slotD[slot]; b.gpstride = p->slot_gps[slot];
   Timed t(p, NAGP_K_SCAN, st);
   if (sc.mode == SM_BIG) {
     MfmaPar mp = mfma_par(p, sc, c, slot);
@@ -1290,12 +1329,12 @@ static int launch_apply_merged(nagp_plan* p, const SweepCtx& sc, int n_own, hipS
     ChunkTab& t = p->h_tab[c];
     const int slot = sc.slot_of[c];
     t.k0 = g.k0; t.nk = g.nk; t.L = g.L; t.ns = g.ns; t.first = (c == 0) ? 1 : 0; t.span0 = tot; t.cap = p->slot_cap[slot];
-    t.G = p->slotG[slot]; t.d = p->slotD[slot];
+    t.G = p->slotG[slot]; t.d = p->slotD[slot]; t.gps = p->slot_gps[slot];
     if (sc.mode == SM_VALU) { t.spanbuf = p->c_spanbuf[c]; t.spanvec = p->c_spanvec[c]; t.bnd = p->c_bnd[c]; t.xbuf = p->c_xbuf[c]; }
     else { t.spanbuf = p->c_mspanbuf[c]; t.spanvec = p->c_mspanvec[c]; t.bnd = p->c_mbnd[c]; t.xbuf = nullptr; }
     tot += g.ns;
   }
-  Bufs b = p->b; b.Gbuf = p->slotG[sc.slot_of[0]]; b.dbuf = p->slotD[sc.slot_of[0]];
+  Bufs b = p->b; b.Gbuf = p->slotG[sc.slot_of[0]]; b.dbuf = p->slotD[sc.slot_of[0]]; b.gpstride = p->slot_gps[sc.slot_of[0]];
   Timed t(p, NAGP_K_SCAN, st);
   dim3 gr(tot, p->B);
   if (sc.mode == SM_BIG) {

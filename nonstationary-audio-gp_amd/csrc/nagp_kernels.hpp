@@ -50,6 +50,8 @@ struct Bufs {
   double* sv;
   double* Gbuf;         // [B][chunk][2][ntiles][16]  (G, Delta) of the current smoother chunk
   double* dbuf;         // [B][chunk][S]              delta of the current chunk
+  size_t gpstride;      // doubles between the problems of Gbuf; 0: chunk * (doubles of one step).  Non-zero for a buffer that lives inside
+                        // PF (column-owner plans whose free memory does not hold a buffer per chunk: nagp_api.hip, "recycled")
   double* state;        // [B][ntiles*16 + S]         scan state (E, e) between chunks; smoothed (P,m) at k=0 for EKF
   double* red;          // [B][8] reduction outputs (sum lZ, maxDiffM, maxDiffP, ...)
   unsigned long long* counters;  // [B][4]
@@ -893,8 +895,24 @@ __global__ void __launch_bounds__(LB) __attribute__((amdgpu_waves_per_eu(LB > 51
   const double* PFk1 = PFk + pf_step_doubles(sh);
   const size_t mstride = gp.dense_sp ? (size_t)gp.dense_sp * gp.dense_sp : (size_t)sh.ntiles * 16;
   const size_t gstep = gp.dense_sp ? gd_step_doubles(gp.dense_sp, gp.dpacked) : 2 * mstride;
-  double* Gout = b.Gbuf + ((size_t)pb * gp.chunk + kk) * gstep;
+  double* Gout = b.Gbuf + (b.gpstride ? (size_t)pb * b.gpstride + (size_t)kk * gstep : ((size_t)pb * gp.chunk + kk) * gstep);
   double* Dout = Gout + mstride;
+  if (b.gpstride && gp.dense_sp) {
+    // a buffer in recycled memory is not zero-filled: write the padding rows / columns (4M .. Sp-1) the tiles below do not cover
+    const int Sp = gp.dense_sp, R4 = 4 * M, np = Sp - R4, NTLd = Sp / 16;
+    for (int i = tid; i < np * Sp; i += NT) Gout[(size_t)(R4 + i / Sp) * Sp + i % Sp] = 0.0;
+    for (int i = tid; i < R4 * np; i += NT) Gout[(size_t)(i / np) * Sp + R4 + i % np] = 0.0;
+    if (gp.dpacked) {      // the last row of 16x16 tiles
+      double* Dl = Dout + (size_t)((NTLd - 1) * NTLd / 2) * 256;
+      for (int i = tid; i < NTLd * 256; i += NT) {
+        const int TJ = i >> 8, r = (i >> 4) & 15, cc = i & 15;
+        if (16 * (NTLd - 1) + r >= R4 || 16 * TJ + cc >= R4) Dl[i] = 0.0;
+      }
+    } else {
+      for (int i = tid; i < np * Sp; i += NT) Dout[(size_t)(R4 + i / Sp) * Sp + i % Sp] = 0.0;
+      for (int i = tid; i < R4 * np; i += NT) Dout[(size_t)(i / np) * Sp + R4 + i % np] = 0.0;
+    }
+  }
   // tile (I,J) -> output location (tile-major: 16 contiguous doubles; dense: 4 rows of 4 at row stride Sp)
   auto put_tile = [&](double* base, int I, int J, const double* t16) {
     if (gp.dense_sp && gp.dpacked && base == Dout) {
@@ -1161,6 +1179,7 @@ struct ChunkTab {
   long long k0;
   int nk, L, ns, first, span0, cap;    // span0: index of the chunk's first span in the merged grid; cap: stride of the chunk's buffer
   double *G, *d, *spanbuf, *spanvec, *bnd, *xbuf;
+  size_t gps;                          // Bufs::gpstride of the chunk's buffer
 };
 
 struct SpanPar {
@@ -1190,7 +1209,7 @@ __device__ __forceinline__ int chunk_select(Par& sp, Bufs& b, int j) {
   const ChunkTab t = sp.tab[c];
   sp.k0 = t.k0; sp.nk = t.nk; sp.L = t.L; sp.ns = t.ns; sp.first = t.first; sp.chunk = t.cap;
   sp.spanbuf = t.spanbuf; sp.spanvec = t.spanvec; sp.bnd = t.bnd; sp.xbuf = t.xbuf;
-  b.Gbuf = t.G; b.dbuf = t.d;
+  b.Gbuf = t.G; b.dbuf = t.d; b.gpstride = t.gps;
   return j - t.span0;
 }
 

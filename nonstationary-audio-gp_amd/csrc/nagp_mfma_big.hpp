@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(64 * NTL) rts_big_kernel(Shape sh, Bufs b, Mfm
   if (MODE == 1) { n_lo = 0; n_hi = sp.ns; }
   else { n_lo = j * sp.L; n_hi = (n_lo + sp.L < sp.nk) ? n_lo + sp.L : sp.nk; }
   auto Gmat = [&](int n) -> const double* {
-    return (MODE == 1) ? sp.spanbuf + (((size_t)pb * sp.ns_max + n) * 2) * SS : b.Gbuf + ((size_t)pb * sp.chunk + n) * gd_step_doubles(Sp, sp.dpacked);
+    return (MODE == 1) ? sp.spanbuf + (((size_t)pb * sp.ns_max + n) * 2) * SS : b.Gbuf + (b.gpstride ? (size_t)pb * b.gpstride + (size_t)n * gd_step_doubles(Sp, sp.dpacked) : ((size_t)pb * sp.chunk + n) * gd_step_doubles(Sp, sp.dpacked));
   };
   auto Dvec = [&](int n) -> double {     // vector term of index n (delta_n, or c of span n), dense row tid
     if (sidx < 0) return 0.0;
@@ -379,7 +379,7 @@ __global__ void __launch_bounds__(64 * NTL) rts_big_phi_kernel(Shape sh, Bufs b,
     for (int r = 0; r < 4; ++r) Ph[K][r] = (K == J && 4 * r + c.kq == c.i) ? 1.0 : 0.0;
   const int n_lo = j * sp.L, n_hi = (n_lo + sp.L < sp.nk) ? n_lo + sp.L : sp.nk;
   for (int n = n_hi - 1; n >= n_lo; --n) {
-    const double* Gk = b.Gbuf + ((size_t)pb * sp.chunk + n) * gd_step_doubles(Sp, sp.dpacked);
+    const double* Gk = b.Gbuf + (b.gpstride ? (size_t)pb * b.gpstride + (size_t)n * gd_step_doubles(Sp, sp.dpacked) : ((size_t)pb * sp.chunk + n) * gd_step_doubles(Sp, sp.dpacked));
     double st[4];
     big_panel_fetch<NTL>(Gk, 0, tid, st);
     big_panel_store<NTL>(c.P, tid, st);

@@ -19,7 +19,7 @@ def run_cases(n, seed, verbose=True):
         if D == 36: N = min(N, 8)
         T = int(rng.integers(40, 700)); B = int(rng.choice([1, 1, 2, 3, 5, 8]))
         chunk = int(rng.choice([0, 8, 16, 24, 50, 100, 200]))
-        slots = int(rng.choice([0, 2, 3, 4]))
+        slots = int(rng.choice([0, 2, 3, 4, 5, 6, 8])); no_recycle = rng.random() < 0.3
         itts = int(rng.integers(2, 4)); p = int(rng.choice([3, 5])) if N > 3 else int(rng.choice([3, 5, 7]))
         want_ps = (not ekf) and rng.random() < 0.25
         probs, ys = [], []
@@ -32,7 +32,7 @@ def run_cases(n, seed, verbose=True):
         kw = dict(ep_itts=itts, l_iter=2) if ekf else dict(mom=Mom('likModulatorNMFPower', p_cubature=p), ep_fraction=0.5, ep_damping=0.5 * np.ones(itts), ep_itts=itts,
                                                             flags=L.FLAG_WANT_PS if want_ps else 0)
         res = {}
-        for name, env in (('pipelined', {'NAGP_PIPELINE_SLOTS': str(slots)} if slots else {}), ('serial', {'NAGP_NO_PIPELINE': '1'})):
+        for name, env in (('pipelined', dict({'NAGP_PIPELINE_SLOTS': str(slots)} if slots else {}, **({'NAGP_NO_RECYCLE': '1'} if no_recycle else {}))), ('serial', {'NAGP_NO_PIPELINE': '1'})):
             os.environ.update(env)
             try:
                 plan = Plan(L.KIND_GIEKF if ekf else L.KIND_GF_EP, probs, T, chunk=chunk, **kw)

@@ -542,7 +542,10 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
   { double* c = nullptr; PLAN_TRY(dalloc(p, &c, (size_t)B * 4)); b.counters = reinterpret_cast<unsigned long long*>(c); }
   // smoother chunk: the unit of the (G, Delta) buffers and of the filter -> smoother pipeline.  About a dozen chunks per sweep
   // (the tail the pipeline cannot hide is one chunk's gain + compose), at least 2048 steps each, at most what one buffer may take.
-  p->chunk = (o->chunk > 0) ? o->chunk : (int)std::min<int64_t>(T, std::max<int64_t>(2048, (T + 11) / 12));
+  {
+    const int64_t n_ch = getenv("NAGP_CHUNKS") ? std::max(1, atoi(getenv("NAGP_CHUNKS"))) : 12;     // developer switch
+    p->chunk = (o->chunk > 0) ? o->chunk : (int)std::min<int64_t>(T, std::max<int64_t>(2048, (T + n_ch - 1) / n_ch));
+  }
   if (p->chunk > T) p->chunk = (int)T;
   PLAN_TRY(dalloc(p, &p->d_stamps, 24));
   if (o->kind != NAGP_KIND_IHGP) {

@@ -1502,33 +1502,38 @@ def test_packed_delta_slots_equal_the_dense_ones_bit_for_bit(monkeypatch):
             assert np.array_equal(getattr(res['packed'][q], f), getattr(res['dense'][q], f), equal_nan=True), (q, f)
 
 
-def test_slots_recycled_from_the_filtered_covariances_equal_the_serial_schedule():
+@pytest.mark.parametrize('kind', ['gf', 'ekf'])
+def test_slots_recycled_from_the_filtered_covariances_equal_the_serial_schedule(kind):
     """When the free memory does not hold a (G, Delta) buffer per chunk, a column-owner plan takes the buffers of the chunks the filter
     finishes last from the part of PF whose gains already exist (nagp_api.hip, "recycled"; padding rows written by the gain kernel,
     the buffer's problems PF's stride apart) instead of computing gains twice.  Forced here with four full buffers for five full chunks
-    (S = 146, Sp = 160, four segments, three sweeps, T - 1 = 6 x 32): every output equals the serial schedule's and the
-    recompute schedule's bit for bit; the plan's memory grows by the delta vectors of the one recycled buffer only."""
-    D, N, T, B, chunk = 32, 6, 193, 4, 32
+    (gf: S = 146, Sp = 160, four segments; EKF: S = 105, Sp = 112, two segments, restart from the smoothed state of step 0, which reads
+    PF_0; three sweeps, T - 1 = 6 x 32): every output equals the serial schedule's and the recompute schedule's bit for bit; the
+    plan's memory grows by the delta vectors of the one recycled buffer only."""
+    ekf = kind == 'ekf'
+    D, N, T, B, chunk = (24, 3, 193, 2, 32) if ekf else (32, 6, 193, 4, 32)
     probs, ys = [], []
     for q in range(B):
         pr = harness.nmf_problem(D, N, T, 9700 + q, 'constraints')
         blk = pss.balance_blocks(pss.ss_blocks_nmf(pr['param1'], pr['param2'], 'matern32', 'matern52'))
-        y = pr['y'].copy(); y[11 * q + 3] = np.nan
+        y = pr['y'].copy()
+        if not ekf: y[11 * q + 3] = np.nan
         probs.append((blk, pr['W'], np.log(pr['w_lik']))); ys.append(y)
-    mom = Mom('likModulatorNMFPower', p_cubature=5); d = 0.5 * np.ones(3)
+    kw = dict(ep_itts=3, l_iter=2) if ekf else dict(mom=Mom('likModulatorNMFPower', p_cubature=5), ep_fraction=0.5, ep_damping=0.5 * np.ones(3), ep_itts=3)
     res, nbytes = {}, {}
     for name, env in (('recycled', {'NAGP_PIPELINE_SLOTS': '4'}), ('recompute', {'NAGP_PIPELINE_SLOTS': '4', 'NAGP_NO_RECYCLE': '1'}),
                       ('serial', {'NAGP_NO_PIPELINE': '1'})):
         os.environ.update(env)
         try:
-            plan = Plan(L.KIND_GF_EP, probs, T, chunk=chunk, mom=mom, ep_fraction=0.5, ep_damping=d, ep_itts=3)
+            plan = Plan(L.KIND_GIEKF if ekf else L.KIND_GF_EP, probs, T, chunk=chunk, **kw)
             plan.upload(ys); plan.execute(); res[name] = plan.download(want_MF=True); nbytes[name] = plan.device_bytes(); plan.close()
         finally:
             for k in env:
                 os.environ.pop(k, None)
     assert nbytes['recycled'] - nbytes['recompute'] == B * chunk * probs[0][0].S * 8
+    fields = ('Eft', 'Varft', 'MS', 'MF', 'maxDiffP') + (() if ekf else ('ttau', 'tnu', 'R', 'lZ', 'nlZ', 'maxDiffM'))
     for q in range(B):
         for other in ('recycled', 'recompute'):
-            for f in ('Eft', 'Varft', 'MS', 'MF', 'ttau', 'tnu', 'R', 'lZ', 'nlZ', 'maxDiffM', 'maxDiffP'):
+            for f in fields:
                 assert np.array_equal(getattr(res[other][q], f), getattr(res['serial'][q], f), equal_nan=True), (other, q, f)
             assert np.array_equal(res[other][q].counters, res['serial'][q].counters)

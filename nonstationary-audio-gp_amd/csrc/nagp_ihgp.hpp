@@ -587,6 +587,10 @@ __global__ void __launch_bounds__(MSR_NT) ihgp_adf8_kernel(Shape sh, Bufs b, Mom
   double* g_fm = b.fm + (size_t)pb * T * M;
   msr_init(CD, D, ws);
   __syncthreads();
+  // developer A/B, ip.dbg_wave & 64 (NAGP_STAMP_WORKER): tables / q0 / s0 of a step on every worker wave for itself (msr_fold) instead
+  // of on wave 1 / workers 3, 4 between two barriers.  Measured slower (profiles/r03_stamps_cycles.txt): a lone wave issues a dependent
+  // VALU instruction every 8 - 10 cycles, so the ~80 instructions of the stage on EVERY worker cost more than barrier B3 saves.
+  const bool fold = (CD * CD <= 48) && (ip.dbg_wave & 64) != 0;
   if (wave >= MSR_W0) {
     // ================= worker role: the parallel stages of the cubature; the same barriers as the serial role below
     const MspLay lay = msp_layout(CD, D, 1);
@@ -612,10 +616,17 @@ __global__ void __launch_bounds__(MSR_NT) ihgp_adf8_kernel(Shape sh, Bufs b, Mom
       msp_qv<CD>(xw, mc);            // workers 0..2
       WK_STAMP(1);
       lds_barrier();                 // B2
-      if (wave == MSR_W0 + 3 || wave == MSR_W0 + 4) msr_q0_or_s0(xw, wave == MSR_W0 + 3, ws + lay.q0, ws + lay.s0);
-      lds_barrier();                 // B3
-      WK_STAMP(2);                   // (B2 .. B3: tables on wave 1, q0 / s0 on worker 3)
-      msp_stage1b<CD>(xw, mc, sp, sn2a, ry[kk], ws);
+      if (fold) {                    // tables, q0, s0 on every worker wave for itself: no barrier B3
+        double q0, s0;
+        if constexpr (CD * CD <= 48) msr_fold<CD>(xw, mc, q0, s0); else { q0 = 0.0; s0 = 0.0; }
+        WK_STAMP(2);
+        msp_stage1b_qs<CD>(xw, mc, sp, sn2a, ry[kk], q0, s0);
+      } else {
+        if (wave == MSR_W0 + 3 || wave == MSR_W0 + 4) msr_q0_or_s0(xw, wave == MSR_W0 + 3, ws + lay.q0, ws + lay.s0);
+        lds_barrier();                 // B3
+        WK_STAMP(2);                   // (B2 .. B3: tables on wave 1, q0 / s0 on worker 3)
+        msp_stage1b<CD>(xw, mc, sp, sn2a, ry[kk], ws);
+      }
       WK_STAMP(3);
       lds_barrier();                 // B4
       WK_STAMP(4);
@@ -740,9 +751,11 @@ __global__ void __launch_bounds__(MSR_NT) ihgp_adf8_kernel(Shape sh, Bufs b, Mom
       if (wave == 1 && !link_early) msp_link<CD>(x, mc);
       lds_barrier();                 // B2
       IH_STAMP(0);
-      if (wave == 1) msp_tables<CD>(x, mc);
-      lds_barrier();                 // B3
-      // (Gaussian weights: worker waves)
+      if (!fold) {
+        if (wave == 1) msp_tables<CD>(x, mc);
+        lds_barrier();                 // B3
+      }
+      // (tables, q0, s0, Gaussian weights: worker waves)
       lds_barrier();                 // B4
       IH_STAMP(1);
       // (MFMA sums: worker waves)

@@ -319,15 +319,23 @@ template <int CD, class X>
 __device__ __forceinline__ void msp_tables(const X& x, const MomCfg& c) {
   const int TN = CD * c.nd;
   if (((int)threadIdx.x & 63) < TN) {
-    const double lk = ((msp_rp)x.a_out)[0];
+    // every operand first -- ONE LDS round trip (left to itself the compiler reads a pair, waits, multiplies, reads the next pair: a dozen
+    // round trips of ~100 cycles on a wave that has its SIMD to itself) -- then arithmetic, then the three stores
+    double lk = ((msp_rp)x.a_out)[0], l0o = *x.a_l0own, qjj = *x.a_qjj, vv = *x.a_v;
+    double qr[CD], l0v[CD];
+#pragma unroll
+    for (int j2 = 0; j2 < CD; ++j2) { qr[j2] = x.a_qrow[j2]; l0v[j2] = *x.a_l0[j2]; }
+#pragma unroll
+    for (int j2 = 0; j2 < CD; ++j2) asm volatile("" : "+v"(qr[j2]), "+v"(l0v[j2]));
+    asm volatile("" : "+v"(lk), "+v"(l0o), "+v"(qjj), "+v"(vv));
     double ql0 = 0.0, ql1 = 0.0;
 #pragma unroll
-    for (int j2 = 0; j2 < CD; ++j2) { if (j2 & 1) ql1 = fma(x.a_qrow[j2], *x.a_l0[j2], ql1); else ql0 = fma(x.a_qrow[j2], *x.a_l0[j2], ql0); }
+    for (int j2 = 0; j2 < CD; ++j2) { if (j2 & 1) ql1 = fma(qr[j2], l0v[j2], ql1); else ql0 = fma(qr[j2], l0v[j2], ql0); }
     const double ql = ql0 + ql1;
-    const double e = lk - *x.a_l0own;
+    const double e = lk - l0o;
     x.a_out[3 * MSP_TS] = e;
-    x.a_out[4 * MSP_TS] = e * fma(*x.a_qjj, e, 2.0 * ql);
-    x.a_out[5 * MSP_TS] = (*x.a_v) * e;
+    x.a_out[4 * MSP_TS] = e * fma(qjj, e, 2.0 * ql);
+    x.a_out[5 * MSP_TS] = vv * e;
   }
 }
 // stage B, q0 = l0' Q l0 and s0 = v' l0 (one wave)
@@ -355,31 +363,69 @@ __device__ __forceinline__ void msp_stageB(const MspCtx<CD>& x, const MomCfg& c,
   else if (wave == __builtin_amdgcn_readfirstlane(x.qw)) msp_q0s0(x, ws + l.q0, ws + l.s0);
 }
 
+__device__ __forceinline__ void msp_wave_fence();
+// Folded stage B of the role layout (CD*CD <= 48): this wave's own copy of the tables -- every worker wave writes the same values to the
+// same LDS words and reads them back behind its own writes (DS operations of a wave complete in issue order) -- and q0 = l0' Q l0,
+// s0 = v' l0 from one 16-lane group sum: rows 0..2 of the wave hold the q0 terms, row 3 the s0 terms, at the lane positions (inside a row)
+// and in the association order of the two-wave form (msr_q0_or_s0), so both sums keep their bits.
+template <int CD, class X>
+__device__ __forceinline__ void msr_fold(const X& x, const MomCfg& c, double& q0, double& s0) {
+  static_assert(CD * CD <= 48, "q0 terms beyond three rows of the wave");
+  const double t = (*x.f_p0) * (*x.f_p1) * (*x.f_p2);      // unused lanes: zero * ...
+  msp_tables<CD>(x, c);
+  const double v = group_sum(t, 16);
+  q0 = (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + 0.0);
+  s0 = (readlane_d(v, 48) + 0.0) + (0.0 + 0.0);
+  msp_wave_fence();
+}
+
 // stage 1b.  After a barrier behind stage B; ends without a barrier.
+template <int CD, class X>
+__device__ __forceinline__ void msp_stage1b_qs(const X& x, const MomCfg& c, const MomSp& sp, double sn2a, double y, double q0, double s0);
 template <int CD, class X>
 __device__ __forceinline__ void msp_stage1b(const X& x, const MomCfg& c, const MomSp& sp, double sn2a, double y, const double* ws) {
   const MspLay l = msp_layout(CD, c.D);      // q0, s0 sit at the same offsets in both layouts
+  msp_stage1b_qs<CD>(x, c, sp, sn2a, y, ws[l.q0], ws[l.s0]);
+}
+template <int CD, class X>
+__device__ __forceinline__ void msp_stage1b_qs(const X& x, const MomCfg& c, const MomSp& sp, double sn2a, double y, double q0, double s0) {
   const bool four = __builtin_amdgcn_readfirstlane(sp.nzmax > 3 ? 1 : 0) != 0;
   const bool three = __builtin_amdgcn_readfirstlane(sp.nzmax > 2 ? 1 : 0) != 0;
-  const double q0 = ws[l.q0], s0 = ws[l.s0];
 #pragma unroll
   for (int u = 0; u < X::NPS; ++u) {
     if (__builtin_amdgcn_readfirstlane(x.p_any[u]) == 0) continue;   // wave-uniform skip
-    const double e0 = x.p_e[u][0][0], e1 = x.p_e[u][1][0];
-    double sam = (s0 + x.p_e[u][0][2 * MSP_TS]) + x.p_e[u][1][2 * MSP_TS];
-    double sa2 = (q0 + x.p_e[u][0][MSP_TS]) + x.p_e[u][1][MSP_TS];
-    double cr = (*x.p_q[u][0]) * e0 * e1;
+    // all table entries of the point first (one LDS round trip; the entries of components a point does not have are reads of the zero
+    // word), then arithmetic in the order of the reference form
+    double ev[MSP_NZ], tv[MSP_NZ], vv[MSP_NZ], qv[6];
+#pragma unroll
+    for (int r = 0; r < MSP_NZ; ++r) {
+      const bool on = r < 2 || (r == 2 && three) || (r == 3 && four);
+      ev[r] = tv[r] = vv[r] = 0.0;
+      if (on) { ev[r] = x.p_e[u][r][0]; tv[r] = x.p_e[u][r][MSP_TS]; vv[r] = x.p_e[u][r][2 * MSP_TS]; }
+    }
+    qv[0] = *x.p_q[u][0];
+    qv[1] = qv[2] = qv[3] = qv[4] = qv[5] = 0.0;
+    if (three) { qv[1] = *x.p_q[u][1]; qv[3] = *x.p_q[u][3]; }
+    if (four) { qv[2] = *x.p_q[u][2]; qv[4] = *x.p_q[u][4]; qv[5] = *x.p_q[u][5]; }
+#pragma unroll
+    for (int r = 0; r < MSP_NZ; ++r) asm volatile("" : "+v"(ev[r]), "+v"(tv[r]), "+v"(vv[r]));
+#pragma unroll
+    for (int r = 0; r < 6; ++r) asm volatile("" : "+v"(qv[r]));
+    const double e0 = ev[0], e1 = ev[1];
+    double sam = (s0 + vv[0]) + vv[1];
+    double sa2 = (q0 + tv[0]) + tv[1];
+    double cr = qv[0] * e0 * e1;
     if (three) {
-      const double e2 = x.p_e[u][2][0];
-      sam += x.p_e[u][2][2 * MSP_TS]; sa2 += x.p_e[u][2][MSP_TS];
-      cr = fma((*x.p_q[u][1]) * e0, e2, cr);
-      cr = fma((*x.p_q[u][3]) * e1, e2, cr);
+      const double e2 = ev[2];
+      sam += vv[2]; sa2 += tv[2];
+      cr = fma(qv[1] * e0, e2, cr);
+      cr = fma(qv[3] * e1, e2, cr);
       if (four) {
-        const double e3 = x.p_e[u][3][0];
-        sam += x.p_e[u][3][2 * MSP_TS]; sa2 += x.p_e[u][3][MSP_TS];
-        cr = fma((*x.p_q[u][2]) * e0, e3, cr);
-        cr = fma((*x.p_q[u][4]) * e1, e3, cr);
-        cr = fma((*x.p_q[u][5]) * e2, e3, cr);
+        const double e3 = ev[3];
+        sam += vv[3]; sa2 += tv[3];
+        cr = fma(qv[2] * e0, e3, cr);
+        cr = fma(qv[4] * e1, e3, cr);
+        cr = fma(qv[5] * e2, e3, cr);
       }
     }
     sa2 += cr;
@@ -522,6 +568,9 @@ struct MsrW {
   static constexpr bool PACKED = PACK;
   int q_kind; msp_rp q_ww, q_src; msp_wp q_out0, q_out1, q_out2, q_out3;
   int b_kind; msp_rp b_p0, b_p1, b_p2;
+  // folded form (msr_fold): EVERY worker wave forms the tables e / t1 / ve (lanes < CD*nd) and q0, s0 for itself between B2 and the
+  // weights -- no barrier B3, no wait for the serial wave
+  msp_rp a_l0[CD], a_l0own, a_qrow, a_qjj, a_v; msp_wp a_out; msp_rp f_p0, f_p1, f_p2;
   msp_rp p_e[1][MSP_NZ], p_q[1][6]; msp_wp p_c[1]; double p_wn[1]; bool p_ok[1]; int p_any[1];
   msp_rp m_a[NST], m_b[NST], m_w0; msp_wp m_part; int nst, m_on;
   msp_rp g_mem[PACK ? MSR_NMEM : 1]; msp_wp g_out;              // last worker: members of this lane's half of a marginal
@@ -593,6 +642,29 @@ __device__ __forceinline__ void msr_setup_W(MsrW<CD, PACK>& x, const MomCfg& c, 
     } else if (L2 >= 0 && L2 < CD) {
       const int j = L2;
       x.b_kind = 2; x.b_p0 = (msp_rp)(ws + l.v + j); x.b_p1 = (msp_rp)(ws + l.lk + j * nd + sp.c0); x.b_p2 = (msp_rp)(ws + l.one);
+    }
+  }
+  // ---- folded form: table lane t = lane (as on the serial wave's lanes, msr_setup_S); q0 terms on lanes 0 .. CD*CD-1 and the s0 terms
+  // on lanes 48 .. 48+CD-1 of ONE 16-lane group sum (CD*CD <= 48), or the layout of the two-wave form twice (msr_fold)
+  {
+    const int TN = CD * nd;
+    const int t = (lane < TN) ? lane : 0;
+    const int j = t / nd;
+    const int oz = opaque_zero();
+#pragma unroll
+    for (int j2 = 0; j2 < CD; ++j2) x.a_l0[j2] = (msp_rp)(ws + l.lk + j2 * nd + sp.c0) + oz;
+    x.a_l0own = (msp_rp)(ws + l.lk + j * nd + sp.c0);
+    x.a_qrow = (msp_rp)(ws + l.Q + j * CD);
+    x.a_qjj = (msp_rp)(ws + l.Q + j * CD + j);
+    x.a_v = (msp_rp)(ws + l.v + j);
+    x.a_out = (msp_wp)(ws + t);
+    x.f_p0 = x.f_p1 = x.f_p2 = (msp_rp)(ws + l.zero);
+    if (lane < CD * CD && CD * CD <= 48) {
+      const int jq = lane / CD, j2 = lane - jq * CD;
+      x.f_p0 = (msp_rp)(ws + l.Q + lane); x.f_p1 = (msp_rp)(ws + l.lk + jq * nd + sp.c0); x.f_p2 = (msp_rp)(ws + l.lk + j2 * nd + sp.c0);
+    } else if (lane >= 48 && lane < 48 + CD && CD * CD <= 48) {
+      const int js = lane - 48;
+      x.f_p0 = (msp_rp)(ws + l.v + js); x.f_p1 = (msp_rp)(ws + l.lk + js * nd + sp.c0); x.f_p2 = (msp_rp)(ws + l.one);
     }
   }
   // ---- Q / 2Q / v on workers 0..2: 4-lane group -> one entry

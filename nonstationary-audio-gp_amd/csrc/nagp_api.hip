@@ -398,7 +398,8 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
   p->TPT = (nt + 511) / 512;   // <= 512 threads per workgroup: 256 VGPRs per lane for the register-resident tiles
   const bool ih = (o->kind == NAGP_KIND_IHGP);   // no covariance tiles: the tile-count limits below do not apply
   if (ih) p->TPT = std::min(p->TPT, 4);
-  if (!ih && (p->TPT > 4 || sh.S > 512)) { const int Mx = sh.M, Sx = sh.S; nagp_plan_destroy(p); FAIL(NAGP_EUNSUPPORTED, "M=%d / S=%d: more than 2048 tiles or 512 states", Mx, Sx); }
+  if (!ih && p->TPT > 4 && p->TPT <= 8) p->TPT = 8;     // instantiated: 1 .. 4 and 8 tiles per thread (8: scratch-resident tiles, 46 .. 64 sites)
+  if (!ih && (p->TPT > 8 || sh.S > 512)) { const int Mx = sh.M, Sx = sh.S; nagp_plan_destroy(p); FAIL(NAGP_EUNSUPPORTED, "M=%d / S=%d: more than 4096 tiles or 512 states", Mx, Sx); }
   p->NT = std::max(roundup64((nt + p->TPT - 1) / p->TPT), std::max(roundup64(sh.S), 128));
   {   // filter: one thread per lower-triangular tile
     const int slots = sh.M * (sh.M + 1) / 2;
@@ -807,11 +808,15 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     if (filter_lds_doubles(sh, t, ekf ? 1 : 0, p->kb_f) * sizeof(double) > cap) p->kb_f = 4;
     if (filter_lds_doubles(sh, t, ekf ? 1 : 0, p->kb_f) * sizeof(double) > cap) t.store_a = 0;
     if (filter_lds_doubles(sh, t, ekf ? 1 : 0, p->kb_f) * sizeof(double) > cap) t.cache_tabs = 0;
+    if (filter_lds_doubles(sh, t, ekf ? 1 : 0, p->kb_f) * sizeof(double) > cap) p->kb_f = 2;      // 59 .. 63 sites: the W panel alone is 110 - 127 KB
+    if (filter_lds_doubles(sh, t, ekf ? 1 : 0, p->kb_f) * sizeof(double) > cap) p->kb_f = 1;
+    if (const char* e = getenv("NAGP_KB_F")) p->kb_f = std::max(1, std::min(16, atoi(e)));      // developer switches: the fall-backs of LDS-tight shapes
+    if (getenv("NAGP_NO_CACHE_TABS")) { t.cache_tabs = 0; t.store_a = 0; }
     p->cache_f = t.cache_tabs; p->sta_f = t.store_a;
     p->lds_filter = filter_lds_doubles(sh, t, ekf ? 1 : 0, p->kb_f) * sizeof(double);
     // pipelined plans: the filter's workgroup asks for the whole LDS of its CU, so that no workgroup of the smoother kernels running
     // beside it on the second stream is placed on the same CU (the filter is the critical path; its time is latency, not occupancy)
-    if (p->pipeline) p->lds_filter = 160 * 1024;
+    if (p->pipeline && p->lds_filter < 160 * 1024) p->lds_filter = 160 * 1024;     // (never BELOW what the kernel needs: set_lds refuses > 160 KiB)
     if (getenv("NAGP_STAMPS")) fprintf(stderr, "[nagp plan] gf filter: LDS %zu B, ring %d steps, cubature tables in LDS %d, mom LDS %zu B, sparse-point ADF %d\n", p->lds_filter, p->kb_f, p->cache_f, ekf ? (size_t)0 : mom_lds_doubles(t) * sizeof(double), p->sp_gf);
     p->lds_gain = gain_lds_doubles(sh) * sizeof(double);
     p->lds_scan = span_lds_doubles(sh, p->LP1, p->LP2) * sizeof(double);
@@ -862,7 +867,8 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
       case 1: PLAN_TRY(set_lds(rts_gain_kernel<1>, p->lds_gain)); PLAN_TRY(set_lds(rts_compose_kernel<1>, p->lds_scan)); PLAN_TRY(set_lds(rts_boundary_kernel<1>, p->lds_scan)); PLAN_TRY(set_lds(rts_apply_kernel<1>, p->lds_scan)); break;
       case 2: PLAN_TRY(set_lds(rts_gain_kernel<2>, p->lds_gain)); PLAN_TRY(set_lds(rts_compose_kernel<2>, p->lds_scan)); PLAN_TRY(set_lds(rts_boundary_kernel<2>, p->lds_scan)); PLAN_TRY(set_lds(rts_apply_kernel<2>, p->lds_scan)); break;
       case 3: PLAN_TRY(set_lds(rts_gain_kernel<3>, p->lds_gain)); PLAN_TRY(set_lds(rts_compose_kernel<3>, p->lds_scan)); PLAN_TRY(set_lds(rts_boundary_kernel<3>, p->lds_scan)); PLAN_TRY(set_lds(rts_apply_kernel<3>, p->lds_scan)); break;
-      default: PLAN_TRY(set_lds(rts_gain_kernel<4>, p->lds_gain)); PLAN_TRY(set_lds(rts_compose_kernel<4>, p->lds_scan)); PLAN_TRY(set_lds(rts_boundary_kernel<4>, p->lds_scan)); PLAN_TRY(set_lds(rts_apply_kernel<4>, p->lds_scan)); break;
+      case 4: PLAN_TRY(set_lds(rts_gain_kernel<4>, p->lds_gain)); PLAN_TRY(set_lds(rts_compose_kernel<4>, p->lds_scan)); PLAN_TRY(set_lds(rts_boundary_kernel<4>, p->lds_scan)); PLAN_TRY(set_lds(rts_apply_kernel<4>, p->lds_scan)); break;
+      default: PLAN_TRY(set_lds(rts_gain_kernel<8>, p->lds_gain)); PLAN_TRY(set_lds(rts_compose_kernel<8>, p->lds_scan)); PLAN_TRY(set_lds(rts_boundary_kernel<8>, p->lds_scan)); PLAN_TRY(set_lds(rts_apply_kernel<8>, p->lds_scan)); break;
     }
   }
   if (!ekf && o->kind == NAGP_KIND_GF_EP && o->mode == NAGP_MODE_PREDICT && !(o->flags & NAGP_FLAG_MIXTURE_RULE) && 4 * sh.M <= 160 && getenv("NAGP_LIN_MFMA")) {
@@ -871,7 +877,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     const int ntl = (4 * sh.M + 15) / 16;
     p->lin_mfma = ntl;
     p->lds_lin = flm_lds_doubles(sh, ntl, 16) * sizeof(double);
-    if (p->pipeline) p->lds_lin = 160 * 1024;      // (the CU to itself, as for the other filter launches)
+    if (p->pipeline && p->lds_lin < 160 * 1024) p->lds_lin = 160 * 1024;      // (the CU to itself, as for the other filter launches)
 #define SETF(N, W) PLAN_TRY(set_lds((gf_filter_lin_mfma_kernel<N, W>), p->lds_lin))
     switch (ntl) { case 1: SETF(1, 4); break; case 2: SETF(2, 4); break; case 3: SETF(3, 4); break; case 4: SETF(4, 4); break; case 5: SETF(5, 4); break;
                    case 6: SETF(6, 8); break; case 7: SETF(7, 8); break; case 8: SETF(8, 8); break; case 9: SETF(9, 8); break; default: SETF(10, 8); break; }
@@ -1170,7 +1176,8 @@ static int launch_gain_chunk(nagp_plan* p, const SweepCtx& sc, int c, int slot, 
     case 1: hipLaunchKernelGGL((rts_gain_kernel<1>), gr, bl, p->lds_gain, st, sh, b, gp); break;
     case 2: hipLaunchKernelGGL((rts_gain_kernel<2>), gr, bl, p->lds_gain, st, sh, b, gp); break;
     case 3: hipLaunchKernelGGL((rts_gain_kernel<3>), gr, bl, p->lds_gain, st, sh, b, gp); break;
-    default: hipLaunchKernelGGL((rts_gain_kernel<4>), gr, bl, p->lds_gain, st, sh, b, gp); break;
+    case 4: hipLaunchKernelGGL((rts_gain_kernel<4>), gr, bl, p->lds_gain, st, sh, b, gp); break;
+    default: hipLaunchKernelGGL((rts_gain_kernel<8>), gr, bl, p->lds_gain, st, sh, b, gp); break;
   }
   HIP_TRY(hipGetLastError());
   return NAGP_OK;
@@ -1222,7 +1229,7 @@ static int launch_compose_chunk(nagp_plan* p, const SweepCtx& sc, int c, int slo
     SpanPar sp = span_par(p, sc, c, slot);
     dim3 gr(g.ns, p->B), bl(p->NT);
 #define LS(TP) hipLaunchKernelGGL((rts_compose_kernel<TP>), gr, bl, p->lds_scan, st, sh, b, sp)
-    switch (p->TPT) { case 1: LS(1); break; case 2: LS(2); break; case 3: LS(3); break; default: LS(4); break; }
+    switch (p->TPT) { case 1: LS(1); break; case 2: LS(2); break; case 3: LS(3); break; case 4: LS(4); break; default: LS(8); break; }
 #undef LS
   }
   HIP_TRY(hipGetLastError());
@@ -1253,7 +1260,7 @@ static int launch_boundary_chunk(nagp_plan* p, const SweepCtx& sc, int c, int sl
     SpanPar sp = span_par(p, sc, c, slot);
     dim3 bl(p->NT);
 #define LS(TP) hipLaunchKernelGGL((rts_boundary_kernel<TP>), g2, bl, p->lds_scan, st, sh, b, sp)
-    switch (p->TPT) { case 1: LS(1); break; case 2: LS(2); break; case 3: LS(3); break; default: LS(4); break; }
+    switch (p->TPT) { case 1: LS(1); break; case 2: LS(2); break; case 3: LS(3); break; case 4: LS(4); break; default: LS(8); break; }
 #undef LS
   }
   HIP_TRY(hipGetLastError());
@@ -1281,7 +1288,7 @@ static int launch_apply_chunk(nagp_plan* p, const SweepCtx& sc, int c, int slot,
     SpanPar sp = span_par(p, sc, c, slot);
     dim3 gr(g.ns, p->B), bl(p->NT);
 #define LS(TP) hipLaunchKernelGGL((rts_apply_kernel<TP>), gr, bl, p->lds_scan, st, sh, b, sp)
-    switch (p->TPT) { case 1: LS(1); break; case 2: LS(2); break; case 3: LS(3); break; default: LS(4); break; }
+    switch (p->TPT) { case 1: LS(1); break; case 2: LS(2); break; case 3: LS(3); break; case 4: LS(4); break; default: LS(8); break; }
 #undef LS
   }
   HIP_TRY(hipGetLastError());
@@ -1357,7 +1364,7 @@ static int launch_apply_merged(nagp_plan* p, const SweepCtx& sc, int n_own, hipS
     SpanPar sp = span_par(p, sc, 0, sc.slot_of[0]); sp.tab = p->h_tab; sp.ntab = n_own;
     dim3 bl(p->NT);
 #define LS(TP) hipLaunchKernelGGL((rts_apply_kernel<TP>), gr, bl, p->lds_scan, st, sh, b, sp)
-    switch (p->TPT) { case 1: LS(1); break; case 2: LS(2); break; case 3: LS(3); break; default: LS(4); break; }
+    switch (p->TPT) { case 1: LS(1); break; case 2: LS(2); break; case 3: LS(3); break; case 4: LS(4); break; default: LS(8); break; }
 #undef LS
   }
   HIP_TRY(hipGetLastError());

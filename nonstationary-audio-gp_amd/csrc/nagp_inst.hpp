@@ -41,6 +41,9 @@
   P void nagp::rts_compose_kernel<TPT>(nagp::Shape, nagp::Bufs, nagp::SpanPar);                                          \
   P void nagp::rts_boundary_kernel<TPT>(nagp::Shape, nagp::Bufs, nagp::SpanPar);                                         \
   P void nagp::rts_apply_kernel<TPT>(nagp::Shape, nagp::Bufs, nagp::SpanPar);
+// eight tiles per thread (2 049 .. 4 096 tiles: 46 .. 64 sites, the source-separation mixture at 48 channels / 9 modulators): the tiles
+// spill to scratch (~3 KB per lane in the gain kernel) -- served, not tuned
+#define NAGP_LIST_SMOOTH8(P) NAGP_LIST_SMOOTH_T(P, 8)
 #define NAGP_LIST_SMOOTH_M(P, NTL)                                                                                         \
   P void nagp::rts_compose_mfma_kernel<NTL>(nagp::Shape, nagp::Bufs, nagp::MfmaPar);                                     \
   P void nagp::rts_boundary_mfma_kernel<NTL>(nagp::Shape, nagp::Bufs, nagp::MfmaPar);                                    \
@@ -119,4 +122,4 @@
 
 #define NAGP_LIST_ALL(P)                                                                                                   \
   NAGP_LIST_GF_ADF1(P) NAGP_LIST_GF_ADF2(P) NAGP_LIST_GF_ADF3(P) NAGP_LIST_GF_ADF4(P) NAGP_LIST_GF_ADF5(P)               \
-  NAGP_LIST_GF_SP12(P) NAGP_LIST_GF_SP34(P) NAGP_LIST_GF_REST(P) NAGP_LIST_SMOOTH(P) NAGP_LIST_BIG(P) NAGP_LIST_GAINM(P) NAGP_LIST_FLM(P) NAGP_LIST_EP(P) NAGP_LIST_EPS(P) NAGP_LIST_IH0(P) NAGP_LIST_IH1(P) NAGP_LIST_IHA(P) NAGP_LIST_IHA8(P)
+  NAGP_LIST_GF_SP12(P) NAGP_LIST_GF_SP34(P) NAGP_LIST_GF_REST(P) NAGP_LIST_SMOOTH(P) NAGP_LIST_SMOOTH8(P) NAGP_LIST_BIG(P) NAGP_LIST_GAINM(P) NAGP_LIST_FLM(P) NAGP_LIST_EP(P) NAGP_LIST_EPS(P) NAGP_LIST_IH0(P) NAGP_LIST_IH1(P) NAGP_LIST_IHA(P) NAGP_LIST_IHA8(P)

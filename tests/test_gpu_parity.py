@@ -1250,11 +1250,11 @@ def _run_schedules(kind, probs, ys, T, chunk, **kw):
     return res
 
 
-@pytest.mark.parametrize('D,N,want_ps', [(32, 6, False), (32, 6, True), (16, 3, False), (16, 3, True), (36, 8, False)])
+@pytest.mark.parametrize('D,N,want_ps', [(32, 6, False), (32, 6, True), (16, 3, False), (16, 3, True), (36, 8, False), (48, 9, False)])
 def test_pipelined_smoother_is_bit_equal_to_the_serial_schedule(D, N, want_ps):
     """Eight (four) segments, several chunks per sweep, three sweeps: 32 channels / 6 components (S = 146, column-owner MFMA passes;
     with smoothed covariances requested the last sweep runs the VALU passes), 16 / 3 (S = 73, dense MFMA passes), 36 / 8 (44 sites: VALU
-    passes only).  Every output of the pipelined schedules equals the serial schedule's bit for bit."""
+    passes only), 48 / 9 (57 sites: eight tiles per thread).  Every output of the pipelined schedules equals the serial schedule's bit for bit."""
     T = 150; B = 8 if D == 32 else 4
     probs, ys = [], []
     for q in range(B):
@@ -1262,7 +1262,7 @@ def test_pipelined_smoother_is_bit_equal_to_the_serial_schedule(D, N, want_ps):
         blk = pss.balance_blocks(pss.ss_blocks_nmf(pr['param1'], pr['param2'], 'matern32', 'matern52'))
         y = pr['y'].copy(); y[7 * q + 5] = np.nan
         probs.append((blk, pr['W'], np.log(pr['w_lik']))); ys.append(y)
-    mom = Mom('likModulatorNMFPower', p_cubature=3 if D == 36 else 5); d = 0.5 * np.ones(3)
+    mom = Mom('likModulatorNMFPower', p_cubature=3 if D >= 36 else 5); d = 0.5 * np.ones(3)
     res = _run_schedules(L.KIND_GF_EP, probs, ys, T, 24, mom=mom, ep_fraction=0.5, ep_damping=d, ep_itts=3, flags=L.FLAG_WANT_PS if want_ps else 0)
     for q in range(B):
         for other in ('pipelined', 'two_buffers'):
@@ -1537,3 +1537,50 @@ def test_slots_recycled_from_the_filtered_covariances_equal_the_serial_schedule(
             for f in fields:
                 assert np.array_equal(getattr(res[other][q], f), getattr(res['serial'][q], f), equal_nan=True), (other, q, f)
             assert np.array_equal(res[other][q].counters, res['serial'][q].counters)
+
+
+def test_mixture_at_the_papers_size_on_the_full_covariance_path():
+    """experiments/source_sep_piano.m:78-90: three sources of 16 channels and 3 NMF components each -- 48 sub-bands + 9 modulators =
+    57 sites, 3 249 covariance tiles: eight tiles per thread in the gain kernel and the (VALU) smoother passes, four lower tiles per
+    thread in the filter.  gf_ep_mods_nmf_mixture with the exp sub-band kernels of the driver (S = 123), and gf_ep_modulator_nmf at the
+    same 48 / 9 with Matern-3/2 sub-bands (S = 219), against the oracle."""
+    shapes = [(16, 3)] * 3; k1 = ['exp'] * 3; k2 = ['matern52'] * 3
+    T = 14; t = np.arange(1, T + 1.0)
+    mp = harness.mixture_problem(shapes, T, 77, k1, k2)
+    mom, omom = _mixture_moms('likModulatorPreCalcwn', 3, 9)
+    a = nagp.gf_ep_mods_nmf_mixture(mp['w'], t, mp['y'], SSHandle(), mom, t, k1, k2, 3, 0.75, 0.2, 2, nargout=6)
+    b = omx.gf_ep_mods_nmf_mixture(mp['w'], t, mp['y'], None, omom, t, k1, k2, 3, 0.75, 0.2, 2)
+    assert a[0].shape == (57, T)
+    assert rel(a[0], b[0]) < TOL_MEAN and rel(a[1], b[1]) < TOL_MEAN
+    assert rel(a[5]['ttau'], b[5]['ttau']) < TOL_SITE and rel(a[5]['tnu'], b[5]['tnu']) < TOL_SITE and rel(a[5]['MS'], b[5]['MS']) < TOL_MEAN
+    D, N, T = 48, 9, 12
+    pr = harness.nmf_problem(D, N, T, 9911); t = np.arange(1, T + 1.0)
+    d = 0.5 * np.ones(2)
+    Eft, Varft, _, _, _, out = nagp.gf_ep_modulator_nmf(pr['w'], t, pr['y'], SSHandle(), Mom('likModulatorNMFPower', p_cubature=3), t, 'matern32', 'matern52', 1, D, N,
+                                                        0.5, d, 2, nargout=6)
+    o = ogf.gf_ep_modulator_nmf(pr['w'], t, pr['y'], None, olik.Mom(olik.LIK_POWER_NMF, p=3), t, 'matern32', 'matern52', 1, D, N, 0.5, d, 2)
+    assert rel(Eft, o[0]) < TOL_MEAN and rel(Varft, o[1]) < TOL_MEAN and relz(out['nlZ'], o[5]['nlZ']) < TOL_LOGZ
+    assert rel(out['ttau'], o[5]['ttau']) < TOL_SITE and rel(out['tnu'], o[5]['tnu']) < TOL_SITE
+
+
+def test_lds_tight_shapes_are_served_or_refused_never_wrong():
+    """59 - 63 sites: the filter's W panel alone is 110 - 127 KB of LDS.  The plan falls back to a shorter I/O ring and cubature tables in
+    global memory; what still does not fit is refused with NAGP_EUNSUPPORTED -- in the pipelined schedule as well, whose filter launch asks
+    for the whole LDS of its CU (that request once replaced a LARGER need: wrong results instead of a refusal)."""
+    D, N, T = 56, 3, 40
+    pr = harness.nmf_problem(D, N, T, 4242, 'constraints')
+    blk = pss.balance_blocks(pss.ss_blocks_nmf(pr['param1'], pr['param2'], 'exp', 'matern32'))
+    assert blk.M == 59
+    d = 0.5 * np.ones(2)
+    o = ogf.run_predict(ogf.assemble(np.log(pr['w_lik']) * np.ones(1), pr['param1'], pr['param2'], pr['W'], 'exp', 'matern32', True), pr['y'],
+                        olik.Mom(olik.LIK_POWER_NMF, p=3), 0.5, d, 2)
+    for chunk in (16, 0):          # several chunks (pipelined) / one chunk (serial)
+        plan = Plan(L.KIND_GF_EP, [(blk, pr['W'], np.log(pr['w_lik']))], T, mom=Mom('likModulatorNMFPower', p_cubature=3), ep_fraction=0.5, ep_damping=d, ep_itts=2, chunk=chunk)
+        plan.upload([pr['y']]); plan.execute(); r = plan.download()[0]; plan.close()
+        assert rel(r.Eft, o['Eft']) < TOL_MEAN and rel(r.Varft, o['Varft']) < TOL_MEAN and relz(r.nlZ, o['nlZ']) < TOL_LOGZ, chunk
+    pr = harness.nmf_problem(54, 9, T, 4243, 'constraints')
+    blk = pss.balance_blocks(pss.ss_blocks_nmf(pr['param1'], pr['param2'], 'exp', 'matern32'))
+    assert blk.M == 63
+    for chunk in (16, 0):
+        with pytest.raises(nagp.NagpError, match='unsupported shape'):
+            Plan(L.KIND_GF_EP, [(blk, pr['W'], np.log(pr['w_lik']))], T, mom=Mom('likModulatorNMFPower', p_cubature=3), ep_fraction=0.5, ep_damping=d, ep_itts=2, chunk=chunk)

@@ -1561,6 +1561,10 @@ def test_mixture_at_the_papers_size_on_the_full_covariance_path():
     o = ogf.gf_ep_modulator_nmf(pr['w'], t, pr['y'], None, olik.Mom(olik.LIK_POWER_NMF, p=3), t, 'matern32', 'matern52', 1, D, N, 0.5, d, 2)
     assert rel(Eft, o[0]) < TOL_MEAN and rel(Varft, o[1]) < TOL_MEAN and relz(out['nlZ'], o[5]['nlZ']) < TOL_LOGZ
     assert rel(out['ttau'], o[5]['ttau']) < TOL_SITE and rel(out['tnu'], o[5]['tnu']) < TOL_SITE
+    # and the EKF family at the same 48 / 9 (two global iterations, two inner ones)
+    r = nagp.gf_giekf_modulator_nmf(pr['w'], t, pr['y'], SSHandle(), None, t, 'exp', 'matern32', 1, D, N, 2, 2, nargout=2)
+    oe = oek.gf_giekf_modulator_nmf(pr['w'], t, pr['y'], None, None, t, 'exp', 'matern32', 1, D, N, 2, 2)
+    assert rel(r[0], oe[0]) < TOL_MEAN and rel(r[1], oe[1]) < TOL_MEAN
 
 
 def test_lds_tight_shapes_are_served_or_refused_never_wrong():

@@ -73,7 +73,7 @@ struct nagp_plan {
   bool want_PS = false;
   bool need_PF = false;
   MomSrc src_all{};     // block structure of Wnmf (n_src >= 2) and which kernels use it
-  int src_f = 0, src_ep = 0, kb_ih = 16;
+  int src_f = 0, src_ep = 0, kb_ih = 16, chunk_cap_f = 0;
   MomSp sp{};           // sparse-point form of likModulatorNMFPower (nagp_momsp.hpp); sp_ih: the IHGP ADF sweep uses it
   int sp_ih = 0, sp_gf = 0, kb_sp = 16, hph_sp = 1; size_t lds_sp = 0;
   int sp_ep = 0; size_t lds_ep_sp = 0;      // site refresh (ep_site_sp_kernel) in the sparse-point form
@@ -810,6 +810,9 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     if (filter_lds_doubles(sh, t, ekf ? 1 : 0, p->kb_f) * sizeof(double) > cap) t.cache_tabs = 0;
     if (filter_lds_doubles(sh, t, ekf ? 1 : 0, p->kb_f) * sizeof(double) > cap) p->kb_f = 2;      // 59 .. 63 sites: the W panel alone is 110 - 127 KB
     if (filter_lds_doubles(sh, t, ekf ? 1 : 0, p->kb_f) * sizeof(double) > cap) p->kb_f = 1;
+    if (filter_lds_doubles(sh, t, ekf ? 1 : 0, p->kb_f) * sizeof(double) > cap) t.chunk_cap = 256;   // ut7 / ut9 in nine dimensions at 57 sites: 256 points per pass
+    if (const char* e = getenv("NAGP_MOM_CHUNK")) t.chunk_cap = std::max(64, atoi(e));      // developer switch
+    p->chunk_cap_f = t.chunk_cap;
     if (const char* e = getenv("NAGP_KB_F")) p->kb_f = std::max(1, std::min(16, atoi(e)));      // developer switches: the fall-backs of LDS-tight shapes
     if (getenv("NAGP_NO_CACHE_TABS")) { t.cache_tabs = 0; t.store_a = 0; }
     p->cache_f = t.cache_tabs; p->sta_f = t.store_a;
@@ -999,7 +1002,7 @@ static int launch_filter(nagp_plan* p, const FilterPar& fp_in) {
   if (p->pipeline && fp.store_PF) { fp.progress = p->h_progress; fp.progress_every = 256; }
   if (const char* e = getenv("NAGP_FILTER_DBG")) fp.dbg = atoi(e);   // developer switch: see FilterPar::dbg
   const bool ekf = p->opts.kind == NAGP_KIND_GIEKF;
-  MomCfg mc = p->mc; mc.DG = p->DG_f; mc.cache_tabs = p->cache_f; mc.store_a = p->sta_f;
+  MomCfg mc = p->mc; mc.DG = p->DG_f; mc.cache_tabs = p->cache_f; mc.store_a = p->sta_f; mc.chunk_cap = p->chunk_cap_f;
   mc.sp = p->sp_gf ? p->sp : MomSp{};
   if (getenv("NAGP_STAMPS")) mc.stamps = reinterpret_cast<unsigned long long*>(p->d_stamps);   // developer diagnostics
   const bool adf = ekf || fp.mom_all || fp.k_end == p->sh.T;   // launches that may call mom (or the EKF filter)

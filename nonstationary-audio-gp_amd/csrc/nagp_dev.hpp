@@ -211,6 +211,7 @@ struct MomCfg {
   int store_a;       // POWER_NMF_SQRT: keep a[d][p] = sqrt(W_d . link(xn_p)) in LDS between the phases (one sqrt per (p, d))
   unsigned long long* stamps;  // developer diagnostics: per-phase cycle sums of thread 0 (null in production)
   MomSrc src;        // n_src >= 2: mom_src instead of the per-point evaluation (needs cache_tabs)
+  int chunk_cap;     // sigma points per pass of the per-point evaluation (0: 1024); smaller for LDS-tight launches (the per-point arrays are 3+ doubles per point)
   MomSp sp;          // enabled: the kernels that have the staged form (nagp_momsp.hpp) use it instead of mom_eval
 };
 
@@ -219,7 +220,7 @@ typedef const double __attribute__((address_space(3))) * lds_f64p;          // a
 constexpr int MOM_NDM = 4;    // NMF likelihoods: sub-bands per lane and pass (their W rows live in registers)
 constexpr int MOM_MAXW = 8;   // waves per workgroup the cross-wave reduction buffers are sized for (launch bounds <= 512)
 
-__host__ __device__ inline int mom_chunk(const MomCfg& c) { return c.n_pts < 1024 ? c.n_pts : 1024; }
+__host__ __device__ inline int mom_chunk(const MomCfg& c) { const int cap = c.chunk_cap > 0 ? c.chunk_cap : 1024; return c.n_pts < cap ? c.n_pts : cap; }
 // LDS workspace layout (offsets in doubles)
 constexpr int MOM_REP = 4;    // POWER_NMF: replicas (16-lane groups) per phase-2 task
 struct MomLay { size_t rows, c0, c1, c2, sg, lkv, xgv, xg2v, sums1, sums2, part, acc, qv, xd, core, tw, tc, total, atab, s2b, smb, cb, ipart; };

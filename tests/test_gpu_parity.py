@@ -1553,6 +1553,11 @@ def test_mixture_at_the_papers_size_on_the_full_covariance_path():
     assert a[0].shape == (57, T)
     assert rel(a[0], b[0]) < TOL_MEAN and rel(a[1], b[1]) < TOL_MEAN
     assert rel(a[5]['ttau'], b[5]['ttau']) < TOL_SITE and rel(a[5]['tnu'], b[5]['tnu']) < TOL_SITE and rel(a[5]['MS'], b[5]['MS']) < TOL_MEAN
+    # the driver's own rule, ut9 in nine dimensions (3 973 sigma points): the ADF launch evaluates them 256 per pass to fit the LDS beside the W panel
+    mom9, omom9 = _mixture_moms('likModulatorPreCalcwn', 9, 9)
+    a = nagp.gf_ep_mods_nmf_mixture(mp['w'], t[:8], mp['y'][:8], SSHandle(), mom9, t[:8], k1, k2, 3, 0.75, 0.2, 2, nargout=6)
+    b = omx.gf_ep_mods_nmf_mixture(mp['w'], t[:8], mp['y'][:8], None, omom9, t[:8], k1, k2, 3, 0.75, 0.2, 2)
+    assert rel(a[0], b[0]) < TOL_MEAN and rel(a[1], b[1]) < TOL_MEAN and rel(a[5]['ttau'], b[5]['ttau']) < TOL_SITE
     D, N, T = 48, 9, 12
     pr = harness.nmf_problem(D, N, T, 9911); t = np.arange(1, T + 1.0)
     d = 0.5 * np.ones(2)

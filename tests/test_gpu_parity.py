@@ -1250,7 +1250,7 @@ def _run_schedules(kind, probs, ys, T, chunk, **kw):
     return res
 
 
-@pytest.mark.parametrize('D,N,want_ps', [(32, 6, False), (32, 6, True), (16, 3, False), (16, 3, True), (36, 8, False), (48, 9, False)])
+@pytest.mark.parametrize('D,N,want_ps', [(32, 6, False), (32, 6, True), (16, 3, False), (16, 3, True), (36, 8, False), (48, 9, False), (48, 9, True)])
 def test_pipelined_smoother_is_bit_equal_to_the_serial_schedule(D, N, want_ps):
     """Eight (four) segments, several chunks per sweep, three sweeps: 32 channels / 6 components (S = 146, column-owner MFMA passes;
     with smoothed covariances requested the last sweep runs the VALU passes), 16 / 3 (S = 73, dense MFMA passes), 36 / 8 (44 sites: VALU

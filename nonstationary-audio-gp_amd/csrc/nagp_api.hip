@@ -821,7 +821,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     // beside it on the second stream is placed on the same CU (the filter is the critical path; its time is latency, not occupancy)
     if (p->pipeline && p->lds_filter < 160 * 1024) p->lds_filter = 160 * 1024;     // (never BELOW what the kernel needs: set_lds refuses > 160 KiB)
     if (getenv("NAGP_STAMPS")) fprintf(stderr, "[nagp plan] gf filter: LDS %zu B, ring %d steps, cubature tables in LDS %d, mom LDS %zu B, sparse-point ADF %d\n", p->lds_filter, p->kb_f, p->cache_f, ekf ? (size_t)0 : mom_lds_doubles(t) * sizeof(double), p->sp_gf);
-    p->lds_gain = gain_lds_doubles(sh) * sizeof(double);
+    p->lds_gain = ((p->TPT == 1) ? gain_lds_doubles_staged(sh) : gain_lds_doubles(sh)) * sizeof(double);     // (rts_gain_kernel: STAGE)
     p->lds_scan = span_lds_doubles(sh, p->LP1, p->LP2) * sizeof(double);
     if (ekf) {
       switch (p->TPT_f) {
@@ -864,6 +864,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     }
     if (nt > 1024 && nt <= 1536 && sh.M * (sh.M + 1) / 2 <= 768 && sh.S <= 768 && !getenv("NAGP_NO_GAIN768")) {
       p->gain768 = 1;
+      p->lds_gain = gain_lds_doubles_staged(sh) * sizeof(double);
       PLAN_TRY(set_lds(rts_gain_kernel<2, 768>, p->lds_gain));
     }
     switch (p->TPT) {

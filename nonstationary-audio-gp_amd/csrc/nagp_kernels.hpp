@@ -770,6 +770,12 @@ __host__ __device__ inline size_t gd_step_doubles(int Sp, int dpacked) {      //
 __host__ __device__ inline size_t gain_lds_doubles(const Shape& s) {
   return LDS_INT_DOUBLES + (size_t)s.M * 16 * 2 + 4 * (size_t)s.M * TS + 8;
 }
+// the 768-thread instantiation (one workgroup per CU anyway) and the one-tile-per-thread one stage PS_k in LDS: its tiles are read three
+// times (PSkp by the lower owners, B = PS A' by the owners of (I,J) and of (J,I)), at 768 threads by lanes that have no registers to hoist the
+// loads with.  Measured (tools/ab_libs.sh, same box): gain launches of 32 x 12 500 steps at S = 146 899 -> ~780 ms (cfg5_fill 1 873 -> 1 755 ms,
+// cfg5 x 8 4 762 -> 4 681), cfg2_batch 557 -> 551 ms; two tiles per thread: no change (not staged: the LDS would cost the second workgroup of a CU
+// at 30+ sites)
+__host__ __device__ inline size_t gain_lds_doubles_staged(const Shape& s) { return ((gain_lds_doubles(s) + 1) & ~(size_t)1) + pf_step_doubles(s); }
 
 // in-place Cholesky of the leading bs x bs lower triangle of a 4x4 tile; padding -> identity.
 // rd[j] = 1 / L(j,j): the triangular solves below multiply by it (sixteen f64 divisions per tile solve otherwise --
@@ -893,6 +899,15 @@ __global__ void __launch_bounds__(LB) __attribute__((amdgpu_waves_per_eu(LB > 51
   }
   const double* PFk = b.PF + ((size_t)pb * T + k) * pf_step_doubles(sh);
   const double* PFk1 = PFk + pf_step_doubles(sh);
+  constexpr bool STAGE = LB > 512 || TPT == 1;      // (one tile per thread: <= 22 sites, 50 KB of LDS with the staged tiles -- three workgroups per CU still fit)
+  double* sPF = lds + ((gain_lds_doubles(sh) + 1) & ~(size_t)1);       // STAGE: PS_k in the layout of PF (pf_off)
+  const double* PSk = STAGE ? sPF : PFk;
+  if constexpr (STAGE) {
+    const double2* src = reinterpret_cast<const double2*>(PFk);
+    double2* dst = reinterpret_cast<double2*>(sPF);
+    const int n2 = (int)(pf_step_doubles(sh) / 2);
+    for (int i = tid; i < n2; i += NT) dst[i] = src[i];
+  }
   const size_t mstride = gp.dense_sp ? (size_t)gp.dense_sp * gp.dense_sp : (size_t)sh.ntiles * 16;
   const size_t gstep = gp.dense_sp ? gd_step_doubles(gp.dense_sp, gp.dpacked) : 2 * mstride;
   double* Gout = b.Gbuf + (b.gpstride ? (size_t)pb * b.gpstride + (size_t)kk * gstep : ((size_t)pb * gp.chunk + kk) * gstep);
@@ -942,7 +957,7 @@ __global__ void __launch_bounds__(LB) __attribute__((amdgpu_waves_per_eu(LB > 51
   // PSkp(I,J) = A_I PS(I,J) A_J' (+ Q, + the jitter of the second attempt), I >= J
   auto pskp_tile = [&](double* Lq, int I, int J, bool jitter) {
     double ps[16], bt[16];
-    pf_load(ps, PFk, I, J);
+    pf_load(ps, PSk, I, J);
     tile_zero(bt);
     tile_mma_nt(bt, ps, sA + (size_t)J * 16);
     tile_zero(Lq);
@@ -968,7 +983,7 @@ __global__ void __launch_bounds__(LB) __attribute__((amdgpu_waves_per_eu(LB > 51
 #pragma unroll
   for (int q = 0; q < TPT; ++q) {
     tile_zero(Bt[q]);
-    if (HOIST && own.ok[q]) pf_load(Bt[q], PFk, own.I[q], own.J[q]);
+    if (HOIST && !STAGE && own.ok[q]) pf_load(Bt[q], PFk, own.I[q], own.J[q]);
   }
 #pragma unroll
   for (int q = 0; q < TPL; ++q) {
@@ -1007,12 +1022,12 @@ __global__ void __launch_bounds__(LB) __attribute__((amdgpu_waves_per_eu(LB > 51
     if (own.ok[q]) {
       const int I = own.I[q], J = own.J[q];
       double ps[16];
-      if constexpr (HOIST) {
+      if constexpr (HOIST && !STAGE) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) ps[e] = Bt[q][e];
         tile_zero(Bt[q]);
       } else {
-        pf_load(ps, PFk, I, J);
+        pf_load(ps, PSk, I, J);
       }
       tile_mma_nt(Bt[q], ps, sA + (size_t)J * 16);          // B = PS A'
       if constexpr (!SPLIT) {
@@ -1051,7 +1066,7 @@ __global__ void __launch_bounds__(LB) __attribute__((amdgpu_waves_per_eu(LB > 51
       for (int q = 0; q < TPT; ++q)
         if (own.ok[q]) {
           double ps[16];
-          pf_load(ps, PFk, own.I[q], own.J[q]);
+          pf_load(ps, PSk, own.I[q], own.J[q]);
           tile_zero(Bt[q]);
           tile_mma_nt(Bt[q], ps, sA + (size_t)own.J[q] * 16);
         }

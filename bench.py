@@ -224,6 +224,14 @@ def run_workload(name, a, rank, local_rank, world, dev, with_cpu, steps, warmup)
                 kern[k] += tm['ms'][k]; launches[k] += tm['launches'][k]
     torch.cuda.synchronize(); nd.barrier()
     dt = nd.allreduce_max(time.perf_counter() - t0, dev)
+    # (outside the timed region) the all-reduced log marginal likelihoods are finite and are the sum of the per-problem values: the ranks'
+    # own sums, gathered on a second path, add up to what the all-reduce returned
+    part = plan.download_nlz() if plan is not None else np.zeros((1, EP_ITTS))
+    per_rank = nd.allgather_sums(part, dev)
+    nlz_ok = bool(np.all(np.isfinite(nlz_total)) and np.all(np.isfinite(part)) and
+                  np.allclose(per_rank.sum(axis=0), nlz_total, rtol=1e-12, atol=0.0) if kind != L.KIND_GIEKF else np.all(np.isfinite(nlz_total)))
+    if not nlz_ok:
+        raise SystemExit('bench.py: %s: nlZ_allreduced %s is not finite / not the sum of the per-problem values %s' % (name, nlz_total, per_rank.sum(axis=0)))
 
     D, N, T = wl['D'], wl['N'], wl['T']
     S = plan.S if plan else 0; M = plan.M if plan else 0

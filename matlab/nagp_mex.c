@@ -223,8 +223,9 @@ static void cmd_batch(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]
   B = mxGetNumberOfElements(prhs[1]);
   if (B < 1 || mxGetNumberOfElements(prhs[2]) != B || (nrhs > 5 && (!mxIsCell(prhs[5]) || mxGetNumberOfElements(prhs[5]) != B)))
     mexErrMsgIdAndTxt("nagp:arg", "models, ys (and tables) must be cell arrays of the same length");
-  ms = (nagp_model*)calloc(B, sizeof *ms); ys = (const double**)calloc(B, sizeof *ys); outs = (nagp_out*)calloc(B, sizeof *outs);
-  if (nrhs > 5) ts = (nagp_ihgp_tables*)calloc(B, sizeof *ts);
+  /* mxCalloc: MATLAB frees these when an argument error below leaves the MEX function through mexErrMsgIdAndTxt (a longjmp) */
+  ms = (nagp_model*)mxCalloc(B, sizeof *ms); ys = (const double**)mxCalloc(B, sizeof *ys); outs = (nagp_out*)mxCalloc(B, sizeof *outs);
+  if (nrhs > 5) ts = (nagp_ihgp_tables*)mxCalloc(B, sizeof *ts);
   for (q = 0; q < B; ++q) {
     size_t n;
     read_model(mxGetCell(prhs[1], q), &ms[q]);
@@ -244,7 +245,7 @@ static void cmd_batch(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]
     mxSetCell(cE, q, e); mxSetCell(cV, q, v); mxSetCell(cZ, q, z);
   }
   { const int st = nagp_batch_run((int32_t)B, ms, ts, ys, (int64_t)T, &o, outs, ng, mxGetPr(plhs[0]));
-    free(ms); free((void*)ys); free(outs); free(ts);
+    mxFree(ms); mxFree((void*)ys); mxFree(outs); if (ts) mxFree(ts);
     fail_if(st); }
   if (nlhs > 1) plhs[1] = cE;
   if (nlhs > 2) plhs[2] = cV;

@@ -109,6 +109,7 @@ struct nagp_plan {
   double* d_model = nullptr; double* d_y = nullptr; double* d_wn = nullptr; double* d_xi = nullptr;
   double* d_stamps = nullptr; double* d_lZs = nullptr; double* d_affspan = nullptr; double* d_affbnd = nullptr; int aff_L = 128, aff_ns = 1; double* d_vprev = nullptr; double* d_tab = nullptr; double* d_r = nullptr;
   std::vector<void*> allocs;
+  std::vector<size_t> alloc_bytes;     // bytes of allocs[i]
   int64_t dev_bytes = 0;
   std::vector<double> nlZ, mdM, mdP;   // [B][ep_itts]
   std::vector<EvRec> evs;
@@ -153,10 +154,24 @@ static int dalloc(nagp_plan* p, double** ptr, size_t n_doubles, bool zero = true
   const size_t bytes = (n_doubles ? n_doubles : 1) * sizeof(double);
   HIP_TRY(hipMalloc(&v, bytes));
   p->allocs.push_back(v);
+  p->alloc_bytes.push_back(bytes);
   p->dev_bytes += (int64_t)bytes;
   if (zero) HIP_TRY(hipMemsetAsync(v, 0, bytes, p->stream));
   *ptr = static_cast<double*>(v);
   return NAGP_OK;
+}
+
+// give back one allocation of the plan (best-effort buffers that turned out not to fit)
+static void dfree(nagp_plan* p, double* ptr) {
+  if (!ptr) return;
+  for (size_t i = p->allocs.size(); i-- > 0;)
+    if (p->allocs[i] == static_cast<void*>(ptr)) {
+      p->dev_bytes -= (int64_t)p->alloc_bytes[i];
+      p->allocs.erase(p->allocs.begin() + (long)i); p->alloc_bytes.erase(p->alloc_bytes.begin() + (long)i);
+      break;
+    }
+  (void)hipStreamSynchronize(p->stream);          // (a memset of the buffer may still be queued)
+  (void)hipFree(ptr);
 }
 
 // run CALL(MV) for the mom variant mv (0 = POWER, 1..9 = NMF cubature dimension; 9 = three sources x three components of the
@@ -635,15 +650,42 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     }
     p->mat_doubles = mat;
     auto add_slot = [&](int cap_steps) -> int {
+      if (const char* e = getenv("NAGP_TEST_SLOT_ENOMEM"))          // test hook: the (n+1)-th slot allocation of a plan fails
+        if ((int)p->slotG.size() >= atoi(e)) return NAGP_ENOMEM;
       double *g = nullptr, *d = nullptr;
       int st = dalloc(p, &g, (size_t)B * cap_steps * p->gstep, true);
       if (st == NAGP_OK) st = dalloc(p, &d, (size_t)B * cap_steps * sh.S, false);
       if (st == NAGP_OK) { p->slotG.push_back(g); p->slotD.push_back(d); p->slot_tiled.push_back(0); p->slot_cap.push_back(cap_steps); p->slot_gps.push_back(0); }
+      else if (g) dfree(p, g);
       return st;
     };
-    for (int q = 0; q < n_slots; ++q) PLAN_TRY(add_slot(p->chunk));
+    // The slots beyond the first are an optimisation sized from ONE hipMemGetInfo snapshot: fragmentation, a second plan or another
+    // process may have taken the memory since.  Best effort -- a slot that cannot be had is done without (fewer retained chunks, or the
+    // serial schedule with the one scratch slot); only slot 0 is indispensable.
+    auto drop_last_slot = [&]() {
+      dfree(p, p->slotG.back()); dfree(p, p->slotD.back());
+      p->slotG.pop_back(); p->slotD.pop_back(); p->slot_tiled.pop_back(); p->slot_cap.pop_back(); p->slot_gps.pop_back();
+    };
+    PLAN_TRY(add_slot(p->chunk));
+    {
+      int got = 1;
+      for (; got < n_slots; ++got) {
+        const int st = add_slot(p->chunk);
+        if (st == NAGP_ENOMEM) { g_last_error.clear(); break; }
+        PLAN_TRY(st);
+      }
+      n_slots = got;
+    }
+    if (p->pipeline) {   // the short chunk of the latest steps has its own small slot
+      const int small = std::min(p->chunk, std::max(64, p->chunk / 8));
+      int st = (n_slots >= 2) ? add_slot(small) : NAGP_ENOMEM;
+      while (st == NAGP_ENOMEM && n_slots > 2) { drop_last_slot(); --n_slots; st = add_slot(small); }
+      if (st == NAGP_ENOMEM) {     // fewer than two full slots beside the small one: serial schedule, slot 0 only
+        while (n_slots > 1) { drop_last_slot(); --n_slots; }
+        p->pipeline = false; g_last_error.clear();
+      } else PLAN_TRY(st);
+    }
     p->n_full_slots = n_slots;
-    if (p->pipeline) PLAN_TRY(add_slot(std::min(p->chunk, std::max(64, p->chunk / 8))));   // the short chunk of the latest steps has its own
     // Recycled slots.  The column-owner passes read PF_k for k = 0 only (the restart state), the gain kernel of a chunk reads the PF of
     // its own steps and of the step behind them, and the gains of the chunks are enqueued in time order on one stream: once the gains
     // of the earliest chunks exist, their part of PF is free until the next sweep's filter.  When the free memory does not hold a slot
@@ -662,13 +704,22 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
         ok = (end + pfs - 1) / pfs <= (size_t)k0s[c];
       }
       if (ok) {
-        for (int j = 0; j < need; ++j) {
+        std::vector<double*> ds;                         // the delta vectors of the recycled slots are memory of their own: all or none
+        for (int j = 0; ok && j < need; ++j) {
           double* d = nullptr;
-          PLAN_TRY(dalloc(p, &d, (size_t)B * p->chunk * sh.S, false));
-          p->slotG.push_back(b.PF + pfs + (size_t)j * p->chunk * p->gstep); p->slotD.push_back(d);
-          p->slot_tiled.push_back(0); p->slot_cap.push_back(p->chunk); p->slot_gps.push_back((size_t)T * pfs);
+          const int st = dalloc(p, &d, (size_t)B * p->chunk * sh.S, false);
+          if (st == NAGP_ENOMEM) { ok = false; break; }
+          PLAN_TRY(st);
+          ds.push_back(d);
         }
-        p->n_recycled = need;
+        if (!ok) { for (double* d : ds) dfree(p, d); g_last_error.clear(); }
+        else {
+          for (int j = 0; j < need; ++j) {
+            p->slotG.push_back(b.PF + pfs + (size_t)j * p->chunk * p->gstep); p->slotD.push_back(ds[j]);
+            p->slot_tiled.push_back(0); p->slot_cap.push_back(p->chunk); p->slot_gps.push_back((size_t)T * pfs);
+          }
+          p->n_recycled = need;
+        }
       }
     }
     p->gbuf_doubles = (size_t)B * p->chunk * p->gstep;
@@ -819,7 +870,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     p->lds_filter = filter_lds_doubles(sh, t, ekf ? 1 : 0, p->kb_f) * sizeof(double);
     // pipelined plans: the filter's workgroup asks for the whole LDS of its CU, so that no workgroup of the smoother kernels running
     // beside it on the second stream is placed on the same CU (the filter is the critical path; its time is latency, not occupancy)
-    if (p->pipeline && p->lds_filter < 160 * 1024) p->lds_filter = 160 * 1024;     // (never BELOW what the kernel needs: set_lds refuses > 160 KiB)
+    if (p->pipeline && B <= 128 && p->lds_filter < 160 * 1024) p->lds_filter = 160 * 1024;     // (never BELOW what the kernel needs: set_lds refuses > 160 KiB)
     if (getenv("NAGP_STAMPS")) fprintf(stderr, "[nagp plan] gf filter: LDS %zu B, ring %d steps, cubature tables in LDS %d, mom LDS %zu B, sparse-point ADF %d\n", p->lds_filter, p->kb_f, p->cache_f, ekf ? (size_t)0 : mom_lds_doubles(t) * sizeof(double), p->sp_gf);
     p->lds_gain = ((p->TPT == 1) ? gain_lds_doubles_staged(sh) : gain_lds_doubles(sh)) * sizeof(double);     // (rts_gain_kernel: STAGE)
     p->lds_scan = span_lds_doubles(sh, p->LP1, p->LP2) * sizeof(double);
@@ -881,7 +932,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     const int ntl = (4 * sh.M + 15) / 16;
     p->lin_mfma = ntl;
     p->lds_lin = flm_lds_doubles(sh, ntl, 16) * sizeof(double);
-    if (p->pipeline && p->lds_lin < 160 * 1024) p->lds_lin = 160 * 1024;      // (the CU to itself, as for the other filter launches)
+    if (p->pipeline && B <= 128 && p->lds_lin < 160 * 1024) p->lds_lin = 160 * 1024;      // (the CU to itself, as for the other filter launches)
 #define SETF(N, W) PLAN_TRY(set_lds((gf_filter_lin_mfma_kernel<N, W>), p->lds_lin))
     switch (ntl) { case 1: SETF(1, 4); break; case 2: SETF(2, 4); break; case 3: SETF(3, 4); break; case 4: SETF(4, 4); break; case 5: SETF(5, 4); break;
                    case 6: SETF(6, 8); break; case 7: SETF(7, 8); break; case 8: SETF(8, 8); break; case 9: SETF(9, 8); break; default: SETF(10, 8); break; }

@@ -243,10 +243,6 @@ extern "C" int nagp_giekf_nlml_grad(int32_t B, const nagp_model* models, const d
     for (int n = 0; same && n <= M; ++n) same = mq.block_offsets[n] == m0.block_offsets[n];
     if (!same) GFAIL(NAGP_EINVAL, "nagp_giekf_nlml_grad: problem %d has a different shape", q);
   }
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) GFAIL(NAGP_ENODEVICE, "no HIP device visible");
-  if (device < 0 || device >= ndev) GFAIL(NAGP_EINVAL, "device ordinal %d out of range", device);
-  GHIP(hipSetDevice(device));
   // pack: diagonal blocks as 4x4 row-major tiles, zero padded
   const size_t msz = gmdl_size(M, D, N), psz = (size_t)M * 48;
   std::vector<double> hm((size_t)B * msz, 0.0), hp((size_t)B * n_param * psz, 0.0);
@@ -270,6 +266,11 @@ extern "C" int nagp_giekf_nlml_grad(int32_t B, const nagp_model* models, const d
       tiles(pj, dA[q] + (size_t)j * SS); tiles(pj + (size_t)M * 16, dQ[q] + (size_t)j * SS); tiles(pj + (size_t)M * 32, dPinf[q] + (size_t)j * SS);
     }
   }
+  // the device is looked at only after every pure-host step (validation AND packing: those run under ASan on GPU-less machines)
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) GFAIL(NAGP_ENODEVICE, "no HIP device visible");
+  if (device < 0 || device >= ndev) GFAIL(NAGP_EINVAL, "device ordinal %d out of range", device);
+  GHIP(hipSetDevice(device));
   auto dmal = [&](void** p, size_t bytes) -> hipError_t { hipError_t e = hipMalloc(p, bytes ? bytes : 8); if (e == hipSuccess) allocs.push_back(*p); return e; };
   double *d_m = nullptr, *d_p = nullptr, *d_dR = nullptr, *d_y = nullptr, *d_e = nullptr, *d_g = nullptr; int *d_i = nullptr, *d_st = nullptr, *d_off = nullptr;
   GHIP(dmal((void**)&d_m, hm.size() * 8)); GHIP(dmal((void**)&d_p, hp.size() * 8)); GHIP(dmal((void**)&d_dR, (size_t)n_param * 8));

@@ -88,6 +88,10 @@ HASH_PATH = LIB_PATH + '.srchash'
 LIB_ASAN_PATH = os.path.join(PKG_ROOT, 'libnagp_asan.so')
 
 
+# translation units that hold HOST code of the C ABI (argument validation, packing): instrumented in the ASan build
+ASAN_UNITS = ('nagp_api.hip', 'nagp_grad.hip')
+
+
 def _tu_hash(f, extra=''):
     """hash of one translation unit: its own text, every header of csrc/ and include/nagp.h, the flags"""
     import hashlib
@@ -124,7 +128,7 @@ def build(force=False, verbose=False, jobs=None, asan=False):
     san = ['-fsanitize=address', '-fno-omit-frame-pointer', '-g', '-shared-libsan'] if asan else []
 
     def compile_one(f):
-        fl = flags + (san if f == 'nagp_api.hip' else [])
+        fl = flags + (san if f in ASAN_UNITS else [])
         obj = os.path.join(objdir, '%s-%s.o' % (f[:-4], _tu_hash(f, ' '.join(fl))))
         if os.path.exists(obj) and not force:
             return f, obj, None, None
@@ -160,7 +164,7 @@ def build(force=False, verbose=False, jobs=None, asan=False):
     keep = {os.path.basename(x[1]) for x in res}                    # drop objects of older sources (both variants keep theirs)
     for o in os.listdir(objdir):
         stem = o.rsplit('-', 1)[0]
-        if o.endswith('.o') and o not in keep and not (stem == 'nagp_api'):
+        if o.endswith('.o') and o not in keep and not (stem + '.hip' in ASAN_UNITS):
             os.remove(os.path.join(objdir, o))
     return lib_path
 
@@ -173,9 +177,10 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise NagpError('libnagp.so is missing (%s): run __graft_entry__.build() -- there is no CPU fallback' % LIB_PATH)
-    L = C.CDLL(LIB_PATH)
+    path = os.environ.get('NAGP_LIB') or LIB_PATH        # NAGP_LIB: developer override (same-box A/B of several builds, tools/ab_libs.sh)
+    if not os.path.exists(path):
+        raise NagpError('libnagp.so is missing (%s): run __graft_entry__.build() -- there is no CPU fallback' % path)
+    L = C.CDLL(path)
     L.nagp_version.restype = C.c_int
     L.nagp_device_count.restype = C.c_int
     L.nagp_strerror.restype = C.c_char_p; L.nagp_strerror.argtypes = [C.c_int]

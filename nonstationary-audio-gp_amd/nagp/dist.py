@@ -54,6 +54,20 @@ def allreduce_nlz(nlz_local, device=None):
     return part.cpu().numpy()
 
 
+def allgather_sums(nlz_local, device=None):
+    """(world, ep_itts): every rank's own sum over its problems, gathered (an independent path to the total allreduce_nlz returns)."""
+    import torch
+    import torch.distributed as dist
+    part = torch.as_tensor(np.asarray(nlz_local, dtype=np.float64).reshape(-1, np.shape(nlz_local)[-1]).sum(axis=0))
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return part.numpy()[None, :]
+    if device is not None:
+        part = part.to(device)
+    outs = [torch.empty_like(part) for _ in range(dist.get_world_size())]
+    dist.all_gather(outs, part)
+    return np.stack([o.cpu().numpy() for o in outs])
+
+
 def allreduce_max(x, device=None):
     import torch
     import torch.distributed as dist

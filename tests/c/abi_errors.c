@@ -1,5 +1,5 @@
 /* abi_errors.c -- the argument-validation paths of the C ABI under AddressSanitizer (libnagp_asan.so: the host code of
- * nagp_api.hip instrumented), on a machine without a GPU: every bad call returns a status, nothing is read out of bounds.
+ * nagp_api.hip and nagp_grad.hip instrumented), on a machine without a GPU: every bad call returns a status, nothing is read out of bounds.
  * Built and run by tests/test_host.py::test_abi_error_paths_under_asan. */
 #include <stdio.h>
 #include <stdlib.h>
@@ -59,6 +59,33 @@ int main(void) {
   EXPECT(nagp_mom_eval(NULL, D, N, W, 0.0, 1, y, y, y, A, A, A), NAGP_EINVAL);
   EXPECT(nagp_iekf_update1(S, D, N, NULL, h, W, 0.1, 0.2, 1, A, P, NULL, NULL, NULL, 0), NAGP_EINVAL);
   EXPECT(nagp_fastfb_run(S, NULL, A, A, A, NULL, y, T, A, NULL, 0), NAGP_EINVAL);
+  /* nagp_giekf_nlml_grad (nagp_grad.hip, instrumented as well): NULL, shape and w_index errors; a well-formed call runs the whole
+     host packing (every block of dA, dQ, dPinf of every slice is read) and stops at the missing device */
+  { enum { NP = 3 };
+    static double dA[NP * S * S], dQ[NP * S * S], dP[NP * S * S];
+    double dR[NP] = {1.0, 0.0, 0.0}, ed[1], gd[NP];
+    int32_t hess[NP] = {1, 1, 0}, widx[NP] = {-1, -1, 1}, wdir[NP] = {0, 0, 0};
+    const double* ys[1] = {y}; const double* pa[1] = {dA}; const double* pq[1] = {dQ}; const double* pp[1] = {dP};
+    EXPECT(nagp_giekf_nlml_grad(0, &m, ys, T, NP, pa, pq, pp, dR, hess, widx, wdir, ed, gd, 0), NAGP_EINVAL);
+    EXPECT(nagp_giekf_nlml_grad(1, NULL, ys, T, NP, pa, pq, pp, dR, hess, widx, wdir, ed, gd, 0), NAGP_EINVAL);
+    EXPECT(nagp_giekf_nlml_grad(1, &m, NULL, T, NP, pa, pq, pp, dR, hess, widx, wdir, ed, gd, 0), NAGP_EINVAL);
+    EXPECT(nagp_giekf_nlml_grad(1, &m, ys, 0, NP, pa, pq, pp, dR, hess, widx, wdir, ed, gd, 0), NAGP_EINVAL);
+    EXPECT(nagp_giekf_nlml_grad(1, &m, ys, T, 0, pa, pq, pp, dR, hess, widx, wdir, ed, gd, 0), NAGP_EINVAL);
+    EXPECT(nagp_giekf_nlml_grad(1, &m, ys, T, NP, NULL, pq, pp, dR, hess, widx, wdir, ed, gd, 0), NAGP_EINVAL);
+    EXPECT(nagp_giekf_nlml_grad(1, &m, ys, T, NP, pa, pq, pp, dR, hess, NULL, wdir, ed, gd, 0), NAGP_EINVAL);
+    EXPECT(nagp_giekf_nlml_grad(1, &m, ys, T, NP, pa, pq, pp, dR, hess, widx, wdir, NULL, gd, 0), NAGP_EINVAL);
+    { const double* none[1] = {NULL}; EXPECT(nagp_giekf_nlml_grad(1, &m, ys, T, NP, pa, none, pp, dR, hess, widx, wdir, ed, gd, 0), NAGP_EINVAL);
+      EXPECT(nagp_giekf_nlml_grad(1, &m, none, T, NP, pa, pq, pp, dR, hess, widx, wdir, ed, gd, 0), NAGP_EINVAL); }
+    { int32_t wbad[NP] = {-1, -1, D * N}; EXPECT(nagp_giekf_nlml_grad(1, &m, ys, T, NP, pa, pq, pp, dR, hess, wbad, wdir, ed, gd, 0), NAGP_EINVAL); }   /* outside Wnmf */
+    { nagp_model q = m; q.M = 4; EXPECT(nagp_giekf_nlml_grad(1, &q, ys, T, NP, pa, pq, pp, dR, hess, widx, wdir, ed, gd, 0), NAGP_EINVAL); }          /* M != D + N */
+    { nagp_model q = m; q.Wnmf = NULL; EXPECT(nagp_giekf_nlml_grad(1, &q, ys, T, NP, pa, pq, pp, dR, hess, widx, wdir, ed, gd, 0), NAGP_EINVAL); }
+    { int32_t big[M + 1] = {0, 5, 6, 7}; nagp_model q = m; q.block_offsets = big; EXPECT(nagp_giekf_nlml_grad(1, &q, ys, T, NP, pa, pq, pp, dR, hess, widx, wdir, ed, gd, 0), NAGP_EUNSUPPORTED); }
+    { int32_t gap[M + 1] = {1, 2, 4, 7}; nagp_model q = m; q.block_offsets = gap; EXPECT(nagp_giekf_nlml_grad(1, &q, ys, T, NP, pa, pq, pp, dR, hess, widx, wdir, ed, gd, 0), NAGP_EINVAL); }
+    { nagp_model two[2]; int32_t other[M + 1] = {0, 3, 4, 7}; const double* y2[2] = {y, y}; const double* a2[2] = {dA, dA};
+      two[0] = m; two[1] = m; two[1].block_offsets = other;
+      EXPECT(nagp_giekf_nlml_grad(2, two, y2, T, NP, a2, a2, a2, dR, hess, widx, wdir, ed, gd, 0), NAGP_EINVAL); }                                      /* shapes differ */
+    if (nagp_device_count() == 0) EXPECT(nagp_giekf_nlml_grad(1, &m, ys, T, NP, pa, pq, pp, dR, hess, widx, wdir, ed, gd, 0), NAGP_ENODEVICE);
+  }
   nagp_plan_destroy(NULL);
   nagp_shutdown();
   printf("%s\n", bad ? "FAILED" : "all error paths returned their status");

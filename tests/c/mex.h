@@ -34,6 +34,8 @@ size_t mxGetNumberOfElements(const mxArray* a);
 mxArray* mxCreateDoubleMatrix(mwSize m, mwSize n, mxComplexity c);
 mxArray* mxCreateNumericMatrix(mwSize m, mwSize n, mxClassID cls, mxComplexity c);
 mxArray* mxCreateNumericArray(mwSize ndim, const mwSize* dims, mxClassID cls, mxComplexity c);
+void* mxCalloc(size_t n, size_t size);   /* memory MATLAB releases by itself when the MEX function is left, also through an error */
+void mxFree(void* p);
 void mexErrMsgIdAndTxt(const char* id, const char* fmt, ...);
 
 /* what a gateway exports */

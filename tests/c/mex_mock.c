@@ -73,6 +73,8 @@ void mock_set(mxArray* s, const char* name, mxArray* v) {
 mxArray* mock_scalar(double v) { return mock_numeric(mxDOUBLE_CLASS, 1, 1, &v); }
 mxArray* mock_string(const char* s) { return mock_numeric(mxCHAR_CLASS, 1, strlen(s), s); }
 mxArray* mxCreateCellMatrix(mwSize m, mwSize n) { return mock_numeric(mxCELL_CLASS, m, n, NULL); }
+void* mxCalloc(size_t n, size_t size) { return calloc(n ? n : 1, size ? size : 1); }
+void mxFree(void* p) { free(p); }
 void mexErrMsgIdAndTxt(const char* id, const char* fmt, ...) {
   va_list ap;
   fprintf(stderr, "MEX error %s: ", id);

@@ -3,7 +3,7 @@
 # PMC traffic + kernel statistics (tools/pmc_run.sh), rocprofv3 kernel traces -> pipeline timelines, then the default bench line.
 # Outputs under gpurun_out/ (copy the summaries into profiles/).
 set -o pipefail
-cd /root/repo
+cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 bash tools/pmc_run.sh r03 cfg3 cfg2 cfg4 > gpurun_out/r03_pmc.log 2>&1 && tail -3 gpurun_out/r03_pmc.log &&

@@ -40,6 +40,10 @@ WORKLOADS = {
     'cfg3_batch': dict(fn='ihgp_ep_modulator_nmf', D=32, N=6, T=4000, p=7, recipe='constraints', balance=True, total_segments=None, per_gpu=256),
     'cfg2_batch': dict(fn='gf_ep_modulator_nmf', D=16, N=3, T=4000, p=9, recipe='demo_nmf', balance=False, total_segments=None, per_gpu=128),
     'cfg5_fill': dict(fn='gf_ep_modulator_nmf_constraints', D=32, N=6, T=12500, p=7, recipe='constraints', balance=True, total_segments=None, per_gpu=32),
+    # cfg3 with the likelihood every paper experiment uses (experiments/likModulatorPreCalcwn.m: amplitudes sqrt(W softplus(g - 1)),
+    # train_model.m:38,55, noise_reduction_speech.m:41) on the same rule (ut7, 305 points, passed in precomputed as the drivers do)
+    'cfg3_sqrt': dict(fn='ihgp_ep_modulator_nmf', D=32, N=6, T=200000, p=7, recipe='constraints', balance=True, total_segments=None,
+                      lik='likModulatorPreCalcwn', link_shift=1.0),
 }
 EP_ITTS = 3
 PEAK_FP64_TFLOPS = 78.6   # MI355X FP64 vector = matrix peak (MI355X_MICROARCH.md / SURVEY App. E)
@@ -58,6 +62,14 @@ def build_problems(wl, seeds):
         probs.append((blk, pr['W'], np.log(pr['w_lik'])))
         ys.append(pr['y'])
     return probs, ys
+
+
+def make_mom(wl):
+    from nagp import Mom, cubature
+    if wl.get('lik', 'likModulatorNMFPower') == 'likModulatorPreCalcwn':
+        wn, xn = cubature.sigma_points(wl['p'], wl['N'], True)
+        return Mom('likModulatorPreCalcwn', link_shift=wl.get('link_shift', 0.0), wn=wn, xn_unscaled=xn)
+    return Mom('likModulatorNMFPower', p_cubature=wl['p'])
 
 
 def usable_cores():
@@ -192,7 +204,7 @@ def run_workload(name, a, rank, local_rank, world, dev, with_cpu, steps, warmup)
         n_total = per_gpu * world; scaling = 'weak'
     n_seg = len(seeds)
     kind = {'gf_ep': L.KIND_GF_EP, 'ihgp_': L.KIND_IHGP, 'gf_gi': L.KIND_GIEKF}[wl['fn'][:5]]
-    mom = None if kind == L.KIND_GIEKF else Mom('likModulatorNMFPower', p_cubature=wl['p'])
+    mom = None if kind == L.KIND_GIEKF else make_mom(wl)
     plan = None
     if n_seg:
         uniq = sorted(set(seeds))
@@ -299,6 +311,38 @@ def run_workload(name, a, rank, local_rank, world, dev, with_cpu, steps, warmup)
         roof['adf_us_per_sample'] = kern[dom] * 1e3 / adf_steps
         roof['algorithmic_bytes_per_launch'] = 8.0 * (8 * M * (M + 1) + S + 5 * M + 2) * adf_steps / max(launches[dom], 1)   # lower tiles + means + sites
     if roof is not None:
+        # per-kernel table of THIS execute: kernel time (HIP events on the kernel's own stream; kernels of the two streams overlap, so the
+        # shares are of the summed kernel time, not of the wall time), algorithmic work and the fraction of the chip's peak
+        sm_steps_k = n_seg * (T - 1) * EP_ITTS * steps
+        if kind == L.KIND_IHGP:
+            work = {'filter': ('hbm', 8.0 * (S + 5 * M + 2) * n_seg * T * steps, 'ADF sweep: MF, five site / marginal arrays, y, lZ'),
+                    'filter_lin': ('hbm', 8.0 * (2 * S + 4 * M) * n_seg * T * (EP_ITTS - 1) * steps, 'fixed-site scans of sweeps >= 2'),
+                    'scan': ('hbm', 8.0 * (2 * S + 3 * M) * sm_steps_k, 'backward mean scans'),
+                    'epsite': ('fp64', float(f_mom) * n_seg * (T - 1) * (EP_ITTS - 1) * steps, 'site refresh (cubature)')}
+        else:
+            work = {'filter': ('fp64', flops, 'ADF / EKF filter launches'),
+                    'filter_lin': ('fp64', per_step * lin_steps, 'fixed-site filter launches'),
+                    'gain': ('fp64', (7.0 / 3.0) * S ** 3 * sm_steps_k, 'chol + two triangular solves'),
+                    'scan': ('fp64', 4.0 * S ** 3 * sm_steps_k, 'G dP G\' (algorithmic; the parallel-in-time passes execute 2.5x)'),
+                    'epsite': ('fp64', float(f_mom) * n_seg * (T - 1) * (EP_ITTS - 1) * steps, 'site refresh (cubature)')}
+        tot_ms = sum(kern[k] for k in work if launches[k]) or 1.0
+        table = []
+        for k, (bound, amount, what) in work.items():
+            if not launches[k] or kern[k] <= 0:
+                continue
+            rate = amount / (kern[k] * 1e-3) / (1e9 if bound == 'hbm' else 1e12)
+            peak = PEAK_HBM_GBS if bound == 'hbm' else PEAK_FP64_TFLOPS
+            table.append(dict(kernel=k, what=what, ms=kern[k] / steps, share=kern[k] / tot_ms, bound=bound, achieved=rate,
+                              unit='GB/s' if bound == 'hbm' else 'TFLOP/s', frac=rate / peak))
+        table.sort(key=lambda r: -r['ms'])
+        roof['per_kernel'] = table
+        roof['dominant_kernel'] = table[0]['kernel'] if table else None
+        if table and name != 'cfg3' and table[0]['kernel'] != dom:
+            # the headline figures of this extra describe the kernel with the largest share of ITS execute
+            t0_ = table[0]
+            roof.update(kernel='%s (%s)' % (t0_['kernel'], t0_['what']), bound=t0_['bound'], achieved=t0_['achieved'], peak=PEAK_HBM_GBS if t0_['bound'] == 'hbm' else PEAK_FP64_TFLOPS,
+                        unit=t0_['unit'], frac=t0_['frac'], avg_launch_ms=kern[t0_['kernel']] / max(launches[t0_['kernel']], 1))
+            dom = t0_['kernel']
         # HBM bytes per launch from separate rocprofv3 --pmc passes (tools/pmc_run.sh -> profiles/pmc_traffic.json); only the
         # figures collected on THIS build (same source hash) and this workload are reported
         try:
@@ -317,8 +361,10 @@ def run_workload(name, a, rank, local_rank, world, dev, with_cpu, steps, warmup)
         'value': value, 'unit': 'samples/s', 'n_gpus': world, 'steps': steps, 'warmup': warmup,
         'ms_per_step': dt / steps * 1e3, 'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None,
         'dtype': 'f64', 'data': 'synthetic',
-        'config': {'workload': '%s: %s, %d channels / %d NMF components, T=%d, %d segment(s) in total = %s per GPU, p=%d cubature (%d points), %d EP sweeps'
-                   % (name, wl['fn'], D, N, T, n_total, ('%d' % n_seg) if scaling == 'weak' else ('%d/%d' % (n_total, world)), wl['p'], n_pts, EP_ITTS),
+        'config': {'workload': '%s: %s%s, %d channels / %d NMF components, T=%d, %d segment(s) in total = %s per GPU, p=%d cubature (%d points), %d EP sweeps%s'
+                   % (name, wl['fn'], (' with ' + wl['lik']) if wl.get('lik') else '', D, N, T, n_total, ('%d' % n_seg) if scaling == 'weak' else ('%d/%d' % (n_total, world)), wl['p'], n_pts, EP_ITTS,
+                      {'cfg2': '; input = synthetic prior sample of the length of audio/speech_74.wav (84 010 samples; kernel time does not depend on the sample values)',
+                       'cfg4': '; input = synthetic prior sample of the length of audio/stim312_wind.wav (88 200 samples)'}.get(name, '')),
                    'state_dim': S, 'sites_per_step': M, 'parallelism': 'segments sharded over %d GPU(s), no data-path collective; nlZ all-reduce (%s)' % (world, nd.backend_name())},
         'end_to_end_samples_per_s': samples_per_step * steps / dt,
         'kernel_ms_per_step': {k: kern[k] / steps for k in kern if launches[k]},
@@ -415,7 +461,15 @@ def main():
         # extras: one warm-up + two timed steps (the contract's K and W apply to the top-level line); CPU baseline for the BASELINE configurations
         ex = run_workload(e, a, rank, local_rank, world, dev, with_cpu and e in ('cfg2', 'cfg4', 'cfg5'), 2, 1)
         key = 'cfg5_strong' if e == 'cfg5' else e
-        line[key] = {k: ex[k] for k in ex if k not in ('n_gpus', 'higher_is_better', 'vs_baseline', 'dtype', 'data')}
+        # (the line has to survive the driver's tail: no repeated prose in the extras)
+        ex['config'] = {k: v for k, v in ex['config'].items() if k != 'parallelism'}
+        if 'cpu_baseline' in ex:
+            ex['cpu_baseline'] = {k: v for k, v in ex['cpu_baseline'].items() if k not in ('sample', 'host_cpu_model', 'host_nproc', 'host_usable_cores')}
+        if ex.get('roofline'):
+            ex['roofline'] = {k: v for k, v in ex['roofline'].items() if k not in ('traffic_source',)}
+            for r in ex['roofline'].get('per_kernel', []):
+                r.pop('what', None)
+        line[key] = {k: ex[k] for k in ex if k not in ('n_gpus', 'higher_is_better', 'vs_baseline', 'dtype', 'data', 'metric', 'unit', 'steps', 'warmup')}
     if rank == 0:
         print(json.dumps(line))
         sys.stdout.flush()

@@ -2204,8 +2204,17 @@ extern "C" int nagp_batch_run(int32_t n_problems, const nagp_model* models, cons
   if (opts->kind == NAGP_KIND_IHGP && !tables) FAIL(NAGP_EINVAL, "IHGP tables missing");
   if (opts->ttau0 || opts->tnu0)
     FAIL(NAGP_EINVAL, "nagp_batch_run takes no warm-start sites (opts.ttau0 / tnu0 describe ONE problem): use nagp_plan_create + nagp_plan_upload_sites");
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) FAIL(NAGP_ENODEVICE, "no HIP device visible");
+  int ndev = 0, ndev_real = 0;
+  if (hipGetDeviceCount(&ndev_real) != hipSuccess) ndev_real = 0;
+  (void)hipGetLastError();
+  // Test hooks (multi-GPU host logic without the hardware): NAGP_TEST_FAKE_DEVICES=n -- the partition, the per-device threads and the error
+  // propagation run for n devices; device d's plan lives on physical device d mod (real devices) (every worker stops at its first device
+  // call on a machine without one) and the nlZ sums are added on the host in device order instead of by RCCL (one card cannot hold two
+  // ranks of a communicator).  NAGP_TEST_FAIL_DEVICE=d -- worker d reports NAGP_EHIP before it creates its plan.
+  const int fake = getenv("NAGP_TEST_FAKE_DEVICES") ? std::max(0, atoi(getenv("NAGP_TEST_FAKE_DEVICES"))) : 0;
+  const int fail_dev = getenv("NAGP_TEST_FAIL_DEVICE") ? atoi(getenv("NAGP_TEST_FAIL_DEVICE")) : -1;
+  ndev = fake ? fake : ndev_real;
+  if (ndev < 1) FAIL(NAGP_ENODEVICE, "no HIP device visible");
   if (n_gpus > ndev) FAIL(NAGP_EINVAL, "n_gpus = %d but %d device(s) visible", n_gpus, ndev);
   const int G = std::min<int>(n_gpus, n_problems);     // a device without a problem takes no part
   const int I = opts->ep_itts;
@@ -2229,12 +2238,14 @@ extern "C" int nagp_batch_run(int32_t n_problems, const nagp_model* models, cons
       os.push_back(o);
     }
     nagp_opts o = *opts;
-    o.device = d; o.ttau0 = nullptr; o.tnu0 = nullptr;
+    o.device = fake ? (ndev_real > 0 ? d % ndev_real : 0) : d; o.ttau0 = nullptr; o.tnu0 = nullptr;
     bool wantPS = false;
     for (const nagp_out& q : os) wantPS = wantPS || q.PS;
     if (wantPS) o.flags |= NAGP_FLAG_WANT_PS;
     nagp_plan* p = nullptr;
-    int st = nagp_plan_create(&p, (int32_t)idx.size(), ms.data(), tables ? ts.data() : nullptr, T, &o);
+    int st = NAGP_OK;
+    if (d == fail_dev) { g_last_error = "injected failure (NAGP_TEST_FAIL_DEVICE)"; st = NAGP_EHIP; }
+    if (st == NAGP_OK) st = nagp_plan_create(&p, (int32_t)idx.size(), ms.data(), tables ? ts.data() : nullptr, T, &o);
     if (st == NAGP_OK) st = nagp_plan_upload_y(p, yv.data());
     if (st == NAGP_OK) st = nagp_plan_execute(p);
     if (st == NAGP_OK) st = nagp_plan_download(p, os.data());
@@ -2255,7 +2266,9 @@ extern "C" int nagp_batch_run(int32_t n_problems, const nagp_model* models, cons
   for (int d = 0; d < G; ++d)
     if (status[d] != NAGP_OK) { g_last_error = "device " + std::to_string(d) + ": " + errs[d]; return status[d]; }
   std::vector<double> total(I, 0.0);
-  if (G > 1 || getenv("NAGP_FORCE_RCCL")) {
+  if (fake && G > 1) {
+    for (int d = 0; d < G; ++d) for (int i = 0; i < I; ++i) total[i] += part[d][i];
+  } else if (G > 1 || getenv("NAGP_FORCE_RCCL")) {
     const int st = allreduce_nlz(G, I, part, total);
     if (st != NAGP_OK) return st;
   } else {

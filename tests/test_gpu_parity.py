@@ -776,6 +776,40 @@ def test_batch_run_one_gpu_is_bit_equal_to_the_plan_and_reduces_nlz(kind_name, m
         nagp.batch_run(kind, probs, ys, T, mom=mom, ep_fraction=0.5, ep_damping=d, ep_itts=3, n_gpus=64)
 
 
+@pytest.mark.parametrize('kind_name', ['gf', 'ihgp'])
+def test_batch_run_threads_of_several_devices_on_one_card(kind_name, monkeypatch):
+    """The multi-device form of nagp_batch_run with its devices mapped onto this one card (NAGP_TEST_FAKE_DEVICES=4): four host threads,
+    four plans alive and executing at the same time, outputs scattered back by problem index -- every problem equals its place in
+    the single plan bit for bit, nlZ_total is the sum in device order; an injected failure of one device comes back as that device's
+    error, and the next call works."""
+    kind = L.KIND_IHGP if kind_name == 'ihgp' else L.KIND_GF_EP
+    probs, ys = _small_batch(kind_name); T = ys[0].size
+    probs = probs + probs[:3]; ys = ys + [y[::-1].copy() for y in ys[:3]]
+    mom = Mom('likModulatorNMFPower', p_cubature=5); d = 0.5 * np.ones(3)
+    plan = Plan(kind, probs, T, mom=mom, ep_fraction=0.5, ep_damping=d, ep_itts=3)
+    plan.upload(ys); plan.execute(); ref = plan.download(); plan.close()
+    monkeypatch.setenv('NAGP_TEST_FAKE_DEVICES', '4')
+    outs, tot = nagp.batch_run(kind, probs, ys, T, mom=mom, ep_fraction=0.5, ep_damping=d, ep_itts=3, n_gpus=4)
+    for a, b in zip(outs, ref):
+        for f in ('Eft', 'Varft', 'ttau', 'tnu', 'lZ', 'nlZ', 'MS'):
+            assert np.array_equal(getattr(a, f), getattr(b, f), equal_nan=True), f
+    dev = nagp.batch_partition(len(probs), 4)
+    exp = np.zeros(3)
+    for g in range(4):
+        part = np.zeros(3)
+        for i in range(len(probs)):
+            if dev[i] == g:
+                part += ref[i].nlZ
+        exp += part
+    assert np.array_equal(tot, exp)
+    monkeypatch.setenv('NAGP_TEST_FAIL_DEVICE', '2')
+    with pytest.raises(nagp.NagpError, match='device 2: injected failure'):
+        nagp.batch_run(kind, probs, ys, T, mom=mom, ep_fraction=0.5, ep_damping=d, ep_itts=3, n_gpus=4)
+    monkeypatch.delenv('NAGP_TEST_FAIL_DEVICE')
+    outs, tot2 = nagp.batch_run(kind, probs, ys, T, mom=mom, ep_fraction=0.5, ep_damping=d, ep_itts=3, n_gpus=4)
+    assert np.array_equal(tot2, tot)
+
+
 def test_warm_start_sites():
     """nagp_plan_upload_sites: zeros are the cold start (bit for bit); the sites of a finished run as the start of the next
     agree with the oracle started from the same sites; dropping them returns to the cold start."""

@@ -173,6 +173,35 @@ def test_batch_partition_round_robin():
         nagp.batch_partition(4, 0)
 
 
+@pytest.mark.parametrize('G', [2, 3, 5, 8])
+def test_batch_run_host_logic_for_several_devices_without_the_hardware(G, monkeypatch):
+    """nagp_batch_run for G = 2 .. 8 devices on a machine with none (test hook NAGP_TEST_FAKE_DEVICES): the partition, one host
+    thread per device, every worker's own host-side validation and packing up to its first device call, and the propagation of the
+    first failing device's status and text.  With NAGP_TEST_FAIL_DEVICE the injected failure of that device is what comes back when
+    it is the first in device order, and the call returns (no worker left behind) whichever device fails."""
+    from nagp import harness, Mom, ss as pss, _lib as L
+    if nagp.lib().nagp_device_count() > 0:
+        pytest.skip('a GPU is visible: the GPU suite covers this path with real plans')
+    monkeypatch.setenv('NAGP_TEST_FAKE_DEVICES', str(G))
+    D, N, T = 3, 2, 12
+    probs, ys = [], []
+    for q in range(11):
+        pr = harness.nmf_problem(D, N, T, 40 + q)
+        probs.append((pss.ss_blocks_nmf(pr['param1'], pr['param2'], 'matern32', 'matern52'), pr['W'], np.log(pr['w_lik']))); ys.append(pr['y'])
+    kw = dict(mom=Mom('likModulatorNMFPower', p_cubature=5), ep_fraction=0.5, ep_damping=0.5 * np.ones(2), ep_itts=2)
+    with pytest.raises(nagp.NagpError, match=r'no HIP device.*device 0: '):
+        nagp.batch_run(L.KIND_GF_EP, probs, ys, T, n_gpus=G, **kw)
+    with pytest.raises(nagp.NagpError, match='n_gpus'):
+        nagp.batch_run(L.KIND_GF_EP, probs, ys, T, n_gpus=G + 1, **kw)          # more than the (fake) devices
+    monkeypatch.setenv('NAGP_TEST_FAIL_DEVICE', '0')
+    with pytest.raises(nagp.NagpError, match=r'HIP runtime error.*device 0: injected failure'):
+        nagp.batch_run(L.KIND_GF_EP, probs, ys, T, n_gpus=G, **kw)
+    monkeypatch.setenv('NAGP_TEST_FAIL_DEVICE', str(G - 1))                     # the last device fails differently: device 0's status still wins
+    with pytest.raises(nagp.NagpError, match=r'no HIP device.*device 0: '):
+        nagp.batch_run(L.KIND_GF_EP, probs, ys, T, n_gpus=G, **kw)
+    monkeypatch.delenv('NAGP_TEST_FAIL_DEVICE')
+
+
 def test_measmodel_handle_raises_the_documented_error():
     H = np.zeros((5, 7)); H[np.arange(5), [0, 1, 2, 3, 5]] = 1.0
     mm = nagp.MeasModel(H, np.ones((3, 2)), 3, 2)

@@ -77,6 +77,7 @@ struct nagp_plan {
   MomSp sp{};           // sparse-point form of likModulatorNMFPower (nagp_momsp.hpp); sp_ih: the IHGP ADF sweep uses it
   int sp_ih = 0, sp_gf = 0, kb_sp = 16, hph_sp = 1; size_t lds_sp = 0;
   int sp_ep = 0; size_t lds_ep_sp = 0;      // site refresh (ep_site_sp_kernel) in the sparse-point form
+  int sq_c0 = -1, sq_ok = 0, sq_ih = 0, kb_sq = 16, hph_sq = 1; size_t lds_sq = 0;   // likModulatorPreCalcwn in the staged form (nagp_momsq.hpp): centre code, rule fits, IHGP ADF sweep uses it
   int sp_ih8 = 0, sp_pack = 0, sp_maxmem = 0; size_t lds_sp8 = 0;   // sp_maxmem: most points sharing one non-centre (dimension, coordinate)   // the role-specialised 512-thread form of the same sweep (ihgp_adf8_kernel)
   hipStream_t stream = nullptr;
   // chunk-pipelined smoother (gf / giekf): while the sequential filter occupies one CU per problem, the parallel smoother kernels
@@ -524,6 +525,23 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
           }
       }
     }
+    if (o->lik_kind == NAGP_LIK_POWER_NMF_SQRT && o->cub_dim <= MSQ_MAXCD && sh.D <= MSQ_MAXD && !getenv("NAGP_NO_SPARSE")) {
+      // staged form of the square-root amplitudes: needs the coordinate value 0 (the marginal sums leave the centre to a difference),
+      // the marginal lists of the packed form (<= 16 per marginal wave, <= 64 members each) and <= 336 sigma points
+      int c0 = -1;
+      const int ndp = (int)xd.size(), CDp = o->cub_dim;
+      for (size_t ci = 0; ci < xd.size(); ++ci) if (xd[ci] == 0.0) c0 = (int)ci;
+      int maxmem = 0;
+      for (int j = 0; j < CDp; ++j)
+        for (int cc = 0; cc < ndp; ++cc) {
+          if (cc == c0) continue;
+          int cnt = 0;
+          for (int q = 0; q < o->n_pts; ++q) cnt += (code[(size_t)q * CDp + j] == cc) ? 1 : 0;
+          maxmem = std::max(maxmem, cnt);
+        }
+      if (c0 >= 0 && ndp >= 2 && ndp * CDp <= MSP_TS - 1 && (ndp - 1) * ((CDp + 1) / 2) <= 16 && (ndp - 1) * CDp <= MSR_NMARG &&
+          maxmem <= 4 * MSR_NMEM && o->n_pts <= MSQ_NP) { p->sq_ok = 1; p->sq_c0 = c0; }
+    }
     if (o->lik_kind != NAGP_LIK_POWER) {
       std::vector<unsigned char> blob;
       MomSrc sc;
@@ -839,6 +857,23 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
         }
       }
     }
+    // likModulatorPreCalcwn: the role-specialised sweep of nagp_momsq.hpp
+    if (p->sq_ok && !p->src_f && sh.M <= 64) {
+      p->kb_sq = IH_KB; p->hph_sq = 1;
+      if (const char* e = getenv("NAGP_IH_KB")) p->kb_sq = std::max(1, std::min(IH_KB, atoi(e)));
+      auto needq = [&]() { return ihgp_adf8sq_lds_doubles(sh, o->cub_dim, p->tb.NG, p->hph_sq, p->kb_sq) * sizeof(double) + 16; };
+      if (needq() > 156 * 1024) p->kb_sq = 8;
+      if (needq() > 156 * 1024) p->hph_sq = 0;
+      if (needq() <= 156 * 1024) {
+        p->sq_ih = 1; p->lds_sq = needq();
+        switch (o->cub_dim) {
+          case 1: PLAN_TRY(set_lds(ihgp_adf8sq_kernel<1>, p->lds_sq)); break; case 2: PLAN_TRY(set_lds(ihgp_adf8sq_kernel<2>, p->lds_sq)); break;
+          case 3: PLAN_TRY(set_lds(ihgp_adf8sq_kernel<3>, p->lds_sq)); break; case 4: PLAN_TRY(set_lds(ihgp_adf8sq_kernel<4>, p->lds_sq)); break;
+          case 5: PLAN_TRY(set_lds(ihgp_adf8sq_kernel<5>, p->lds_sq)); break; default: PLAN_TRY(set_lds(ihgp_adf8sq_kernel<6>, p->lds_sq)); break;
+        }
+      }
+    }
+    if (getenv("NAGP_STAMPS")) fprintf(stderr, "[nagp plan] ihgp ADF sweep, square-root amplitudes in the staged form: %d (LDS %zu B, ring %d steps, hph table in LDS %d)\n", p->sq_ih, p->lds_sq, p->kb_sq, p->hph_sq);
     if (getenv("NAGP_STAMPS")) fprintf(stderr, "[nagp plan] ihgp ADF sweep in the sparse-point form: %d (LDS %zu B, ring %d steps, hph table in LDS %d), role-specialised waves %d (LDS %zu B), packed MFMA steps %d\n", p->sp_ih, p->lds_sp, p->kb_sp, p->hph_sp, p->sp_ih8, p->lds_sp8, p->sp_pack);
 #define SL(V) PLAN_TRY(set_lds(ihgp_filter_kernel<V, false>, p->lds_ih))
 #define SLS(V) PLAN_TRY(set_lds(ihgp_filter_kernel<V, true>, p->lds_ih))
@@ -1708,7 +1743,13 @@ static int exec_ihgp(nagp_plan* p) {
       Timed t(p, itt == 1 ? NAGP_K_FILTER : NAGP_K_FILTER_LIN);
 #define LI(V) hipLaunchKernelGGL((ihgp_filter_kernel<V, false>), dim3(B), dim3(p->NT_ih), p->lds_ih, p->stream, sh, p->b, mcf, p->tb, ip)
 #define LIS(V) hipLaunchKernelGGL((ihgp_filter_kernel<V, true>), dim3(B), dim3(p->NT_ih), p->lds_ih, p->stream, sh, p->b, mcf, p->tb, ip)
-      if (p->sp_ih) {
+      if (p->sq_ih) {
+        IhgpPar ia = ip; ia.hph_lds = p->hph_sq; ia.kb = p->kb_sq;
+        MomSp sq{}; sq.c0 = p->sq_c0;
+#define LQ(V) hipLaunchKernelGGL((ihgp_adf8sq_kernel<V>), dim3(B), dim3(MSR_NT), p->lds_sq, p->stream, sh, p->b, mcf, sq, p->tb, ia)
+        switch (mcf.cdim) { case 1: LQ(1); break; case 2: LQ(2); break; case 3: LQ(3); break; case 4: LQ(4); break; case 5: LQ(5); break; default: LQ(6); break; }
+#undef LQ
+      } else if (p->sp_ih) {
         IhgpPar ia = ip; ia.hph_lds = p->hph_sp; ia.kb = p->kb_sp;
 #define LA(V) hipLaunchKernelGGL((ihgp_adf_kernel<V>), dim3(B), dim3(MSP_NT), p->lds_sp, p->stream, sh, p->b, mcf, p->sp, p->tb, ia)
 #define LA8(V, PK) hipLaunchKernelGGL((ihgp_adf8_kernel<V, PK>), dim3(B), dim3(MSR_NT), p->lds_sp8, p->stream, sh, p->b, mcf, p->sp, p->tb, ia)

@@ -6,7 +6,7 @@
 // The EP refresh (:397-436) reuses ep_site_kernel (parallel over steps).
 #pragma once
 #include "nagp_kernels.hpp"
-#include "nagp_momsp.hpp"
+#include "nagp_momsq.hpp"
 
 namespace nagp {
 
@@ -768,6 +768,284 @@ __global__ void __launch_bounds__(MSR_NT) ihgp_adf8_kernel(Shape sh, Bufs b, Mom
           const int ko = kk * M;
           double Z, d1, d2;
           msp_outputs<CD>(x.accp, sub, n - D, wrow, pEP1, mc.jitter, Z, d1, d2);
+          if (stamp) { asm volatile("" :: "v"(d2)); IH_STAMP(4); }
+          const double t_old = p_tt[ko], n_old = p_tn[ko];
+          // site update (:265-266): -d2/(1+d2 HPH), (d1 - fmu d2)/(1+d2 HPH) through one reciprocal
+          const double r1 = rcp_nr(fma(d2, hph, 1.0));
+          double tnew = fma(ip.w_new, -d2 * r1, ip.w_old * t_old);
+          const double nnew = fma(ip.w_new, fma(-fmun, d2, d1) * r1, ip.w_old * n_old);
+          if (!(tnew > 0.0)) ++n_clamped;
+          tnew = max0(tnew);                                               // :274 (NaN -> 0, C-3)
+          double Rn = 1.0 / tnew;                                          // R = 1/ttau: the look-up key and an output, exact division
+          // (for tnew > 0 the reference's R(:,k) = 1./ttau before the clamp is this value; otherwise :287 overwrites it with Inf)
+          // R = inf: ttau = 0, or ttau of underflow size (1/ttau overflows while ys = tnu/ttau stays finite): the reference's
+          // (ys - fmu)/(HPH + R) is 0 there; the reciprocal form below would multiply inf by 0
+          double g = 0.0;
+          if (Rn < INFINITY) g = fma(nnew, Rn, -fmun) * rcp_nr(hph + Rn);  // (ys - fmu)/(HPH + R), ys = tnu/ttau (:277, :289-292)
+          typedef double d2v __attribute__((ext_vector_type(2)));
+          d2v m01, m23;
+          mreg[0] = fma(wc[0], g, Am[0]); mreg[1] = fma(wc[1], g, Am[1]); mreg[2] = fma(wc[2], g, Am[2]); mreg[3] = fma(wc[3], g, Am[3]);
+          m01.x = mreg[0]; m01.y = mreg[1]; m23.x = mreg[2]; m23.y = mreg[3];
+          p_tt[ko] = tnew; p_tn[ko] = nnew; p_R[ko] = Rn;
+          typedef d2v __attribute__((address_space(3))) * lds_d2p;
+          lds_d2p mf = (lds_d2p)(p_MF + 4 * ko);
+          mf[0] = m01; mf[1] = m23;
+          p_fm[ko] = hn * mreg[0];
+          Rprev = Rn;
+          if (n == 0) rZ[kk] = Z;
+          if (stamp) { asm volatile("" :: "v"(Rprev)); IH_STAMP(5); }
+        }
+        if (k + 1 < T) {
+          head(k + 1);
+          if (wave == 1 && link_early) { msp_wave_fence(); msp_link<CD>(x, mc); }     // fmu / HPH of the modulators just written by this wave
+        }
+      }
+    }
+    // ---- flush the ring
+    __syncthreads();
+    for (int i = tid; i < nb; i += NT) g_lZ[k0 + i] = (rZ[i] < 0.0) ? rlZ[i] : log(rZ[i]);
+    for (int i = tid; i < nb * M; i += NT) {
+      g_tt[(size_t)k0 * M + i] = rtt[i]; g_tn[(size_t)k0 * M + i] = rtn[i]; g_R[(size_t)k0 * M + i] = rR[i];
+      g_fm[(size_t)k0 * M + i] = rfm[i];
+    }
+    for (int i = tid; i < nb * S; i += NT) { const int q = i / S, e = i - q * S; g_MF[(size_t)k0 * S + i] = rMF[(size_t)q * M * 4 + smap[e]]; }
+    __syncthreads();
+  }
+#undef IH_STAMP
+  if (act && n_clamped) atomicAdd(&b.counters[(size_t)pb * 4 + 1], (unsigned long long)n_clamped);
+  if (stamp)
+    for (int i = 0; i < 8; ++i) mc.stamps[i] += st[i];
+}
+
+// The role-specialised sweep for likModulatorPreCalcwn (experiments/likModulatorPreCalcwn.m:28-86; nagp_momsq.hpp): 512 threads, waves
+// 0 / 1 carry the sites exactly as in ihgp_adf8_kernel, waves 2..7 the staged cubature of the square-root amplitudes.  sp.c0 = code of
+// the centre coordinate.  D <= 32 sub-bands, <= 6 components, <= 336 sigma points (the host checks).
+struct MsqS { int lw; double xdc; msp_rp a_mu, a_s2; msp_wp a_out; msp_rp accp, partp; };
+__host__ __device__ inline size_t ihgp_adf8sq_lds_doubles(const Shape& s, int CD, int NG, int hph_lds, int kb) {
+  return ihgp_adf_lds_doubles(s, CD, NG, hph_lds, kb) - msp_lds_doubles(CD, s.D) + msq_lds_doubles(CD) + 512;
+}
+template <int CD>
+__global__ void __launch_bounds__(MSR_NT) ihgp_adf8sq_kernel(Shape sh, Bufs b, MomCfg mc, MomSp sp, IhgpTabs tb, IhgpPar ip) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int NT = MSR_NT;
+  const int S = sh.S, M = sh.M, D = sh.D, NG = tb.NG;
+  const int64_t T = sh.T;
+  const int pb = blockIdx.x;
+  const double* mdl = b.model + (size_t)pb * mdl_size(sh);
+  const double* tab = tb.base + (size_t)pb * itab_size(sh, NG);
+
+  const int KB = ip.kb;
+  double* rMF = lds;                                 // ring: m (filtered) [KB][M][4]   (16-byte aligned)
+  double* rtt = rMF + (size_t)KB * M * 4;            //       ttau[KB][M]
+  double* rtn = rtt + (size_t)KB * M;                //       tnu
+  double* rR = rtn + (size_t)KB * M;                 //       R
+  double* rfm = rR + (size_t)KB * M;                 //       H*m (filtered)
+  double* ry = rfm + (size_t)KB * M;                 //       y[KB]
+  double* rlZ = ry + KB;                             //       lZ[KB]
+  double* rZ = rlZ + KB;                             //       Z of the step; log taken at the flush
+  double* sW = rZ + KB;                              // [D][CD]
+  double* fmu = sW + (size_t)D * CD;                 // [68]: M sites, zero padded (stage A of the cubature reads 4*K entries)
+  double* HPH = fmu + 68;
+  double* rg = HPH + 68;                          // [NG] look-up grid
+  double* thph = rg + NG;                            // [M][NG] H PP H' table (ip.hph_lds)
+  int* smap = reinterpret_cast<int*>(thph + (ip.hph_lds ? (size_t)M * NG : 0));   // [S] state -> padded ring slot 4*block + row
+  double* wt = reinterpret_cast<double*>(smap) + (S + 1) / 2;      // [8][64] W transposed for t = W' s2 (stage A)
+  double* ws = wt + 512;
+  for (int i = tid; i < D * CD; i += NT) sW[i] = mdl[mdl_W(sh) + i];
+  for (int i = tid; i < NG; i += NT) rg[i] = tb.r[i];
+  if (ip.hph_lds)
+    for (int i = tid; i < M * NG; i += NT) thph[i] = tab[itab_hph(sh, NG) + i];
+  for (int i = tid; i < 68; i += NT) { fmu[i] = 0.0; HPH[i] = 0.0; }
+  for (int i = tid; i < M; i += NT)
+    for (int r = 0; r < sh.bsz[i]; ++r) smap[sh.off[i] + r] = 4 * i + r;
+  const double sn2 = mdl[mdl_sn2(sh)];
+  const double sn2a = sn2 / ip.mom_alpha;
+  const double pEP1 = mom_pEP(mc, sn2, ip.mom_alpha);
+  const double rmax = tb.r[NG - 1];
+  __syncthreads();
+  // global rows of this problem (both roles fill and flush the ring)
+  const double* yv = b.y + (size_t)pb * T;
+  double* g_tt = b.ttau + (size_t)pb * T * M;
+  double* g_tn = b.tnu + (size_t)pb * T * M;
+  double* g_R = b.R + (size_t)pb * T * M;
+  double* g_lZ = b.lZ + (size_t)pb * T;
+  double* g_MF = b.MF + (size_t)pb * T * S;
+  double* g_fm = b.fm + (size_t)pb * T * M;
+  msq_init(CD, ws, NT);
+  __syncthreads();
+  const MsqLay lay = msq_layout(CD);
+  if (wave >= MSR_W0) {
+    // ================= worker role: the parallel stages of the cubature; the same barriers as the serial role below
+    MsqW<CD> xw;
+    msq_setup_W<CD>(xw, mc, sp.c0, sW, fmu, HPH, ws, wave - MSR_W0, tid - 64 * MSR_W0, wt);
+    double amp[2 * MSQ_NST];
+#pragma unroll
+    for (int i = 0; i < 2 * MSQ_NST; ++i) amp[i] = 0.0;
+    // developer diagnostics (NAGP_STAMPS): time lines of worker 0 in stamps[8..15] and of the last worker (marginal sums) in stamps[16..23]
+    const int wk_slot = (wave == MSR_W0 + (ip.dbg_wave & 7)) ? 8 : ((wave == MSR_W0 + MSR_NWK - 1) ? 16 : -1);
+    const bool wk_stamp = mc.stamps && wk_slot >= 0 && (tid & 63) == 0;
+    unsigned long long wk_a = 0, wk_b = 0, wk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (wk_stamp) wk_a = __builtin_readcyclecounter();
+#define WK_STAMP(slot) do { if (wk_stamp) { wk_b = __builtin_readcyclecounter(); wk[slot] += wk_b - wk_a; wk_a = wk_b; } } while (0)
+  for (int64_t k0 = ip.k_start; k0 < T; k0 += KB) {
+    const int nb = (T - k0 < KB) ? (int)(T - k0) : KB;
+    // ---- fill the ring for steps k0 .. k0+nb-1
+    for (int i = tid; i < nb; i += NT) { ry[i] = yv[k0 + i]; rlZ[i] = g_lZ[k0 + i]; rZ[i] = -1.0; }
+    for (int i = tid; i < nb * M; i += NT) { rtt[i] = g_tt[(size_t)k0 * M + i]; rtn[i] = g_tn[(size_t)k0 * M + i]; }
+    __syncthreads();
+    for (int kk = 0; kk < nb; ++kk) {
+      lds_barrier();                 // B1
+      WK_STAMP(0);                   // (wait at B1: the serial waves' tail and head)
+      msq_stageA<CD>(xw);            // worker 0: t = W' s2_z
+      WK_STAMP(1);
+      lds_barrier();                 // B2: link tables (wave 1)
+      msq_stageS<CD>(xw, amp);       // gather, square roots, mu_p
+      WK_STAMP(2);
+      lds_barrier();                 // B3
+      msq_stage1b<CD>(xw, sn2a, ry[kk], ws);
+      WK_STAMP(3);
+      lds_barrier();                 // B4
+      WK_STAMP(4);
+      if (wave >= MSR_W0 + MSQ_NWK - 2) msq_marginals<CD>(xw);
+      WK_STAMP(5);
+      msq_stageS2<CD>(xw, amp);
+      WK_STAMP(6);
+      lds_barrier();                 // B5
+      WK_STAMP(7);
+    }
+    // ---- flush the ring
+    __syncthreads();
+    for (int i = tid; i < nb; i += NT) g_lZ[k0 + i] = (rZ[i] < 0.0) ? rlZ[i] : log(rZ[i]);
+    for (int i = tid; i < nb * M; i += NT) {
+      g_tt[(size_t)k0 * M + i] = rtt[i]; g_tn[(size_t)k0 * M + i] = rtn[i]; g_R[(size_t)k0 * M + i] = rR[i];
+      g_fm[(size_t)k0 * M + i] = rfm[i];
+    }
+    for (int i = tid; i < nb * S; i += NT) { const int q = i / S, e = i - q * S; g_MF[(size_t)k0 * S + i] = rMF[(size_t)q * M * 4 + smap[e]]; }
+    __syncthreads();
+  }
+    if (wk_stamp)
+      for (int i = 0; i < 8; ++i) mc.stamps[wk_slot + i] += wk[i];
+#undef WK_STAMP
+    return;
+  }
+  // ================= serial role (waves 0 and 1)
+  MsqS x;
+  {
+    const int nd = mc.nd, TN = CD * nd, tl = tid - 64;
+    const int t = (tl >= 0 && tl < TN) ? tl : 0;
+    const int j = t / nd, cc = t - j * nd;
+    x.lw = 1; x.xdc = mc.xd[cc];
+    x.a_mu = (msp_rp)(fmu + D + j); x.a_s2 = (msp_rp)(HPH + D + j);
+    x.a_out = (msp_wp)(ws + t);
+    x.accp = (msp_rp)(ws + lay.acc + ((wave == 1) ? 32 : 0)) + opaque_zero();
+    const int dl = tid & 63;
+    x.partp = (msp_rp)(ws + lay.part + (dl & 15) + 16 * ((dl >> 4) & 1));
+  }
+
+  // wave 0, lane d < D owns sub-band block d; wave 1, lane j < N owns modulator block D + j
+  const int lane = tid & 63;
+  const bool sub = (wave == 0) && lane < D;
+  const bool act = sub || ((wave == 1) && lane < sh.N);
+  const int n = (wave == 0) ? lane : D + lane;
+  const int nn = act ? n : 0;
+  double A4[16], mreg[4] = {0, 0, 0, 0};
+  double hn = 0.0;
+  tile_zero(A4);
+  if (act) {
+    tile_load(A4, mdl + mdl_A(sh) + (size_t)n * 16);
+    hn = mdl[mdl_h(sh) + n];
+    const int o = sh.off[n], bs = sh.bsz[n];
+    if (ip.k_start > 0) {      // continue from the filtered mean of the previous step
+      const double* mp = b.MF + ((size_t)pb * T + (ip.k_start - 1)) * S;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (i < bs) mreg[i] = mp[o + i];
+    } else if (ip.itt > 1) {   // m is NOT reset between sweeps (SURVEY C-22): smoothed mean at k=0
+      const double* ms0 = b.MS + (size_t)pb * T * S;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (i < bs) mreg[i] = ms0[o + i];
+    }
+  }
+  // per-lane ring / table addresses (vector registers; the step index adds an immediate-free scalar offset)
+  const msp_wp p_tt = (msp_wp)(rtt + nn), p_tn = (msp_wp)(rtn + nn), p_R = (msp_wp)(rR + nn), p_fm = (msp_wp)(rfm + nn);
+  const msp_wp p_MF = (msp_wp)(rMF + 4 * nn);
+  const msp_wp p_fmu = (msp_wp)(fmu + nn), p_HPH = (msp_wp)(HPH + nn);
+  const msp_rp p_hph = (msp_rp)(thph + (size_t)nn * NG);
+  const msp_rp p_rg = (msp_rp)rg + opaque_zero();
+  const double* g_wcol = tab + itab_wcol(sh, NG) + (size_t)nn * NG * 4;
+  const double* g_hph = tab + itab_hph(sh, NG) + (size_t)nn * NG;
+  double Rprev = (act && ip.k_start > 0) ? b.R[((size_t)pb * T + (ip.k_start - 1)) * M + n] : 0.0;
+  unsigned int n_clamped = 0;
+  unsigned long long st_a = 0, st_b = 0, st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const bool stamp = mc.stamps && tid == ((ip.dbg_wave & 32) ? 64 : 0);      // time line of wave 0 (NAGP_STAMP_WORKER & 32: of wave 1)
+#define IH_STAMP(slot) do { if (stamp) { st_b = __builtin_readcyclecounter(); st[slot] += st_b - st_a; st_a = st_b; } } while (0)
+
+  // head of step k: table look-up, A m, the cubature's inputs (wave 0, no barrier)
+  double hph = 0.0, wc[4] = {0, 0, 0, 0}, Am[4] = {0, 0, 0, 0}, fmun = 0.0;
+  auto head = [&](int64_t k) {
+    if (act) {
+      if (k > 0) {
+        const int idx = nearest_idx3(p_rg, NG, tb.lr0, tb.inv_dlr, rmax, Rprev);
+        if (stamp) { asm volatile("" :: "v"(idx)); IH_STAMP(6); }
+        hph = ip.hph_lds ? p_hph[idx] : g_hph[idx];
+        const double2* w = reinterpret_cast<const double2*>(g_wcol + (size_t)idx * 4);
+        const double2 w0 = w[0], w1 = w[1];
+        wc[0] = w0.x; wc[1] = w0.y; wc[2] = w1.x; wc[3] = w1.y;
+      } else {
+        hph = tab[itab_hph0(sh, NG) + n];
+        const double* w = tab + itab_wcol0(sh, NG) + (size_t)n * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wc[i] = w[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        double a0 = A4[4 * i] * mreg[0], a1 = A4[4 * i + 1] * mreg[1];
+        a0 = fma(A4[4 * i + 2], mreg[2], a0); a1 = fma(A4[4 * i + 3], mreg[3], a1);
+        Am[i] = a0 + a1;
+      }
+      fmun = hn * Am[0];
+      *p_fmu = fmun; *p_HPH = hph;
+      if (stamp) { IH_STAMP(7); }
+    }
+  };
+  if (wave <= 1) head(ip.k_start);
+  // link tables of a step (the exp / log chain of the modulators' sigma-point coordinates, ~1 000 cycles on wave 1): evaluated BEHIND
+  // barrier B1, beside the worker waves' Q / 2Q / v stage -- nothing reads them before wave 1's own msp_tables behind B2.  (Evaluated
+  // ahead of B1 they were the tail of the serial chain: wave 0 waited ~800 cycles at B1 for them.)  ip.dbg_wave & 16: the old placement.
+  const bool link_early = (ip.dbg_wave & 16) != 0;
+  if (wave == 1 && link_early) { msp_wave_fence(); msp_link<CD>(x, mc); }      // link tables of the first step
+  if (stamp) st_a = __builtin_readcyclecounter();
+
+  for (int64_t k0 = ip.k_start; k0 < T; k0 += KB) {
+    const int nb = (T - k0 < KB) ? (int)(T - k0) : KB;
+    // ---- fill the ring for steps k0 .. k0+nb-1
+    for (int i = tid; i < nb; i += NT) { ry[i] = yv[k0 + i]; rlZ[i] = g_lZ[k0 + i]; rZ[i] = -1.0; }
+    for (int i = tid; i < nb * M; i += NT) { rtt[i] = g_tt[(size_t)k0 * M + i]; rtn[i] = g_tn[(size_t)k0 * M + i]; }
+    __syncthreads();
+    for (int kk = 0; kk < nb; ++kk) {
+      const int64_t k = k0 + kk;
+      lds_barrier();                 // B1: fmu, HPH of step k; its link tables (written by wave 1 on its way here)
+      IH_STAMP(3);
+      // (t = W' s2_z: worker 0)
+      if (wave == 1 && !link_early) msp_link<CD>(x, mc);
+      lds_barrier();                 // B2
+      IH_STAMP(0);
+      // (gather, square roots, mu_p: worker waves)
+      lds_barrier();                 // B3
+      // (Gaussian weights: worker waves)
+      lds_barrier();                 // B4
+      IH_STAMP(1);
+      // (sum c1 a, sum c2 a^2, marginal sums: worker waves)
+      lds_barrier();                 // B5
+      IH_STAMP(2);
+      {
+        if (act) {
+          const int ko = kk * M;
+          double Z, d1, d2;
+          msq_outputs<CD>(x.accp, x.partp, sub, n - D, pEP1, mc.jitter, Z, d1, d2);
           if (stamp) { asm volatile("" :: "v"(d2)); IH_STAMP(4); }
           const double t_old = p_tt[ko], n_old = p_tn[ko];
           // site update (:265-266): -d2/(1+d2 HPH), (d1 - fmu d2)/(1+d2 HPH) through one reciprocal

@@ -120,6 +120,12 @@
   P void nagp::ihgp_adf8_kernel<3, true> NAGP_SIG_IHA; P void nagp::ihgp_adf8_kernel<4, true> NAGP_SIG_IHA;              \
   P void nagp::ihgp_adf8_kernel<5, true> NAGP_SIG_IHA; P void nagp::ihgp_adf8_kernel<6, true> NAGP_SIG_IHA;
 
+// the role-specialised sweep for likModulatorPreCalcwn (nagp_momsq.hpp)
+#define NAGP_LIST_IHA8Q(P)                                                                                                 \
+  P void nagp::ihgp_adf8sq_kernel<1> NAGP_SIG_IHA; P void nagp::ihgp_adf8sq_kernel<2> NAGP_SIG_IHA;                      \
+  P void nagp::ihgp_adf8sq_kernel<3> NAGP_SIG_IHA; P void nagp::ihgp_adf8sq_kernel<4> NAGP_SIG_IHA;                      \
+  P void nagp::ihgp_adf8sq_kernel<5> NAGP_SIG_IHA; P void nagp::ihgp_adf8sq_kernel<6> NAGP_SIG_IHA;
+
 #define NAGP_LIST_ALL(P)                                                                                                   \
   NAGP_LIST_GF_ADF1(P) NAGP_LIST_GF_ADF2(P) NAGP_LIST_GF_ADF3(P) NAGP_LIST_GF_ADF4(P) NAGP_LIST_GF_ADF5(P)               \
-  NAGP_LIST_GF_SP12(P) NAGP_LIST_GF_SP34(P) NAGP_LIST_GF_REST(P) NAGP_LIST_SMOOTH(P) NAGP_LIST_SMOOTH8(P) NAGP_LIST_BIG(P) NAGP_LIST_GAINM(P) NAGP_LIST_FLM(P) NAGP_LIST_EP(P) NAGP_LIST_EPS(P) NAGP_LIST_IH0(P) NAGP_LIST_IH1(P) NAGP_LIST_IHA(P) NAGP_LIST_IHA8(P)
+  NAGP_LIST_GF_SP12(P) NAGP_LIST_GF_SP34(P) NAGP_LIST_GF_REST(P) NAGP_LIST_SMOOTH(P) NAGP_LIST_SMOOTH8(P) NAGP_LIST_BIG(P) NAGP_LIST_GAINM(P) NAGP_LIST_FLM(P) NAGP_LIST_EP(P) NAGP_LIST_EPS(P) NAGP_LIST_IH0(P) NAGP_LIST_IH1(P) NAGP_LIST_IHA(P) NAGP_LIST_IHA8(P) NAGP_LIST_IHA8Q(P)

@@ -51,7 +51,7 @@ __device__ __forceinline__ double sqrt_pos(double x) {
 }
 
 // LDS workspace (offsets in doubles)
-struct MsqLay { int lk, xg, xg2, t, lkp, sam, c0, c1, c2, marg, acc, part, total; };
+struct MsqLay { int lk, xg, xg2, t, lkp, sam, c0, c1, c2, marg, acc, part, scr, total; };
 __host__ __device__ inline int msq_cdp(int CD) { return (CD + 1) & ~1; }      // row stride of lkp (16-byte rows)
 __host__ __device__ inline MsqLay msq_layout(int CD) {
   MsqLay l;
@@ -64,7 +64,8 @@ __host__ __device__ inline MsqLay msq_layout(int CD) {
   l.marg = l.c2 + MSQ_NP + 64;            // [MSR_NMARG]
   l.acc = l.marg + MSR_NMARG;             // [2][32]: g1[8] | g2[8] | Z, one copy per serial wave
   l.part = l.acc + 64;                    // [MSQ_NWK][2][32]
-  l.total = l.part + MSQ_NWK * 64;
+  l.scr = l.part + MSQ_NWK * 64;          // [64] scratch: the stores of lanes that own nothing (stage S: one word per step)
+  l.total = l.scr + 64;
   return l;
 }
 __host__ __device__ inline size_t msq_lds_doubles(int CD) { return (size_t)msq_layout(CD).total; }
@@ -88,7 +89,7 @@ struct MsqW {
   int t_on; msp_rp t_w, t_src; msp_wp t_out;
   // marginal sums (the last two workers), as MsrW
   msp_rp g_mem[MSR_NMEM]; msp_wp g_out;
-  msp_rp h_marg, h_xg, h_xg2, h_c0p; msp_wp h_acc0, h_acc1; int h_nd, h_c0, h_nj, h_z;
+  msp_rp h_marg, h_xg, h_xg2, h_c0p; msp_wp h_acc0, h_acc1, h_z0, h_z1; int h_nd, h_c0, h_nj, h_z;
 };
 
 // `wr`: rank of this wave among the W workers; `tl`: index of the thread among the worker threads (0 .. 64 W - 1)
@@ -134,7 +135,7 @@ __device__ __forceinline__ void msq_setup_W(MsqW<CD>& x, const MomCfg& c, int c0
   {
     const int p0 = 4 * x.st0 + row;
     x.s_lkp = (msp_rp)(ws + l.lkp + p0 * cdp);
-    x.s_sam = (d == 0) ? (msp_wp)(ws + l.sam + p0) : (msp_wp)(ws + l.acc + 62);       // scratch word: the offset of a step stays inside acc
+    x.s_sam = (d == 0) ? (msp_wp)(ws + l.sam + p0) : (msp_wp)(ws + l.scr);        // (+ 4 per step: 4 * MSQ_NST <= 64)
     x.s_c1 = (msp_rp)(ws + l.c1 + p0);
     x.s_part = (msp_wp)(ws + l.part + wr * 64 + d);
   }
@@ -178,6 +179,7 @@ __device__ __forceinline__ void msq_setup_W(MsqW<CD>& x, const MomCfg& c, int c0
     x.h_xg = (msp_rp)(ws + l.xg + jm * nd);
     x.h_xg2 = (msp_rp)(ws + l.xg2 + jm * nd);
     x.h_acc0 = (msp_wp)(ws + l.acc + jm); x.h_acc1 = (msp_wp)(ws + l.acc + 32 + jm);
+    x.h_z0 = (msp_wp)(ws + l.acc + 16); x.h_z1 = (msp_wp)(ws + l.acc + 48);
     x.h_c0p = (msp_rp)(ws + l.c0 + lane);
     int pos = 0, cnt = 0;
 #pragma unroll
@@ -330,7 +332,7 @@ __device__ __forceinline__ void msq_marginals(const MsqW<CD>& x) {
     g2 = fma(zraw - ms, bc, g2);      // xg of the centre coordinate is zero
     x.h_acc0[0] = g1; x.h_acc0[8] = g2; x.h_acc1[0] = g1; x.h_acc1[8] = g2;
   }
-  if (lane == 0 && __builtin_amdgcn_readfirstlane(x.h_z)) { x.h_acc0[16 - 0] = zraw; x.h_acc1[16 - 0] = zraw; }
+  if (lane == 0 && __builtin_amdgcn_readfirstlane(x.h_z)) { *x.h_z0 = zraw; *x.h_z1 = zraw; }
 }
 
 // outputs of one site (after the barrier behind stage S2).  Sub-band d: fixed-order sums of the worker partials; modulator j: g1, g2.

@@ -877,6 +877,40 @@ def test_sparse_point_cubature_equals_the_generic_form_and_the_oracle(fn, shape,
     assert np.array_equal(np.isnan(a[5]['tnu']), np.isnan(b[5]['tnu']))
 
 
+@pytest.mark.parametrize('fn', ['ihgp', 'gf'])
+@pytest.mark.parametrize('shape', [(32, 6, 7, 'softplus', 1.0), (16, 3, 9, 'softplus', 0.0), (5, 2, 5, 'exp', 0.0), (21, 1, 9, 'softplus', 1.0),
+                                   (17, 4, 7, 'softplus', 0.5), (9, 5, 7, 'softplus', 0.0)])
+def test_sqrt_amplitude_likelihood_staged_form_equals_the_generic_form_and_the_oracle(fn, shape, monkeypatch):
+    """likModulatorPreCalcwn (experiments/likModulatorPreCalcwn.m:28-86, the likelihood of train_model.m:55 / noise_reduction_speech.m:41)
+    in the staged form of nagp_momsq.hpp -- square roots on a (sigma point, sub-band) lane grid, amplitudes kept in registers between the
+    weights and the sub-band sums, modulator sums from marginal sums -- against the generic mom_eval (NAGP_NO_SPARSE=1) and the oracle:
+    two sweeps (ADF sweep, smoother, site refresh, second filter pass), missing observations, 1 .. 6 components, one and two sub-bands
+    per lane (D <= 16 / > 16), odd sub-band counts, ut3 / 5 / 7 / 9, both links."""
+    D, N, p, link, shift = shape; T = 50
+    from nagp import cubature
+    pr = harness.nmf_problem(D, N, T, 1300 + D, 'constraints'); t = np.arange(1, T + 1.0)
+    y = pr['y'].copy(); y[17:19] = np.nan
+    wn, xn = cubature.utp_ws(p, N)
+    mom = Mom('likModulatorPreCalcwn', link=link, link_shift=shift, wn=wn, xn_unscaled=xn); d = np.array([0.5, 0.4])
+    omom = olik.Mom(olik.LIK_POWER_NMF_SQRT, link=(olik.exp_link() if link == 'exp' else olik.softplus_link(shift)), wn=wn, xn_unscaled=xn)
+    f = nagp.ihgp_ep_modulator_nmf if fn == 'ihgp' else nagp.gf_ep_modulator_nmf
+    of = oih.ihgp_ep_modulator_nmf if fn == 'ihgp' else ogf.gf_ep_modulator_nmf
+    res = {}
+    for mode in ('generic', 'staged'):
+        monkeypatch.delenv('NAGP_NO_SPARSE', raising=False)
+        if mode == 'generic': monkeypatch.setenv('NAGP_NO_SPARSE', '1')
+        res[mode] = f(pr['w'], t, y, SSHandle(), mom, t, 'matern32', 'matern52', 1, D, N, 0.5, d, 2, nargout=6)
+    monkeypatch.delenv('NAGP_NO_SPARSE', raising=False)
+    ref = of(pr['w'], t, y, None, omom, t, 'matern32', 'matern52', 1, D, N, 0.5, d, 2)
+    for mode in ('generic', 'staged'):
+        Eft, Varft, out = res[mode][0], res[mode][1], res[mode][5]
+        assert rel(Eft, ref[0]) < TOL_MEAN and rel(Varft, ref[1]) < TOL_MEAN and relz(out['nlZ'], ref[5]['nlZ']) < TOL_LOGZ, mode
+        assert rel(out['ttau'], ref[5]['ttau']) < TOL_SITE and rel(out['tnu'], ref[5]['tnu']) < TOL_SITE, mode
+    a, b = res['generic'], res['staged']
+    assert rel(a[0], b[0]) < 1e-9 and rel(a[5]['ttau'], b[5]['ttau']) < 1e-8 and relz(a[5]['nlZ'], b[5]['nlZ']) < 1e-11
+    assert np.array_equal(np.isnan(a[5]['tnu']), np.isnan(b[5]['tnu']))
+
+
 _RANK_WORKER = r"""
 import os, sys
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], 'nonstationary-audio-gp_amd'))

@@ -527,7 +527,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     }
     if (o->lik_kind == NAGP_LIK_POWER_NMF_SQRT && o->cub_dim <= MSQ_MAXCD && sh.D <= MSQ_MAXD && !getenv("NAGP_NO_SPARSE")) {
       // staged form of the square-root amplitudes: needs the coordinate value 0 (the marginal sums leave the centre to a difference),
-      // the marginal lists of the packed form (<= 16 per marginal wave, <= 64 members each) and <= 336 sigma points
+      // the marginal lists of the packed form (<= 16 per marginal wave, <= 64 members each) and <= 320 sigma points
       int c0 = -1;
       const int ndp = (int)xd.size(), CDp = o->cub_dim;
       for (size_t ci = 0; ci < xd.size(); ++ci) if (xd[ci] == 0.0) c0 = (int)ci;
@@ -540,7 +540,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
           maxmem = std::max(maxmem, cnt);
         }
       if (c0 >= 0 && ndp >= 2 && ndp * CDp <= MSP_TS - 1 && (ndp - 1) * ((CDp + 1) / 2) <= 16 && (ndp - 1) * CDp <= MSR_NMARG &&
-          maxmem <= 4 * MSR_NMEM && o->n_pts <= MSQ_NP) { p->sq_ok = 1; p->sq_c0 = c0; }
+          maxmem <= 4 * MSR_NMEM && o->n_pts <= MSQ_MAXPTS) { p->sq_ok = 1; p->sq_c0 = c0; }
     }
     if (o->lik_kind != NAGP_LIK_POWER) {
       std::vector<unsigned char> blob;
@@ -1746,7 +1746,7 @@ static int exec_ihgp(nagp_plan* p) {
       if (p->sq_ih) {
         IhgpPar ia = ip; ia.hph_lds = p->hph_sq; ia.kb = p->kb_sq;
         MomSp sq{}; sq.c0 = p->sq_c0;
-#define LQ(V) hipLaunchKernelGGL((ihgp_adf8sq_kernel<V>), dim3(B), dim3(MSR_NT), p->lds_sq, p->stream, sh, p->b, mcf, sq, p->tb, ia)
+#define LQ(V) hipLaunchKernelGGL((ihgp_adf8sq_kernel<V>), dim3(B), dim3(MSQ_NT), p->lds_sq, p->stream, sh, p->b, mcf, sq, p->tb, ia)
         switch (mcf.cdim) { case 1: LQ(1); break; case 2: LQ(2); break; case 3: LQ(3); break; case 4: LQ(4); break; case 5: LQ(5); break; default: LQ(6); break; }
 #undef LQ
       } else if (p->sp_ih) {

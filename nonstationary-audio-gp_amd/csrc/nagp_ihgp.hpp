@@ -818,18 +818,18 @@ __global__ void __launch_bounds__(MSR_NT) ihgp_adf8_kernel(Shape sh, Bufs b, Mom
 }
 
 // The role-specialised sweep for likModulatorPreCalcwn (experiments/likModulatorPreCalcwn.m:28-86; nagp_momsq.hpp): 512 threads, waves
-// 0 / 1 carry the sites exactly as in ihgp_adf8_kernel, waves 2..7 the staged cubature of the square-root amplitudes.  sp.c0 = code of
+// 0 / 1 carry the sites exactly as in ihgp_adf8_kernel, waves 2 .. MSQ_NWK + 1 the staged cubature of the square-root amplitudes.  sp.c0 = code of
 // the centre coordinate.  D <= 32 sub-bands, <= 6 components, <= 336 sigma points (the host checks).
 struct MsqS { int lw; double xdc; msp_rp a_mu, a_s2; msp_wp a_out; msp_rp accp, partp; };
 __host__ __device__ inline size_t ihgp_adf8sq_lds_doubles(const Shape& s, int CD, int NG, int hph_lds, int kb) {
   return ihgp_adf_lds_doubles(s, CD, NG, hph_lds, kb) - msp_lds_doubles(CD, s.D) + msq_lds_doubles(CD) + 512;
 }
 template <int CD>
-__global__ void __launch_bounds__(MSR_NT) ihgp_adf8sq_kernel(Shape sh, Bufs b, MomCfg mc, MomSp sp, IhgpTabs tb, IhgpPar ip) {
+__global__ void __launch_bounds__(MSQ_NT) ihgp_adf8sq_kernel(Shape sh, Bufs b, MomCfg mc, MomSp sp, IhgpTabs tb, IhgpPar ip) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  constexpr int NT = MSR_NT;
+  constexpr int NT = MSQ_NT;
   const int S = sh.S, M = sh.M, D = sh.D, NG = tb.NG;
   const int64_t T = sh.T;
   const int pb = blockIdx.x;
@@ -884,7 +884,7 @@ __global__ void __launch_bounds__(MSR_NT) ihgp_adf8sq_kernel(Shape sh, Bufs b, M
 #pragma unroll
     for (int i = 0; i < 2 * MSQ_NST; ++i) amp[i] = 0.0;
     // developer diagnostics (NAGP_STAMPS): time lines of worker 0 in stamps[8..15] and of the last worker (marginal sums) in stamps[16..23]
-    const int wk_slot = (wave == MSR_W0 + (ip.dbg_wave & 7)) ? 8 : ((wave == MSR_W0 + MSR_NWK - 1) ? 16 : -1);
+    const int wk_slot = (wave == MSR_W0 + (ip.dbg_wave & 7)) ? 8 : ((wave == MSR_W0 + MSQ_NWK - 1) ? 16 : -1);
     const bool wk_stamp = mc.stamps && wk_slot >= 0 && (tid & 63) == 0;
     unsigned long long wk_a = 0, wk_b = 0, wk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (wk_stamp) wk_a = __builtin_readcyclecounter();
@@ -904,11 +904,10 @@ __global__ void __launch_bounds__(MSR_NT) ihgp_adf8sq_kernel(Shape sh, Bufs b, M
       msq_stageS<CD>(xw, amp);       // gather, square roots, mu_p
       WK_STAMP(2);
       lds_barrier();                 // B3
-      msq_stage1b<CD>(xw, sn2a, ry[kk], ws);
+      msq_stage1b<CD>(xw, sn2a, ry[kk]);
       WK_STAMP(3);
       lds_barrier();                 // B4
       WK_STAMP(4);
-      if (wave >= MSR_W0 + MSQ_NWK - 2) msq_marginals<CD>(xw);
       WK_STAMP(5);
       msq_stageS2<CD>(xw, amp);
       WK_STAMP(6);
@@ -943,6 +942,8 @@ __global__ void __launch_bounds__(MSR_NT) ihgp_adf8sq_kernel(Shape sh, Bufs b, M
     const int dl = tid & 63;
     x.partp = (msp_rp)(ws + lay.part + (dl & 15) + 16 * ((dl >> 4) & 1));
   }
+  MsqM xm;      // marginal sums of c0 -> g1, g2, Z: the serial waves, idle between B4 and B5, take half of the dimensions each
+  msq_setup_M<CD>(xm, mc, sp.c0, ws, wave);
 
   // wave 0, lane d < D owns sub-band block d; wave 1, lane j < N owns modulator block D + j
   const int lane = tid & 63;
@@ -1038,7 +1039,7 @@ __global__ void __launch_bounds__(MSR_NT) ihgp_adf8sq_kernel(Shape sh, Bufs b, M
       // (Gaussian weights: worker waves)
       lds_barrier();                 // B4
       IH_STAMP(1);
-      // (sum c1 a, sum c2 a^2, marginal sums: worker waves)
+      msq_marginals<CD>(xm);         // (sum c1 a, sum c2 a^2: worker waves)
       lds_barrier();                 // B5
       IH_STAMP(2);
       {

@@ -14,9 +14,14 @@
 // difference of nearly equal sums would lose digits).
 //
 // Lane layout of the square-root stage: a wave step takes four sigma points x 16 sub-bands (lane = 16 * point + sub-band), twice
-// when D > 16 (sub-bands d and d + 16 on the same lane); the sum over the sub-bands is a 16-lane DPP sum; the amplitudes stay in
-// the lane's registers until the weights c1, c2 exist, then sum_p c1 a and sum_p c2 a^2 accumulate per lane (fixed sub-band) and
-// are added over the four point rows of the wave once per time step.
+// when D > 16 (sub-bands d and d + 16 on the same lane).  Four steps form a TILE: the 16 x 16 block of arguments W_d . lk_p is one
+// product on v_mfma_f64_16x16x4 (A = the points' link values, B = W, eight components in two k-steps) whose accumulator layout
+// (lane = column + 16 kq, register r <-> row 4 r + kq) hands register r the argument of step r at this lane's (point row, sub-band);
+// eight independent square-root chains per tile; the sums over the sub-bands of the four steps are ONE transposing 16-lane DPP
+// reduction (27 instructions instead of 4 x 12).  The amplitudes stay in the lane's registers until the weights c1, c2 exist, then
+// sum_p c1 a and sum_p c2 a^2 accumulate per lane (fixed sub-band) and are added over the four point rows of the wave once per
+// time step.  Every wave owns 64 ROWS of the per-point arrays (its points first, zero padding behind them): a step beyond the wave's
+// range multiplies zero rows -- no branches, no selects.
 //
 // Stages (W worker waves; a workgroup barrier between them):
 //   A    link wave: lk, xg, xg2 tables | one worker: t = W' s2_z | every worker: mu_z of its sub-bands
@@ -29,65 +34,101 @@
 
 namespace nagp {
 
-constexpr int MSQ_NWK = 6;        // worker waves (role layout of ihgp_adf8sq_kernel)
-constexpr int MSQ_NST = 14;       // four-point steps per worker wave: 6 * 14 * 4 = 336 sigma points
-constexpr int MSQ_NP = 4 * MSQ_NWK * MSQ_NST;
-constexpr int MSQ_NGA = 6;        // gather entries per lane: 4 * MSQ_NST * CD / 64 <= 6 for CD <= 6
+// Worker waves of the role layout (ihgp_adf8sq_kernel).  A lone wave issues an FP64 instruction every ~8 cycles whatever its
+// neighbours do and a SIMD takes one every 4, so the stage is priced in instructions per wave (profiles/r04_sqrt_stages.txt).
+constexpr int MSQ_NWK = 6;
+constexpr int MSQ_NTL = 4;                                // tiles of four steps per worker wave
+constexpr int MSQ_NST = 4 * MSQ_NTL;                      // four-point steps per worker wave
+constexpr int MSQ_RW = 4 * MSQ_NST;                       // rows (sigma points + padding) per worker wave: 64
+constexpr int MSQ_NP = MSQ_NWK * MSQ_RW;                  // 384 rows; <= 336 sigma points fill at most 14 steps of every wave
+constexpr int MSQ_NGA = 6;                                // gather entries per lane: 4 * 14 * CD / 64 <= 6 for CD <= 6
+constexpr int MSQ_NT = 64 * (MSQ_NWK + 2);                // threads: two serial waves + the workers
 constexpr int MSQ_MAXCD = 6;
 constexpr int MSQ_MAXD = 32;      // sub-bands: two per lane of a 16-lane row
+constexpr int MSQ_MAXPTS = 320;     // 80 steps = 20 tiles dealt 3 : 3 : 4 : 4 : 3 : 3
 
-// square root of x >= 0 (NaN stays NaN): hardware reciprocal square root, one coupled Goldschmidt step and two corrections
-// (the sequence the compiler emits for sqrt(), without its rescaling of arguments below 2^-767)
+// square root of x >= 0 (NaN stays NaN, 0 -> 0): hardware reciprocal square root (2^-23), one Goldschmidt step (2^-45) and one
+// correction -- the compiler's sqrt() sequence without the update of the slope, the second correction and the rescaling of arguments
+// below 2^-767.
+// (x = +inf gives NaN: an overflowed link value, which nothing downstream survives either.)
 __device__ __forceinline__ double sqrt_pos(double x) {
-  const double y = __builtin_amdgcn_rsq(x);
-  double g = x * y, h = 0.5 * y;
-  const double r = fma(-h, g, 0.5);
-  g = fma(g, r, g); h = fma(h, r, h);
-  double d = fma(-g, g, x);
-  g = fma(d, h, g);
-  d = fma(-g, g, x);
-  g = fma(d, h, g);
-  return (x == 0.0 || x == __builtin_inf()) ? x : g;
+  const double y = fmin(__builtin_amdgcn_rsq(x), 1e150);      // x = 0: rsq = inf -> a finite factor, every product below is 0
+  double g = x * y;
+  const double h = 0.5 * y;                                    // 1 / (2 sqrt x) to 2^-23: the slope of both corrections
+  g = fma(fma(-h, g, 0.5), g, g);                              // Goldschmidt step: 2^-45
+  return fma(fma(-g, g, x), h, g);                             // correction: error 2^-45 * 2^-23 beyond the rounding
 }
 
-// LDS workspace (offsets in doubles)
+// LDS workspace (offsets in doubles).  lkp, sam, c0, c1, c2 are indexed by ROW: worker w owns rows 64 w .. 64 w + 63.
 struct MsqLay { int lk, xg, xg2, t, lkp, sam, c0, c1, c2, marg, acc, part, scr, total; };
-__host__ __device__ inline int msq_cdp(int CD) { return (CD + 1) & ~1; }      // row stride of lkp (16-byte rows)
 __host__ __device__ inline MsqLay msq_layout(int CD) {
   MsqLay l;
+  (void)CD;
   l.lk = 0; l.xg = MSP_TS; l.xg2 = 2 * MSP_TS;
   l.t = 3 * MSP_TS;                       // [8]
-  l.lkp = l.t + 8;                        // [MSQ_NP][cdp]
-  l.sam = l.lkp + MSQ_NP * msq_cdp(CD);   // [MSQ_NP]
-  l.c0 = l.sam + MSQ_NP;                  // c0 | c1 | c2, stride MSQ_NP + 64 (the sums over c0 read 384 entries)
-  l.c1 = l.c0 + MSQ_NP + 64; l.c2 = l.c1 + MSQ_NP + 64;
-  l.marg = l.c2 + MSQ_NP + 64;            // [MSR_NMARG]
-  l.acc = l.marg + MSR_NMARG;             // [2][32]: g1[8] | g2[8] | Z, one copy per serial wave
+  l.lkp = l.t + 8;                        // [MSQ_NP][8]: link values of the row's point, components 6, 7 zero
+  l.sam = l.lkp + MSQ_NP * 8;             // [MSQ_NP]
+  l.c0 = l.sam + MSQ_NP;                  // c0 | c1 | c2
+  l.c1 = l.c0 + MSQ_NP; l.c2 = l.c1 + MSQ_NP;
+  l.marg = l.c2 + MSQ_NP;                 // [MSR_NMARG]
+  l.acc = l.marg + MSR_NMARG;             // [2][32]: g1[8] | g2[8] | Z, one copy per serial wave; words 56 .. 63: scratch / zero
   l.part = l.acc + 64;                    // [MSQ_NWK][2][32]
-  l.scr = l.part + MSQ_NWK * 64;          // [64] scratch: the stores of lanes that own nothing (stage S: one word per step)
+  l.scr = l.part + MSQ_NWK * 64;          // [64] scratch: one word per lane
   l.total = l.scr + 64;
   return l;
 }
 __host__ __device__ inline size_t msq_lds_doubles(int CD) { return (size_t)msq_layout(CD).total; }
 
+// Steps of worker w: whole tiles of four steps, contiguous ranges.  Waves w and w + 4 of the workgroup share a SIMD: workers 0, 4 and
+// 1, 5 are two busy waves on theirs (the SIMD's FP64 issue -- one instruction per 4 cycles, 64 per MFMA -- is the limit), workers 2, 3
+// sit beside the serial waves, which idle through the stage (a lone wave issues every 8 cycles).  Measured with equal shares: 6 000
+// cycles on workers 0 .. 3, 8 000 - 9 100 on workers 4, 5 (profiles/r04_sqrt_stages.txt); hence tiles dealt 3 : 3 : 4 : 4 : 3 : 3.
+__host__ __device__ inline void msq_steps(int npt, int w, int& st0, int& nst) {
+  const int nstep = (npt + 3) >> 2, ntile = (nstep + 3) >> 2;
+  const int wt[MSQ_NWK] = {3, 3, 4, 4, 3, 3};
+  int tl[MSQ_NWK] = {0, 0, 0, 0, 0, 0};
+  for (int t = 0; t < ntile; ++t) {          // the next tile goes to the worker with the smallest (tiles + 1) / weight
+    int best = 0;
+    for (int v = 1; v < MSQ_NWK; ++v)
+      if (tl[v] < MSQ_NTL && (tl[best] >= MSQ_NTL || (tl[v] + 1) * wt[best] < (tl[best] + 1) * wt[v])) best = v;
+    ++tl[best];
+  }
+  int t0 = 0;
+  for (int v = 0; v < w; ++v) t0 += tl[v];
+  st0 = 4 * t0;
+  nst = 4 * tl[w];
+  if (st0 + nst > nstep) nst = (nstep > st0) ? nstep - st0 : 0;
+}
+__host__ __device__ inline int msq_row(int npt, int p) {
+  const int step = p >> 2;
+  for (int w = 0; w < MSQ_NWK; ++w) {
+    int st0, nst;
+    msq_steps(npt, w, st0, nst);
+    if (step < st0 + nst) return MSQ_RW * w + 4 * (step - st0) + (p & 3);
+  }
+  return 0;
+}
+
 // Register-resident state of a worker lane; everything here is computed once per kernel.
 template <int CD>
 struct MsqW {
   int wr;                                    // worker rank 0 .. MSQ_NWK-1
-  int nst, st0;                              // this wave's steps: points 4*(st0 + s) + row
+  int ntl;                                   // tiles this wave has steps in (wave-uniform)
   int two;                                   // D > 16: the lane owns sub-bands d and d + 16 (wave-uniform)
-  double wlo[CD], whi[CD];                   // W rows of the lane's sub-bands (zero rows beyond D)
+  double b0lo, b1lo, b0hi, b1hi;             // B operands: W(d, kq), W(d, 4 + kq) of the lane's two sub-bands (zero beyond D / CD)
   msp_rp mu_lo, mu_hi;                       // fmu of the two sub-bands (zero padding beyond D)
-  msp_rp ga_src[MSQ_NGA]; msp_wp ga_dst[MSQ_NGA];      // gather lk[j][code] -> lkp[p][j] of this wave's points
-  msp_rp s_lkp;                              // lkp row of the lane's point of step 0 (+ 4 * cdp per step)
-  msp_wp s_sam;                              // sam of that point (lane & 15 == 0 writes)
-  msp_rp s_c1;                               // c1 of that point (c2 at + MSQ_NP + 64)
+  msp_rp ga_src[MSQ_NGA]; msp_wp ga_dst[MSQ_NGA];      // gather lk[j][code] -> lkp[row][j] of this wave's points
+  msp_rp a_lkp;                              // A operand of tile 0, k-step 0: lkp[64 w + (lane & 15)][lane >> 4] (+ 4: k-step 1, + 128: next tile)
+  msp_wp s_sam;                              // sam of the step this lane writes for tile 0 (+ 16 per tile); lanes with (lane & 15) >= 4: scratch
+  msp_rp s_c1;                               // c1 of the row of step 0 at this lane's point row (+ 4 per step; c2 at + MSQ_NP)
   msp_wp s_part;                             // this wave's partial sums, + sub-band
   // stage 1b: lane = sigma point
-  msp_rp p_lkp, p_sam; msp_wp p_c; double p_wn; bool p_ok; int p_any;
+  msp_rp p_lkp, p_sam, p_t; msp_wp p_c; double p_wn; bool p_ok; int p_any;
   // t = W' s2_z on worker 0: four lanes per component
   int t_on; msp_rp t_w, t_src; msp_wp t_out;
-  // marginal sums (the last two workers), as MsrW
+};
+// marginal sums of c0 (two waves, each half of the dimensions; the packed form of nagp_momsp.hpp: lane = 4 * (local marginal) + quarter)
+struct MsqM {
   msp_rp g_mem[MSR_NMEM]; msp_wp g_out;
   msp_rp h_marg, h_xg, h_xg2, h_c0p; msp_wp h_acc0, h_acc1, h_z0, h_z1; int h_nd, h_c0, h_nj, h_z;
 };
@@ -95,58 +136,50 @@ struct MsqW {
 // `wr`: rank of this wave among the W workers; `tl`: index of the thread among the worker threads (0 .. 64 W - 1)
 template <int CD>
 __device__ __forceinline__ void msq_setup_W(MsqW<CD>& x, const MomCfg& c, int c0code, const double* Wl /* LDS D x CD */, const double* fmu,
-                                             const double* HPH, double* ws, int wr, int tl, double* wt /* LDS [D][CD] copy for stage A */) {
+                                             const double* HPH, double* ws, int wr, int tl, double* wt /* LDS [8][64]: W transposed for stage A */) {
   const int lane = threadIdx.x & 63;
   const int nd = c.nd, D = c.D, npt = c.n_pts;
   const MsqLay l = msq_layout(CD);
-  const int cdp = msq_cdp(CD);
   x.wr = wr;
-  // ---- steps: contiguous ranges, the first (nstep mod W) waves one longer
-  {
-    const int nstep = (npt + 3) >> 2;
-    const int base = nstep / MSQ_NWK, rem = nstep - base * MSQ_NWK;
-    x.st0 = wr * base + (wr < rem ? wr : rem);
-    x.nst = base + (wr < rem ? 1 : 0);
-  }
+  int st0, nst;
+  msq_steps(npt, wr, st0, nst);
+  x.ntl = (nst + 3) >> 2;
   x.two = (D > 16) ? 1 : 0;
-  const int d = lane & 15, row = lane >> 4;
-#pragma unroll
-  for (int j = 0; j < CD; ++j) {
-    x.wlo[j] = (d < D) ? Wl[d * CD + j] : 0.0;
-    x.whi[j] = (d + 16 < D) ? Wl[(d + 16) * CD + j] : 0.0;
-  }
+  const int d = lane & 15, kq = lane >> 4;
+  x.b0lo = (d < D && kq < CD) ? Wl[d * CD + kq] : 0.0;
+  x.b1lo = (d < D && 4 + kq < CD) ? Wl[d * CD + 4 + kq] : 0.0;
+  x.b0hi = (d + 16 < D && kq < CD) ? Wl[(d + 16) * CD + kq] : 0.0;
+  x.b1hi = (d + 16 < D && 4 + kq < CD) ? Wl[(d + 16) * CD + 4 + kq] : 0.0;
   x.mu_lo = (msp_rp)(fmu + d);               // fmu is zero padded to 68 entries; D <= 32 keeps d + 16 < 48 -- sites of the modulators
   x.mu_hi = (msp_rp)(fmu + d + 16);          // sit behind the sub-bands there and meet zero W rows
   // ---- gather: entry e = lane + 64 u of this wave's 4 * nst * CD (point, component) pairs
   {
-    const int n_ent = 4 * x.nst * CD;
+    const int n_ent = 4 * nst * CD;
 #pragma unroll
     for (int u = 0; u < MSQ_NGA; ++u) {
       const int e = lane + 64 * u;
-      int p = 4 * x.st0 + e / CD; const int j = e % CD;
+      int p = 4 * st0 + e / CD; const int j = e % CD;
       const bool ok = e < n_ent && p < npt;
       if (!ok) p = 0;
-      // beyond the points: lk of the centre (finite; the weights of those points are zero, their amplitudes never reach a sum)
+      // beyond the points (the unused rows of the last step): lk of the centre -- finite; the weights of those rows stay zero
       const int code = ok ? c.code[(size_t)p * CD + j] : c0code;
       x.ga_src[u] = (msp_rp)(ws + l.lk + j * nd + code);
-      x.ga_dst[u] = (e < n_ent) ? (msp_wp)(ws + l.lkp + (4 * x.st0 + e / CD) * cdp + j) : (msp_wp)(ws + l.acc + 63);      // scratch word
+      x.ga_dst[u] = (e < n_ent) ? (msp_wp)(ws + l.lkp + (MSQ_RW * wr + e / CD) * 8 + j) : (msp_wp)(ws + l.acc + 63);      // scratch word
     }
   }
-  {
-    const int p0 = 4 * x.st0 + row;
-    x.s_lkp = (msp_rp)(ws + l.lkp + p0 * cdp);
-    x.s_sam = (d == 0) ? (msp_wp)(ws + l.sam + p0) : (msp_wp)(ws + l.scr);        // (+ 4 per step: 4 * MSQ_NST <= 64)
-    x.s_c1 = (msp_rp)(ws + l.c1 + p0);
-    x.s_part = (msp_wp)(ws + l.part + wr * 64 + d);
-  }
+  x.a_lkp = (msp_rp)(ws + l.lkp + (MSQ_RW * wr + d) * 8 + kq);
+  x.s_sam = (d < 4) ? (msp_wp)(ws + l.sam + MSQ_RW * wr + 4 * d + kq) : (msp_wp)(ws + l.scr + lane);
+  x.s_c1 = (msp_rp)(ws + l.c1 + MSQ_RW * wr + kq);
+  x.s_part = (msp_wp)(ws + l.part + wr * 64 + d);
   // ---- stage 1b: worker thread tl = sigma point
   {
     int p = tl;
     const bool ok = p < npt;
     x.p_ok = ok; x.p_any = (__builtin_amdgcn_ballot_w64(ok) != 0) ? 1 : 0;
     if (!ok) p = 0;
-    x.p_lkp = (msp_rp)(ws + l.lkp + p * cdp); x.p_sam = (msp_rp)(ws + l.sam + p);
-    x.p_c = (msp_wp)(ws + l.c0 + p);
+    const int q = msq_row(npt, p);
+    x.p_lkp = (msp_rp)(ws + l.lkp + q * 8); x.p_sam = (msp_rp)(ws + l.sam + q); x.p_t = (msp_rp)(ws + l.t);
+    x.p_c = (msp_wp)(ws + l.c0 + q);
     x.p_wn = ok ? c.wn[p] : 0.0;
   }
   // ---- t_j = sum_d W_dj s2_d: worker 0, four lanes per component, sub-bands sub, sub + 4, ...
@@ -160,40 +193,44 @@ __device__ __forceinline__ void msq_setup_W(MsqW<CD>& x, const MomCfg& c, int c0
     x.t_src = (msp_rp)(HPH + sub);
     x.t_out = (x.t_on && sub == 0) ? (msp_wp)(ws + l.t + jj) : (msp_wp)(ws + l.acc + 61);
   }
-  // ---- marginal sums of c0 on the last two workers (the packed form of nagp_momsp.hpp: lane = 4 * (local marginal) + quarter)
-  {
-    const msp_rp zero = (msp_rp)(ws + l.acc + 60);      // a word that stays zero
-    const int jsplit = (CD + 1) / 2;
-    const bool mw = wr >= MSQ_NWK - 2;
-    const int jlo = (wr == MSQ_NWK - 2) ? 0 : jsplit, jhi = (wr == MSQ_NWK - 2) ? jsplit : CD;
-    const int ml = lane >> 2, quarter = lane & 3;
-    const int jj = jlo + ml / (nd - 1), cc = ml % (nd - 1);
-    const bool valid = mw && jj < jhi;
-    const int j = valid ? jj : 0;
-    const int code = (cc < c0code) ? cc : cc + 1;
-    x.g_out = (valid && quarter == 0) ? (msp_wp)(ws + l.marg + j * (nd - 1) + cc) : (msp_wp)(ws + l.acc + 59);
-    const int jm = (jlo + lane < jhi) ? jlo + lane : 0;
-    x.h_nd = nd; x.h_c0 = c0code; x.h_nj = mw ? jhi - jlo : 0;
-    x.h_z = (wr == MSQ_NWK - 2) ? 1 : 0;
-    x.h_marg = (msp_rp)(ws + l.marg + jm * (nd - 1));
-    x.h_xg = (msp_rp)(ws + l.xg + jm * nd);
-    x.h_xg2 = (msp_rp)(ws + l.xg2 + jm * nd);
-    x.h_acc0 = (msp_wp)(ws + l.acc + jm); x.h_acc1 = (msp_wp)(ws + l.acc + 32 + jm);
-    x.h_z0 = (msp_wp)(ws + l.acc + 16); x.h_z1 = (msp_wp)(ws + l.acc + 48);
-    x.h_c0p = (msp_rp)(ws + l.c0 + lane);
-    int pos = 0, cnt = 0;
+}
+
+// which = 0: the dimensions below (CD + 1) / 2 and the sum of all c0 (Z), which = 1: the other dimensions
+template <int CD>
+__device__ __forceinline__ void msq_setup_M(MsqM& x, const MomCfg& c, int c0code, double* ws, int which) {
+  const int lane = threadIdx.x & 63;
+  const int nd = c.nd, npt = c.n_pts;
+  const MsqLay l = msq_layout(CD);
+  const msp_rp zero = (msp_rp)(ws + l.acc + 60);      // a word that stays zero
+  const int jsplit = (CD + 1) / 2;
+  const int jlo = (which == 0) ? 0 : jsplit, jhi = (which == 0) ? jsplit : CD;
+  const int ml = lane >> 2, quarter = lane & 3;
+  const int jj = jlo + ml / (nd - 1), cc = ml % (nd - 1);
+  const bool valid = jj < jhi;
+  const int j = valid ? jj : 0;
+  const int code = (cc < c0code) ? cc : cc + 1;
+  x.g_out = (valid && quarter == 0) ? (msp_wp)(ws + l.marg + j * (nd - 1) + cc) : (msp_wp)(ws + l.acc + 59 - which);
+  const int jm = (jlo + lane < jhi) ? jlo + lane : 0;
+  x.h_nd = nd; x.h_c0 = c0code; x.h_nj = jhi - jlo;
+  x.h_z = (which == 0) ? 1 : 0;
+  x.h_marg = (msp_rp)(ws + l.marg + jm * (nd - 1));
+  x.h_xg = (msp_rp)(ws + l.xg + jm * nd);
+  x.h_xg2 = (msp_rp)(ws + l.xg2 + jm * nd);
+  x.h_acc0 = (msp_wp)(ws + l.acc + jm); x.h_acc1 = (msp_wp)(ws + l.acc + 32 + jm);
+  x.h_z0 = (msp_wp)(ws + l.acc + 16); x.h_z1 = (msp_wp)(ws + l.acc + 48);
+  x.h_c0p = (msp_rp)(ws + l.c0 + lane);
+  int pos = 0, cnt = 0;
 #pragma unroll
-    for (int k = 0; k < MSR_NMEM; ++k) {
-      int found = -1;
-      while (valid && pos < npt && found < 0) {
-        if (c.code[(size_t)pos * CD + j] == code) {
-          if ((cnt & 3) == quarter) found = pos;
-          ++cnt;
-        }
-        ++pos;
+  for (int k = 0; k < MSR_NMEM; ++k) {
+    int found = -1;
+    while (valid && pos < npt && found < 0) {
+      if (c.code[(size_t)pos * CD + j] == code) {
+        if ((cnt & 3) == quarter) found = pos;
+        ++cnt;
       }
-      x.g_mem[k] = (found >= 0) ? (msp_rp)(ws + l.c0 + found) : zero;
+      ++pos;
     }
+    x.g_mem[k] = (found >= 0) ? (msp_rp)(ws + l.c0 + msq_row(npt, found)) : zero;
   }
 }
 
@@ -219,11 +256,57 @@ __device__ __forceinline__ void msq_stageA(const MsqW<CD>& x) {
   *x.t_out = a;            // lanes other than the first of a component: scratch word
 }
 
-// stage S: gather, square roots, mu_p.  After the barrier behind the link tables; ends without a barrier.
-// amp[2 * s], amp[2 * s + 1]: the amplitudes of the lane's two sub-bands at the point of step s (kept for stage S2)
+// sums over the 16 lanes of a row of FOUR values at once: lane c of the row ends with the sum of v[c & 3]
+// (two transposing levels -- keep one value of a pair, hand the other to the neighbour -- then two plain levels over the quads)
+__device__ __forceinline__ double row_sum4(const double v[4]) {
+  const int c = threadIdx.x;
+  const bool b0 = (c & 1) != 0, b1 = (c & 2) != 0;
+  const double w01 = (b0 ? v[1] : v[0]) + dpp_mov<0xB1>(b0 ? v[0] : v[1]);
+  const double w23 = (b0 ? v[3] : v[2]) + dpp_mov<0xB1>(b0 ? v[2] : v[3]);
+  double z = (b1 ? w23 : w01) + dpp_mov<0x4E>(b1 ? w01 : w23);
+  z += dpp_mov<0x124>(z);      // row_ror:4
+  z += dpp_mov<0x128>(z);      // row_ror:8
+  return z;
+}
+
+// stage S: gather, arguments (MFMA), square roots, mu_p.  After the barrier behind the link tables; ends without a barrier.
+// amp[8 * T + 2 * r], amp[.. + 1]: the amplitudes of the lane's two sub-bands at the point of step 4 T + r (kept for stage S2)
+template <int CD, bool TWO, int NTL>      // NTL tiles, straight-line (a branch per tile costs a register copy per amplitude)
+__device__ __forceinline__ void msq_stageS_tiles(const MsqW<CD>& x, double* amp, double mlo, double mhi) {
+#pragma unroll
+  for (int T = 0; T < NTL; ++T) {
+    const double a0 = x.a_lkp[128 * T], a1 = x.a_lkp[128 * T + 4];      // (components beyond CD: zero columns of lkp, zero B operands)
+    const v4d z = {0.0, 0.0, 0.0, 0.0};
+    v4d lo = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, x.b0lo, z, 0, 0, 0);
+    lo = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, x.b1lo, lo, 0, 0, 0);
+    v4d hi = z;
+    if (TWO) {
+      hi = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, x.b0hi, z, 0, 0, 0);
+      hi = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, x.b1hi, hi, 0, 0, 0);
+    }
+    double sm[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double al = sqrt_pos(lo[r]);
+      sm[r] = al * mlo;
+      amp[8 * T + 2 * r] = al;
+      if (TWO) { const double ah = sqrt_pos(hi[r]); sm[r] = fma(ah, mhi, sm[r]); amp[8 * T + 2 * r + 1] = ah; }
+    }
+    x.s_sam[16 * T] = row_sum4(sm);      // lane c < 4 of a row: step 4 T + c; the other lanes: scratch words
+  }
+}
+template <int CD, bool TWO>
+__device__ __forceinline__ void msq_stageS_two(const MsqW<CD>& x, double* amp, double mlo, double mhi) {
+  switch (__builtin_amdgcn_readfirstlane(x.ntl)) {
+    case 0: break;
+    case 1: msq_stageS_tiles<CD, TWO, 1>(x, amp, mlo, mhi); break;
+    case 2: msq_stageS_tiles<CD, TWO, 2>(x, amp, mlo, mhi); break;
+    case 3: msq_stageS_tiles<CD, TWO, 3>(x, amp, mlo, mhi); break;
+    default: msq_stageS_tiles<CD, TWO, 4>(x, amp, mlo, mhi); break;
+  }
+}
 template <int CD>
-__device__ __forceinline__ void msq_stageS(const MsqW<CD>& x, double* amp /* [2 * MSQ_NST] */) {
-  constexpr int cdp = (CD + 1) & ~1;
+__device__ __forceinline__ void msq_stageS(const MsqW<CD>& x, double* amp /* [2 * MSQ_NST], zero beyond the wave's tiles */) {
   {
     double g[MSQ_NGA];
 #pragma unroll
@@ -233,35 +316,17 @@ __device__ __forceinline__ void msq_stageS(const MsqW<CD>& x, double* amp /* [2 
   }
   const double mlo = *x.mu_lo, mhi = *x.mu_hi;
   msp_wave_fence();                      // the gathered rows are this wave's own writes
-  const int nst = __builtin_amdgcn_readfirstlane(x.nst);
-  const bool two = __builtin_amdgcn_readfirstlane(x.two) != 0;
-#pragma unroll
-  for (int s = 0; s < MSQ_NST; ++s) {
-    if (s < nst) {
-      double lk[cdp];
-#pragma unroll
-      for (int j = 0; j < cdp; ++j) lk[j] = x.s_lkp[4 * cdp * s + j];
-      double al = x.wlo[0] * lk[0], ah = x.whi[0] * lk[0];
-#pragma unroll
-      for (int j = 1; j < CD; ++j) { al = fma(x.wlo[j], lk[j], al); if (two) ah = fma(x.whi[j], lk[j], ah); }
-      al = sqrt_pos(al);
-      double sm = al * mlo;
-      if (two) { ah = sqrt_pos(ah); sm = fma(ah, mhi, sm); } else ah = 0.0;
-      amp[2 * s] = al; amp[2 * s + 1] = ah;
-      sm = group_sum(sm, 16);
-      x.s_sam[4 * s] = sm;               // lanes d != 0: scratch word
-    }
-  }
+  if (__builtin_amdgcn_readfirstlane(x.two)) msq_stageS_two<CD, true>(x, amp, mlo, mhi);
+  else msq_stageS_two<CD, false>(x, amp, mlo, mhi);
 }
 
 // stage 1b: one lane per sigma point.  After a barrier behind stage S; ends without a barrier.
 template <int CD>
-__device__ __forceinline__ void msq_stage1b(const MsqW<CD>& x, double sn2a, double y, const double* ws) {
+__device__ __forceinline__ void msq_stage1b(const MsqW<CD>& x, double sn2a, double y) {
   if (__builtin_amdgcn_readfirstlane(x.p_any) == 0) return;
-  const MsqLay l = msq_layout(CD);
   double lk[CD], t[CD];
 #pragma unroll
-  for (int j = 0; j < CD; ++j) { lk[j] = x.p_lkp[j]; t[j] = ws[l.t + j]; }
+  for (int j = 0; j < CD; ++j) { lk[j] = x.p_lkp[j]; t[j] = x.p_t[j]; }
   const double sam = *x.p_sam;
   double s0 = sn2a, s1 = 0.0;
 #pragma unroll
@@ -271,8 +336,8 @@ __device__ __forceinline__ void msq_stage1b(const MsqW<CD>& x, double sn2a, doub
   const double w0 = x.p_wn * pdf;
   if (x.p_ok) {
     x.p_c[0] = w0;
-    x.p_c[MSQ_NP + 64] = w0 * q;
-    x.p_c[2 * (MSQ_NP + 64)] = w0 * (q * q - inv);
+    x.p_c[MSQ_NP] = w0 * q;
+    x.p_c[2 * MSQ_NP] = w0 * (q * q - inv);
   }
 }
 
@@ -284,28 +349,34 @@ __device__ __forceinline__ double rows_sum(double v) {
 }
 
 // stage S2: sum_p c1 a_d(p), sum_p c2 a_d(p)^2 over this wave's points -> part[wave][0 / 1][sub-band].  After a barrier behind stage 1b.
+// All tiles without a branch (every weight of a tile first: one LDS round trip): the amplitudes beyond the wave's tiles are zero, the
+// weights of padding rows as well.
 template <int CD>
 __device__ __forceinline__ void msq_stageS2(const MsqW<CD>& x, const double* amp) {
-  const int nst = __builtin_amdgcn_readfirstlane(x.nst);
-  double s1l = 0.0, s1h = 0.0, s2l = 0.0, s2h = 0.0;
+  double s1l[2] = {0.0, 0.0}, s1h[2] = {0.0, 0.0}, s2l[2] = {0.0, 0.0}, s2h[2] = {0.0, 0.0};
 #pragma unroll
-  for (int s = 0; s < MSQ_NST; ++s) {
-    if (s < nst) {
-      const double c1 = x.s_c1[4 * s], c2 = x.s_c1[4 * s + MSQ_NP + 64];
-      const double al = amp[2 * s], ah = amp[2 * s + 1];
-      s1l = fma(c1, al, s1l); s1h = fma(c1, ah, s1h);
-      s2l = fma(c2 * al, al, s2l); s2h = fma(c2 * ah, ah, s2h);
+  for (int T = 0; T < MSQ_NTL; ++T) {      // (tiles beyond the wave's: zero amplitudes, weights of padding rows)
+    double c1[4], c2[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { c1[r] = x.s_c1[16 * T + 4 * r]; c2[r] = x.s_c1[16 * T + 4 * r + MSQ_NP]; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(c1[r]), "+v"(c2[r]));      // (all reads of the tile before its arithmetic)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double al = amp[8 * T + 2 * r], ah = amp[8 * T + 2 * r + 1];
+      s1l[r & 1] = fma(c1[r], al, s1l[r & 1]); s1h[r & 1] = fma(c1[r], ah, s1h[r & 1]);
+      s2l[r & 1] = fma(c2[r] * al, al, s2l[r & 1]); s2h[r & 1] = fma(c2[r] * ah, ah, s2h[r & 1]);
     }
   }
-  s1l = rows_sum(s1l); s1h = rows_sum(s1h); s2l = rows_sum(s2l); s2h = rows_sum(s2h);
+  const double a = rows_sum(s1l[0] + s1l[1]), b = rows_sum(s1h[0] + s1h[1]), c = rows_sum(s2l[0] + s2l[1]), d = rows_sum(s2h[0] + s2h[1]);
   if (((int)threadIdx.x & 63) < 16) {
-    x.s_part[0] = s1l; x.s_part[16] = s1h; x.s_part[32] = s2l; x.s_part[48] = s2h;
+    x.s_part[0] = a; x.s_part[16] = b; x.s_part[32] = c; x.s_part[48] = d;
   }
 }
 
-// marginal sums of c0, g1_j and g2_j of this wave's dimensions, Z (the last two workers; after the barrier behind stage 1b)
+// marginal sums of c0, g1_j and g2_j of this wave's dimensions, Z (two waves; after the barrier behind stage 1b)
 template <int CD>
-__device__ __forceinline__ void msq_marginals(const MsqW<CD>& x) {
+__device__ __forceinline__ void msq_marginals(const MsqM& x) {
   const int lane = threadIdx.x & 63;
   const int nd = __builtin_amdgcn_readfirstlane(x.h_nd), c0 = __builtin_amdgcn_readfirstlane(x.h_c0);
   double mem[MSR_NMEM];

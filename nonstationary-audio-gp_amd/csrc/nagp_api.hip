@@ -108,6 +108,7 @@ struct nagp_plan {
   IhgpTabs tb{};
   double* d_tt0 = nullptr; double* d_tn0 = nullptr; bool warm = false;   // warm start (nagp_plan_upload_sites)
   double* d_model = nullptr; double* d_y = nullptr; double* d_wn = nullptr; double* d_xi = nullptr;
+  double* d_gstamps = nullptr;   // per-phase cycle counters of rts_gain_kernel (GainPar::stamps)
   double* d_stamps = nullptr; double* d_lZs = nullptr; double* d_affspan = nullptr; double* d_affbnd = nullptr; int aff_L = 128, aff_ns = 1; double* d_vprev = nullptr; double* d_tab = nullptr; double* d_r = nullptr;
   std::vector<void*> allocs;
   std::vector<size_t> alloc_bytes;     // bytes of allocs[i]
@@ -582,6 +583,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
   }
   if (p->chunk > T) p->chunk = (int)T;
   PLAN_TRY(dalloc(p, &p->d_stamps, 24));
+  PLAN_TRY(dalloc(p, &p->d_gstamps, 8));
   if (o->kind != NAGP_KIND_IHGP) {
     {   // FP64 MFMA smoother for padded dimensions up to 96 (set NAGP_NO_MFMA=1 to force the VALU passes)
       const int Sp = ((4 * sh.M + 15) / 16) * 16;
@@ -1242,9 +1244,48 @@ static void sweep_begin(nagp_plan* p, SweepCtx& sc, bool write_PSs) {
   sc.s2_used = false;
 }
 
+// Ownership map of rts_gain_kernel<2, 768> (GainPar::gmapB / gmapL): the B groups (64 column-major tiles each) are paired early with
+// late -- group g with group nB-1-g -- so that every wave's two slots together take part in about M trailing updates of the
+// factorisation AND about M of the backward solve; the lower-triangle groups (their cost grows with the column) go heaviest first to the
+// wave with the lightest load of its SIMD (waves w, w+4, w+8 share one).
+static void gain_map(const Shape& sh, GainPar& gp) {
+  const int M = sh.M, nB = (sh.ntiles + 63) / 64, nlow = M * (M + 1) / 2, nL = (nlow + 63) / 64;
+  gp.use_map = 0;
+  if (nB > 24 || nL > 12 || !getenv("NAGP_GAIN_MAP")) return;      // opt-in: measured without effect (profiles/r04_gain_phases.txt)
+  for (int w = 0; w < 12; ++w) { gp.gmapB[0][w] = gp.gmapB[1][w] = gp.gmapL[w] = -1; }
+  double load[12];
+  auto colB = [&](int g) { return ((double)g * 64 + 32) / M; };                 // column of the middle tile of a B group
+  auto colL = [&](int g) {                                                        // ... of a lower-triangle group
+    const int t = std::min(g * 64 + 32, nlow - 1);
+    int J = 0;
+    while (J + 1 < M && (J + 1) * M - (J + 1) * J / 2 <= t) ++J;
+    return (double)J;
+  };
+  int lo = 0, hi = nB - 1, w = 0;
+  for (; lo < hi && w < 12; ++lo, --hi, ++w) { gp.gmapB[0][w] = (signed char)lo; gp.gmapB[1][w] = (signed char)hi; load[w] = colB(lo) + colB(hi); }
+  if (lo == hi && w < 12) { gp.gmapB[0][w] = (signed char)lo; load[w] = colB(lo); ++w; }
+  for (; w < 12; ++w) load[w] = 0.0;
+  for (int g = nL - 1; g >= 0; --g) {                                             // heaviest lower group first
+    int best = -1; double bl = 0.0;
+    for (int v = 0; v < 12; ++v) {
+      if (gp.gmapL[v] >= 0) continue;
+      const double simd = load[v] + load[(v + 4) % 12] + load[(v + 8) % 12];    // the SIMD's load decides, the wave's own breaks ties
+      const double key = simd * 16.0 + load[v];
+      if (best < 0 || key < bl) { best = v; bl = key; }
+    }
+    gp.gmapL[best] = (signed char)g; load[best] += colL(g);
+  }
+  gp.use_map = 1;
+}
+
 static int launch_gain_chunk(nagp_plan* p, const SweepCtx& sc, int c, int slot, hipStream_t st) {
   const Shape& sh = p->sh; const ChunkGeom& g = sc.ch[c];
-  GainPar gp{g.k0, g.nk, p->slot_cap[slot], (sc.mode != SM_VALU) ? p->mfma_sp : 0, getenv("NAGP_GAINM_DBG") ? atoi(getenv("NAGP_GAINM_DBG")) : 0, 0};
+  GainPar gp{};
+  gp.k0 = g.k0; gp.nk = g.nk; gp.chunk = p->slot_cap[slot]; gp.dense_sp = (sc.mode != SM_VALU) ? p->mfma_sp : 0;
+  gp.dbg = getenv("NAGP_GAINM_DBG") ? atoi(getenv("NAGP_GAINM_DBG")) : 0;
+  if (getenv("NAGP_STAMPS") && p->d_gstamps) gp.stamps = reinterpret_cast<unsigned long long*>(p->d_gstamps);
+  gp.use_map = 0;
+  if (p->gain768) gain_map(sh, gp);
   gp.dpacked = (sc.mode == SM_BIG) ? p->dpacked : 0;
   if (gp.dense_sp && p->slot_tiled[slot]) {
     HIP_TRY(hipMemsetAsync(p->slotG[slot], 0, (size_t)p->B * p->slot_cap[slot] * p->gstep * sizeof(double), st)); p->slot_tiled[slot] = 0;
@@ -1808,6 +1849,7 @@ extern "C" int nagp_plan_execute(nagp_plan* p) {
   RUN(zero_async(p, p->b.counters, (size_t)p->B * 32));
   RUN(zero_async(p, p->b.state, (size_t)p->B * ((size_t)sh.ntiles * 16 + sh.S) * 8));
   if (p->d_stamps) RUN(zero_async(p, p->d_stamps, 24 * 8));
+  if (p->d_gstamps) RUN(zero_async(p, p->d_gstamps, 8 * 8));
   std::fill(p->nlZ.begin(), p->nlZ.end(), 0.0);
   std::fill(p->mdM.begin(), p->mdM.end(), 0.0);
   std::fill(p->mdP.begin(), p->mdP.end(), 0.0);
@@ -1828,6 +1870,12 @@ extern "C" int nagp_plan_execute(nagp_plan* p) {
   }
   HIP_TRY(hipEventRecord(p->ev_t1, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
+  if (getenv("NAGP_STAMPS") && p->d_gstamps && p->opts.kind != NAGP_KIND_IHGP) {
+    unsigned long long g[8];
+    if (hipMemcpy(g, p->d_gstamps, sizeof g, hipMemcpyDeviceToHost) == hipSuccess && g[6])
+      fprintf(stderr, "[nagp stamps] rts_gain_kernel, cycles per workgroup (thread 0 of %llu sampled): prologue %llu | diagonal tiles %llu | column solves %llu | trailing updates %llu | backward solve %llu | G store %llu\n",
+              g[6], g[0] / g[6], g[1] / g[6], g[2] / g[6], g[3] / g[6], g[4] / g[6], g[5] / g[6]);
+  }
   if (getenv("NAGP_STAMPS") && p->d_stamps) {
     unsigned long long st[24];
     if (hipMemcpy(st, p->d_stamps, sizeof st, hipMemcpyDeviceToHost) == hipSuccess) {

@@ -761,6 +761,16 @@ struct GainPar {
   int dbg;      // developer switch of rts_gain_mfma_kernel (NAGP_GAINM_DBG): skip phases to time the others (results are garbage)
   int dpacked;  // dense_sp > 0: Delta is stored as its lower-triangular 16x16 tiles, tile (TI,TJ), TI >= TJ, at [TI(TI+1)/2+TJ][16][16]
                 // (all the column-owner smoother passes read of it): a step of the slot is Sp^2 + NTL(NTL+1)/2*256 doubles instead of 2 Sp^2
+  // Ownership map of the 768-thread instantiation: slot q of wave w holds the 64 consecutive (column-major) tiles of group gmapB[q][w]
+  // (B = PS A', two slots) / gmapL[w] (lower triangle of PSkp); -1 = none; use_map = 0: group = w + 12 q (tile = tid + q * 768).
+  // A tile of column J takes part in J trailing updates of the factorisation and in M - J of the backward solve: with the groups in
+  // column order the last waves work through every column (94 slot-columns on the last wave against 22 on the first); the host can pair
+  // early with late groups (nagp_api.hip: gain_map, NAGP_GAIN_MAP=1).  Measured WITHOUT effect -- the trailing phase is bound by the LDS
+  // operand reads and the SIMDs' FP64 issue of ALL active tiles, not by the slowest wave (profiles/r04_gain_phases.txt): opt-in.
+  signed char gmapB[2][12], gmapL[12]; int use_map;
+  unsigned long long* stamps;   // developer diagnostics (NAGP_STAMPS): cycles of thread 0 of every 64th workgroup per phase of rts_gain_kernel:
+                // [0] prologue (loads, B = PS A', PSkp, Delta) [1] diagonal tiles [2] column solves [3] trailing updates [4] backward
+                // solve [5] G store [6] workgroups sampled
 };
 __host__ __device__ inline size_t gd_step_doubles(int Sp, int dpacked) {      // doubles of (G, Delta) of one step in a dense slot
   const size_t ntl = (size_t)Sp / 16;
@@ -859,6 +869,10 @@ __global__ void __launch_bounds__(LB) __attribute__((amdgpu_waves_per_eu(LB > 51
 
   int* ioff = reinterpret_cast<int*>(lds);
   int* ibsz = ioff + (MAXM + 1);
+  const bool stamp = gp.stamps && tid == ((gp.dbg > 0 && gp.dbg < NT) ? gp.dbg : 0) && (blockIdx.x & 63) == 0;      // (NAGP_GAINM_DBG = the stamped thread)
+  unsigned long long st_a = 0, st_b = 0, st[6] = {0, 0, 0, 0, 0, 0};
+  if (stamp) st_a = __builtin_readcyclecounter();
+#define GK_STAMP(slot) do { if (stamp) { st_b = __builtin_readcyclecounter(); st[slot] += st_b - st_a; st_a = st_b; } } while (0)
   double* sA = lds + LDS_INT_DOUBLES;          // [M][16]
   double* sLd = sA + (size_t)M * 16;           // [M][16] diagonal Cholesky factors
   double* bufX = sLd + (size_t)M * 16;         // [2][M][TS]
@@ -874,9 +888,11 @@ __global__ void __launch_bounds__(LB) __attribute__((amdgpu_waves_per_eu(LB > 51
   // columns behind it (the trailing updates) -- consecutive threads, so whole waves skip a phase they have no tile in.  With the
   // row-major order of the span kernels every wave executed every phase for one or two active lanes.
   TileOwner<TPT> own;
+  const bool mapped = (LB > 512) && gp.use_map != 0;      // (the 768-thread instantiation only)
 #pragma unroll
   for (int q = 0; q < TPT; ++q) {
-    const int t = tid + q * NT;
+    int t = tid + q * NT;
+    if (mapped) { const int g = (q < 2) ? gp.gmapB[q < 2 ? q : 0][tid >> 6] : -1; t = (g >= 0) ? g * 64 + (tid & 63) : sh.ntiles; }
     own.ok[q] = t < sh.ntiles;
     const int tt_ = own.ok[q] ? t : 0;
     own.J[q] = tt_ / M; own.I[q] = tt_ - own.J[q] * M;
@@ -887,7 +903,8 @@ __global__ void __launch_bounds__(LB) __attribute__((amdgpu_waves_per_eu(LB > 51
     if constexpr (SPLIT) {
       // lower triangle, column by column: column J holds rows J .. M-1 and starts at J*M - J(J-1)/2
       const int nlow = M * (M + 1) / 2;
-      const int t = tid + q * NT;
+      int t = tid + q * NT;
+      if (mapped) { const int g = (q == 0) ? gp.gmapL[tid >> 6] : -1; t = (g >= 0) ? g * 64 + (tid & 63) : nlow; }
       low.ok[q] = t < nlow;
       const int tt_ = low.ok[q] ? t : 0;
       int J = 0;
@@ -1057,6 +1074,7 @@ __global__ void __launch_bounds__(LB) __attribute__((amdgpu_waves_per_eu(LB > 51
     b.dbuf[((size_t)pb * gp.chunk + kk) * S + tid] = acc;
   }
 
+  GK_STAMP(0);
   // ---- Cholesky of the lower triangle (two attempts: plain, then + jitter, SURVEY C-7)
   bool failed = false;
   for (int attempt = 0; attempt < 2; ++attempt) {
@@ -1101,6 +1119,7 @@ __global__ void __launch_bounds__(LB) __attribute__((amdgpu_waves_per_eu(LB > 51
           for (int j = 0; j < 4; ++j) sLd[(size_t)jb * 16 + 5 * j] = rd[j];      // the solves want 1 / L(j,j)
         }
       lds_barrier();
+      GK_STAMP(1);
       // column jb of L (rows below the diagonal) and -- fused, it needs nothing else -- column jb of X in X L' = B
 #pragma unroll
       for (int q = 0; q < TPL; ++q)
@@ -1115,6 +1134,7 @@ __global__ void __launch_bounds__(LB) __attribute__((amdgpu_waves_per_eu(LB > 51
           tile_store(bufX + ((size_t)par * M + own.I[q]) * TS, Bt[q]);
         }
       lds_barrier();
+      GK_STAMP(2);
       // trailing updates: L (lower tiles) and the remaining columns of B
 #pragma unroll
       for (int q = 0; q < TPL; ++q)
@@ -1128,6 +1148,7 @@ __global__ void __launch_bounds__(LB) __attribute__((amdgpu_waves_per_eu(LB > 51
           tile_mms_nt(Bt[q], bufX + ((size_t)par * M + own.I[q]) * TS, bufP + ((size_t)par * M + own.J[q]) * TS);
           __builtin_amdgcn_sched_barrier(0);
         }
+      GK_STAMP(3);
     }
     lds_barrier();
     failed = (flag[attempt] != 0);
@@ -1159,6 +1180,7 @@ __global__ void __launch_bounds__(LB) __attribute__((amdgpu_waves_per_eu(LB > 51
         __builtin_amdgcn_sched_barrier(0);
       }
   }
+  GK_STAMP(4);
 #pragma unroll
   for (int q = 0; q < TPT; ++q)
     if (own.ok[q]) {
@@ -1171,6 +1193,12 @@ __global__ void __launch_bounds__(LB) __attribute__((amdgpu_waves_per_eu(LB > 51
           if (i >= bI || j >= bJ) Bt[q][4 * i + j] = 0.0;
       put_tile(Gout, own.I[q], own.J[q], Bt[q]);
     }
+  GK_STAMP(5);
+  if (stamp) {
+    for (int i = 0; i < 6; ++i) atomicAdd(&gp.stamps[i], st[i]);
+    atomicAdd(&gp.stamps[6], 1ull);
+  }
+#undef GK_STAMP
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -31,9 +31,9 @@ import numpy as np  # noqa: E402
 
 WORKLOADS = {
     # name: function, D, N, T, cubature order, parameter recipe, balance, segments IN TOTAL (None: `per_gpu` segments on every GPU)
-    'cfg2': dict(fn='gf_ep_modulator_nmf', D=16, N=3, T=84010, p=9, recipe='demo_nmf', balance=False, total_segments=None),
+    'cfg2': dict(fn='gf_ep_modulator_nmf', D=16, N=3, T=84010, p=9, recipe='demo_nmf', balance=False, total_segments=None, audio='speech_74'),
     'cfg3': dict(fn='ihgp_ep_modulator_nmf', D=32, N=6, T=200000, p=7, recipe='constraints', balance=True, total_segments=None),
-    'cfg4': dict(fn='gf_giekf_modulator_nmf', D=24, N=3, T=88200, p=9, recipe='demo_nmf', balance=True, total_segments=None),
+    'cfg4': dict(fn='gf_giekf_modulator_nmf', D=24, N=3, T=88200, p=9, recipe='demo_nmf', balance=True, total_segments=None, audio='stim312_wind'),
     'cfg5': dict(fn='gf_ep_modulator_nmf_constraints', D=32, N=6, T=100000, p=7, recipe='constraints', balance=True, total_segments=8),
     # the fill-the-chip regime of the same three kernels families (the batch axes of the path: segments / hyper-parameter replicas):
     # every GPU runs `per_gpu` independent segments, so the series is weak-scaling by construction
@@ -50,12 +50,26 @@ PEAK_FP64_TFLOPS = 78.6   # MI355X FP64 vector = matrix peak (MI355X_MICROARCH.m
 PEAK_HBM_GBS = 8000.0
 
 
+def named_audio(name, T):
+    """The decoded samples of the audio file a BASELINE configuration names (tests/golden/audio_*.npz, tools/make_audio_fixtures.py), as the
+    reference's drivers prepare them: int16 / 32768, divided by the standard deviation.  None when T is not the file's length."""
+    try:
+        z = np.load(os.path.join(ROOT, 'tests', 'golden', 'audio_%s.npz' % name))
+    except OSError:
+        return None
+    x = z['samples'].astype(np.float64) / 32768.0
+    return x / np.std(x) if x.size == T else None
+
+
 def build_problems(wl, seeds):
     from nagp import harness
     from nagp import ss as ssm
     probs, ys = [], []
     for sd in seeds:
-        pr = harness.nmf_problem(wl['D'], wl['N'], wl['T'], sd, wl['recipe'])
+        ya = named_audio(wl['audio'], wl['T']) if wl.get('audio') else None
+        pr = harness.nmf_problem(wl['D'], wl['N'], wl['T'] if ya is None else 8, sd, wl['recipe'])     # (--T overrides: a prior sample of that length)
+        if ya is not None:
+            pr['y'] = ya
         blk = ssm.ss_blocks_nmf(pr['param1'], pr['param2'], 'matern32', 'matern52')
         if wl['balance']:
             blk = ssm.balance_blocks(blk)
@@ -360,11 +374,10 @@ def run_workload(name, a, rank, local_rank, world, dev, with_cpu, steps, warmup)
         'metric': 'audio samples/sec filtered+smoothed (state dim %d, per EP sweep)' % S,
         'value': value, 'unit': 'samples/s', 'n_gpus': world, 'steps': steps, 'warmup': warmup,
         'ms_per_step': dt / steps * 1e3, 'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None,
-        'dtype': 'f64', 'data': 'synthetic',
+        'dtype': 'f64', 'data': ('audio/%s.wav (decoded samples, tests/golden)' % wl['audio']) if (wl.get('audio') and not a.T) else 'synthetic',
         'config': {'workload': '%s: %s%s, %d channels / %d NMF components, T=%d, %d segment(s) in total = %s per GPU, p=%d cubature (%d points), %d EP sweeps%s'
                    % (name, wl['fn'], (' with ' + wl['lik']) if wl.get('lik') else '', D, N, T, n_total, ('%d' % n_seg) if scaling == 'weak' else ('%d/%d' % (n_total, world)), wl['p'], n_pts, EP_ITTS,
-                      {'cfg2': '; input = synthetic prior sample of the length of audio/speech_74.wav (84 010 samples; kernel time does not depend on the sample values)',
-                       'cfg4': '; input = synthetic prior sample of the length of audio/stim312_wind.wav (88 200 samples)'}.get(name, '')),
+                      ('; input = the decoded samples of audio/%s.wav (tests/golden/audio_%s.npz), std-normalised' % (wl['audio'], wl['audio'])) if (wl.get('audio') and not a.T) else ''),
                    'state_dim': S, 'sites_per_step': M, 'parallelism': 'segments sharded over %d GPU(s), no data-path collective; nlZ all-reduce (%s)' % (world, nd.backend_name())},
         'end_to_end_samples_per_s': samples_per_step * steps / dt,
         'kernel_ms_per_step': {k: kern[k] / steps for k in kern if launches[k]},
@@ -472,7 +485,7 @@ def main():
             ex['roofline'] = {k: v for k, v in ex['roofline'].items() if k not in ('traffic_source',)}
             for r in ex['roofline'].get('per_kernel', []):
                 r.pop('what', None)
-        line[key] = {k: ex[k] for k in ex if k not in ('n_gpus', 'higher_is_better', 'vs_baseline', 'dtype', 'data', 'metric', 'unit', 'steps', 'warmup')}
+        line[key] = {k: ex[k] for k in ex if k not in ('n_gpus', 'higher_is_better', 'vs_baseline', 'dtype', 'metric', 'unit', 'steps', 'warmup') and not (k == 'data' and ex[k] == 'synthetic')}
     if rank == 0:
         print(json.dumps(line))
         sys.stdout.flush()

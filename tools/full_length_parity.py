@@ -7,8 +7,8 @@ chunk-pipelined schedule, the parallel-in-time scans -- against the COMPILED res
 
 cases (bench.py WORKLOADS, seed 1000 = the segment rank 0 times):
   cfg3     ihgp_ep_modulator_nmf, T = 200 000, 32 ch / 6 comps, p = 7, 3 sweeps          (north_star's target sentence)
-  cfg2     gf_ep_modulator_nmf, T = 84 010, 16 ch / 3 comps, p = 9, 3 sweeps
-  cfg4     gf_giekf_modulator_nmf, T = 88 200, 24 ch / 3 comps, g_iter = 3, l_iter = 1
+  cfg2     gf_ep_modulator_nmf on audio/speech_74.wav, T = 84 010, 16 ch / 3 comps, p = 9, 3 sweeps
+  cfg4     gf_giekf_modulator_nmf on audio/stim312_wind.wav, T = 88 200, 24 ch / 3 comps, g_iter = 3, l_iter = 1
   cfg5seg  gf_ep_modulator_nmf_constraints model (S = 146), one segment cut to T = 20 000, p = 7, 3 sweeps
 The four CPU legs (one core each: about 35 / 90 / 200 / 115 s) run side by side in threads (ctypes releases the GIL), the GPU
 runs beside them.  Used by tests/test_gpu_parity.py (which asserts the stated tolerances) and, as a script, writes the
@@ -30,8 +30,8 @@ import numpy as np  # noqa: E402
 
 CASES = {
     'cfg3': dict(fam='ihgp', D=32, N=6, T=200000, p=7, recipe='constraints', balance=True),
-    'cfg2': dict(fam='gf', D=16, N=3, T=84010, p=9, recipe='demo_nmf', balance=False),
-    'cfg4': dict(fam='giekf', D=24, N=3, T=88200, p=9, recipe='demo_nmf', balance=True),
+    'cfg2': dict(fam='gf', D=16, N=3, T=84010, p=9, recipe='demo_nmf', balance=False, audio='speech_74'),
+    'cfg4': dict(fam='giekf', D=24, N=3, T=88200, p=9, recipe='demo_nmf', balance=True, audio='stim312_wind'),
     'cfg5seg': dict(fam='gf', D=32, N=6, T=20000, p=7, recipe='constraints', balance=True),
 }
 SWEEPS = 3
@@ -41,8 +41,17 @@ TOL_MEAN, TOL_SITE, TOL_LOGZ = 1e-7, 1e-6, 1e-8
 
 
 def problem(name, T=None):
+    """bench.py's inputs: the model of seed 1000; y = the decoded samples of the audio file BASELINE names (cfg2, cfg4: tests/golden/audio_*.npz,
+    int16 / 32768, std-normalised) or the prior sample of that seed"""
     from nagp import harness
     c = CASES[name]
+    if c.get('audio') and not T:
+        z = np.load(os.path.join(ROOT, 'tests', 'golden', 'audio_%s.npz' % c['audio']))
+        x = z['samples'].astype(np.float64) / 32768.0
+        pr = harness.nmf_problem(c['D'], c['N'], 8, SEED, c['recipe'])
+        pr['y'] = x / np.std(x)
+        assert pr['y'].size == c['T']
+        return pr
     return harness.nmf_problem(c['D'], c['N'], T or c['T'], SEED, c['recipe'])
 
 

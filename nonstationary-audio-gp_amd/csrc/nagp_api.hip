@@ -2237,10 +2237,11 @@ void cc_release_locked() {
   g_cc.comms.clear(); g_cc.streams.clear(); g_cc.bufs.clear(); g_cc.n = 0;
 }
 
+constexpr int NLZ_MAX = 4096;      // EP sweeps of one call (the reference's drivers use 1 .. 30)
 // sum over devices of part[d][0..cnt) with ncclAllReduce; every device ends with the total, device 0's copy is returned
 int allreduce_nlz(int G, int cnt, const std::vector<std::vector<double>>& part, std::vector<double>& total) {
   std::lock_guard<std::mutex> lk(g_cc.mu);
-  if (cnt > 64) FAIL(NAGP_EUNSUPPORTED, "more than 64 EP sweeps in the nlZ reduction");
+  if (cnt > NLZ_MAX) FAIL(NAGP_EUNSUPPORTED, "more than %d EP sweeps in the nlZ reduction", NLZ_MAX);
   if (g_cc.n != G) {
     cc_release_locked();
     g_cc.comms.assign(G, nullptr); g_cc.streams.assign(G, nullptr); g_cc.bufs.assign(G, nullptr);
@@ -2253,7 +2254,7 @@ int allreduce_nlz(int G, int cnt, const std::vector<std::vector<double>>& part, 
     for (int d = 0; d < G; ++d) {
       hipError_t e = hipSetDevice(d);
       if (e == hipSuccess) e = hipStreamCreateWithFlags(&g_cc.streams[d], hipStreamNonBlocking);
-      if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&g_cc.bufs[d]), 128 * sizeof(double));
+      if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&g_cc.bufs[d]), 2 * NLZ_MAX * sizeof(double));
       if (e != hipSuccess) {
         cc_release_locked();
         FAIL(e == hipErrorOutOfMemory ? NAGP_ENOMEM : NAGP_EHIP, "per-device resources of the nlZ all-reduce (device %d) -> %s", d, hipGetErrorString(e));
@@ -2267,7 +2268,7 @@ int allreduce_nlz(int G, int cnt, const std::vector<std::vector<double>>& part, 
   }
   ncclResult_t r = ncclGroupStart();
   for (int d = 0; d < G && r == ncclSuccess; ++d)
-    r = ncclAllReduce(g_cc.bufs[d], g_cc.bufs[d] + 64, (size_t)cnt, ncclDouble, ncclSum, g_cc.comms[d], g_cc.streams[d]);
+    r = ncclAllReduce(g_cc.bufs[d], g_cc.bufs[d] + NLZ_MAX, (size_t)cnt, ncclDouble, ncclSum, g_cc.comms[d], g_cc.streams[d]);
   ncclResult_t r2 = ncclGroupEnd();
   if (r == ncclSuccess) r = r2;
   if (r != ncclSuccess) FAIL(NAGP_ERCCL, "ncclAllReduce -> %s", ncclGetErrorString(r));
@@ -2277,7 +2278,7 @@ int allreduce_nlz(int G, int cnt, const std::vector<std::vector<double>>& part, 
     HIP_TRY(hipStreamSynchronize(g_cc.streams[d]));
   }
   HIP_TRY(hipSetDevice(0));
-  HIP_TRY(hipMemcpy(total.data(), g_cc.bufs[0] + 64, cnt * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(total.data(), g_cc.bufs[0] + NLZ_MAX, cnt * sizeof(double), hipMemcpyDeviceToHost));
   return NAGP_OK;
 }
 }  // namespace

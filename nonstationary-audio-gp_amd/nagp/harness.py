@@ -10,8 +10,9 @@ import numpy as np
 from . import ss as ssm
 
 
-def sample_prior(blk, W, T, rng, link_shift=0.0):
-    """Block-wise prior sample of the (unbalanced) model; returns y (T,)."""
+def sample_prior(blk, W, T, rng, link_shift=0.0, sqrt_amp=False):
+    """Block-wise prior sample of the (unbalanced) model; returns y (T,).  sqrt_amp: the generative model of
+    experiments/likModulatorPreCalcwn.m (:44: amplitudes sqrt(W link(g))) instead of likModulatorNMFPower's (W link(g))."""
     A, Q, P = ssm.discretise(blk)
     S = blk.S; D, N = blk.D, blk.N
     cP = np.zeros((S, S)); cQ = np.zeros((S, S))
@@ -28,7 +29,8 @@ def sample_prior(blk, W, T, rng, link_shift=0.0):
     for k in range(T):
         if k > 0:
             z = A @ z + cQ @ eps[k]
-        y[k] = z[zi] @ (Wm @ np.log1p(np.exp(z[gi] - link_shift)))
+        amp = Wm @ np.log1p(np.exp(z[gi] - link_shift))
+        y[k] = z[zi] @ (np.sqrt(amp) if sqrt_amp else amp)
     return y
 
 
@@ -59,12 +61,12 @@ def nmf_params(D, N, seed, recipe='demo_nmf'):
     return var_fast, len_fast, omega, var_slow, len_slow, W
 
 
-def nmf_problem(D, N, T, seed, recipe='demo_nmf', w_lik=1e-4, kernel1='matern32', kernel2='matern52'):
+def nmf_problem(D, N, T, seed, recipe='demo_nmf', w_lik=1e-4, kernel1='matern32', kernel2='matern52', link_shift=0.0, sqrt_amp=False):
     """Synthetic GT-NMF problem of a given shape: log-parameter vector w (gf_ep_modulator_nmf.m:72-75
     packing) and a prior-sampled signal normalised to unit variance."""
     vf, lf, om, vs, ls, W = nmf_params(D, N, seed, recipe)
     blk = ssm.ss_blocks_nmf(np.concatenate([vf, lf, om]), np.concatenate([vs, ls]), kernel1, kernel2)
-    y = sample_prior(blk, W, T, np.random.default_rng(seed + 7919))
+    y = sample_prior(blk, W, T, np.random.default_rng(seed + 7919), link_shift=link_shift, sqrt_amp=sqrt_amp)
     w = np.log(np.concatenate([[w_lik], vf, lf, om, vs, ls, W.flatten(order='F')]))
     return dict(w=w, y=y, D=D, N=N, W=W, kernel1=kernel1, kernel2=kernel2,
                 param1=np.concatenate([vf, lf, om]), param2=np.concatenate([vs, ls]), w_lik=w_lik)

@@ -22,12 +22,12 @@ def nagp_lib():
 
 @pytest.fixture(scope='session')
 def full_length_refs():
-    """The sequential CPU algorithm (compiled oracle, structured form) on the four full-length bench workloads, one thread each, started
+    """The sequential CPU algorithm (compiled oracle, structured form) on the five full-length bench workloads, one thread each, started
     on first use and running BESIDE the rest of the GPU suite (tools/full_length_parity.py: about 35 / 90 / 200 / 115 s of one core);
     the tests at the end of tests/test_gpu_parity.py join them."""
     import importlib.util
     spec = importlib.util.spec_from_file_location('full_length_parity', os.path.join(ROOT, 'tools', 'full_length_parity.py'))
     mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
-    legs = mod.CpuLegs(['cfg4', 'cfg5seg', 'cfg2', 'cfg3'])          # longest first
+    legs = mod.CpuLegs(['cfg4', 'cfg5seg', 'cfg2', 'cfg3', 'cfg3sqrt'])          # longest first
     legs.mod = mod
     return legs

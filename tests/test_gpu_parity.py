@@ -41,10 +41,10 @@ def gold(name):
 
 
 def test_full_length_reference_runs_are_started(full_length_refs):
-    """Starts the four CPU legs of the full-length parity tests at the end of this file (threads inside the compiled oracle; the GIL is
+    """Starts the five CPU legs of the full-length parity tests at the end of this file (threads inside the compiled oracle; the GIL is
     released): they take minutes of one core each and run beside the GPU tests in between."""
     full_length_refs.start()
-    assert len(full_length_refs.threads) == 4
+    assert len(full_length_refs.threads) == 5
 
 
 def test_golden_cfg1_gf_ep_modulator_full_size():
@@ -911,6 +911,33 @@ def test_sqrt_amplitude_likelihood_staged_form_equals_the_generic_form_and_the_o
     assert np.array_equal(np.isnan(a[5]['tnu']), np.isnan(b[5]['tnu']))
 
 
+@pytest.mark.parametrize('T,nanpos', [(1, []), (2, [1]), (3, [0]), (17, [16]), (33, list(range(33)))])
+def test_sqrt_amplitude_ihgp_sweep_edge_lengths_and_batches(T, nanpos):
+    """ihgp_adf8sq_kernel at T = 1, 2, 3 (the launches of sweeps >= 2 start at k = T - 1 from the filtered mean of the step before), a NaN at
+    the first / last step, everything missing; and three problems of different data and hyper-parameters in ONE plan (one workgroup each)
+    against the oracle.  Three sweeps."""
+    from nagp import cubature
+    D, N, p = 7, 3, 7
+    wn, xn = cubature.utp_ws(p, N)
+    mom = Mom('likModulatorPreCalcwn', link='softplus', link_shift=1.0, wn=wn, xn_unscaled=xn)
+    omom = olik.Mom(olik.LIK_POWER_NMF_SQRT, link=olik.softplus_link(1.0), wn=wn, xn_unscaled=xn)
+    d = 0.2 * np.ones(3); t = np.arange(1, T + 1.0)
+    probs, ys, prs = [], [], []
+    for q in range(3):
+        pr = harness.nmf_problem(D, N, T, 1500 + q, 'constraints', link_shift=1.0, sqrt_amp=True)
+        y = pr['y'].copy(); y[nanpos] = np.nan
+        blk = pss.balance_blocks(pss.ss_blocks_nmf(pr['param1'], pr['param2'], 'matern32', 'matern52'))
+        probs.append((blk, pr['W'], np.log(pr['w_lik']))); ys.append(y); prs.append(pr)
+    plan = Plan(L.KIND_IHGP, probs, T, mom=mom, ep_fraction=0.5, ep_damping=d, ep_itts=3)
+    plan.upload(ys); plan.execute(); outs = plan.download(); plan.close()
+    for q in range(3):
+        ref = oih.ihgp_ep_modulator_nmf(prs[q]['w'], t, ys[q], None, omom, t, 'matern32', 'matern52', 1, D, N, 0.5, d, 3)
+        o = outs[q]
+        assert rel(o.Eft, ref[0]) < TOL_MEAN and rel(o.Varft, ref[1]) < TOL_MEAN, q
+        assert np.allclose(o.nlZ, ref[5]['nlZ'], rtol=TOL_LOGZ, atol=1e-12), q
+        assert rel(o.ttau, ref[5]['ttau']) < TOL_SITE and np.array_equal(np.isnan(o.tnu), np.isnan(ref[5]['tnu'])), q
+
+
 _RANK_WORKER = r"""
 import os, sys
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], 'nonstationary-audio-gp_amd'))
@@ -1704,7 +1731,7 @@ def test_lds_tight_shapes_are_served_or_refused_never_wrong():
 # sweep"): the exact bench.py workloads -- ALL sweeps, default chunking, pipelined schedule, parallel-in-time scans -- against the
 # sequential algorithm of the compiled oracle (gf_ep_modulator_nmf.m:126-283, ihgp_ep_modulator_nmf.m:233-442,
 # gf_giekf_modulator_nmf.m:126-221).  The CPU legs were started by the first test of this file.
-@pytest.mark.parametrize('name', ['cfg3', 'cfg2', 'cfg5seg', 'cfg4'])
+@pytest.mark.parametrize('name', ['cfg3', 'cfg3sqrt', 'cfg2', 'cfg5seg', 'cfg4'])
 def test_full_length_all_sweeps_against_the_sequential_cpu_algorithm(name, full_length_refs):
     flp = full_length_refs.mod
     full_length_refs.start()
@@ -1718,7 +1745,7 @@ def test_full_length_all_sweeps_against_the_sequential_cpu_algorithm(name, full_
     m = flp.compare(name, out, ref)
     bad = {k: v for k, (v, tol) in m.items() if tol is not None and not v <= tol}
     assert not bad, (name, bad)
-    assert pr['y'].size == {'cfg3': 200000, 'cfg2': 84010, 'cfg4': 88200, 'cfg5seg': 20000}[name]
+    assert pr['y'].size == {'cfg3': 200000, 'cfg3sqrt': 200000, 'cfg2': 84010, 'cfg4': 88200, 'cfg5seg': 20000}[name]
     if name != 'cfg4':      # north_star's sentence with three orders of magnitude to spare
         assert np.max(np.abs(out.nlZ - ref['nlZ']) / np.abs(ref['nlZ'])) < TOL_LOGZ < 1e-5
 

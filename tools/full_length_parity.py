@@ -7,9 +7,10 @@ chunk-pipelined schedule, the parallel-in-time scans -- against the COMPILED res
 
 cases (bench.py WORKLOADS, seed 1000 = the segment rank 0 times):
   cfg3     ihgp_ep_modulator_nmf, T = 200 000, 32 ch / 6 comps, p = 7, 3 sweeps          (north_star's target sentence)
-  cfg2     gf_ep_modulator_nmf on audio/speech_74.wav, T = 84 010, 16 ch / 3 comps, p = 9, 3 sweeps
-  cfg4     gf_giekf_modulator_nmf on audio/stim312_wind.wav, T = 88 200, 24 ch / 3 comps, g_iter = 3, l_iter = 1
+  cfg2     gf_ep_modulator_nmf, T = 84 010 (the length of audio/speech_74.wav; prior sample), 16 ch / 3 comps, p = 9, 3 sweeps
+  cfg4     gf_giekf_modulator_nmf, T = 88 200 (the length of audio/stim312_wind.wav; prior sample), 24 ch / 3 comps, g_iter = 3, l_iter = 1
   cfg5seg  gf_ep_modulator_nmf_constraints model (S = 146), one segment cut to T = 20 000, p = 7, 3 sweeps
+  cfg3sqrt cfg3 with experiments/likModulatorPreCalcwn.m (bench.py's cfg3_sqrt: ihgp_adf8sq_kernel), T = 200 000, 3 sweeps
 The four CPU legs (one core each: about 35 / 90 / 200 / 115 s) run side by side in threads (ctypes releases the GIL), the GPU
 runs beside them.  Used by tests/test_gpu_parity.py (which asserts the stated tolerances) and, as a script, writes the
 measured differences to profiles/.
@@ -30,14 +31,22 @@ import numpy as np  # noqa: E402
 
 CASES = {
     'cfg3': dict(fam='ihgp', D=32, N=6, T=200000, p=7, recipe='constraints', balance=True),
-    'cfg2': dict(fam='gf', D=16, N=3, T=84010, p=9, recipe='demo_nmf', balance=False, audio='speech_74'),
-    'cfg4': dict(fam='giekf', D=24, N=3, T=88200, p=9, recipe='demo_nmf', balance=True, audio='stim312_wind'),
+    'cfg2': dict(fam='gf', D=16, N=3, T=84010, p=9, recipe='demo_nmf', balance=False),
+    'cfg4': dict(fam='giekf', D=24, N=3, T=88200, p=9, recipe='demo_nmf', balance=True),
     'cfg5seg': dict(fam='gf', D=32, N=6, T=20000, p=7, recipe='constraints', balance=True),
+    # INFORMATIVE only (script mode, --audio): bench.py's cfg2 / cfg4 inputs, the decoded audio files BASELINE names, with the bench's untrained
+    # hyper-parameters -- the reference algorithm itself is ill-conditioned there (the oracle moves by tens of per cent under a 1e-13 relative
+    # change of y: printed next to the GPU - CPU difference), so nothing is asserted on them
+    'cfg2audio': dict(fam='gf', D=16, N=3, T=84010, p=9, recipe='demo_nmf', balance=False, audio='speech_74', informative=True),
+    'cfg4audio': dict(fam='giekf', D=24, N=3, T=88200, p=9, recipe='demo_nmf', balance=True, audio='stim312_wind', informative=True),
+    # bench.py's cfg3_sqrt: the same model with experiments/likModulatorPreCalcwn.m (sqrt amplitudes, softplus(g - 1), ut7 passed in precomputed)
+    'cfg3sqrt': dict(fam='ihgp', D=32, N=6, T=200000, p=7, recipe='constraints', balance=True, lik='sqrt', link_shift=1.0, damping=0.1),
 }
 SWEEPS = 3
 SEED = 1000
 # stated tolerances (tests/test_gpu_parity.py): means / variances relative to the array's largest magnitude, sites, log Z
 TOL_MEAN, TOL_SITE, TOL_LOGZ = 1e-7, 1e-6, 1e-8
+SITE_MAX = 1e8       # tools/fuzz_conditioning.py
 
 
 def problem(name, T=None):
@@ -52,7 +61,7 @@ def problem(name, T=None):
         pr['y'] = x / np.std(x)
         assert pr['y'].size == c['T']
         return pr
-    return harness.nmf_problem(c['D'], c['N'], T or c['T'], SEED, c['recipe'])
+    return harness.nmf_problem(c['D'], c['N'], T or c['T'], SEED, c['recipe'], link_shift=c.get('link_shift', 0.0), sqrt_amp=c.get('lik') == 'sqrt')
 
 
 class CpuLegs:
@@ -82,14 +91,20 @@ class CpuLegs:
             c = CASES[name]; pr = self.problems[name]; D, N = c['D'], c['N']
             lik_param, p1, p2, W = oss.unpack_log(pr['w'], 1, D, N)
             model = ogf.assemble(lik_param, p1, p2, W, 'matern32', 'matern52', c['balance'], c['fam'] == 'ihgp')
-            d = 0.5 * np.ones(SWEEPS)
+            d = c.get('damping', 0.5) * np.ones(SWEEPS)
+            if c.get('lik') == 'sqrt':
+                from oracle import cubature as ocub
+                wn, xn = ocub.sigma_points(c['p'], N, True)
+                omom = olik.Mom(olik.LIK_POWER_NMF_SQRT, link=olik.softplus_link(c['link_shift']), wn=wn, xn_unscaled=xn)
+            else:
+                omom = olik.Mom(olik.LIK_POWER_NMF, p=c['p'])
             t0 = time.perf_counter()
             if c['fam'] == 'ihgp':
-                r = ocpu.ihgp_predict(model, pr['y'], olik.Mom(olik.LIK_POWER_NMF, p=c['p']), 0.5, d, SWEEPS, D, N, oih.build_tables(model), structured=True)
+                r = ocpu.ihgp_predict(model, pr['y'], omom, 0.5, d, SWEEPS, D, N, oih.build_tables(model), structured=True)
             elif c['fam'] == 'giekf':
                 r = ocpu.giekf_predict(model, pr['y'], D, N, SWEEPS, 1, structured=True)
             else:
-                r = ocpu.gf_predict(model, pr['y'], olik.Mom(olik.LIK_POWER_NMF, p=c['p']), 0.5, d, SWEEPS, D, N, structured=True)
+                r = ocpu.gf_predict(model, pr['y'], omom, 0.5, d, SWEEPS, D, N, structured=True)
             self.secs[name] = time.perf_counter() - t0
             self.res[name] = r
         except BaseException as e:          # handed to the waiting test
@@ -111,12 +126,19 @@ def gpu_run(name, pr=None, env=None):
     if c['balance']:
         blk = ssm.balance_blocks(blk)
     kind = {'gf': L.KIND_GF_EP, 'ihgp': L.KIND_IHGP, 'giekf': L.KIND_GIEKF}[c['fam']]
-    mom = None if c['fam'] == 'giekf' else Mom('likModulatorNMFPower', p_cubature=c['p'])
+    if c['fam'] == 'giekf':
+        mom = None
+    elif c.get('lik') == 'sqrt':
+        from nagp import cubature
+        wn, xn = cubature.sigma_points(c['p'], c['N'], True)
+        mom = Mom('likModulatorPreCalcwn', link_shift=c['link_shift'], wn=wn, xn_unscaled=xn)
+    else:
+        mom = Mom('likModulatorNMFPower', p_cubature=c['p'])
     old = {}
     for k, v in (env or {}).items():
         old[k] = os.environ.get(k); os.environ[k] = v
     try:
-        plan = Plan(kind, [(blk, pr['W'], np.log(pr['w_lik']))], pr['y'].size, mom=mom, ep_fraction=0.5, ep_damping=0.5 * np.ones(SWEEPS), ep_itts=SWEEPS, l_iter=1)
+        plan = Plan(kind, [(blk, pr['W'], np.log(pr['w_lik']))], pr['y'].size, mom=mom, ep_fraction=0.5, ep_damping=c.get('damping', 0.5) * np.ones(SWEEPS), ep_itts=SWEEPS, l_iter=1)
     finally:
         for k, v in old.items():
             if v is None:
@@ -145,11 +167,19 @@ def compare(name, out, ref):
         for i in range(SWEEPS):
             m['dlogZ/logZ sweep %d' % (i + 1)] = (float(nl[i]), TOL_LOGZ)
         fin = np.isfinite(ref['ttau'])
-        m['ttau'] = (_rel(out.ttau, ref['ttau']), TOL_SITE)
+        # A site update is -d2 / (1 + d2 v): where 1 + d2 v = O(1e-9 .. 1e-15) its size and sign are rounding noise IN THE REFERENCE ALGORITHM
+        # (tools/fuzz_conditioning.py: SITE_MAX = 1e8 -- e.g. ONE of the 7.6 M sites of cfg3sqrt, 1.3e9 where its neighbours are 1e-3 .. 18, and
+        # the oracle moves it by 1.3e-4 under a 1e-13 relative change of y).  Such elements are counted and left out of the site comparison;
+        # what they do to the marginals is in Eft / Varft, which are compared in full.
+        wild = (np.abs(ref['ttau']) > SITE_MAX) | (np.abs(out.ttau) > SITE_MAX)
+        tt_o, tt_r = np.where(wild, 0.0, out.ttau), np.where(wild, 0.0, ref['ttau'])
+        tn_o, tn_r = np.where(wild, 0.0, out.tnu), np.where(wild, 0.0, ref['tnu'])
+        m['sites beyond 1e8 (rounding noise of the reference; excluded below)'] = (float(np.sum(wild)), None)
+        m['ttau'] = (_rel(tt_o, tt_r), TOL_SITE)
         # tnu is NaN at missing observations in the IHGP path (SURVEY C-3): the NaN pattern is part of the comparison
-        m['tnu'] = (_rel(out.tnu, ref['tnu']), TOL_SITE)
+        m['tnu'] = (_rel(tn_o, tn_r), TOL_SITE)
         # the worst single site relative to ITS OWN size (informative: the stated tolerance is relative to the array)
-        big = fin & (np.abs(ref['ttau']) > 1e-6 * np.nanmax(np.abs(ref['ttau'])))
+        big = fin & ~wild & (np.abs(ref['ttau']) > 1e-6 * np.nanmax(np.abs(tt_r)))
         m['ttau worst element, relative to itself (informative)'] = (float(np.max(np.abs(out.ttau[big] - ref['ttau'][big]) / np.abs(ref['ttau'][big]))), None)
         if c['fam'] == 'ihgp':
             m['R: Inf pattern equal'] = (0.0 if np.array_equal(np.isinf(out.R), np.isinf(ref['R'])) else float('inf'), 0.5)
@@ -169,8 +199,9 @@ def bit_equal(a, b, fields=('Eft', 'Varft', 'ttau', 'tnu', 'lZ', 'nlZ', 'maxDiff
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--cases', default='cfg3,cfg2,cfg4,cfg5seg')
+    ap.add_argument('--cases', default='cfg3,cfg2,cfg4,cfg5seg,cfg3sqrt')
     ap.add_argument('--out', default=os.path.join(ROOT, 'profiles', 'r04_full_length_parity.txt'))
+    ap.add_argument('--audio', action='store_true', help='also the informative audio-input section (four more CPU legs)')
     a = ap.parse_args()
     names = [n for n in a.cases.split(',') if n]
     import nagp
@@ -178,6 +209,15 @@ def main():
     t_all = time.perf_counter()
     probs = {n: problem(n) for n in names}
     legs = CpuLegs(names, probs).start()
+    la = lb = None
+    if a.audio:      # the informative audio legs run beside the others from the start (eight more minutes of CPU otherwise)
+        an = ['cfg2audio', 'cfg4audio']
+        pa = {n: problem(n) for n in an}
+        pb = {}
+        for n in an:
+            q = dict(pa[n]); q['y'] = q['y'] * (1.0 + 1e-13); pb[n] = q
+        la = CpuLegs(an, pa).start(); lb = CpuLegs(an, pb).start()
+    print('CPU legs started', flush=True)
     lines = ['# GPU (libnagp.so, source hash %s) against the compiled sequential restatement oracle/cpu/nagp_cpu.cpp (structured form),' % nagp._lib.source_hash(),
              '# the exact bench.py workloads: all %d sweeps, default chunking, pipelined schedule, parallel-in-time scans.' % SWEEPS,
              '# differences are max |gpu - cpu| / max |cpu| over the whole array unless stated; tolerance in brackets.', '']
@@ -193,6 +233,7 @@ def main():
     for n in names:
         c = CASES[n]
         ref = legs.result(n)
+        print('joined', n, flush=True)
         m = compare(n, gpu[n][0], ref)
         lines.append('%s  (%s, T = %d, %d ch / %d comps; GPU execute %.2f s, CPU one core %.0f s)' % (n, c['fam'], c['T'], c['D'], c['N'], gpu[n][1], legs.secs[n]))
         for k, (v, tol) in m.items():
@@ -202,6 +243,22 @@ def main():
             lines.append('    nlZ cpu %s' % np.array2string(ref['nlZ'], precision=12))
         lines.append('')
         ok = ok and passed(m)
+    if a.audio:
+        # informative: the audio files BASELINE names with the bench's untrained hyper-parameters.  GPU - CPU next to the ORACLE's own movement
+        # under y -> y (1 + 1e-13) (tools/fuzz_conditioning.py's criterion): where the reference algorithm itself is chaotic nothing can be asserted.
+        lines += ['# INFORMATIVE (nothing asserted): bench.py inputs cfg2 / cfg4 = the decoded audio files BASELINE names, untrained hyper-parameters of the bench.',
+                  '# "oracle moves" = the sequential CPU algorithm on y against itself on y (1 + 1e-13): the conditioning of the reference algorithm on this input.', '']
+        for n in an:
+            c = CASES[n]
+            out, dt = gpu_run(n, pa[n])
+            ra, rb = la.result(n), lb.result(n)
+            lines.append('%s  (%s on audio/%s.wav, T = %d; GPU execute %.2f s)' % (n, c['fam'], c['audio'], c['T'], dt))
+            keys = ('Eft', 'Varft') + (() if c['fam'] == 'giekf' else ('ttau', 'nlZ'))
+            for k in keys:
+                g = getattr(out, k)
+                lines.append('    %-8s gpu - cpu %.3e      oracle moves %.3e      largest |value| %.3e' % (k, _rel(g, ra[k]), _rel(rb[k], ra[k]), float(np.nanmax(np.abs(ra[k])))))
+            lines.append('    outputs finite: %s' % bool(np.all(np.isfinite(out.Eft)) and np.all(np.isfinite(out.Varft))))
+            lines.append('')
     lines.append('# wall time of this script: %.0f s; all within tolerance: %s' % (time.perf_counter() - t_all, ok))
     txt = '\n'.join(lines) + '\n'
     os.makedirs(os.path.dirname(a.out), exist_ok=True)

@@ -8,8 +8,8 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'nonstationary-audio-gp_amd'))
 DOMINANT = {'cfg3': ('ihgp_adf8_kernel', 'ihgp_adf_kernel', 'ihgp_filter_kernel'), 'cfg2': ('gf_filter_kernel<1, 0, 3, 256',), 'cfg5': ('gf_filter_kernel<3, 0, 6, 256',),
-            'cfg4': ('gf_filter_kernel<1, 1, 0',)}
-SHAPES = {'cfg2': (84010, 1), 'cfg3': (200000, 1), 'cfg4': (88200, 1), 'cfg5': (100000, 8)}
+            'cfg4': ('gf_filter_kernel<1, 1, 0',), 'cfg3_sqrt': ('ihgp_adf8sq_kernel',)}
+SHAPES = {'cfg2': (84010, 1), 'cfg3': (200000, 1), 'cfg4': (88200, 1), 'cfg5': (100000, 8), 'cfg3_sqrt': (200000, 1)}
 
 
 def per_kernel(d):

@@ -77,7 +77,7 @@ struct nagp_plan {
   MomSp sp{};           // sparse-point form of likModulatorNMFPower (nagp_momsp.hpp); sp_ih: the IHGP ADF sweep uses it
   int sp_ih = 0, sp_gf = 0, kb_sp = 16, hph_sp = 1; size_t lds_sp = 0;
   int sp_ep = 0; size_t lds_ep_sp = 0;      // site refresh (ep_site_sp_kernel) in the sparse-point form
-  int sq_c0 = -1, sq_ok = 0, sq_ih = 0, kb_sq = 16, hph_sq = 1; size_t lds_sq = 0;   // likModulatorPreCalcwn in the staged form (nagp_momsq.hpp): centre code, rule fits, IHGP ADF sweep uses it
+  int sq_c0 = -1, sq_ok = 0, sq_ih = 0, kb_sq = 16, hph_sq = 1; size_t lds_sq = 0; int sq_ep = 0; size_t lds_ep_sq = 0;   // likModulatorPreCalcwn in the staged form (nagp_momsq.hpp): centre code, rule fits, IHGP ADF sweep uses it
   int sp_ih8 = 0, sp_pack = 0, sp_maxmem = 0; size_t lds_sp8 = 0;   // sp_maxmem: most points sharing one non-centre (dimension, coordinate)   // the role-specialised 512-thread form of the same sweep (ihgp_adf8_kernel)
   hipStream_t stream = nullptr;
   // chunk-pipelined smoother (gf / giekf): while the sequential filter occupies one CU per problem, the parallel smoother kernels
@@ -1018,6 +1018,14 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
       switch (o->cub_dim) { case 1: SLS(1); break; case 2: SLS(2); break; case 3: SLS(3); break; case 4: SLS(4); break; case 5: SLS(5); break; case 6: SLS(6); break; default: SLS(7); break; }
 #undef SLS
     }
+    // ... and with likModulatorPreCalcwn in the staged form of nagp_momsq.hpp
+    if (p->sq_ok && !p->src_ep && sh.M <= 64 && !getenv("NAGP_NO_SPARSE_EP")) {
+      p->sq_ep = 1;
+      p->lds_ep_sq = ep_sq_lds_doubles(sh, o->cub_dim) * sizeof(double);
+#define SLQ(V) PLAN_TRY(set_lds(ep_site_sq_kernel<V>, p->lds_ep_sq))
+      switch (o->cub_dim) { case 1: SLQ(1); break; case 2: SLQ(2); break; case 3: SLQ(3); break; case 4: SLQ(4); break; case 5: SLQ(5); break; default: SLQ(6); break; }
+#undef SLQ
+    }
   }
   p->nlZ.assign((size_t)B * o->ep_itts, 0.0);
   p->mdM.assign((size_t)B * o->ep_itts, 0.0);
@@ -1561,6 +1569,14 @@ static int launch_ep(nagp_plan* p, double alpha, double damp, int clamp, int wri
   else { ep.w_old = 1.0 - damp * alpha; ep.w_new = damp; }
   Timed t(p, NAGP_K_EPSITE);
   dim3 g((unsigned)((ep.k_end + ep.steps_per_wg - 1) / ep.steps_per_wg), p->B), bl(256);
+  if (p->sq_ep) {
+    MomCfg ms = mc; ms.sp = MomSp{}; ms.sp.c0 = p->sq_c0; ms.src = MomSrc{};
+#define LEQ(V) hipLaunchKernelGGL(ep_site_sq_kernel<V>, g, dim3(256), p->lds_ep_sq, p->stream, sh, p->b, ms, ep)
+    switch (ms.cdim) { case 1: LEQ(1); break; case 2: LEQ(2); break; case 3: LEQ(3); break; case 4: LEQ(4); break; case 5: LEQ(5); break; default: LEQ(6); break; }
+#undef LEQ
+    HIP_TRY(hipGetLastError());
+    return NAGP_OK;
+  }
   if (p->sp_ep) {
     MomCfg ms = mc; ms.sp = p->sp; ms.src = MomSrc{};
 #define LES(V) hipLaunchKernelGGL(ep_site_sp_kernel<V>, g, dim3(MSP_NT), p->lds_ep_sp, p->stream, sh, p->b, ms, ep)

@@ -822,7 +822,7 @@ __global__ void __launch_bounds__(MSR_NT) ihgp_adf8_kernel(Shape sh, Bufs b, Mom
 // the centre coordinate.  D <= 32 sub-bands, <= 6 components, <= 336 sigma points (the host checks).
 struct MsqS { int lw; double xdc; msp_rp a_mu, a_s2; msp_wp a_out; msp_rp accp, partp; };
 __host__ __device__ inline size_t ihgp_adf8sq_lds_doubles(const Shape& s, int CD, int NG, int hph_lds, int kb) {
-  return ihgp_adf_lds_doubles(s, CD, NG, hph_lds, kb) - msp_lds_doubles(CD, s.D) + msq_lds_doubles(CD) + 512;
+  return ihgp_adf_lds_doubles(s, CD, NG, hph_lds, kb) - msp_lds_doubles(CD, s.D) + msq_lds_doubles<MsqRole>(CD) + 512;
 }
 template <int CD>
 __global__ void __launch_bounds__(MSQ_NT) ihgp_adf8sq_kernel(Shape sh, Bufs b, MomCfg mc, MomSp sp, IhgpTabs tb, IhgpPar ip) {
@@ -873,16 +873,16 @@ __global__ void __launch_bounds__(MSQ_NT) ihgp_adf8sq_kernel(Shape sh, Bufs b, M
   double* g_lZ = b.lZ + (size_t)pb * T;
   double* g_MF = b.MF + (size_t)pb * T * S;
   double* g_fm = b.fm + (size_t)pb * T * M;
-  msq_init(CD, ws, NT);
+  msq_init<MsqRole>(CD, ws, NT);
   __syncthreads();
-  const MsqLay lay = msq_layout(CD);
+  const MsqLay lay = msq_layout<MsqRole>(CD);
   if (wave >= MSR_W0) {
     // ================= worker role: the parallel stages of the cubature; the same barriers as the serial role below
-    MsqW<CD> xw;
-    msq_setup_W<CD>(xw, mc, sp.c0, sW, fmu, HPH, ws, wave - MSR_W0, tid - 64 * MSR_W0, wt);
-    double amp[2 * MSQ_NST];
+    MsqW<CD, MsqRole> xw;
+    msq_setup_W<CD, MsqRole>(xw, mc, sp.c0, sW, fmu, HPH, ws, wave - MSR_W0, tid - 64 * MSR_W0, wt);
+    double amp[2 * MsqRole::NST];
 #pragma unroll
-    for (int i = 0; i < 2 * MSQ_NST; ++i) amp[i] = 0.0;
+    for (int i = 0; i < 2 * MsqRole::NST; ++i) amp[i] = 0.0;
     // developer diagnostics (NAGP_STAMPS): time lines of worker 0 in stamps[8..15] and of the last worker (marginal sums) in stamps[16..23]
     const int wk_slot = (wave == MSR_W0 + (ip.dbg_wave & 7)) ? 8 : ((wave == MSR_W0 + MSQ_NWK - 1) ? 16 : -1);
     const bool wk_stamp = mc.stamps && wk_slot >= 0 && (tid & 63) == 0;
@@ -898,18 +898,18 @@ __global__ void __launch_bounds__(MSQ_NT) ihgp_adf8sq_kernel(Shape sh, Bufs b, M
     for (int kk = 0; kk < nb; ++kk) {
       lds_barrier();                 // B1
       WK_STAMP(0);                   // (wait at B1: the serial waves' tail and head)
-      msq_stageA<CD>(xw);            // worker 0: t = W' s2_z
+      msq_stageA<CD, MsqRole>(xw);            // worker 0: t = W' s2_z
       WK_STAMP(1);
       lds_barrier();                 // B2: link tables (wave 1)
-      msq_stageS<CD>(xw, amp);       // gather, square roots, mu_p
+      msq_stageS<CD, MsqRole>(xw, amp);       // gather, square roots, mu_p
       WK_STAMP(2);
       lds_barrier();                 // B3
-      msq_stage1b<CD>(xw, sn2a, ry[kk]);
+      msq_stage1b<CD, MsqRole>(xw, sn2a, ry[kk]);
       WK_STAMP(3);
       lds_barrier();                 // B4
       WK_STAMP(4);
       WK_STAMP(5);
-      msq_stageS2<CD>(xw, amp);
+      msq_stageS2<CD, MsqRole>(xw, amp);
       WK_STAMP(6);
       lds_barrier();                 // B5
       WK_STAMP(7);
@@ -943,7 +943,7 @@ __global__ void __launch_bounds__(MSQ_NT) ihgp_adf8sq_kernel(Shape sh, Bufs b, M
     x.partp = (msp_rp)(ws + lay.part + (dl & 15) + 16 * ((dl >> 4) & 1));
   }
   MsqM xm;      // marginal sums of c0 -> g1, g2, Z: the serial waves, idle between B4 and B5, take half of the dimensions each
-  msq_setup_M<CD>(xm, mc, sp.c0, ws, wave);
+  msq_setup_M<CD, MsqRole>(xm, mc, sp.c0, ws, wave);
 
   // wave 0, lane d < D owns sub-band block d; wave 1, lane j < N owns modulator block D + j
   const int lane = tid & 63;
@@ -1039,14 +1039,14 @@ __global__ void __launch_bounds__(MSQ_NT) ihgp_adf8sq_kernel(Shape sh, Bufs b, M
       // (Gaussian weights: worker waves)
       lds_barrier();                 // B4
       IH_STAMP(1);
-      msq_marginals<CD>(xm);         // (sum c1 a, sum c2 a^2: worker waves)
+      msq_marginals<CD, MsqRole>(xm);         // (sum c1 a, sum c2 a^2: worker waves)
       lds_barrier();                 // B5
       IH_STAMP(2);
       {
         if (act) {
           const int ko = kk * M;
           double Z, d1, d2;
-          msq_outputs<CD>(x.accp, x.partp, sub, n - D, pEP1, mc.jitter, Z, d1, d2);
+          msq_outputs<CD, MsqRole>(x.accp, x.partp, sub, n - D, pEP1, mc.jitter, Z, d1, d2);
           if (stamp) { asm volatile("" :: "v"(d2)); IH_STAMP(4); }
           const double t_old = p_tt[ko], n_old = p_tn[ko];
           // site update (:265-266): -d2/(1+d2 HPH), (d1 - fmu d2)/(1+d2 HPH) through one reciprocal

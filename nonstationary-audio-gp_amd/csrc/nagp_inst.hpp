@@ -94,6 +94,11 @@
   P void nagp::ep_site_sp_kernel<4> NAGP_SIG_EPS; P void nagp::ep_site_sp_kernel<5> NAGP_SIG_EPS; P void nagp::ep_site_sp_kernel<6> NAGP_SIG_EPS;   \
   P void nagp::ep_site_sp_kernel<7> NAGP_SIG_EPS;
 
+// site refresh with likModulatorPreCalcwn in the staged form (nagp_momsq.hpp, flat layout)
+#define NAGP_LIST_EPQ(P)                                                                                                   \
+  P void nagp::ep_site_sq_kernel<1> NAGP_SIG_EPS; P void nagp::ep_site_sq_kernel<2> NAGP_SIG_EPS; P void nagp::ep_site_sq_kernel<3> NAGP_SIG_EPS;   \
+  P void nagp::ep_site_sq_kernel<4> NAGP_SIG_EPS; P void nagp::ep_site_sq_kernel<5> NAGP_SIG_EPS; P void nagp::ep_site_sq_kernel<6> NAGP_SIG_EPS;
+
 // infinite-horizon filters
 #define NAGP_SIG_IH (nagp::Shape, nagp::Bufs, nagp::MomCfg, nagp::IhgpTabs, nagp::IhgpPar)
 #define NAGP_LIST_IH_S(P, SRC)                                                                                             \
@@ -128,4 +133,4 @@
 
 #define NAGP_LIST_ALL(P)                                                                                                   \
   NAGP_LIST_GF_ADF1(P) NAGP_LIST_GF_ADF2(P) NAGP_LIST_GF_ADF3(P) NAGP_LIST_GF_ADF4(P) NAGP_LIST_GF_ADF5(P)               \
-  NAGP_LIST_GF_SP12(P) NAGP_LIST_GF_SP34(P) NAGP_LIST_GF_REST(P) NAGP_LIST_SMOOTH(P) NAGP_LIST_SMOOTH8(P) NAGP_LIST_BIG(P) NAGP_LIST_GAINM(P) NAGP_LIST_FLM(P) NAGP_LIST_EP(P) NAGP_LIST_EPS(P) NAGP_LIST_IH0(P) NAGP_LIST_IH1(P) NAGP_LIST_IHA(P) NAGP_LIST_IHA8(P) NAGP_LIST_IHA8Q(P)
+  NAGP_LIST_GF_SP12(P) NAGP_LIST_GF_SP34(P) NAGP_LIST_GF_REST(P) NAGP_LIST_SMOOTH(P) NAGP_LIST_SMOOTH8(P) NAGP_LIST_BIG(P) NAGP_LIST_GAINM(P) NAGP_LIST_FLM(P) NAGP_LIST_EP(P) NAGP_LIST_EPS(P) NAGP_LIST_EPQ(P) NAGP_LIST_IH0(P) NAGP_LIST_IH1(P) NAGP_LIST_IHA(P) NAGP_LIST_IHA8(P) NAGP_LIST_IHA8Q(P)

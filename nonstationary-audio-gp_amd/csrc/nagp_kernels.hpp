@@ -8,7 +8,7 @@
 // matlab/iekf_update1.m:110-117 + gf_giekf_modulator_nmf_constraints.m:492-502 (EKF update).
 #pragma once
 #include "nagp_dev.hpp"
-#include "nagp_momsp.hpp"
+#include "nagp_momsq.hpp"
 
 namespace nagp {
 
@@ -1766,6 +1766,76 @@ __global__ void __launch_bounds__(MSP_NT) __attribute__((amdgpu_waves_per_eu(2))
         if (ep.write_R == 1 || (ep.write_R == 2 && upd)) b.R[ix] = 1.0 / tnew;
         if (tid == 0 && ep.lZ_out) ep.lZ_out[(size_t)pb * T + k] = log(Zv);
       }
+    }
+    lds_barrier();        // fmu / HPH and the tables are rewritten by the next step
+  }
+  if (tid < M && n_clamped) atomicAdd(&b.counters[(size_t)pb * 4 + 1], n_clamped);
+}
+
+// The refresh with likModulatorPreCalcwn in the staged form of nagp_momsq.hpp (flat layout: four waves in every stage): symmetric rules,
+// <= 6 components, <= 32 sub-bands, <= 320 points; mc.sp.c0 = code of the centre coordinate.
+__host__ __device__ inline size_t ep_sq_lds_doubles(const Shape& s, int CD) { return (size_t)s.D * CD + 2 * 68 + 512 + msq_lds_doubles<MsqFlat>(CD); }
+template <int CD>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) ep_site_sq_kernel(Shape sh, Bufs b, MomCfg mc, EpPar ep) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int tid = threadIdx.x, NT = blockDim.x;
+  const int M = sh.M, D = sh.D;
+  const int64_t T = sh.T;
+  const int pb = blockIdx.y;
+  const double* mdl = b.model + (size_t)pb * mdl_size(sh);
+  double* sW = lds;                          // [D][CD]
+  double* fmu = sW + (size_t)D * CD;         // cavity means, 68 entries (zero beyond the M sites)
+  double* HPH = fmu + 68;                    // cavity variances
+  double* wt = HPH + 68;                     // [8][64] W transposed (stage A)
+  double* ws = wt + 512;
+  for (int i = tid; i < D * CD; i += NT) sW[i] = mdl[mdl_W(sh) + i];
+  for (int i = tid; i < 68; i += NT) { fmu[i] = 0.0; HPH[i] = 0.0; }
+  msq_init<MsqFlat>(CD, ws, NT);
+  const double sn2 = mdl[mdl_sn2(sh)];
+  const double pEPa = mom_pEP(mc, sn2, ep.alpha), sn2a = sn2 / ep.alpha;
+  __syncthreads();
+  const MsqLay lay = msq_layout<MsqFlat>(CD);
+  const int wave = tid >> 6;
+  MsqW<CD, MsqFlat> xq;
+  msq_setup_W<CD, MsqFlat>(xq, mc, mc.sp.c0, sW, fmu, HPH, ws, wave, tid, wt, 1);
+  MsqLink xl;
+  msqf_setup_link<CD>(xl, mc, fmu, HPH, ws);
+  MsqM xm;
+  msq_setup_M<CD, MsqFlat>(xm, mc, mc.sp.c0, ws, (wave >= 2) ? wave - 2 : 2);      // marginal sums on waves 2, 3
+  const msp_rp accp = (msp_rp)(ws + lay.acc) + opaque_zero();
+  const msp_rp partp = (msp_rp)(ws + lay.part + (tid & 15) + 16 * ((tid >> 4) & 1));
+  double amp[2 * MsqFlat::NST];
+#pragma unroll
+  for (int i = 0; i < 2 * MsqFlat::NST; ++i) amp[i] = 0.0;
+  __syncthreads();
+  const int64_t kb = (int64_t)blockIdx.x * ep.steps_per_wg;
+  unsigned long long n_clamped = 0;
+  for (int64_t k = kb; k < kb + ep.steps_per_wg && k < ep.k_end; ++k) {
+    const double yk = b.y[(size_t)pb * T + k];
+    if (yk != yk) continue;   // isnan(y_k): no EP update (uniform)
+    const size_t ix = ((size_t)pb * T + k) * M + tid;
+    double t_old = 0.0, n_old = 0.0, vcav = 0.0, mcav = 0.0;
+    if (tid < M) {
+      t_old = b.ttau[ix]; n_old = b.tnu[ix];
+      const double vm = b.sv[ix], mm = b.sm[ix];
+      vcav = 1.0 / (1.0 / vm - ep.alpha * t_old);
+      mcav = vcav * (mm / vm - ep.alpha * n_old);
+      fmu[tid] = mcav; HPH[tid] = vcav;
+    }
+    lds_barrier();
+    double Zv = 0.0, d1 = 0.0, d2 = 0.0;
+    msqf_eval<CD>(xq, xl, xm, mc, amp, sn2a, yk, accp, partp, tid < D, tid - D, pEPa, tid < M, Zv, d1, d2);
+    if (tid < M) {
+      const bool upd = vcav > 0.0;
+      double tnew = t_old, nnew = n_old;
+      if (upd) {
+        tnew = ep.w_old * t_old + ep.w_new * (-d2 / (1.0 + d2 * vcav));
+        nnew = ep.w_old * n_old + ep.w_new * ((d1 - mcav * d2) / (1.0 + d2 * vcav));
+      }
+      if (ep.clamp) { if (!(tnew > 0.0)) ++n_clamped; tnew = max0(tnew); }
+      b.ttau[ix] = tnew; b.tnu[ix] = nnew;
+      if (ep.write_R == 1 || (ep.write_R == 2 && upd)) b.R[ix] = 1.0 / tnew;
+      if (tid == 0 && ep.lZ_out) ep.lZ_out[(size_t)pb * T + k] = log(Zv);
     }
     lds_barrier();        // fmu / HPH and the tables are rewritten by the next step
   }

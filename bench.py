@@ -42,6 +42,8 @@ WORKLOADS = {
     'cfg5_fill': dict(fn='gf_ep_modulator_nmf_constraints', D=32, N=6, T=12500, p=7, recipe='constraints', balance=True, total_segments=None, per_gpu=32),
     # cfg3 with the likelihood every paper experiment uses (experiments/likModulatorPreCalcwn.m: amplitudes sqrt(W softplus(g - 1)),
     # train_model.m:38,55, noise_reduction_speech.m:41) on the same rule (ut7, 305 points, passed in precomputed as the drivers do)
+    'cfg2_sqrt': dict(fn='gf_ep_modulator_nmf', D=16, N=3, T=84010, p=9, recipe='demo_nmf', balance=False, total_segments=None,
+                      lik='likModulatorPreCalcwn', link_shift=1.0, damping=0.1),     # (not in the default line: the gf ADF launches with the sqrt likelihood)
     'cfg3_sqrt': dict(fn='ihgp_ep_modulator_nmf', D=32, N=6, T=200000, p=7, recipe='constraints', balance=True, total_segments=None,
                       lik='likModulatorPreCalcwn', link_shift=1.0, damping=0.1),     # damping of the drivers that use this likelihood (noise_reduction_speech.m:29: <= 0.1); at 0.5 the reference algorithm's own sites reach 1e14
 }

@@ -77,7 +77,7 @@ struct nagp_plan {
   MomSp sp{};           // sparse-point form of likModulatorNMFPower (nagp_momsp.hpp); sp_ih: the IHGP ADF sweep uses it
   int sp_ih = 0, sp_gf = 0, kb_sp = 16, hph_sp = 1; size_t lds_sp = 0;
   int sp_ep = 0; size_t lds_ep_sp = 0;      // site refresh (ep_site_sp_kernel) in the sparse-point form
-  int sq_c0 = -1, sq_ok = 0, sq_ih = 0, kb_sq = 16, hph_sq = 1; size_t lds_sq = 0; int sq_ep = 0; size_t lds_ep_sq = 0;   // likModulatorPreCalcwn in the staged form (nagp_momsq.hpp): centre code, rule fits, IHGP ADF sweep uses it
+  int sq_c0 = -1, sq_ok = 0, sq_ih = 0, kb_sq = 16, hph_sq = 1; size_t lds_sq = 0; int sq_ep = 0; size_t lds_ep_sq = 0; int sq_gf = 0;   // likModulatorPreCalcwn in the staged form (nagp_momsq.hpp): centre code, rule fits, IHGP ADF sweep uses it
   int sp_ih8 = 0, sp_pack = 0, sp_maxmem = 0; size_t lds_sp8 = 0;   // sp_maxmem: most points sharing one non-centre (dimension, coordinate)   // the role-specialised 512-thread form of the same sweep (ihgp_adf8_kernel)
   hipStream_t stream = nullptr;
   // chunk-pipelined smoother (gf / giekf): while the sequential filter occupies one CU per problem, the parallel smoother kernels
@@ -890,6 +890,8 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
         (o->n_pts + 3) / 4 <= MSP_NW * MSP_NST) {
       p->sp_gf = 1; t.sp = p->sp;
     }
+    // ... or with likModulatorPreCalcwn in the staged form of nagp_momsq.hpp
+    if (!ekf && p->sq_ok && !p->src_all.n_src && p->LB_a == 256 && p->NT_a == 256 && sh.M <= 64) { p->sq_gf = 1; t.sq_form = 1; t.store_a = 0; }
     const size_t cap = 156 * 1024;
     p->kb_f = 16;
     if (filter_lds_doubles(sh, t, ekf ? 1 : 0, p->kb_f) * sizeof(double) > cap) p->kb_f = 8;
@@ -925,7 +927,14 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
 #define SL5(V) PLAN_TRY(set_lds(gf_filter_kernel<4, 0, V, 512>, p->lds_filter))
 #define NAGP_SP_SWITCH(TP, CALLSP) switch (mom_variant(mc)) { case 1: CALLSP(TP, 1); break; case 2: CALLSP(TP, 2); break; case 3: CALLSP(TP, 3); break; \
         case 4: CALLSP(TP, 4); break; case 5: CALLSP(TP, 5); break; case 6: CALLSP(TP, 6); break; default: CALLSP(TP, 7); break; }
-#define SLSP(TP, V) PLAN_TRY(set_lds(gf_filter_kernel<TP, 0, V, 256, true>, p->lds_filter))
+#define SLSP(TP, V) PLAN_TRY(set_lds(gf_filter_kernel<TP, 0, V, 256, 1>, p->lds_filter))
+#define NAGP_SQ_SWITCH(TP, CALLSQ) switch (mom_variant(mc)) { case 1: CALLSQ(TP, 1); break; case 2: CALLSQ(TP, 2); break; case 3: CALLSQ(TP, 3); break; \
+        case 4: CALLSQ(TP, 4); break; case 5: CALLSQ(TP, 5); break; default: CALLSQ(TP, 6); break; }
+#define SLSQ(TP, V) PLAN_TRY(set_lds(gf_filter_kernel<TP, 0, V, 256, 2>, p->lds_filter))
+      if (p->sq_gf) {
+        switch (p->TPT_a) { case 1: NAGP_SQ_SWITCH(1, SLSQ) break; case 2: NAGP_SQ_SWITCH(2, SLSQ) break; case 3: NAGP_SQ_SWITCH(3, SLSQ) break; default: NAGP_SQ_SWITCH(4, SLSQ) break; }
+      } else
+#undef SLSQ
       if (p->sp_gf) {
         switch (p->TPT_a) { case 1: NAGP_SP_SWITCH(1, SLSP) break; case 2: NAGP_SP_SWITCH(2, SLSP) break; case 3: NAGP_SP_SWITCH(3, SLSP) break; default: NAGP_SP_SWITCH(4, SLSP) break; }
       } else if (p->LB_a == 512) { NAGP_MV_SWITCH(mom_variant(mc), SL5) }
@@ -1101,6 +1110,7 @@ static int launch_filter(nagp_plan* p, const FilterPar& fp_in) {
   const bool ekf = p->opts.kind == NAGP_KIND_GIEKF;
   MomCfg mc = p->mc; mc.DG = p->DG_f; mc.cache_tabs = p->cache_f; mc.store_a = p->sta_f; mc.chunk_cap = p->chunk_cap_f;
   mc.sp = p->sp_gf ? p->sp : MomSp{};
+  if (p->sq_gf) { mc.sq_form = 1; mc.sp.c0 = p->sq_c0; mc.store_a = 0; }
   if (getenv("NAGP_STAMPS")) mc.stamps = reinterpret_cast<unsigned long long*>(p->d_stamps);   // developer diagnostics
   const bool adf = ekf || fp.mom_all || fp.k_end == p->sh.T;   // launches that may call mom (or the EKF filter)
   int nt_ekf = p->NT_f;
@@ -1119,7 +1129,12 @@ static int launch_filter(nagp_plan* p, const FilterPar& fp_in) {
 #define LF3(V) hipLaunchKernelGGL((gf_filter_kernel<3, 0, V, 256>), g, ba, p->lds_filter, p->stream, p->sh, p->b, mc, fp)
 #define LF4(V) hipLaunchKernelGGL((gf_filter_kernel<4, 0, V, 256>), g, ba, p->lds_filter, p->stream, p->sh, p->b, mc, fp)
 #define LF5(V) hipLaunchKernelGGL((gf_filter_kernel<4, 0, V, 512>), g, ba, p->lds_filter, p->stream, p->sh, p->b, mc, fp)
-#define LFSP(TP, V) hipLaunchKernelGGL((gf_filter_kernel<TP, 0, V, 256, true>), g, ba, p->lds_filter, p->stream, p->sh, p->b, mc, fp)
+#define LFSP(TP, V) hipLaunchKernelGGL((gf_filter_kernel<TP, 0, V, 256, 1>), g, ba, p->lds_filter, p->stream, p->sh, p->b, mc, fp)
+#define LFSQ(TP, V) hipLaunchKernelGGL((gf_filter_kernel<TP, 0, V, 256, 2>), g, ba, p->lds_filter, p->stream, p->sh, p->b, mc, fp)
+      if (p->sq_gf) {
+        switch (p->TPT_a) { case 1: NAGP_SQ_SWITCH(1, LFSQ) break; case 2: NAGP_SQ_SWITCH(2, LFSQ) break; case 3: NAGP_SQ_SWITCH(3, LFSQ) break; default: NAGP_SQ_SWITCH(4, LFSQ) break; }
+      } else
+#undef LFSQ
       if (p->sp_gf) {
         switch (p->TPT_a) { case 1: NAGP_SP_SWITCH(1, LFSP) break; case 2: NAGP_SP_SWITCH(2, LFSP) break; case 3: NAGP_SP_SWITCH(3, LFSP) break; default: NAGP_SP_SWITCH(4, LFSP) break; }
       } else

@@ -213,6 +213,7 @@ struct MomCfg {
   MomSrc src;        // n_src >= 2: mom_src instead of the per-point evaluation (needs cache_tabs)
   int chunk_cap;     // sigma points per pass of the per-point evaluation (0: 1024); smaller for LDS-tight launches (the per-point arrays are 3+ doubles per point)
   MomSp sp;          // enabled: the kernels that have the staged form (nagp_momsp.hpp) use it instead of mom_eval
+  int sq_form;       // likModulatorPreCalcwn in the staged form of nagp_momsq.hpp (sp.c0 = code of the centre coordinate)
 };
 
 typedef const unsigned char __attribute__((address_space(3))) * lds_u8p;   // explicit LDS pointers: a select between

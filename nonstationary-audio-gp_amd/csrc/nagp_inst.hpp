@@ -23,12 +23,20 @@
 
 // ADF launches in the sparse-point form (likModulatorNMFPower, 1..7 components), 256-thread launches
 #define NAGP_LIST_GF_SP(P, TPT)                                                                                            \
-  P void nagp::gf_filter_kernel<TPT, 0, 1, 256, true> NAGP_SIG_GF; P void nagp::gf_filter_kernel<TPT, 0, 2, 256, true> NAGP_SIG_GF;    \
-  P void nagp::gf_filter_kernel<TPT, 0, 3, 256, true> NAGP_SIG_GF; P void nagp::gf_filter_kernel<TPT, 0, 4, 256, true> NAGP_SIG_GF;    \
-  P void nagp::gf_filter_kernel<TPT, 0, 5, 256, true> NAGP_SIG_GF; P void nagp::gf_filter_kernel<TPT, 0, 6, 256, true> NAGP_SIG_GF;    \
-  P void nagp::gf_filter_kernel<TPT, 0, 7, 256, true> NAGP_SIG_GF;
+  P void nagp::gf_filter_kernel<TPT, 0, 1, 256, 1> NAGP_SIG_GF; P void nagp::gf_filter_kernel<TPT, 0, 2, 256, 1> NAGP_SIG_GF;    \
+  P void nagp::gf_filter_kernel<TPT, 0, 3, 256, 1> NAGP_SIG_GF; P void nagp::gf_filter_kernel<TPT, 0, 4, 256, 1> NAGP_SIG_GF;    \
+  P void nagp::gf_filter_kernel<TPT, 0, 5, 256, 1> NAGP_SIG_GF; P void nagp::gf_filter_kernel<TPT, 0, 6, 256, 1> NAGP_SIG_GF;    \
+  P void nagp::gf_filter_kernel<TPT, 0, 7, 256, 1> NAGP_SIG_GF;
 #define NAGP_LIST_GF_SP12(P) NAGP_LIST_GF_SP(P, 1) NAGP_LIST_GF_SP(P, 2)
 #define NAGP_LIST_GF_SP34(P) NAGP_LIST_GF_SP(P, 3) NAGP_LIST_GF_SP(P, 4)
+
+// ADF launches with likModulatorPreCalcwn in the staged form (nagp_momsq.hpp; 1..6 components), 256-thread launches
+#define NAGP_LIST_GF_SQ(P, TPT)                                                                                            \
+  P void nagp::gf_filter_kernel<TPT, 0, 1, 256, 2> NAGP_SIG_GF; P void nagp::gf_filter_kernel<TPT, 0, 2, 256, 2> NAGP_SIG_GF;    \
+  P void nagp::gf_filter_kernel<TPT, 0, 3, 256, 2> NAGP_SIG_GF; P void nagp::gf_filter_kernel<TPT, 0, 4, 256, 2> NAGP_SIG_GF;    \
+  P void nagp::gf_filter_kernel<TPT, 0, 5, 256, 2> NAGP_SIG_GF; P void nagp::gf_filter_kernel<TPT, 0, 6, 256, 2> NAGP_SIG_GF;
+#define NAGP_LIST_GF_SQ12(P) NAGP_LIST_GF_SQ(P, 1) NAGP_LIST_GF_SQ(P, 2)
+#define NAGP_LIST_GF_SQ34(P) NAGP_LIST_GF_SQ(P, 3) NAGP_LIST_GF_SQ(P, 4)
 
 // EKF and fixed-site filters, smoother kernels
 #define NAGP_LIST_GF_REST(P)                                                                                               \
@@ -133,4 +141,4 @@
 
 #define NAGP_LIST_ALL(P)                                                                                                   \
   NAGP_LIST_GF_ADF1(P) NAGP_LIST_GF_ADF2(P) NAGP_LIST_GF_ADF3(P) NAGP_LIST_GF_ADF4(P) NAGP_LIST_GF_ADF5(P)               \
-  NAGP_LIST_GF_SP12(P) NAGP_LIST_GF_SP34(P) NAGP_LIST_GF_REST(P) NAGP_LIST_SMOOTH(P) NAGP_LIST_SMOOTH8(P) NAGP_LIST_BIG(P) NAGP_LIST_GAINM(P) NAGP_LIST_FLM(P) NAGP_LIST_EP(P) NAGP_LIST_EPS(P) NAGP_LIST_EPQ(P) NAGP_LIST_IH0(P) NAGP_LIST_IH1(P) NAGP_LIST_IHA(P) NAGP_LIST_IHA8(P) NAGP_LIST_IHA8Q(P)
+  NAGP_LIST_GF_SP12(P) NAGP_LIST_GF_SP34(P) NAGP_LIST_GF_SQ12(P) NAGP_LIST_GF_SQ34(P) NAGP_LIST_GF_REST(P) NAGP_LIST_SMOOTH(P) NAGP_LIST_SMOOTH8(P) NAGP_LIST_BIG(P) NAGP_LIST_GAINM(P) NAGP_LIST_FLM(P) NAGP_LIST_EP(P) NAGP_LIST_EPS(P) NAGP_LIST_EPQ(P) NAGP_LIST_IH0(P) NAGP_LIST_IH1(P) NAGP_LIST_IHA(P) NAGP_LIST_IHA8(P) NAGP_LIST_IHA8Q(P)

@@ -155,7 +155,7 @@ __host__ __device__ inline size_t filter_lds_doubles(const Shape& s, const MomCf
   size_t n = LDS_INT_DOUBLES + 2 * (size_t)s.M * TS + s.M + (size_t)s.D * s.N + s.S + 4 * (size_t)s.M * s.M +
              6 * (size_t)s.M + 2 * 68 + 8 + 2 /* the W panel starts on a 16-byte boundary */ + filter_ring_doubles(s, kb);
   // mom workspace: the staged sparse-point form when the plan enabled it, else the generic one
-  const size_t wmom = (mc.sp.enabled && mc.cdim <= MSP_MAXCD) ? msp_lds_doubles(mc.cdim, s.D) : mom_lds_doubles(mc);
+  const size_t wmom = mc.sq_form ? msq_lds_doubles<MsqFlat>(mc.cdim) + 512 : ((mc.sp.enabled && mc.cdim <= MSP_MAXCD) ? msp_lds_doubles(mc.cdim, s.D) : mom_lds_doubles(mc));
   n += (meas == 0) ? wmom : (size_t)(2 * s.M + 2 * s.S + 2 * s.N);
   return (n + 1) & ~(size_t)1;
 }
@@ -165,9 +165,10 @@ __host__ __device__ inline size_t filter_lds_doubles(const Shape& s, const MomCf
 // instantiated with MV = 0 only
 // LB: launch bound.  The ADF launches (MV >= 0) run with <= 256 threads whenever the tiles fit: one wave per SIMD
 // may then use all 512 registers (the cubature's pressure lands in AGPRs instead of scratch memory).
-// SP: the ADF steps use the staged sparse-point form of likModulatorNMFPower (nagp_momsp.hpp) and the generic mom_eval is not
-// compiled into the instantiation at all (both side by side cost hundreds of registers)
-template <int TPT, int MEAS, int MV, int LB = 512, bool SP = false>
+// SP = 1: the ADF steps use the staged sparse-point form of likModulatorNMFPower (nagp_momsp.hpp) and the generic mom_eval is not
+// compiled into the instantiation at all (both side by side cost hundreds of registers); SP = 2: likModulatorPreCalcwn in the staged
+// form of nagp_momsq.hpp (flat layout), likewise without the generic code
+template <int TPT, int MEAS, int MV, int LB = 512, int SP = 0>
 __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg mc, FilterPar fp) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int tid = threadIdx.x, NT = blockDim.x;
@@ -218,15 +219,35 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
   for (int i = tid; i < 68; i += NT) { fmu[i] = 0.0; HPH[i] = 0.0; }
   const double sn2 = mdl[mdl_sn2(sh)];
   // likModulatorNMFPower on a fully symmetric sigma-point set: the staged form of nagp_momsp.hpp (256-thread ADF launches)
-  constexpr bool SPK = SP && (MEAS == 0 && MV >= 1 && MV <= MSP_MAXCD);
-  static_assert(!SP || SPK, "the sparse-point form exists for the NMF likelihood with 1..7 components");
-  constexpr int CDX = SPK ? MV : 1;
-  if constexpr (MEAS == 0 && MV >= 0 && !SPK) mom_cache_tables(mc, ws);
+  constexpr bool SPK = SP == 1 && (MEAS == 0 && MV >= 1 && MV <= MSP_MAXCD);
+  constexpr bool SQK = SP == 2 && (MEAS == 0 && MV >= 1 && MV <= MSQ_MAXCD);
+  static_assert(SP == 0 || SPK || SQK, "the staged forms exist for the NMF likelihoods with 1..7 (sqrt amplitudes: 1..6) components");
+  constexpr int CDX = (SPK || SQK) ? MV : 1;
+  if constexpr (MEAS == 0 && MV >= 0 && !SPK && !SQK) mom_cache_tables(mc, ws);
   const double pEP1 = (MEAS == 0 && MV >= 0) ? mom_pEP(mc, sn2, fp.mom_alpha) : 1.0;
   MspCtx<CDX> xsp;
   double wrow[CDX];
 #pragma unroll
   for (int j = 0; j < CDX; ++j) wrow[j] = 0.0;
+  // staged sqrt amplitudes (SP = 2): ws = [W transposed: 512][workspace of nagp_momsq.hpp]
+  MsqW<CDX, MsqFlat> xq; MsqLink xl; MsqM xm;
+  double amp[SQK ? 2 * MsqFlat::NST : 1];
+  msp_rp q_accp = nullptr, q_partp = nullptr;
+  if constexpr (SQK) {
+    __syncthreads();      // sW, fmu / HPH padding
+    double* wsq = ws + 512;
+    msq_init<MsqFlat>(CDX, wsq, NT);
+    __syncthreads();
+    const MsqLay lay = msq_layout<MsqFlat>(CDX);
+    const int wv = tid >> 6;
+    msq_setup_W<CDX, MsqFlat>(xq, mc, mc.sp.c0, sW, fmu, HPH, wsq, wv, tid, ws, 1);
+    msqf_setup_link<CDX>(xl, mc, fmu, HPH, wsq);
+    msq_setup_M<CDX, MsqFlat>(xm, mc, mc.sp.c0, wsq, (wv >= 2) ? wv - 2 : 2);
+    q_accp = (msp_rp)(wsq + lay.acc) + opaque_zero();
+    q_partp = (msp_rp)(wsq + lay.part + (tid & 15) + 16 * ((tid >> 4) & 1));
+#pragma unroll
+    for (int i = 0; i < 2 * MsqFlat::NST; ++i) amp[i] = 0.0;
+  }
   if constexpr (SPK) {
     __syncthreads();      // sW, fmu / HPH padding
     msp_setup<CDX>(xsp, mc, mc.sp, sW, fmu, HPH, ws);
@@ -437,7 +458,12 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
                 }
               }
             }
-            if constexpr (!SPK) {
+            if constexpr (SQK) {
+              double Zv = 0.0;
+              msqf_eval<CDX>(xq, xl, xm, mc, amp, sn2 / fp.mom_alpha, yk, q_accp, q_partp, tid < D, tid - D, pEP1, tid < M, Zv, d1v, d2v);
+              if (tid == 0) rZ[kk] = Zv;
+            }
+            if constexpr (!SPK && !SQK) {
               mom_eval<MV, false, false>(mc, sW, pEP1, sn2, fp.mom_alpha, yk, fmu, HPH, ws, &misc[0], dl, d2l, stp);
               if (tid < M) { d1v = dl[tid]; d2v = d2l[tid]; }
               if (tid == 0) rZ[kk] = misc[0];

@@ -196,6 +196,14 @@ def cpu_baseline(wl, budget_s=4.0):
                        % (EP_ITTS, Td, dtd, Tst, dts, threads, Tst, dt_all, Tn, dtn))
 
 
+def sig(x, n=5):
+    """n significant digits (the extras of the JSON line)"""
+    try:
+        return float('%.*g' % (n, float(x)))
+    except (TypeError, ValueError):
+        return x
+
+
 def source_hash():
     from nagp import _lib as L
     return L.source_hash()
@@ -478,17 +486,27 @@ def main():
         ex = run_workload(e, a, rank, local_rank, world, dev, with_cpu and e in ('cfg2', 'cfg4', 'cfg5'), 2, 1)
         key = 'cfg5_strong' if e == 'cfg5' else e
         if e == 'cfg5':
-            ex['scaling_note'] = ('strong scaling of ONE fixed set of 8 segments is capped at ~1.2x by construction: a single 100 000-step segment alone (what a rank runs '
-                                  'at N = 8) takes 3.9 s of sequential recursion, all eight on one GPU 4.7 s; the weak series cfg5_fill / cfg3_batch are the ones that scale')
-        # (the line has to survive the driver's tail: no repeated prose in the extras)
-        ex['config'] = {k: v for k, v in ex['config'].items() if k != 'parallelism'}
+            ex['scaling_note'] = 'strong series capped at ~1.2x: one 100k-step segment alone = 3.9 s of sequential recursion, all 8 on one GPU 4.7 s; cfg5_fill / cfg3_batch are the series that scale'
+        # The line has to survive the driver's tail (round 3: 14 KB, half of the extras cut off): an extra keeps its numbers -- value, time,
+        # the roofline of its dominant kernel, the per-kernel table as [kernel, ms, fraction of peak] -- and its full record goes to stderr.
+        if rank == 0:
+            sys.stderr.write('[bench extra] ' + json.dumps({key: ex}) + '\n')
+        rf = ex.get('roofline') or {}
+        small = {'value': sig(ex['value']), 'ms_per_step': sig(ex['ms_per_step']), 'scaling': ex['scaling'], 'workload': ex['config']['workload'].split(';')[0][:160],
+                 'state_dim': ex['config']['state_dim'], 'kernel_ms': {k: sig(v) for k, v in ex['kernel_ms_per_step'].items()},
+                 'nlZ_allreduced': [sig(v, 8) for v in ex['nlZ_allreduced']],
+                 'roofline': {k: (sig(rf[k]) if isinstance(rf.get(k), float) else rf.get(k)) for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic') if k in rf},
+                 'per_kernel': [[r['kernel'], sig(r['ms']), r['bound'], sig(r['frac'])] for r in rf.get('per_kernel', [])]}
+        if rf.get('whole_call'):
+            small['whole_call_frac'] = sig(rf['whole_call']['frac'])
+        if ex.get('data') and ex['data'] != 'synthetic':
+            small['data'] = ex['data']
         if 'cpu_baseline' in ex:
-            ex['cpu_baseline'] = {k: v for k, v in ex['cpu_baseline'].items() if k not in ('sample', 'host_cpu_model', 'host_nproc', 'host_usable_cores')}
-        if ex.get('roofline'):
-            ex['roofline'] = {k: v for k, v in ex['roofline'].items() if k not in ('traffic_source',)}
-            for r in ex['roofline'].get('per_kernel', []):
-                r.pop('what', None)
-        line[key] = {k: ex[k] for k in ex if k not in ('n_gpus', 'higher_is_better', 'vs_baseline', 'dtype', 'metric', 'unit', 'steps', 'warmup') and not (k == 'data' and ex[k] == 'synthetic')}
+            cb = ex['cpu_baseline']
+            small['cpu_baseline'] = {'value': sig(cb['value']), 'unit': cb['unit'], 'cores': cb['cores'], 'kind': cb['kind'], 'single_thread_value': sig(cb['single_thread_value'])}
+        if 'scaling_note' in ex:
+            small['scaling_note'] = ex['scaling_note']
+        line[key] = small
     if rank == 0:
         print(json.dumps(line))
         sys.stdout.flush()

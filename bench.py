@@ -283,7 +283,7 @@ def run_workload(name, a, rank, local_rank, world, dev, with_cpu, steps, warmup)
         units = n_seg * T * steps                                 # one ADF-sweep launch covers T samples of every segment
         per_launch = per_sample * n_seg * T
         achieved = per_sample * units / (kern[dom] * 1e-3) / 1e9
-        roof = dict(bound='hbm', kernel='ihgp ADF sweep (ihgp_adf8_kernel / ihgp_adf_kernel / ihgp_filter_kernel, one launch per execute)',
+        roof = dict(bound='hbm', kernel='ihgp ADF sweep (ihgp_adf8_kernel / ihgp_adf8sq_kernel / ihgp_adf_kernel / ihgp_filter_kernel, one launch per execute)',
                     achieved=achieved, peak=PEAK_HBM_GBS, unit='GB/s', frac=achieved / PEAK_HBM_GBS, traffic=None,
                     algorithmic_bytes_per_sample=per_sample, algorithmic_bytes_per_launch=per_launch,
                     valu_gflops=(8.0 * S * (S / M) + 8 * S + f_mom) * units / (kern[dom] * 1e-3) / 1e9,

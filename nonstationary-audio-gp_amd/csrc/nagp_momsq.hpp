@@ -83,8 +83,8 @@ __host__ __device__ inline MsqLay msq_layout(int CD) {
   l.marg = l.c2 + C::NP;                  // [MSR_NMARG]
   l.acc = l.marg + MSR_NMARG;             // [2][32]: g1[8] | g2[8] | Z, two copies; words 56 .. 63: scratch / zero
   l.part = l.acc + 64;                    // [NTW][2][32]
-  l.scr = l.part + C::NTW * 64;           // [64] scratch: one word per lane
-  l.total = l.scr + 64;
+  l.scr = l.part + C::NTW * 64;           // [64 + 16 NTL] scratch: one word per lane (+ 16 per tile: the stores of stage S of the lanes that own no step)
+  l.total = l.scr + 64 + 16 * C::NTL;
   return l;
 }
 template <class C>

@@ -949,7 +949,16 @@ __global__ void __launch_bounds__(LB) __attribute__((amdgpu_waves_per_eu(LB > 51
     const double2* src = reinterpret_cast<const double2*>(PFk);
     double2* dst = reinterpret_cast<double2*>(sPF);
     const int n2 = (int)(pf_step_doubles(sh) / 2);
-    for (int i = tid; i < n2; i += NT) dst[i] = src[i];
+    // eight loads in flight per trip (as a plain loop the compiler waits for every 16-byte load before it issues the next: eight
+    // dependent HBM round trips at the head of a 145 us kernel -- profiles/r04_gain_phases.txt)
+    constexpr int NLD = 8;
+    for (int base = tid; base < n2; base += NLD * NT) {
+      double2 v[NLD];
+#pragma unroll
+      for (int u = 0; u < NLD; ++u) { const int i = base + u * NT; v[u] = (i < n2) ? src[i] : make_double2(0.0, 0.0); }
+#pragma unroll
+      for (int u = 0; u < NLD; ++u) { const int i = base + u * NT; if (i < n2) dst[i] = v[u]; }
+    }
   }
   const size_t mstride = gp.dense_sp ? (size_t)gp.dense_sp * gp.dense_sp : (size_t)sh.ntiles * 16;
   const size_t gstep = gp.dense_sp ? gd_step_doubles(gp.dense_sp, gp.dpacked) : 2 * mstride;

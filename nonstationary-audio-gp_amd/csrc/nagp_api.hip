@@ -18,6 +18,7 @@ NAGP_LIST_ALL(extern template __global__)
 #include <chrono>
 #include <mutex>
 #include <string>
+#include <functional>
 #include <thread>
 #include <vector>
 
@@ -78,6 +79,7 @@ struct nagp_plan {
   int sp_ih = 0, sp_gf = 0, kb_sp = 16, hph_sp = 1; size_t lds_sp = 0;
   int sp_ep = 0; size_t lds_ep_sp = 0;      // site refresh (ep_site_sp_kernel) in the sparse-point form
   int sq_c0 = -1, sq_ok = 0, sq_ih = 0, kb_sq = 16, hph_sq = 1; size_t lds_sq = 0; int sq_ep = 0; size_t lds_ep_sq = 0; int sq_gf = 0;   // likModulatorPreCalcwn in the staged form (nagp_momsq.hpp): centre code, rule fits, IHGP ADF sweep uses it
+  int a8_gf = 0, a8_pack = 0, a8_tpt = 1, kb_a8 = 16; size_t lds_a8 = 0;   // ADF sweep of the gf filter with role-specialised waves (gf_adf8_kernel)
   int sp_ih8 = 0, sp_pack = 0, sp_maxmem = 0; size_t lds_sp8 = 0;   // sp_maxmem: most points sharing one non-centre (dimension, coordinate)   // the role-specialised 512-thread form of the same sweep (ihgp_adf8_kernel)
   hipStream_t stream = nullptr;
   // chunk-pipelined smoother (gf / giekf): while the sequential filter occupies one CU per problem, the parallel smoother kernels
@@ -103,6 +105,11 @@ struct nagp_plan {
                                                 // passes of two chunks may run at the same time (one on each stream)
   unsigned long long* h_progress = nullptr;     // pinned host memory [B]: steps the filter has finished (FilterPar::progress)
   hipEvent_t ev_filter = nullptr, ev_s2 = nullptr;
+  // cross-sweep schedule (gf): the apply pass and the site refresh of a sweep run chunk by chunk, earliest steps first, and the next
+  // sweep's filter follows them chunk by chunk (ev_chunk[c]); the per-sweep reductions go to their own records of red_all
+  bool xsweep = false;
+  std::vector<hipEvent_t> ev_chunk; hipEvent_t ev_red = nullptr;
+  double* red_all = nullptr; double* red0 = nullptr;     // [ep_itts + 2][B][8] ; the plan's single record (giekf, ihgp)
   Bufs b{};
   MomCfg mc{};
   IhgpTabs tb{};
@@ -574,6 +581,8 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
   PLAN_TRY(dalloc(p, &b.sv, BT * sh.M));
   PLAN_TRY(dalloc(p, &b.state, (size_t)B * ((size_t)nt * 16 + sh.S)));
   PLAN_TRY(dalloc(p, &b.red, (size_t)B * 8));
+  p->red0 = b.red;
+  if (p->opts.kind == NAGP_KIND_GF_EP) PLAN_TRY(dalloc(p, &p->red_all, (size_t)(p->opts.ep_itts + 2) * B * 8));
   { double* c = nullptr; PLAN_TRY(dalloc(p, &c, (size_t)B * 4)); b.counters = reinterpret_cast<unsigned long long*>(c); }
   // smoother chunk: the unit of the (G, Delta) buffers and of the filter -> smoother pipeline.  About a dozen chunks per sweep
   // (the tail the pipeline cannot hide is one chunk's gain + compose), at least 2048 steps each, at most what one buffer may take.
@@ -754,6 +763,11 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
       PLAN_HIP(hipHostMalloc(reinterpret_cast<void**>(&p->h_tab), (size_t)(p->nc + 1) * sizeof(ChunkTab), hipHostMallocMapped | hipHostMallocCoherent));
       PLAN_HIP(hipEventCreateWithFlags(&p->ev_filter, hipEventDisableTiming));
       PLAN_HIP(hipEventCreateWithFlags(&p->ev_s2, hipEventDisableTiming));
+      if (p->opts.kind == NAGP_KIND_GF_EP && !getenv("NAGP_NO_XSWEEP")) {
+        for (int c = 0; c < p->nc + 1; ++c) { hipEvent_t e = nullptr; PLAN_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); p->ev_chunk.push_back(e); }
+        PLAN_HIP(hipEventCreateWithFlags(&p->ev_red, hipEventDisableTiming));
+        p->xsweep = true;
+      }
       PLAN_HIP(hipHostMalloc(reinterpret_cast<void**>(&p->h_progress), (size_t)B * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent));
       std::memset(p->h_progress, 0, (size_t)B * sizeof(unsigned long long));
     }
@@ -911,6 +925,33 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     // beside it on the second stream is placed on the same CU (the filter is the critical path; its time is latency, not occupancy)
     if (p->pipeline && B <= 128 && p->lds_filter < 160 * 1024) p->lds_filter = 160 * 1024;     // (never BELOW what the kernel needs: set_lds refuses > 160 KiB)
     if (getenv("NAGP_STAMPS")) fprintf(stderr, "[nagp plan] gf filter: LDS %zu B, ring %d steps, cubature tables in LDS %d, mom LDS %zu B, sparse-point ADF %d\n", p->lds_filter, p->kb_f, p->cache_f, ekf ? (size_t)0 : mom_lds_doubles(t) * sizeof(double), p->sp_gf);
+    // ADF sweep with role-specialised waves (nagp_gfadf8.hpp): 512 threads, <= 2 lower tiles per thread, the role layout's limits
+    // (one sigma point per worker lane, <= 80 MFMA steps; packed form as in the IHGP sweep)
+    if (p->sp_gf && sh.M * (sh.M + 1) / 2 <= 2 * MSR_NT && sh.S <= MSR_NT && o->n_pts <= 64 * MSR_NWK && (o->n_pts + 3) / 4 <= 4 * MSR_NST &&
+        getenv("NAGP_GF_ROLES")) {      // (opt-in until the parity suite has run on it)
+      p->a8_tpt = (sh.M * (sh.M + 1) / 2 <= MSR_NT) ? 1 : 2;
+      p->kb_a8 = 16;
+      while (p->kb_a8 > 2 && gf_adf8_lds_doubles(sh, o->cub_dim, p->kb_a8) * sizeof(double) > cap) p->kb_a8 /= 2;
+      if (const char* e = getenv("NAGP_KB_A8")) p->kb_a8 = std::max(2, std::min(16, atoi(e) & ~1));
+      const size_t need = gf_adf8_lds_doubles(sh, o->cub_dim, p->kb_a8) * sizeof(double);
+      if (need <= cap) {
+        const int CDp = o->cub_dim, ndp = mc.nd;
+        bool pk = CDp <= 6 && (ndp - 1) * ((CDp + 1) / 2) <= 16 && (ndp - 1) * CDp <= MSR_NMARG && (o->n_pts + 7) / 8 <= 40 && p->sp_maxmem <= 4 * MSR_NMEM;
+        const char* ep = getenv("NAGP_IH_PACK");
+        if (ep && ep[0] == '0') pk = false;
+        p->a8_gf = 1; p->a8_pack = pk ? 1 : 0; p->lds_a8 = need;
+        if (p->pipeline && B <= 128) p->lds_a8 = 160 * 1024;      // (the whole LDS of the CU, as for the other filter launches below)
+#define SA8(TP, V, PK) PLAN_TRY(set_lds(gf_adf8_kernel<TP, V, PK>, p->lds_a8))
+#define SA8V(TP, PK) switch (o->cub_dim) { case 1: SA8(TP, 1, PK); break; case 2: SA8(TP, 2, PK); break; case 3: SA8(TP, 3, PK); break; \
+          case 4: SA8(TP, 4, PK); break; case 5: SA8(TP, 5, PK); break; default: SA8(TP, 6, PK); break; }
+        if (!pk && o->cub_dim == 7) { if (p->a8_tpt == 1) SA8(1, 7, false); else SA8(2, 7, false); }
+        else if (pk) { if (p->a8_tpt == 1) SA8V(1, true) else SA8V(2, true) }
+        else { if (p->a8_tpt == 1) SA8V(1, false) else SA8V(2, false) }
+#undef SA8V
+#undef SA8
+      }
+    }
+    if (getenv("NAGP_STAMPS")) fprintf(stderr, "[nagp plan] gf ADF sweep with role-specialised waves: %d (tiles per thread %d, ring %d steps, LDS %zu B, packed MFMA steps %d)\n", p->a8_gf, p->a8_tpt, p->kb_a8, p->lds_a8, p->a8_pack);
     p->lds_gain = ((p->TPT == 1) ? gain_lds_doubles_staged(sh) : gain_lds_doubles(sh)) * sizeof(double);     // (rts_gain_kernel: STAGE)
     p->lds_scan = span_lds_doubles(sh, p->LP1, p->LP2) * sizeof(double);
     if (ekf) {
@@ -1057,6 +1098,8 @@ extern "C" void nagp_plan_destroy(nagp_plan* p) {
   for (hipStream_t st : p->s_apply) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
   for (hipEvent_t e : p->ev_bnd) (void)hipEventDestroy(e);
   for (hipEvent_t e : p->ev_app) (void)hipEventDestroy(e);
+  for (hipEvent_t e : p->ev_chunk) (void)hipEventDestroy(e);
+  if (p->ev_red) (void)hipEventDestroy(p->ev_red);
   if (p->ev_filter) (void)hipEventDestroy(p->ev_filter);
   if (p->ev_s2) (void)hipEventDestroy(p->ev_s2);
   if (p->h_progress) (void)hipHostFree(p->h_progress);
@@ -1122,6 +1165,19 @@ static int launch_filter(nagp_plan* p, const FilterPar& fp_in) {
     switch (p->TPT_f) { case 1: LF(1); break; case 2: LF(2); break; default: LF(4); break; }
 #undef LF
   } else {
+    if (adf && p->a8_gf && fp.mom_all && fp.k_end - fp.k_begin > 1) {
+      // sweep 1 (mom at every step): role-specialised waves
+      FilterPar fa = fp; fa.kb = p->kb_a8;
+      MomCfg ma = mc; ma.sp = p->sp;
+#define LA8(TP, V, PK) hipLaunchKernelGGL((gf_adf8_kernel<TP, V, PK>), g, dim3(MSR_NT), p->lds_a8, p->stream, p->sh, p->b, ma, fa)
+#define LA8V(TP, PK) switch (mc.cdim) { case 1: LA8(TP, 1, PK); break; case 2: LA8(TP, 2, PK); break; case 3: LA8(TP, 3, PK); break; \
+        case 4: LA8(TP, 4, PK); break; case 5: LA8(TP, 5, PK); break; default: LA8(TP, 6, PK); break; }
+      if (!p->a8_pack && mc.cdim == 7) { if (p->a8_tpt == 1) LA8(1, 7, false); else LA8(2, 7, false); }
+      else if (p->a8_pack) { if (p->a8_tpt == 1) LA8V(1, true) else LA8V(2, true) }
+      else { if (p->a8_tpt == 1) LA8V(1, false) else LA8V(2, false) }
+#undef LA8V
+#undef LA8
+    } else
     if (adf) {
       dim3 ba(p->NT_a);
 #define LF1(V) hipLaunchKernelGGL((gf_filter_kernel<1, 0, V, 256>), g, ba, p->lds_filter, p->stream, p->sh, p->b, mc, fp)
@@ -1186,6 +1242,7 @@ struct SweepCtx {
   std::vector<char> composed;    // gain + compose of the chunk were enqueued on the second stream while the filter ran
   int next = -1;                 // next chunk the pump may start (counts down to 1; chunk 0 needs the complete filter)
   bool s2_used = false;
+  bool xs = false;               // sweep_finish ran the cross-sweep form: apply + site refresh per chunk, ev_chunk[c] recorded behind each
 };
 
 static void sweep_begin(nagp_plan* p, SweepCtx& sc, bool write_PSs) {
@@ -1529,7 +1586,8 @@ static int launch_apply_merged(nagp_plan* p, const SweepCtx& sc, int n_own, hipS
 // the main stream (the carry between chunks is its order).  The apply passes of the chunks that own a (G, Delta) buffer run as ONE
 // merged grid on a side stream once the boundary chain has passed them (a span length of latency instead of one per chunk);
 // the chunks without a buffer follow on the main stream: gains again into the scratch buffer, boundary, apply.
-static int sweep_finish(nagp_plan* p, SweepCtx& sc) {
+using EpRange = std::function<int(int64_t, int64_t, hipStream_t)>;
+static int sweep_finish(nagp_plan* p, SweepCtx& sc, const EpRange* ep_chunk = nullptr) {
   const int nc = (int)sc.ch.size();
   bool waited = !sc.s2_used;       // the main stream has to wait ONCE for the second stream's work (one event behind all of it)
   auto wait_s2 = [&]() -> int {
@@ -1538,6 +1596,11 @@ static int sweep_finish(nagp_plan* p, SweepCtx& sc) {
   };
   int n_own = 0;                   // chunks 0 .. n_own-1 own a buffer (pipelined plans; slot_of is a prefix by construction)
   if (p->pipeline) while (n_own < nc && sc.slot_of[n_own] >= 0) ++n_own;
+  // Cross-sweep form (every chunk owns a buffer, another sweep follows): behind the boundary chain the apply pass and the site refresh
+  // run chunk by chunk on the side stream, the chunk of the EARLIEST steps first, and an event behind each lets the next sweep's filter
+  // follow them chunk by chunk -- only the first chunk's apply + refresh stays exposed.  Chunks whose buffer is recycled from PF (it lies
+  // in the PF of early steps, which that filter overwrites first) go before all others.
+  sc.xs = ep_chunk && p->xsweep && n_own == nc && nc > 1;
   for (int c = 0; c < nc; ++c) {
     const int slot = sc.slot_of[c] >= 0 ? sc.slot_of[c] : 0;
     if (!sc.composed[c]) {
@@ -1555,38 +1618,53 @@ static int sweep_finish(nagp_plan* p, SweepCtx& sc) {
         hipStream_t st = p->s_apply[0];
         HIP_TRY(hipEventRecord(p->ev_bnd[0], p->stream));
         HIP_TRY(hipStreamWaitEvent(st, p->ev_bnd[0], 0));
-        RUN(launch_apply_merged(p, sc, n_own, st));
-        HIP_TRY(hipEventRecord(p->ev_app[0], st));
+        if (sc.xs) {
+          while ((int)p->ev_chunk.size() < nc) { hipEvent_t e = nullptr; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); p->ev_chunk.push_back(e); }
+          std::vector<int> order;
+          for (int c2 = 0; c2 < nc; ++c2) if (p->slot_gps[sc.slot_of[c2]] != 0) order.push_back(c2);
+          for (int c2 = nc - 1; c2 >= 0; --c2) if (p->slot_gps[sc.slot_of[c2]] == 0) order.push_back(c2);
+          for (int c2 : order) {
+            RUN(launch_apply_chunk(p, sc, c2, sc.slot_of[c2], st));
+            RUN((*ep_chunk)(sc.ch[c2].k0, sc.ch[c2].k0 + sc.ch[c2].nk, st));
+            HIP_TRY(hipEventRecord(p->ev_chunk[c2], st));
+          }
+        } else {
+          RUN(launch_apply_merged(p, sc, n_own, st));
+          HIP_TRY(hipEventRecord(p->ev_app[0], st));
+        }
       }
     } else {
       RUN(launch_apply_chunk(p, sc, c, slot, p->stream));    // (scratch buffer: the next chunk's gains overwrite it)
     }
   }
   RUN(wait_s2());
-  if (n_own > 0) HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_app[0], 0));
+  if (n_own > 0 && !sc.xs) HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_app[0], 0));
   return NAGP_OK;
 }
 
 static bool mixture_rule(const nagp_plan* p) { return (p->opts.flags & NAGP_FLAG_MIXTURE_RULE) != 0; }
 
-static int launch_ep(nagp_plan* p, double alpha, double damp, int clamp, int write_R, double* lZ_out) {
+static int launch_ep(nagp_plan* p, double alpha, double damp, int clamp, int write_R, double* lZ_out, int64_t k_lo = 0, int64_t k_hi = -1, hipStream_t st = nullptr) {
   const Shape& sh = p->sh;
   if (sh.T < 2) return NAGP_OK;
   MomCfg mc = p->mc; mc.DG = p->DG_ep; mc.cache_tabs = p->cache_ep; mc.store_a = p->sta_ep;
   if (p->src_ep) mc.src = p->src_all;
   EpPar ep{};
-  ep.k_end = sh.T - 1;
+  if (!st) st = p->stream;
+  ep.k_begin = k_lo;
+  ep.k_end = (k_hi < 0) ? sh.T - 1 : k_hi;          // steps [k_lo, k_end): the whole sequence, or one smoother chunk (cross-sweep schedule)
+  if (ep.k_end <= ep.k_begin) return NAGP_OK;
   // ~8192 workgroups over all problems (32 per CU): enough to fill the chip, and the per-workgroup set-up (cubature tables, the static
   // addresses of the sparse-point stages) is amortised over the steps of a workgroup when many problems share the launch
-  ep.steps_per_wg = (int)std::max<int64_t>(1, ((int64_t)p->B * ep.k_end + 8191) / 8192);
+  ep.steps_per_wg = (int)std::max<int64_t>(1, ((int64_t)p->B * (sh.T - 1) + 8191) / 8192);
   ep.alpha = alpha; ep.clamp = clamp; ep.write_R = write_R; ep.lZ_out = lZ_out;
   if (mixture_rule(p)) { ep.w_old = 1.0 - damp; ep.w_new = damp / alpha; }
   else { ep.w_old = 1.0 - damp * alpha; ep.w_new = damp; }
-  Timed t(p, NAGP_K_EPSITE);
-  dim3 g((unsigned)((ep.k_end + ep.steps_per_wg - 1) / ep.steps_per_wg), p->B), bl(256);
+  Timed t(p, NAGP_K_EPSITE, st);
+  dim3 g((unsigned)((ep.k_end - ep.k_begin + ep.steps_per_wg - 1) / ep.steps_per_wg), p->B), bl(256);
   if (p->sq_ep) {
     MomCfg ms = mc; ms.sp = MomSp{}; ms.sp.c0 = p->sq_c0; ms.src = MomSrc{};
-#define LEQ(V) hipLaunchKernelGGL(ep_site_sq_kernel<V>, g, dim3(256), p->lds_ep_sq, p->stream, sh, p->b, ms, ep)
+#define LEQ(V) hipLaunchKernelGGL(ep_site_sq_kernel<V>, g, dim3(256), p->lds_ep_sq, st, sh, p->b, ms, ep)
     switch (ms.cdim) { case 1: LEQ(1); break; case 2: LEQ(2); break; case 3: LEQ(3); break; case 4: LEQ(4); break; case 5: LEQ(5); break; default: LEQ(6); break; }
 #undef LEQ
     HIP_TRY(hipGetLastError());
@@ -1594,22 +1672,23 @@ static int launch_ep(nagp_plan* p, double alpha, double damp, int clamp, int wri
   }
   if (p->sp_ep) {
     MomCfg ms = mc; ms.sp = p->sp; ms.src = MomSrc{};
-#define LES(V) hipLaunchKernelGGL(ep_site_sp_kernel<V>, g, dim3(MSP_NT), p->lds_ep_sp, p->stream, sh, p->b, ms, ep)
+#define LES(V) hipLaunchKernelGGL(ep_site_sp_kernel<V>, g, dim3(MSP_NT), p->lds_ep_sp, st, sh, p->b, ms, ep)
     switch (ms.cdim) { case 1: LES(1); break; case 2: LES(2); break; case 3: LES(3); break; case 4: LES(4); break; case 5: LES(5); break; case 6: LES(6); break; default: LES(7); break; }
 #undef LES
     HIP_TRY(hipGetLastError());
     return NAGP_OK;
   }
-#define LE(V) hipLaunchKernelGGL(ep_site_kernel<V>, g, bl, p->lds_ep, p->stream, sh, p->b, mc, ep)
+#define LE(V) hipLaunchKernelGGL(ep_site_kernel<V>, g, bl, p->lds_ep, st, sh, p->b, mc, ep)
   NAGP_MV_SWITCH9(mom_variant(mc), LE)
 #undef LE
   HIP_TRY(hipGetLastError());
   return NAGP_OK;
 }
 
-static int reduce_sum(nagp_plan* p, const double* v, int64_t k_lo, int64_t k_hi, int slot) {
-  Timed t(p, NAGP_K_REDUCE);
-  hipLaunchKernelGGL(sum_kernel, dim3(p->B), dim3(1024), 0, p->stream, v, p->sh.T, k_lo, k_hi, p->b.red, slot);
+static int reduce_sum(nagp_plan* p, const double* v, int64_t k_lo, int64_t k_hi, int slot, hipStream_t st = nullptr, double* out = nullptr) {
+  if (!st) st = p->stream;
+  Timed t(p, NAGP_K_REDUCE, st);
+  hipLaunchKernelGGL(sum_kernel, dim3(p->B), dim3(1024), 0, st, v, p->sh.T, k_lo, k_hi, out ? out : p->b.red, slot);
   HIP_TRY(hipGetLastError());
   return NAGP_OK;
 }
@@ -1649,8 +1728,15 @@ static int zero_async(nagp_plan* p, void* ptr, size_t bytes) {
 static int exec_gf(nagp_plan* p) {
   const Shape& sh = p->sh; const nagp_opts& o = p->opts; const int I = o.ep_itts, B = p->B;
   const bool nlml = (o.mode == NAGP_MODE_NLML);
-  std::vector<double> red;
+  // Reduction records, one per sweep, fetched once at the end (no host synchronisation between the sweeps):
+  // record 0 = sum of the filter's lZ (sweep 1; nlml: the final sum), record itt = (lZ sum after the refresh, maxDiffM, maxDiffP) of sweep itt
+  const size_t RR = (size_t)B * 8;
+  RUN(zero_async(p, p->red_all, (size_t)(I + 2) * RR * sizeof(double)));
+  struct RestoreRed { nagp_plan* p; ~RestoreRed() { p->b.red = p->red0; } } restore{p};
+  bool xs_pending = false;             // the previous sweep ended in the cross-sweep form: ev_chunk[c] per chunk, ev_red behind everything
+  std::vector<ChunkGeom> xs_ch;
   for (int itt = 1; itt <= I; ++itt) {
+    p->b.red = p->red_all + (size_t)itt * RR;
     const bool run_filter = !nlml || itt == 1 || itt < I;
     const bool run_smoother = !nlml || itt < I;
     SweepCtx sc;
@@ -1666,39 +1752,62 @@ static int exec_gf(nagp_plan* p) {
       fp.store_PF = p->need_PF ? 1 : 0; fp.l_iter = 0;
       fp.k_begin = 0; fp.k_end = sh.T;
       if (!fp.mom_all && p->need_PF && sh.T > 1) {   // fixed sites for k < T-1: lean kernel, then the ADF step at k = T-1
-        fp.k_end = sh.T - 1;
-        RUN(launch_filter(p, fp));
+        if (xs_pending) {
+          // one launch per chunk of the previous sweep's smoother, each behind that chunk's apply pass and site refresh
+          for (int c = (int)xs_ch.size() - 1; c >= 0; --c) {
+            HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_chunk[c], 0));
+            fp.k_begin = xs_ch[c].k0; fp.k_end = xs_ch[c].k0 + xs_ch[c].nk;
+            RUN(launch_filter(p, fp));
+          }
+          HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_red, 0));      // (the lZ sum reads lZ[T-1], which the ADF step rewrites)
+          xs_pending = false;
+        } else {
+          fp.k_end = sh.T - 1;
+          RUN(launch_filter(p, fp));
+        }
         fp.k_begin = sh.T - 1; fp.k_end = sh.T;
       }
+      if (xs_pending) { HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_red, 0)); xs_pending = false; }
       RUN(launch_filter(p, fp));
       if (smooth) RUN(sweep_pump(p, sc));      // gain + compose of the finished chunks on the second stream while the filter runs
     }
-    if (itt == 1 && !nlml) {
-      RUN(reduce_sum(p, p->b.lZ, 0, sh.T, 0));
-      RUN(fetch_red(p, red));
-      for (int q = 0; q < B; ++q) p->nlZ[(size_t)q * I] = -red[(size_t)q * 8];
-    }
+    if (xs_pending) { HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_red, 0)); xs_pending = false; }
+    if (itt == 1 && !nlml) RUN(reduce_sum(p, p->b.lZ, 0, sh.T, 0, nullptr, p->red_all));
     if (run_smoother && run_filter) {
-      RUN(zero_async(p, p->b.red, (size_t)B * 8 * sizeof(double)));
       RUN(seed_last_step(p));
-      if (smooth) RUN(sweep_finish(p, sc));
+      const double ep_damp = (itt < I) ? p->damping[itt] : 0.0;
+      const int ep_clamp = (nlml || mixture_rule(p)) ? 0 : 1, ep_wR = nlml ? 0 : 1;
+      double* ep_lZ = mixture_rule(p) ? nullptr : p->b.lZ;   // the mixture variant leaves the clamp to the next filter pass (gf_ep_mods_nmf_mixture.m:195, 280-284)
+      const EpRange ep_range = [&](int64_t lo, int64_t hi, hipStream_t st) { return launch_ep(p, o.ep_fraction, ep_damp, ep_clamp, ep_wR, ep_lZ, lo, hi, st); };
+      if (smooth) RUN(sweep_finish(p, sc, itt < I ? &ep_range : nullptr));
       if (itt < I) {
-        // the mixture variant leaves the clamp to the next filter pass (gf_ep_mods_nmf_mixture.m:195, 280-284)
-        RUN(launch_ep(p, o.ep_fraction, p->damping[itt], (nlml || mixture_rule(p)) ? 0 : 1, nlml ? 0 : 1, mixture_rule(p) ? nullptr : p->b.lZ));
-        if (!nlml) RUN(reduce_sum(p, p->b.lZ, 0, sh.T, 0));
-      }
-      RUN(fetch_red(p, red));
-      for (int q = 0; q < B; ++q) {
-        if (itt < I && !nlml) p->nlZ[(size_t)q * I + itt] = -red[(size_t)q * 8];
-        p->mdM[(size_t)q * I + itt - 1] = red[(size_t)q * 8 + 1];
-        p->mdP[(size_t)q * I + itt - 1] = red[(size_t)q * 8 + 2];
+        if (sc.xs) {
+          hipStream_t st = p->s_apply[0];
+          if (!nlml) RUN(reduce_sum(p, p->b.lZ, 0, sh.T, 0, st));
+          HIP_TRY(hipEventRecord(p->ev_red, st));
+          xs_pending = true; xs_ch = sc.ch;
+        } else {
+          RUN(ep_range(0, -1, p->stream));
+          if (!nlml) RUN(reduce_sum(p, p->b.lZ, 0, sh.T, 0));
+        }
       }
     }
   }
-  if (nlml) {
-    RUN(reduce_sum(p, p->b.lZ, 0, sh.T, 0));
-    RUN(fetch_red(p, red));
-    for (int q = 0; q < B; ++q) p->nlZ[(size_t)q * I] = -red[(size_t)q * 8];
+  if (xs_pending) HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_red, 0));
+  if (nlml) RUN(reduce_sum(p, p->b.lZ, 0, sh.T, 0, nullptr, p->red_all));
+  std::vector<double> red((size_t)(I + 2) * RR);
+  HIP_TRY(hipMemcpyAsync(red.data(), p->red_all, red.size() * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  for (int q = 0; q < B; ++q) {
+    p->nlZ[(size_t)q * I] = -red[(size_t)q * 8];
+    for (int itt = 1; itt <= I; ++itt) {
+      const double* r = &red[(size_t)itt * RR + (size_t)q * 8];
+      const bool ran = (!nlml || itt < I) && (!nlml || itt == 1 || itt < I);
+      if (!ran) continue;
+      if (itt < I && !nlml) p->nlZ[(size_t)q * I + itt] = -r[0];
+      p->mdM[(size_t)q * I + itt - 1] = r[1];
+      p->mdP[(size_t)q * I + itt - 1] = r[2];
+    }
   }
   return NAGP_OK;
 }

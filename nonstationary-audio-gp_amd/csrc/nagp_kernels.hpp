@@ -1673,6 +1673,7 @@ struct EpPar {
   int write_R;         // 0: none (nlml), 1: all sites (gf predict), 2: updated sites only (ihgp)
   double* lZ_out;      // [B][T] where the per-step log Z goes (gf: b.lZ ; ihgp: separate array ; null: dropped, gf_ep_mods_nmf_mixture.m:277)
   int const_var;       // ihgp: marginal variance is read from sv[k] as usual (kept for clarity)
+  int64_t k_begin;     // first step of this launch (0: the whole sequence; > 0: one smoother chunk of the cross-sweep schedule)
 };
 
 __host__ __device__ inline size_t ep_lds_doubles(const Shape& s, const MomCfg& mc) {
@@ -1700,7 +1701,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) e
   mom_cache_tables(mc, ws);
   const double pEPa = mom_pEP(mc, sn2, ep.alpha);
   lds_barrier();
-  const int64_t kb = (int64_t)blockIdx.x * ep.steps_per_wg;
+  const int64_t kb = ep.k_begin + (int64_t)blockIdx.x * ep.steps_per_wg;
   unsigned long long n_clamped = 0;
   for (int64_t k = kb; k < kb + ep.steps_per_wg && k < ep.k_end; ++k) {
     const double yk = b.y[(size_t)pb * T + k];
@@ -1761,7 +1762,7 @@ __global__ void __launch_bounds__(MSP_NT) __attribute__((amdgpu_waves_per_eu(2))
 #pragma unroll
   for (int j = 0; j < CD; ++j) wrow[j] = (tid < D) ? sW[tid * CD + j] : 0.0;
   __syncthreads();
-  const int64_t kb = (int64_t)blockIdx.x * ep.steps_per_wg;
+  const int64_t kb = ep.k_begin + (int64_t)blockIdx.x * ep.steps_per_wg;
   unsigned long long n_clamped = 0;
   for (int64_t k = kb; k < kb + ep.steps_per_wg && k < ep.k_end; ++k) {
     const double yk = b.y[(size_t)pb * T + k];
@@ -1843,7 +1844,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) e
 #pragma unroll
   for (int i = 0; i < 2 * MsqFlat::NST; ++i) amp[i] = 0.0;
   __syncthreads();
-  const int64_t kb = (int64_t)blockIdx.x * ep.steps_per_wg;
+  const int64_t kb = ep.k_begin + (int64_t)blockIdx.x * ep.steps_per_wg;
   unsigned long long n_clamped = 0;
   for (int64_t k = kb; k < kb + ep.steps_per_wg && k < ep.k_end; ++k) {
     const double yk = b.y[(size_t)pb * T + k];

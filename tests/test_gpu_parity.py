@@ -1519,7 +1519,7 @@ def test_mfma_fixed_site_filter_equals_the_valu_filter(D, N, k1):
         try:
             plan = Plan(L.KIND_GF_EP, probs, T, mom=mom, ep_fraction=0.5, ep_damping=d, ep_itts=3, chunk=24)
             plan.upload(ys); plan.execute(); res[mode] = plan.download(want_MF=True); tm = plan.timings(); plan.close()
-            assert tm['launches']['filter_lin'] == 2                      # sweeps 2 and 3 ran the fixed-site kernel
+            assert tm['launches']['filter_lin'] >= 2                      # sweeps 2 and 3 ran the fixed-site kernel (one launch per sweep, or per chunk behind the previous sweep's smoother)
         finally:
             os.environ.pop('NAGP_LIN_MFMA', None)
     for q in range(2):

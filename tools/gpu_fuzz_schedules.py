@@ -1,5 +1,5 @@
 """Randomised check of the chunk-pipelined smoother schedule (developer tool): random shape, family, number of segments, chunk length,
-number of (G, Delta) buffers, sweeps, missing data; every output of the pipelined plan must equal the serial plan's bit for bit
+number of (G, Delta) buffers, sweeps, missing data; every output of the pipelined plan (with and without the cross-sweep form, NAGP_NO_XSWEEP=1) must equal the serial plan's bit for bit
 (NAGP_NO_PIPELINE=1), and the serial plan is the one the oracle tests pin.
 python tools/gpu_fuzz_schedules.py [n_cases] [seed]"""
 import os, sys, time
@@ -32,7 +32,9 @@ def run_cases(n, seed, verbose=True):
         kw = dict(ep_itts=itts, l_iter=2) if ekf else dict(mom=Mom('likModulatorNMFPower', p_cubature=p), ep_fraction=0.5, ep_damping=0.5 * np.ones(itts), ep_itts=itts,
                                                             flags=L.FLAG_WANT_PS if want_ps else 0)
         res = {}
-        for name, env in (('pipelined', dict({'NAGP_PIPELINE_SLOTS': str(slots)} if slots else {}, **({'NAGP_NO_RECYCLE': '1'} if no_recycle else {}))), ('serial', {'NAGP_NO_PIPELINE': '1'})):
+        penv = dict({'NAGP_PIPELINE_SLOTS': str(slots)} if slots else {}, **({'NAGP_NO_RECYCLE': '1'} if no_recycle else {}))
+        # 'pipelined' = the default schedule (cross-sweep form whenever every chunk owns a buffer), 'one_sweep' = the same without it
+        for name, env in (('pipelined', penv), ('one_sweep', dict(penv, NAGP_NO_XSWEEP='1')), ('serial', {'NAGP_NO_PIPELINE': '1'})):
             os.environ.update(env)
             try:
                 plan = Plan(L.KIND_GIEKF if ekf else L.KIND_GF_EP, probs, T, chunk=chunk, **kw)
@@ -45,8 +47,9 @@ def run_cases(n, seed, verbose=True):
             finally:
                 for k in env: os.environ.pop(k, None)
         fields = ('Eft', 'Varft', 'MS', 'MF', 'maxDiffP') + (() if ekf else ('ttau', 'tnu', 'R', 'lZ', 'nlZ', 'maxDiffM')) + (('PS',) if want_ps else ())
-        diff = [(q, f) for q in range(B) for f in fields if not np.array_equal(getattr(res['pipelined'][0][q], f), getattr(res['serial'][0][q], f), equal_nan=True)]
-        same_status = res['pipelined'][1] == res['serial'][1]
+        diff = [(q, f, v) for v in ('pipelined', 'one_sweep') for q in range(B) for f in fields
+                if not np.array_equal(getattr(res[v][0][q], f), getattr(res['serial'][0][q], f), equal_nan=True)]
+        same_status = res['pipelined'][1] == res['serial'][1] == res['one_sweep'][1]
         ok = not diff and same_status
         bad += (not ok)
         if verbose: print('case %2d %s D=%2d N=%d T=%3d B=%d chunk=%3d slots=%d sweeps=%d p=%d PS=%d: %s%s' % (

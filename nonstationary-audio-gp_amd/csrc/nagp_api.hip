@@ -928,7 +928,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     // ADF sweep with role-specialised waves (nagp_gfadf8.hpp): 512 threads, <= 2 lower tiles per thread, the role layout's limits
     // (one sigma point per worker lane, <= 80 MFMA steps; packed form as in the IHGP sweep)
     if (p->sp_gf && sh.M * (sh.M + 1) / 2 <= 2 * MSR_NT && sh.S <= MSR_NT && o->n_pts <= 64 * MSR_NWK && (o->n_pts + 3) / 4 <= 4 * MSR_NST &&
-        getenv("NAGP_GF_ROLES")) {      // (opt-in until the parity suite has run on it)
+        !getenv("NAGP_NO_GF_ROLES")) {
       p->a8_tpt = (sh.M * (sh.M + 1) / 2 <= MSR_NT) ? 1 : 2;
       p->kb_a8 = 16;
       while (p->kb_a8 > 2 && gf_adf8_lds_doubles(sh, o->cub_dim, p->kb_a8) * sizeof(double) > cap) p->kb_a8 /= 2;

@@ -79,7 +79,7 @@ struct nagp_plan {
   int sp_ih = 0, sp_gf = 0, kb_sp = 16, hph_sp = 1; size_t lds_sp = 0;
   int sp_ep = 0; size_t lds_ep_sp = 0;      // site refresh (ep_site_sp_kernel) in the sparse-point form
   int sq_c0 = -1, sq_ok = 0, sq_ih = 0, kb_sq = 16, hph_sq = 1; size_t lds_sq = 0; int sq_ep = 0; size_t lds_ep_sq = 0; int sq_gf = 0;   // likModulatorPreCalcwn in the staged form (nagp_momsq.hpp): centre code, rule fits, IHGP ADF sweep uses it
-  int a8_gf = 0, a8_pack = 0, a8_tpt = 1, kb_a8 = 16; size_t lds_a8 = 0;   // ADF sweep of the gf filter with role-specialised waves (gf_adf8_kernel)
+  int a8_gf = 0, a8_pack = 0, a8_tpt = 1, a8_st = 0, kb_a8 = 16; size_t lds_a8 = 0;   // ADF sweep of the gf filter with role-specialised waves (gf_adf8_kernel)
   int sp_ih8 = 0, sp_pack = 0, sp_maxmem = 0; size_t lds_sp8 = 0;   // sp_maxmem: most points sharing one non-centre (dimension, coordinate)   // the role-specialised 512-thread form of the same sweep (ihgp_adf8_kernel)
   hipStream_t stream = nullptr;
   // chunk-pipelined smoother (gf / giekf): while the sequential filter occupies one CU per problem, the parallel smoother kernels
@@ -929,7 +929,10 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     // (one sigma point per worker lane, <= 80 MFMA steps; packed form as in the IHGP sweep)
     if (p->sp_gf && sh.M * (sh.M + 1) / 2 <= 2 * MSR_NT && sh.S <= MSR_NT && o->n_pts <= 64 * MSR_NWK && (o->n_pts + 3) / 4 <= 4 * MSR_NST &&
         !getenv("NAGP_NO_GF_ROLES")) {
-      p->a8_tpt = (sh.M * (sh.M + 1) / 2 <= MSR_NT) ? 1 : 2;
+      // tiles per thread / who owns them: 1 or 2 on the six worker waves (<= 384 / 768 lower tiles), else 2 on all eight waves
+      const int nlow8 = sh.M * (sh.M + 1) / 2, ntw = MSR_NT - 64 * MSR_W0;
+      p->a8_tpt = (nlow8 <= ntw) ? 1 : 2; p->a8_st = (nlow8 <= 2 * ntw) ? 0 : 1;
+      if (getenv("NAGP_A8_ST")) { p->a8_tpt = 2; p->a8_st = 1; }       // developer switch: tiles on all eight waves
       p->kb_a8 = 16;
       while (p->kb_a8 > 2 && gf_adf8_lds_doubles(sh, o->cub_dim, p->kb_a8) * sizeof(double) > cap) p->kb_a8 /= 2;
       if (const char* e = getenv("NAGP_KB_A8")) p->kb_a8 = std::max(2, std::min(16, atoi(e) & ~1));
@@ -941,7 +944,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
         if (ep && ep[0] == '0') pk = false;
         p->a8_gf = 1; p->a8_pack = pk ? 1 : 0; p->lds_a8 = need;
         if (p->pipeline && B <= 128) p->lds_a8 = 160 * 1024;      // (the whole LDS of the CU, as for the other filter launches below)
-#define SA8(TP, V, PK) PLAN_TRY(set_lds(gf_adf8_kernel<TP, V, PK>, p->lds_a8))
+#define SA8(TP, V, PK) do { if (p->a8_st) PLAN_TRY(set_lds((gf_adf8_kernel<2, V, PK, true>), p->lds_a8)); else PLAN_TRY(set_lds((gf_adf8_kernel<TP, V, PK, false>), p->lds_a8)); } while (0)
 #define SA8V(TP, PK) switch (o->cub_dim) { case 1: SA8(TP, 1, PK); break; case 2: SA8(TP, 2, PK); break; case 3: SA8(TP, 3, PK); break; \
           case 4: SA8(TP, 4, PK); break; case 5: SA8(TP, 5, PK); break; default: SA8(TP, 6, PK); break; }
         if (!pk && o->cub_dim == 7) { if (p->a8_tpt == 1) SA8(1, 7, false); else SA8(2, 7, false); }
@@ -1169,7 +1172,8 @@ static int launch_filter(nagp_plan* p, const FilterPar& fp_in) {
       // sweep 1 (mom at every step): role-specialised waves
       FilterPar fa = fp; fa.kb = p->kb_a8;
       MomCfg ma = mc; ma.sp = p->sp;
-#define LA8(TP, V, PK) hipLaunchKernelGGL((gf_adf8_kernel<TP, V, PK>), g, dim3(MSR_NT), p->lds_a8, p->stream, p->sh, p->b, ma, fa)
+#define LA8(TP, V, PK) do { if (p->a8_st) hipLaunchKernelGGL((gf_adf8_kernel<2, V, PK, true>), g, dim3(MSR_NT), p->lds_a8, p->stream, p->sh, p->b, ma, fa); \
+        else hipLaunchKernelGGL((gf_adf8_kernel<TP, V, PK, false>), g, dim3(MSR_NT), p->lds_a8, p->stream, p->sh, p->b, ma, fa); } while (0)
 #define LA8V(TP, PK) switch (mc.cdim) { case 1: LA8(TP, 1, PK); break; case 2: LA8(TP, 2, PK); break; case 3: LA8(TP, 3, PK); break; \
         case 4: LA8(TP, 4, PK); break; case 5: LA8(TP, 5, PK); break; default: LA8(TP, 6, PK); break; }
       if (!p->a8_pack && mc.cdim == 7) { if (p->a8_tpt == 1) LA8(1, 7, false); else LA8(2, 7, false); }

@@ -10,6 +10,7 @@
 // Same inputs, outputs, ring and progress protocol as gf_filter_kernel; serves the launches with mom at every step (sweep 1).
 #pragma once
 #include "nagp_kernels.hpp"
+#include <type_traits>
 
 namespace nagp {
 
@@ -19,11 +20,15 @@ __host__ __device__ inline size_t gf_adf8_lds_doubles(const Shape& s, int CD, in
   return (n + 1) & ~(size_t)1;
 }
 
-template <int TPT, int CD, bool PACK>
+// ST = false: the two serial waves own NO tiles (the tiles of <= 384 * TPT lower tiles sit on the six worker waves): the serial role --
+// the tail of every step's dependence chain -- then holds its sites and nothing else
+template <int TPT, int CD, bool PACK, bool ST>
 __global__ void __launch_bounds__(MSR_NT) gf_adf8_kernel(Shape sh, Bufs b, MomCfg mc, FilterPar fp) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int tid = threadIdx.x;
   constexpr int NT = MSR_NT;
+  constexpr int NTT = ST ? MSR_NT : MSR_NT - 64 * MSR_W0;     // threads that own tiles
+  const int tix = ST ? tid : tid - 64 * MSR_W0;                 // tile-thread index (< 0: none)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int S = sh.S, M = sh.M, D = sh.D, KB = fp.kb;
   const int64_t T = sh.T;
@@ -75,8 +80,8 @@ __global__ void __launch_bounds__(MSR_NT) gf_adf8_kernel(Shape sh, Bufs b, MomCf
   const int nlow = M * (M + 1) / 2;
 #pragma unroll
   for (int q = 0; q < TPT; ++q) {
-    const int t = tid + q * NT;
-    own.ok[q] = t < nlow;
+    const int t = tix + q * NTT;
+    own.ok[q] = tix >= 0 && t < nlow;
     const int tt_ = own.ok[q] ? t : 0;
     int I = (int)((sqrt(8.0 * tt_ + 1.0) - 1.0) * 0.5);
     while ((I + 1) * (I + 2) / 2 <= tt_) ++I;
@@ -90,7 +95,7 @@ __global__ void __launch_bounds__(MSR_NT) gf_adf8_kernel(Shape sh, Bufs b, MomCf
     tile_zero(P[q]);
     if (own.ok[q]) {
       if (fp.k_begin > 0)
-        pf_tile_load(P[q], b.PF + ((size_t)pb * T + (fp.k_begin - 1)) * (size_t)(((nlow + 63) & ~63) * 16), tid + q * NT);
+        pf_tile_load(P[q], b.PF + ((size_t)pb * T + (fp.k_begin - 1)) * (size_t)(((nlow + 63) & ~63) * 16), tix + q * NTT);
       else if (fp.init_from_state && !fp.reset_P)
         tile_load(P[q], st + (size_t)(own.I[q] * M + own.J[q]) * 16);
       else if (own.I[q] == own.J[q])
@@ -124,7 +129,7 @@ __global__ void __launch_bounds__(MSR_NT) gf_adf8_kernel(Shape sh, Bufs b, MomCf
 
   // ---- the covariance phases of a step, shared by both roles (inlined into each loop)
   // S0: prediction (registers), publish W = P H', diag(H P H'), fmu = H m; returns the predicted mean of this state lane
-  auto phase_predict = [&](bool pred) -> double {
+  auto phase_predict = [&](bool pred, auto tiles) -> double {
     double rm = 0.0;
     if (slane) {
       if (pred) {
@@ -138,6 +143,7 @@ __global__ void __launch_bounds__(MSR_NT) gf_adf8_kernel(Shape sh, Bufs b, MomCf
       }
       if (myrow == 0) fmu[myblk] = shv[myblk] * rm;
     }
+    if constexpr (decltype(tiles)::value)
 #pragma unroll
     for (int q = 0; q < TPT; ++q) {
       if (own.ok[q]) {
@@ -164,7 +170,7 @@ __global__ void __launch_bounds__(MSR_NT) gf_adf8_kernel(Shape sh, Bufs b, MomCf
     return rm;
   };
   // mean update m += W cm (state lanes), P -= sum_n cA[n] W[:,n] W[:,n]' (tiles)
-  auto phase_update = [&](double rm) -> double {
+  auto phase_update = [&](double rm, auto tiles) -> double {
     if (slane) {
       double a0 = rm, a1 = 0.0, a2 = 0.0, a3 = 0.0;
       const double* wp = Wl + ((size_t)(myrow >> 1) * M + myblk) * 2 + (myrow & 1);
@@ -192,6 +198,7 @@ __global__ void __launch_bounds__(MSR_NT) gf_adf8_kernel(Shape sh, Bufs b, MomCf
       rm = (a0 + a1) + (a2 + a3);
       m[tid] = rm;
     }
+    if constexpr (decltype(tiles)::value)
 #pragma unroll
     for (int q = 0; q < TPT; ++q) {
       if (own.ok[q]) {
@@ -233,19 +240,21 @@ __global__ void __launch_bounds__(MSR_NT) gf_adf8_kernel(Shape sh, Bufs b, MomCf
     return rm;
   };
   // per-step outputs -> ring ; covariance tiles -> HBM
-  auto phase_outputs = [&](int kk, int64_t k, double rm) {
+  auto phase_outputs = [&](int kk, int64_t k, double rm, auto tiles) {
     if (slane) {
       rMF[(size_t)kk * S + tid] = rm;
       if (myrow == 0) rfm[kk * M + myblk] = shv[myblk] * rm;
     }
+    if constexpr (decltype(tiles)::value) {
 #pragma unroll
     for (int q = 0; q < TPT; ++q)
       if (own.ok[q] && own.I[q] == own.J[q])
         rfv[kk * M + own.I[q]] = shv[own.I[q]] * shv[own.I[q]] * P[q][0];
-    if (g_PF) {
+    }
+    if (decltype(tiles)::value && g_PF) {
 #pragma unroll
       for (int q = 0; q < TPT; ++q)
-        if (own.ok[q]) pf_tile_store(g_PF + (size_t)k * pf_tiles * 16, tid + q * NT, P[q]);
+        if (own.ok[q]) pf_tile_store(g_PF + (size_t)k * pf_tiles * 16, tix + q * NTT, P[q]);
     }
   };
   auto ring_fill = [&](int64_t k0, int nb) {
@@ -284,7 +293,7 @@ __global__ void __launch_bounds__(MSR_NT) gf_adf8_kernel(Shape sh, Bufs b, MomCf
         const double yk = ry[kk];
         const bool pred = (k > 0) || fp.predict_k1;
         const bool upd = !(yk != yk);
-        double rm = phase_predict(pred);
+        double rm = phase_predict(pred, std::true_type{});
         lds_barrier();                   // B1: panel, fmu, HPH
         if (slane) m[tid] = rm;
         if (upd) {
@@ -300,9 +309,9 @@ __global__ void __launch_bounds__(MSR_NT) gf_adf8_kernel(Shape sh, Bufs b, MomCf
           // (moments, site update, gain coefficients: serial waves)
           if (fp.legacy_update) lds_barrier();
           lds_barrier();                 // B6: cA, cm
-          rm = phase_update(rm);
+          rm = phase_update(rm, std::true_type{});
         }
-        phase_outputs(kk, k, rm);
+        phase_outputs(kk, k, rm, std::true_type{});
         lds_barrier();                   // B7
       }
       ring_flush(k0, nb);
@@ -310,7 +319,7 @@ __global__ void __launch_bounds__(MSR_NT) gf_adf8_kernel(Shape sh, Bufs b, MomCf
     return;
   }
 
-  // ================= serial role (waves 0 and 1): covariance tiles + the sites
+  // ================= serial role (waves 0 and 1): the sites (+ covariance tiles when ST)
   MsrS<CD, PACK> x;
   msr_setup_S<CD, PACK>(x, mc, mc.sp, fmu, HPH, ws);
   const int lane = tid & 63;
@@ -331,7 +340,7 @@ __global__ void __launch_bounds__(MSR_NT) gf_adf8_kernel(Shape sh, Bufs b, MomCf
       const double yk = ry[kk];
       const bool pred = (k > 0) || fp.predict_k1;
       const bool upd = !(yk != yk);
-      double rm = phase_predict(pred);
+      double rm = phase_predict(pred, std::integral_constant<bool, ST>{});
       lds_barrier();                     // B1
       if (slane) m[tid] = rm;
       if (upd) {
@@ -379,11 +388,11 @@ __global__ void __launch_bounds__(MSR_NT) gf_adf8_kernel(Shape sh, Bufs b, MomCf
           }
         }
         lds_barrier();                   // B6
-        rm = phase_update(rm);
+        rm = phase_update(rm, std::integral_constant<bool, ST>{});
       } else if (tid == 0) {
         ++n_nan;
       }
-      phase_outputs(kk, k, rm);
+      phase_outputs(kk, k, rm, std::integral_constant<bool, ST>{});
       lds_barrier();                     // B7
     }
     ring_flush(k0, nb);

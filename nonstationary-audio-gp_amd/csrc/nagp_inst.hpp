@@ -141,17 +141,18 @@
   P void nagp::ihgp_adf8sq_kernel<5> NAGP_SIG_IHA; P void nagp::ihgp_adf8sq_kernel<6> NAGP_SIG_IHA;
 
 // the ADF sweep of the full-covariance filter with role-specialised waves (nagp_gfadf8.hpp): one or two lower tiles per thread
-#define NAGP_LIST_GF_A8T(P, TPT)                                                                                           \
-  P void nagp::gf_adf8_kernel<TPT, 1, false> NAGP_SIG_GF; P void nagp::gf_adf8_kernel<TPT, 2, false> NAGP_SIG_GF;        \
-  P void nagp::gf_adf8_kernel<TPT, 3, false> NAGP_SIG_GF; P void nagp::gf_adf8_kernel<TPT, 4, false> NAGP_SIG_GF;        \
-  P void nagp::gf_adf8_kernel<TPT, 5, false> NAGP_SIG_GF; P void nagp::gf_adf8_kernel<TPT, 6, false> NAGP_SIG_GF;        \
-  P void nagp::gf_adf8_kernel<TPT, 7, false> NAGP_SIG_GF;                                                                \
-  P void nagp::gf_adf8_kernel<TPT, 1, true> NAGP_SIG_GF; P void nagp::gf_adf8_kernel<TPT, 2, true> NAGP_SIG_GF;          \
-  P void nagp::gf_adf8_kernel<TPT, 3, true> NAGP_SIG_GF; P void nagp::gf_adf8_kernel<TPT, 4, true> NAGP_SIG_GF;          \
-  P void nagp::gf_adf8_kernel<TPT, 5, true> NAGP_SIG_GF; P void nagp::gf_adf8_kernel<TPT, 6, true> NAGP_SIG_GF;
-#define NAGP_LIST_GF_A81(P) NAGP_LIST_GF_A8T(P, 1)
-#define NAGP_LIST_GF_A82(P) NAGP_LIST_GF_A8T(P, 2)
+#define NAGP_LIST_GF_A8T(P, TPT, ST)                                                                                       \
+  P void nagp::gf_adf8_kernel<TPT, 1, false, ST> NAGP_SIG_GF; P void nagp::gf_adf8_kernel<TPT, 2, false, ST> NAGP_SIG_GF;        \
+  P void nagp::gf_adf8_kernel<TPT, 3, false, ST> NAGP_SIG_GF; P void nagp::gf_adf8_kernel<TPT, 4, false, ST> NAGP_SIG_GF;        \
+  P void nagp::gf_adf8_kernel<TPT, 5, false, ST> NAGP_SIG_GF; P void nagp::gf_adf8_kernel<TPT, 6, false, ST> NAGP_SIG_GF;        \
+  P void nagp::gf_adf8_kernel<TPT, 7, false, ST> NAGP_SIG_GF;                                                                \
+  P void nagp::gf_adf8_kernel<TPT, 1, true, ST> NAGP_SIG_GF; P void nagp::gf_adf8_kernel<TPT, 2, true, ST> NAGP_SIG_GF;          \
+  P void nagp::gf_adf8_kernel<TPT, 3, true, ST> NAGP_SIG_GF; P void nagp::gf_adf8_kernel<TPT, 4, true, ST> NAGP_SIG_GF;          \
+  P void nagp::gf_adf8_kernel<TPT, 5, true, ST> NAGP_SIG_GF; P void nagp::gf_adf8_kernel<TPT, 6, true, ST> NAGP_SIG_GF;
+#define NAGP_LIST_GF_A81(P) NAGP_LIST_GF_A8T(P, 1, false)
+#define NAGP_LIST_GF_A82(P) NAGP_LIST_GF_A8T(P, 2, false)
+#define NAGP_LIST_GF_A83(P) NAGP_LIST_GF_A8T(P, 2, true)
 
 #define NAGP_LIST_ALL(P)                                                                                                   \
   NAGP_LIST_GF_ADF1(P) NAGP_LIST_GF_ADF2(P) NAGP_LIST_GF_ADF3(P) NAGP_LIST_GF_ADF4(P) NAGP_LIST_GF_ADF5(P)               \
-  NAGP_LIST_GF_SP12(P) NAGP_LIST_GF_SP34(P) NAGP_LIST_GF_SQ12(P) NAGP_LIST_GF_SQ34(P) NAGP_LIST_GF_REST(P) NAGP_LIST_SMOOTH(P) NAGP_LIST_SMOOTH8(P) NAGP_LIST_BIG(P) NAGP_LIST_GAINM(P) NAGP_LIST_FLM(P) NAGP_LIST_EP(P) NAGP_LIST_EPS(P) NAGP_LIST_EPQ(P) NAGP_LIST_IH0(P) NAGP_LIST_IH1(P) NAGP_LIST_IHA(P) NAGP_LIST_IHA8(P) NAGP_LIST_IHA8Q(P) NAGP_LIST_GF_A81(P) NAGP_LIST_GF_A82(P)
+  NAGP_LIST_GF_SP12(P) NAGP_LIST_GF_SP34(P) NAGP_LIST_GF_SQ12(P) NAGP_LIST_GF_SQ34(P) NAGP_LIST_GF_REST(P) NAGP_LIST_SMOOTH(P) NAGP_LIST_SMOOTH8(P) NAGP_LIST_BIG(P) NAGP_LIST_GAINM(P) NAGP_LIST_FLM(P) NAGP_LIST_EP(P) NAGP_LIST_EPS(P) NAGP_LIST_EPQ(P) NAGP_LIST_IH0(P) NAGP_LIST_IH1(P) NAGP_LIST_IHA(P) NAGP_LIST_IHA8(P) NAGP_LIST_IHA8Q(P) NAGP_LIST_GF_A81(P) NAGP_LIST_GF_A82(P) NAGP_LIST_GF_A83(P)

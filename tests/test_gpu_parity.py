@@ -911,6 +911,50 @@ def test_sqrt_amplitude_likelihood_staged_form_equals_the_generic_form_and_the_o
     assert np.array_equal(np.isnan(a[5]['tnu']), np.isnan(b[5]['tnu']))
 
 
+@pytest.mark.parametrize('mode', ['predict', 'nlml', 'mixture'])
+@pytest.mark.parametrize('shape', [(3, 2, 5, 'matern32'), (16, 3, 5, 'matern32'), (24, 4, 5, 'exp'), (32, 6, 7, 'matern32'), (36, 4, 5, 'matern32'),
+                                   (20, 7, 3, 'matern32')])
+def test_role_specialised_gf_adf_sweep_equals_the_256_thread_form(shape, mode, monkeypatch):
+    """gf_adf8_kernel (nagp_gfadf8.hpp: 512 threads, the cubature in the role layout of the IHGP sweep, the covariance tiles on the worker
+    waves) against gf_filter_kernel<TPT, 0, V, 256, 1> (NAGP_NO_GF_ROLES=1), which the oracle tests pin: 5 / 19 / 28 / 38 / 40 / 27 sites =
+    one tile per thread, two tiles on the six worker waves (38 sites = 741 tiles), two tiles on all eight waves (40 sites = 820 tiles);
+    packed and unpacked MFMA steps (ut3 / ut5 / ut7, seven components), 2-state sub-band blocks, missing observations, two problems per
+    plan, three sweeps; predict mode, the nlml mode (legacy update: one more barrier per step) and the mixture rule (mom at power
+    ep_fraction, raw R).  Everything the sweeps return, to rounding; clamp counters equal."""
+    D, N, p, k1 = shape; T = 44
+    probs, ys = [], []
+    for q in range(2):
+        pr = harness.nmf_problem(D, N, T, 7100 + 10 * D + q, 'constraints')
+        blk = pss.balance_blocks(pss.ss_blocks_nmf(pr['param1'], pr['param2'], k1, 'matern52'))
+        y = pr['y'].copy(); y[11 + q] = np.nan; y[T - 1] = np.nan if q else y[T - 1]
+        probs.append((blk, pr['W'], np.log(pr['w_lik']))); ys.append(y)
+    mom = Mom('likModulatorNMFPower', p_cubature=p)
+    kw = dict(mom=mom, ep_fraction=0.5 if mode != 'mixture' else 0.75, ep_damping=np.array([0.6, 0.5, 0.4]), ep_itts=3,
+              mode=L.MODE_NLML if mode == 'nlml' else L.MODE_PREDICT, flags=L.FLAG_MIXTURE_RULE if mode == 'mixture' else 0)
+    res = {}
+    for form in ('roles', 'flat'):
+        monkeypatch.delenv('NAGP_NO_GF_ROLES', raising=False)
+        if form == 'flat': monkeypatch.setenv('NAGP_NO_GF_ROLES', '1')
+        plan = Plan(L.KIND_GF_EP, probs, T, **kw); plan.upload(ys); plan.execute()
+        res[form] = plan.download(want_MF=True); tm = plan.timings(); plan.close()
+        assert tm['launches']['filter'] >= 1
+    monkeypatch.delenv('NAGP_NO_GF_ROLES', raising=False)
+    for q in range(2):
+        a, v = res['roles'][q], res['flat'][q]
+        fields = (('nlZ', 1e-10),) if mode == 'nlml' else (('Eft', 1e-9), ('Varft', 1e-9), ('MS', 1e-9), ('MF', 1e-9), ('lZ', 1e-9), ('ttau', 1e-7), ('tnu', 1e-7))
+        for f, tol in fields:
+            x, z = getattr(a, f), getattr(v, f)
+            if f in ('ttau', 'tnu'):
+                # sites beyond 1e8 are rounding noise of the algorithm itself (1 + d2 HPH ~ 0; tools/fuzz_conditioning.py: SITE_MAX) -- the
+                # mixture rule does not clamp them away; they must be wild in BOTH forms, the rest must agree
+                wild = (np.abs(res['flat'][q].ttau) > 1e8) | (np.abs(res['roles'][q].ttau) > 1e8)
+                assert wild.sum() <= 4 and np.array_equal(np.abs(res['flat'][q].ttau) > 1e6, np.abs(res['roles'][q].ttau) > 1e6), (q, f)
+                x, z = np.where(wild, 0.0, x), np.where(wild, 0.0, z)
+            assert (relz(x[:1], z[:1]) if f == 'nlZ' else rel(x, z)) < tol, (q, f)      # (nlml mode: one energy per call)
+        assert np.array_equal(a.counters, v.counters)
+        assert np.all(np.isfinite(a.nlZ))
+
+
 @pytest.mark.parametrize('T,nanpos', [(1, []), (2, [1]), (3, [0]), (17, [16]), (33, list(range(33)))])
 def test_sqrt_amplitude_ihgp_sweep_edge_lengths_and_batches(T, nanpos):
     """ihgp_adf8sq_kernel at T = 1, 2, 3 (the launches of sweeps >= 2 start at k = T - 1 from the filtered mean of the step before), a NaN at

@@ -22,6 +22,7 @@ def run_cases(n, seed, verbose=True):
         slots = int(rng.choice([0, 2, 3, 4, 5, 6, 8])); no_recycle = rng.random() < 0.3
         itts = int(rng.integers(2, 4)); p = int(rng.choice([3, 5])) if N > 3 else int(rng.choice([3, 5, 7]))
         want_ps = (not ekf) and rng.random() < 0.25
+        nlml = (not ekf) and (not want_ps) and rng.random() < 0.25      # energy mode: sweeps 1 .. I-1 filter + smooth + refresh, no filter in sweep I
         probs, ys = [], []
         for q in range(B):
             pr = harness.nmf_problem(D, N, T, int(rng.integers(1, 1 << 30)), 'constraints')
@@ -30,7 +31,7 @@ def run_cases(n, seed, verbose=True):
             if rng.random() < 0.5: y[rng.integers(0, T, size=max(1, T // 40))] = np.nan
             probs.append((blk, pr['W'], np.log(pr['w_lik']))); ys.append(y)
         kw = dict(ep_itts=itts, l_iter=2) if ekf else dict(mom=Mom('likModulatorNMFPower', p_cubature=p), ep_fraction=0.5, ep_damping=0.5 * np.ones(itts), ep_itts=itts,
-                                                            flags=L.FLAG_WANT_PS if want_ps else 0)
+                                                            flags=L.FLAG_WANT_PS if want_ps else 0, mode=L.MODE_NLML if nlml else L.MODE_PREDICT)
         res = {}
         penv = dict({'NAGP_PIPELINE_SLOTS': str(slots)} if slots else {}, **({'NAGP_NO_RECYCLE': '1'} if no_recycle else {}))
         # 'pipelined' = the default schedule (cross-sweep form whenever every chunk owns a buffer), 'one_sweep' = the same without it
@@ -53,7 +54,7 @@ def run_cases(n, seed, verbose=True):
         ok = not diff and same_status
         bad += (not ok)
         if verbose: print('case %2d %s D=%2d N=%d T=%3d B=%d chunk=%3d slots=%d sweeps=%d p=%d PS=%d: %s%s' % (
-            case, 'ekf' if ekf else 'gf ', D, N, T, B, chunk, slots, itts, p, want_ps, 'bit-equal' if ok else 'DIFFERENT %s' % diff[:4],
+            case, 'ekf' if ekf else ('nlm' if nlml else 'gf '), D, N, T, B, chunk, slots, itts, p, want_ps, 'bit-equal' if ok else 'DIFFERENT %s' % diff[:4],
             '' if res['serial'][1] == 'ok' else ' [status: %s / %s]' % (res['pipelined'][1], res['serial'][1]))); sys.stdout.flush()
     if verbose: print('%d cases, %d different, %.0f s' % (n, bad, time.time() - t0))
     return bad

@@ -43,6 +43,12 @@ for case in range(n):
     plan.upload([y]); plan.execute(); r = plan.download()[0]; plan.close()
     o = ogf.run_predict(ogf.assemble(np.log(pr['w_lik']) * np.ones(1), pr['param1'], pr['param2'], pr['W'], k1, k2, True), y, om, alpha, damp, itts)
     e_gf = max(rel(r.Eft, o['Eft']), rel(r.Varft, o['Varft']), rel(r.nlZ, o['nlZ']))
+    if e_gf > 1e-7:      # the reference itself unstable here?  (the rule of tools/gpu_fuzz.py / fuzz_conditioning.py: oracle on y (1 + 1e-13))
+        o3 = ogf.run_predict(ogf.assemble(np.log(pr['w_lik']) * np.ones(1), pr['param1'], pr['param2'], pr['W'], k1, k2, True), y * (1 + 1e-13), om, alpha, damp, itts)
+        sens = max(rel(o3['Eft'], o['Eft']), rel(o3['Varft'], o['Varft']))
+        big = max(np.nanmax(np.abs(np.nan_to_num(x, posinf=0.0))) for x in (r.ttau, r.tnu, o['ttau'], o['tnu']))
+        if big > 1e8 or e_gf < 1e3 * sens or not np.isfinite(sens):
+            print('   [gf: unstable instance, oracle self-sensitivity %.1e, largest site %.1e, device difference %.1e]' % (sens, big, e_gf)); e_gf = 0.0
     pr2 = harness.nmf_problem(D, N, T, 2000 + 17 * case + seed); tt = np.arange(1, T + 1.0)
     r2 = nagp.ihgp_ep_modulator_nmf(pr2['w'], tt, pr2['y'], nagp.SSHandle(), mom, tt, k1, k2, 1, D, N, alpha, damp, itts, nargout=6)
     o2 = oih.ihgp_ep_modulator_nmf(pr2['w'], tt, pr2['y'], None, om, tt, k1, k2, 1, D, N, alpha, damp, itts)

@@ -955,6 +955,20 @@ def test_role_specialised_gf_adf_sweep_equals_the_256_thread_form(shape, mode, m
         assert np.all(np.isfinite(a.nlZ))
 
 
+@pytest.mark.parametrize('D,N', [(5, 2), (32, 6)])
+@pytest.mark.parametrize('T,nanpos', [(1, []), (2, [1]), (2, []), (3, [0]), (5, [4]), (17, [16]), (33, list(range(33)))])
+def test_gf_sweeps_at_edge_lengths_against_the_oracle(T, nanpos, D, N):
+    """gf_ep_modulator_nmf, three sweeps, at T = 1, 2, 3, 5, 17 with a NaN at the first / last step and with everything missing: the
+    role-specialised ADF launch needs two steps (T = 1 and the single ADF step k = T-1 of later sweeps take the 256-thread form), the
+    fixed-site launches of sweeps >= 2 cover k < T-1 (none at T = 1), the smoother has no step at T = 1 -- 7 and 38 sites."""
+    pr = harness.nmf_problem(D, N, T, 900 + T + D, 'constraints'); t = np.arange(1, T + 1.0)
+    y = pr['y'].copy(); y[nanpos] = np.nan
+    mom = Mom('likModulatorNMFPower', p_cubature=5); om = olik.Mom(olik.LIK_POWER_NMF, p=5); d = np.array([0.6, 0.5, 0.4])
+    r = nagp.gf_ep_modulator_nmf(pr['w'], t, y, SSHandle(), mom, t, 'matern32', 'matern52', 1, D, N, 0.5, d, 3, nargout=6)
+    o = ogf.gf_ep_modulator_nmf(pr['w'], t, y, None, om, t, 'matern32', 'matern52', 1, D, N, 0.5, d, 3)
+    assert rel(r[0], o[0]) < 1e-10 and rel(r[1], o[1]) < 1e-10 and rel(r[5]['ttau'], o[5]['ttau']) < 1e-9 and rel(r[5]['nlZ'], o[5]['nlZ']) < 1e-10
+
+
 @pytest.mark.parametrize('T,nanpos', [(1, []), (2, [1]), (3, [0]), (17, [16]), (33, list(range(33)))])
 def test_sqrt_amplitude_ihgp_sweep_edge_lengths_and_batches(T, nanpos):
     """ihgp_adf8sq_kernel at T = 1, 2, 3 (the launches of sweeps >= 2 start at k = T - 1 from the filtered mean of the step before), a NaN at

@@ -517,8 +517,7 @@ def main():
         print(json.dumps(compact(line)))
         sys.stdout.flush()
     if world > 1:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+        nd.finalize()                      # barrier + destroy: no rank leaves while a peer's threads still hold its sockets
 
 
 if __name__ == '__main__':

@@ -85,6 +85,16 @@ def barrier():
         dist.barrier()
 
 
+def finalize():
+    """Leave the process group in step: a barrier, then destroy it.  A rank that simply exits while a peer's gloo / RCCL
+    threads still hold its sockets makes the peer abort at interpreter exit ("terminate called ... connection reset")."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        if dist.get_world_size() > 1:
+            dist.barrier()
+        dist.destroy_process_group()
+
+
 def world_size():
     """World size the initialised process group reports (1 without one)."""
     import torch.distributed as dist

@@ -1016,8 +1016,8 @@ mine = nd.shard(NSEG, rank, world)
 tot = nd.allreduce_nlz(run(mine))
 serial = run(list(range(NSEG))).sum(axis=0)
 assert np.allclose(tot, serial, rtol=1e-14), (tot, serial)
-nd.barrier()
-print('rank', rank, 'ok', tot)
+print('rank', rank, 'ok', tot, flush=True)
+nd.finalize()
 """
 
 

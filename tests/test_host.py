@@ -236,7 +236,8 @@ assert sorted(sum([nd.shard(NSEG, r, world) for r in range(world)], [])) == list
 # a rank without segments (more ranks than segments) still takes part in the reduction
 none = nd.allreduce_nlz(np.zeros((0, I)).reshape(-1, I) if rank == 1 else np.ones((1, I)))
 assert np.allclose(none, 1.0)
-print('rank', rank, 'ok')
+print('rank', rank, 'ok', flush=True)
+nd.finalize()
 """
 
 

@@ -592,7 +592,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
   }
   if (p->chunk > T) p->chunk = (int)T;
   PLAN_TRY(dalloc(p, &p->d_stamps, 24));
-  PLAN_TRY(dalloc(p, &p->d_gstamps, 8));
+  PLAN_TRY(dalloc(p, &p->d_gstamps, 32));
   if (o->kind != NAGP_KIND_IHGP) {
     {   // FP64 MFMA smoother for padded dimensions up to 96 (set NAGP_NO_MFMA=1 to force the VALU passes)
       const int Sp = ((4 * sh.M + 15) / 16) * 16;
@@ -605,7 +605,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     // column-owner passes (96 < Sp <= 160) read the symmetric Delta through its lower 16x16 tiles only: the slots hold it packed
     // (Sp = 160: 315 KB per step instead of 410 -- eight chunks of the 8-segment cfg5 plan keep their slot where six did).  Not when a
     // sweep stores smoothed covariances (its VALU passes use the tile-major layout of the same slots) or with the opt-in MFMA gain kernel.
-    p->dpacked = (p->big_sp && !p->want_PS && !getenv("NAGP_GAIN_MFMA") && !getenv("NAGP_DENSE_DELTA")) ? 1 : 0;
+    p->dpacked = (p->big_sp && !p->want_PS && !getenv("NAGP_DENSE_DELTA")) ? 1 : 0;
     p->gstep = p->mfma_sp ? gd_step_doubles(p->mfma_sp, p->dpacked) : 2 * mat;
     const double per_step = (double)B * ((double)p->gstep + sh.S) * 8.0;                   // one step of a (G, Delta, delta) chunk buffer
     {
@@ -1028,11 +1028,11 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
                    case 6: SETF(6, 8); break; case 7: SETF(7, 8); break; case 8: SETF(8, 8); break; case 9: SETF(9, 8); break; default: SETF(10, 8); break; }
 #undef SETF
   }
-  // rts_gain_mfma_kernel (16x16 tiles on the matrix cores) is opt-in: measured on MI355X it is still behind the 4x4-tile VALU kernel
-  // (32 x 12 500 steps at Sp = 160: 1 195 ms against 972 ms; phase table in profiles/r03_gain_mfma_phases.txt)
-  if (p->mfma_sp && getenv("NAGP_GAIN_MFMA")) {
+  // rts_gain_mfma_kernel (16x16 tiles on the matrix cores, the dependence chain of the blocked Cholesky on a wave of its own) serves every
+  // plan whose smoother passes take dense (G, Delta); NAGP_NO_GAIN_MFMA=1 (developer switch) keeps the 4x4-tile VALU kernel
+  if (p->mfma_sp && !getenv("NAGP_NO_GAIN_MFMA")) {
     p->gain_mfma = 1;
-    const size_t lg = gainm_lds_doubles(p->mfma_sp / 16) * sizeof(double);
+    const size_t lg = gainm_lds_doubles(p->mfma_sp / 16, sh) * sizeof(double);
 #define SETG(N) PLAN_TRY(set_lds(rts_gain_mfma_kernel<N>, lg))
     switch (p->mfma_sp / 16) { case 1: SETG(1); break; case 2: SETG(2); break; case 3: SETG(3); break; case 4: SETG(4); break; case 5: SETG(5); break;
                                case 6: SETG(6); break; case 7: SETG(7); break; case 8: SETG(8); break; case 9: SETG(9); break; default: SETG(10); break; }
@@ -1380,8 +1380,8 @@ static int launch_gain_chunk(nagp_plan* p, const SweepCtx& sc, int c, int slot, 
   dim3 gr(g.nk, p->B), bl(p->NT);
   if (gp.dense_sp && p->gain_mfma) {
     const int ntl = p->mfma_sp / 16;
-    const size_t lg = gainm_lds_doubles(ntl) * sizeof(double);
-#define LG(N) hipLaunchKernelGGL((rts_gain_mfma_kernel<N>), gr, dim3(64 * N), lg, st, sh, b, gp)
+    const size_t lg = gainm_lds_doubles(ntl, sh) * sizeof(double);
+#define LG(N) hipLaunchKernelGGL((rts_gain_mfma_kernel<N>), gr, dim3(64 * (N + 1)), lg, st, sh, b, gp)
     switch (ntl) { case 1: LG(1); break; case 2: LG(2); break; case 3: LG(3); break; case 4: LG(4); break; case 5: LG(5); break;
                    case 6: LG(6); break; case 7: LG(7); break; case 8: LG(8); break; case 9: LG(9); break; default: LG(10); break; }
 #undef LG
@@ -1993,7 +1993,7 @@ extern "C" int nagp_plan_execute(nagp_plan* p) {
   RUN(zero_async(p, p->b.counters, (size_t)p->B * 32));
   RUN(zero_async(p, p->b.state, (size_t)p->B * ((size_t)sh.ntiles * 16 + sh.S) * 8));
   if (p->d_stamps) RUN(zero_async(p, p->d_stamps, 24 * 8));
-  if (p->d_gstamps) RUN(zero_async(p, p->d_gstamps, 8 * 8));
+  if (p->d_gstamps) RUN(zero_async(p, p->d_gstamps, 32 * 8));
   std::fill(p->nlZ.begin(), p->nlZ.end(), 0.0);
   std::fill(p->mdM.begin(), p->mdM.end(), 0.0);
   std::fill(p->mdP.begin(), p->mdP.end(), 0.0);
@@ -2015,8 +2015,16 @@ extern "C" int nagp_plan_execute(nagp_plan* p) {
   HIP_TRY(hipEventRecord(p->ev_t1, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
   if (getenv("NAGP_STAMPS") && p->d_gstamps && p->opts.kind != NAGP_KIND_IHGP) {
-    unsigned long long g[8];
-    if (hipMemcpy(g, p->d_gstamps, sizeof g, hipMemcpyDeviceToHost) == hipSuccess && g[6])
+    unsigned long long g[32];
+    if (hipMemcpy(g, p->d_gstamps, sizeof g, hipMemcpyDeviceToHost) == hipSuccess && p->gain_mfma && g[12]) {
+      static const char* nm[12] = {"staging", "prologue barriers", "B' | delta_k", "PSkp", "Delta | tile 0", "trailing | 4 products", "factor+invert", "forward row", "interval barrier", "retry check", "backward", "G store"};
+      for (int r = 0; r < 2; ++r) {
+        if (!g[16 * r + 12]) continue;
+        fprintf(stderr, "[nagp stamps] rts_gain_mfma_kernel, %s wave, cycles per workgroup (%llu sampled):", r ? "chain" : "column", g[16 * r + 12]);
+        for (int q = 0; q < 12; ++q) fprintf(stderr, " %s %llu |", nm[q], g[16 * r + q] / g[16 * r + 12]);
+        fprintf(stderr, "\n");
+      }
+    } else if (!p->gain_mfma && g[6])
       fprintf(stderr, "[nagp stamps] rts_gain_kernel, cycles per workgroup (thread 0 of %llu sampled): prologue %llu | diagonal tiles %llu | column solves %llu | trailing updates %llu | backward solve %llu | G store %llu\n",
               g[6], g[0] / g[6], g[1] / g[6], g[2] / g[6], g[3] / g[6], g[4] / g[6], g[5] / g[6]);
   }

@@ -3,32 +3,45 @@
 //   B = PS_k A' ; PSkp = A B + Q ; L = chol(PSkp,'lower') (jitter retry) ; G = B / L' / L ; Delta_k = PS_{k+1} - PSkp ;
 //   delta_k = MF_{k+1} - A MF_k                                                        (gf_ep_modulator_nmf.m:210-230)
 //
-// One workgroup of NTL = Sp/16 waves per (step, problem); the work is organised on 16x16 tiles of the padded dense matrices
-// (dense index = 4*block + row) instead of the 4x4 tiles of rts_gain_kernel, whose ~3M barrier-separated phases per step
-// (114 at 38 sites) left the CUs waiting:
-//   * build: wave J forms tile column J of B' = A PS_k (accumulator layout, in registers for the rest of the kernel) and the
-//     lower tiles (I >= J) of PSkp = B' A' + Q, which go to LDS; Delta goes straight to HBM;
-//   * factorisation: right-looking on 16x16 tiles, NTL block columns.  Wave j factors the diagonal tile (4x4 sub-tiles, its
-//     own LDS traffic only, no workgroup barrier) and inverts it; the panel L_Ij = A_Ij inv(L_jj)' and the trailing update
-//     A_IK -= L_Ij L_Kj' are 16x16x16 products on v_mfma_f64_16x16x4 with both operands read from LDS in the orientation
-//     they are stored in (rows of the left factor, rows of the transposed right factor);
-//   * solves: G' = L'^-1 (L^-1 B').  The right-hand-side columns are independent, so wave J solves ITS tile column with no
-//     synchronisation at all: forward  Y_I = inv(L_II) (B'_I - sum_{K<I} L_IK Y_K), backward W_I = inv(L_II)' (Y_I - sum_{K>I}
-//     L_KI' W_K).  The accumulator layout of the MFMA (lane = col + 16*kq, register t <-> row 4t+kq) IS its B-operand layout,
-//     so Y_K, W_K are multiplied from the registers they were accumulated in; only the L tiles travel (LDS -> A operand);
-//   * G = W' is written to HBM as 32-byte runs.
-// LDS: NTL(NTL+1)/2 + NTL tiles of 2 KiB (130 KiB at Sp = 160).  Columns of a tile are stored permuted (column 4s+kq at
-// position 4kq+s) so that the four k-steps of a lane's A operand are 32 contiguous bytes.
+// One workgroup of NTL + 1 waves (NTL = Sp/16) per (step, problem), on 16x16 tiles of the padded dense matrices (dense index =
+// 4*block + row).  A gain step is 2.33 S^3 multiply-adds behind ONE dependence chain -- diagonal tile J factored -> sub-diagonal
+// tile (J+1,J) -> diagonal tile J+1 updated -> factored ... -- and what a step costs is how much of everything else runs beside
+// that chain.  So the chain has a wave of its own and nobody ever waits for anything but it:
+//   * one wave, the CHAIN wave: per block column J it finishes the two tiles the chain runs through -- (J+1,J) and (J+1,J+1):
+//     the contribution of column J-1 (whose tiles the other waves finished one interval earlier), the panel product with
+//     inv(L_JJ)', the square of the new sub-diagonal tile -- with its own LDS traffic only, then factors AND inverts tile J+1 in
+//     registers (nagp_chol16.hpp: a row per lane, DPP broadcasts, no LDS), and publishes inv(L_{J+1,J+1}).  ONE workgroup barrier per
+//     block column;
+//   * the other NTL waves, the COLUMN waves, in the same interval: the trailing update with column J-1 of every other live tile (fused
+//     with the panel product for the tiles of column J), dealt round robin, and -- wave c owns tile column c of B' = A PS_k in
+//     accumulator registers from the prologue to the G store -- row J of the forward solve Y = L^-1 B', which needs row J of L only
+//     and therefore runs INSIDE the factorisation, lagging one interval behind it;
+//   * after the last column: the backward solve W = L'^-1 Y, wave c on its own tile column, no synchronisation at all.
+//     The accumulator layout of the MFMA (lane = col + 16*kq, register t <-> row 4t+kq) IS its B-operand layout, so Y_K, W_K are
+//     multiplied from the registers they were accumulated in; only the L tiles travel (LDS -> A operand), and the triangular
+//     solves with the diagonal tiles are products with their inverses;
+//   * prologue: PS_k is copied into LDS once (coalesced 16-byte pieces, the layout of PF), every column wave forms its tile column
+//     of B' from there (4x4 block products on the VALU), PSkp = B' A' + Q comes out of the B' registers by DPP quad broadcasts
+//     (the four columns of a state block sit in the four lanes of a quad) and goes to LDS over the dead staging copy; Delta_k is
+//     one pass over those tiles against PS_{k+1}, whose loads are issued before PSkp is formed;
+//   * G = W' leaves as 32-byte runs, Delta as 512-byte runs (packed lower 16x16 tiles) or 128-byte row pieces (dense).
+// LDS: max(NTL(NTL+1)/2 tiles of 2 KiB, PS_k) + NTL inverse tiles (130 KiB at Sp = 160: one workgroup per CU; 40 KiB at Sp = 80).
+// Columns of a tile are stored permuted (column 4s+kq at position 4kq+s) so that the four k-steps of a lane's A operand are 32
+// contiguous bytes.
 #pragma once
 #include "nagp_mfma.hpp"
+#include "nagp_chol16.hpp"
 
 namespace nagp {
 
-__host__ __device__ inline size_t gainm_lds_doubles(int NTL) {
-  return (size_t)(NTL * (NTL + 1) / 2 + NTL) * 256 + (size_t)MAXM * 16 + 64 + 16;
+__host__ __device__ inline size_t gainm_union_doubles(int NTL, const Shape& sh) {
+  const size_t lt = (size_t)(NTL * (NTL + 1) / 2) * 256, st = pf_step_doubles(sh);
+  return lt > st ? lt : st;
+}
+__host__ __device__ inline size_t gainm_lds_doubles(int NTL, const Shape& sh) {
+  return gainm_union_doubles(NTL, sh) + (size_t)NTL * 256 + (size_t)MAXM * 16 + MAXM + 8;
 }
 __device__ __forceinline__ int gm_p(int c) { return ((c & 3) << 2) + (c >> 2); }                  // stored position of column c
-__device__ __forceinline__ int gm_at(int r, int c) { return r * 16 + gm_p(c); }
 __device__ __forceinline__ int gm_tix(int K, int L) { return (K * (K + 1) / 2 + L) * 256; }      // K >= L
 
 // acc += sgn * X * Yt'  with X, Yt 16x16 tiles in LDS (rows of X, rows of Yt = columns of Yt'): both "direct" reads
@@ -72,276 +85,419 @@ __device__ __forceinline__ v4d gm_load_acc(const double* Tl, int i, int kq) {
   for (int t = 0; t < 4; ++t) v[t] = Tl[(4 * t + kq) * 16 + pi];
   return v;
 }
+// the transposed tile in accumulator layout: element (4t+kq, i) of Tl'
+__device__ __forceinline__ v4d gm_load_accT(const double* Tl, int i, int kq) {
+  v4d v;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) v[t] = Tl[i * 16 + gm_p(4 * t + kq)];
+  return v;
+}
 __device__ __forceinline__ void gm_wave_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// value of lane q of this lane's quad (DPP quad_perm broadcast).  The builtin must be the operand of a plain `return` of the right type:
+// passed straight into an overloaded function (fma) clang types the call as int and converts the bit pattern numerically.
+template <int CTRL>
+__device__ __forceinline__ double gm_quad(double v) { return __builtin_amdgcn_update_dpp(0.0, v, CTRL, 0xF, 0xF, true); }
+// the value is computed HERE: without it the IR-level sinking moves the multiply-adds of B' down to their first use two phases later, every LDS
+// operand stays live until then and is spilled the moment it is read (477 spilled registers in the B' phase alone)
+__device__ __forceinline__ void gm_pin(double& v) { asm volatile("" : "+v"(v)); }
+// an opaque copy of a lane index: address arithmetic that depends on it is not hoisted out of the enclosing loop (the compiler otherwise
+// computes the ~200 per-lane LDS addresses of a whole gain step in front of the retry loop and spills them)
+__device__ __forceinline__ int gm_opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 
-// Cholesky of the 16x16 tile T (LDS, lower part meaningful) in place and its inverse into Ti, by ONE wave: lanes 0..15 own the
-// 4x4 sub-tiles (a = lane>>2, b = lane&3); four block columns, the wave's own LDS traffic orders the phases.  Returns false
-// (to every lane) when a pivot was not positive.
-__device__ __attribute__((noinline)) bool gm_chol16(double* T, double* Ti, double* rdv, int lane) {
-  const int a = (lane >> 2) & 3, b = lane & 3;
-  const bool on = lane < 16 && a >= b;
-  bool ok = true;
-  auto ld = [&](const double* base, int ta, int tb, double* t) {
+// the chain wave: tile T (LDS, lower part meaningful) -> inv(chol(T)) into Ti (LDS, full tile, zeros above the diagonal)
+__device__ __forceinline__ bool gm_chol_inv_tile(const double* T, double* Ti, int lane) {
+  const int row = lane & 15;
+  double a[16], x[16];
+  const double2* src = reinterpret_cast<const double2*>(T + row * 16);
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) t[4 * r + c] = base[gm_at(4 * ta + r, 4 * tb + c)];
-  };
-  auto st = [&](double* base, int ta, int tb, const double* t) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) base[gm_at(4 * ta + r, 4 * tb + c)] = t[4 * r + c];
-  };
-  for (int bb = 0; bb < 4; ++bb) {
-    if (on && a == bb && b == bb) {
-      double t[16], rd[4];
-      ld(T, bb, bb, t);
-      if (!tile_chol(t, 4, rd)) ok = false;
-      st(T, bb, bb, t);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) rdv[4 * bb + q] = rd[q];      // 1 / L(q,q): the solves and the inverse multiply by it
-    }
-    gm_wave_fence();
-    if (on && b == bb && a > bb) {          // X L_bb' = T_ab
-      double t[16], l[16];
-      ld(T, a, bb, t); ld(T, bb, bb, l);
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          double v = t[4 * r + c];
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (q < c) v = fma(-t[4 * r + q], l[4 * c + q], v);
-          t[4 * r + c] = v * rdv[4 * bb + c];
-        }
-      st(T, a, bb, t);
-    }
-    gm_wave_fence();
-    if (on && b > bb) {                     // trailing update T_ab -= X_a X_b'
-      double t[16], xa[16], xb[16];
-      ld(T, a, b, t); ld(T, a, bb, xa); ld(T, b, bb, xb);
-      tile_mms_nt(t, xa, xb);
-      st(T, a, b, t);
-    }
-    gm_wave_fence();
+  for (int m = 0; m < 8; ++m) {      // positions 2m, 2m+1 hold columns 4(q&3) + (q>>2)
+    const double2 v = src[m];
+    a[4 * ((2 * m) & 3) + ((2 * m) >> 2)] = v.x;
+    a[4 * ((2 * m + 1) & 3) + ((2 * m + 1) >> 2)] = v.y;
   }
-  // zero the strictly upper sub-tiles of L (the panel products read whole rows)
-  if (lane < 16 && a < b) { double z[16]; tile_zero(z); st(T, a, b, z); }
-  // inverse, diagonal sub-tiles first, then the sub-diagonals: X_ab = -X_aa sum_{c=b}^{a-1} L_ac X_cb
-  for (int dl = 0; dl < 4; ++dl) {
-    if (on && a - b == dl) {
-      double x[16];
-      tile_zero(x);
-      if (dl == 0) {
-        double l[16];
-        ld(T, a, a, l);
+  const bool ok = chol16_inv_rows(a, x, row);
+  if (lane < 16) {
+    double2* dst = reinterpret_cast<double2*>(Ti + row * 16);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {       // column c of inv(L_aa) by forward substitution
-          x[4 * c + c] = rdv[4 * a + c];
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (r > c) {
-              double v = 0.0;
-#pragma unroll
-              for (int q = 0; q < 4; ++q)
-                if (q >= c && q < r) v = fma(-l[4 * r + q], x[4 * q + c], v);
-              x[4 * r + c] = v * rdv[4 * a + r];
-            }
-        }
-      } else {
-        double acc[16], xaa[16];
-        tile_zero(acc);
-        for (int c = b; c < a; ++c) {
-          double l[16], xc[16];
-          ld(T, a, c, l); ld(Ti, c, b, xc);
-          tile_mma(acc, l, xc);
-        }
-        ld(Ti, a, a, xaa);
-        tile_mma(x, xaa, acc);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) x[e] = -x[e];
-      }
-      st(Ti, a, b, x);
-    }
-    if (dl == 0 && lane < 16 && a < b) { double z[16]; tile_zero(z); st(Ti, a, b, z); }
-    gm_wave_fence();
+    for (int m = 0; m < 8; ++m)
+      dst[m] = make_double2(x[4 * ((2 * m) & 3) + ((2 * m) >> 2)], x[4 * ((2 * m + 1) & 3) + ((2 * m + 1) >> 2)]);
   }
-  const unsigned long long bad = __ballot(!ok);
-  return bad == 0ull;
+  return __ballot(!ok) == 0ull;
 }
 
+// LDS offset (doubles) of the first element of tile t in the layout of PF (pf_off(t, 0))
+__device__ __forceinline__ int gm_tpart(int t) { return ((t >> 6) << 10) + ((t & 63) << 1); }
+
 template <int NTL>
-__global__ void __launch_bounds__(64 * NTL) rts_gain_mfma_kernel(Shape sh, Bufs b, GainPar gp) {
+__global__ void __launch_bounds__(64 * (NTL + 1)) rts_gain_mfma_kernel(Shape sh, Bufs b, GainPar gp) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  constexpr int Sp = 16 * NTL, NT = 64 * NTL;
-  const int tid = threadIdx.x, lane = tid & 63, i = lane & 15, kq = lane >> 4;
-  const int J = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int Sp = 16 * NTL, NT = 64 * (NTL + 1), NLOW = NTL * (NTL + 1) / 2;
+  constexpr int ND = 6;                                           // Delta tiles per column wave and round
+  constexpr int NLD = ((2 * NTL * (4 * NTL + 1) + 63) / 64 * 64 * 8 + NT - 1) / NT;      // 16-byte pieces of PS_k per thread (M <= 4 NTL)
+  const int tid = threadIdx.x, lane = tid & 63, i0 = lane & 15, kq0 = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // wave 3 is the chain wave: waves are dealt to the four SIMDs round robin, so with NTL + 1 <= 11 waves SIMD 3 holds the chain and ONE
+  // column wave instead of two (an FP64 MFMA holds its SIMD's issue for its duration: every MFMA of a SIMD-mate delays the chain)
+  constexpr int CW = (NTL >= 4) ? 3 : NTL;
+  const bool chain = (w == CW);
+  const int c = (w > CW) ? w - 1 : w;                             // tile column of a column wave
   const int S = sh.S, M = sh.M;
   const int64_t T = sh.T;
   const int kk = blockIdx.x, pb = blockIdx.y;
   const int64_t k = gp.k0 + kk;
   const double* mdl = b.model + (size_t)pb * mdl_size(sh);
-  double* Lt = lds;                                             // lower tiles of PSkp -> L
-  double* Li = Lt + (size_t)(NTL * (NTL + 1) / 2) * 256;        // inverses of the diagonal tiles
-  double* sA = Li + (size_t)NTL * 256;                          // [M][16]
-  int* ibsz = reinterpret_cast<int*>(sA + (size_t)MAXM * 16);   // [MAXM]
-  int* flag = ibsz + MAXM + 2;                                  // [2]
-  double* rdv = sA + (size_t)MAXM * 16 + 48;                    // [16] reciprocal pivots of the diagonal tile being factored
-  for (int q = tid; q < M * 16; q += NT) sA[q] = mdl[mdl_A(sh) + q];
-  for (int q = tid; q < M; q += NT) ibsz[q] = sh.bsz[q];
-  if (tid == 0) { flag[0] = 0; flag[1] = 0; }
-  __syncthreads();
+  double* Lt = lds;                                               // lower tiles of PSkp -> L; before that: PS_k in the layout of PF
+  double* Li = Lt + gainm_union_doubles(NTL, sh);                 // inverses of the diagonal factors
+  double* sA = Li + (size_t)NTL * 256;                            // [M][16]
+  int* ibsz = reinterpret_cast<int*>(sA + (size_t)MAXM * 16);     // [MAXM]
+  int* ioff = ibsz + MAXM;                                        // [MAXM + 1]  (the kernel argument itself is only indexed statically:
+                                                                  // one dynamic index and the whole struct is copied to scratch)
+  int* flag = ioff + MAXM + 1;                                    // [2]
+  // developer diagnostics (NAGP_STAMPS): cycles per phase of lane 0 of column wave 0 ([0..15]) and of the chain wave ([16..31]) of every 64th
+  // workgroup -- slot 0 staging | 1 barrier waits of the prologue | 2 B' (chain: delta_k) | 3 PSkp | 4 Delta (chain: tile 0) | 5 trailing tasks
+  // (chain: its four products) | 6 chain: factor + invert | 7 forward row | 8 interval barrier wait | 9 flag, retry | 10 backward | 11 G store
+  // | 12 workgroups sampled
+  const bool stamp = gp.stamps && lane == 0 && (w == 0 || chain) && (blockIdx.x & 63) == 0;
+  unsigned long long st_a = stamp ? __builtin_readcyclecounter() : 0ull;
+#define GM_STAMP(slot) do { if (stamp) { const unsigned long long st_b = __builtin_readcyclecounter(); atomicAdd(&gp.stamps[(chain ? 16 : 0) + (slot)], st_b - st_a); st_a = st_b; } } while (0)
 
   const double* PFk = b.PF + ((size_t)pb * T + k) * pf_step_doubles(sh);
   const double* PFk1 = PFk + pf_step_doubles(sh);
   const size_t SS = (size_t)Sp * Sp;
-  double* Gout = b.Gbuf + (((size_t)pb * gp.chunk + kk) * 2) * SS;
+  const size_t gstep = gd_step_doubles(Sp, gp.dpacked);
+  double* Gout = b.Gbuf + (b.gpstride ? (size_t)pb * b.gpstride + (size_t)kk * gstep : ((size_t)pb * gp.chunk + kk) * gstep);
   double* Dout = Gout + SS;
-
-  // ---- delta_k = MF_{k+1} - A MF_k
-  if (tid < S) {
-    int blk = 0;
-    while (sh.off[blk + 1] <= tid) ++blk;
-    const int row = tid - sh.off[blk];
-    const double* mf = b.MF + ((size_t)pb * T + k) * S;
-    double acc = mf[S + tid];
-    for (int l = 0; l < ibsz[blk]; ++l) acc = fma(-sA[(size_t)blk * 16 + 4 * row + l], mf[sh.off[blk] + l], acc);
-    b.dbuf[((size_t)pb * gp.chunk + kk) * S + tid] = acc;
-  }
-
-  // ---- element (16I + 4t + kq, 16J + i) of B' = A PS_k: row kq of block br = 4I+t, column ci of block bc.  The four lanes kq of a
-  // column need the same four entries PS[(br, l)][(bc, ci)], l = 0..3: every lane loads the one with l = kq, the others arrive by
-  // cross-lane reads -- a quarter of the loads
-  const int bc = 4 * J + (i >> 2), ci = i & 3;                  // block / column-in-block of this lane's column
-  const bool colok = bc < M && ci < ibsz[bc < M ? bc : 0];
-  auto bprime = [&](int br) -> double {
-    const bool rowok = br < M && kq < ibsz[br < M ? br : 0];
-    double mine = 0.0;
-    if (rowok && colok) mine = pf_elem(PFk, br, bc, kq, ci);
-    double v = 0.0;
+  const int NTOT = gp.dpacked ? NLOW : NTL * NTL;                 // tiles of Delta that are stored
+  auto dtile = [&](int q, int& I, int& K) {
+    if (gp.dpacked) { I = 0; while ((I + 1) * (I + 2) / 2 <= q) ++I; K = q - I * (I + 1) / 2; }
+    else { I = q / NTL; K = q - I * NTL; }
+  };
+  // validity of this lane's rows and columns: bit br of rowbits <=> row kq of block br exists; bit K of colbits <=> column i of tile
+  // column K exists (block 4K + (i >> 2), column i & 3).  Block sizes straight from the kernel arguments (static indices)
+  unsigned long long rowbits = 0;
+  unsigned colbits = 0;
 #pragma unroll
-    for (int l = 0; l < 4; ++l) {
-      const double pl = __shfl(mine, i + 16 * l, 64);
-      if (br < M) v = fma(sA[(size_t)br * 16 + 4 * kq + l], pl, v);
-    }
-    return (rowok && colok) ? v : 0.0;
+  for (int br = 0; br < 4 * NTL; ++br)
+    if (br < M && kq0 < sh.bsz[br]) rowbits |= 1ull << br;
+#pragma unroll
+  for (int K = 0; K < NTL; ++K) {
+    const int q = i0 >> 2;
+    const int bs = (q == 0) ? sh.bsz[4 * K] : (q == 1) ? sh.bsz[4 * K + 1] : (q == 2) ? sh.bsz[4 * K + 2] : sh.bsz[4 * K + 3];
+    if (4 * K + q < M && (i0 & 3) < bs) colbits |= 1u << K;
+  }
+  for (int q = tid; q < M * 16; q += NT) sA[q] = mdl[mdl_A(sh) + q];
+  if (tid < MAXM) {
+    int bs = 0, of = 0;
+#pragma unroll
+    for (int q = 0; q < 4 * NTL; ++q) if (q == tid) { bs = sh.bsz[q]; of = sh.off[q]; }
+    ibsz[tid] = bs; ioff[tid] = (tid >= M) ? S : of;
+  }
+  if (tid == MAXM) ioff[MAXM] = S;
+  if (tid == 0) { flag[0] = 0; flag[1] = 0; }
+
+  const int bc0 = 4 * c + (i0 >> 2);                              // block of this lane's column (column waves)
+  const bool bcin = !chain && bc0 < M;
+  const bool colok = !chain && ((colbits >> c) & 1u);
+  const double qd = colok ? mdl[mdl_Q(sh) + (size_t)bc0 * 16 + 4 * kq0 + (i0 & 3)] : 0.0;      // entry (kq, ci) of this column's diagonal block of Q
+  const int diag_t = (((i0 - kq0) & 3) == 0 && i0 >= kq0) ? ((i0 - kq0) >> 2) : -1;             // register t with 4t + kq == i (the tile's diagonal)
+  // staged copy of PS_k (the layout of PF: pf_off): every 16-byte piece of the step in flight at once
+  auto stage = [&]() {
+    const double2* src = reinterpret_cast<const double2*>(PFk);
+    double2* dst = reinterpret_cast<double2*>(Lt);
+    const int n2 = (int)(pf_step_doubles(sh) / 2);
+    const int tq = gm_opaque(tid);      // (addresses formed here: hoisted out of the retry loop they are spilled, and every reload waits for the load before it)
+    static_assert(NLD <= 10, "gm_pin_all takes ten pieces");
+    double2 v[10];
+#pragma unroll
+    for (int u = 0; u < 10; ++u) { const int q = tq + u * NT; v[u] = (u < NLD) ? src[q < n2 ? q : n2 - 1] : make_double2(0.0, 0.0); }      // unconditional loads
+    // ONE statement that needs all of them: the compiler otherwise sinks every load into the conditional store below -- load, wait, LDS
+    // write, next load: ten HBM round trips in a row (38 k cycles of a 260 k-cycle step)
+    asm volatile("" : "+v"(v[0].x), "+v"(v[0].y), "+v"(v[1].x), "+v"(v[1].y), "+v"(v[2].x), "+v"(v[2].y), "+v"(v[3].x), "+v"(v[3].y), "+v"(v[4].x), "+v"(v[4].y),
+                      "+v"(v[5].x), "+v"(v[5].y), "+v"(v[6].x), "+v"(v[6].y), "+v"(v[7].x), "+v"(v[7].y), "+v"(v[8].x), "+v"(v[8].y), "+v"(v[9].x), "+v"(v[9].y));
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) { const int q = tq + u * NT; if (q < n2) dst[q] = v[u]; }
   };
 
-  bool failed = false;
-  for (int attempt = 0; attempt < 2; ++attempt) {
-    // ---- PSkp = B' A' + Q (+ jitter): the whole tile column J (Delta = PS_{k+1} - PSkp leaves as 128-byte row runs, first attempt
-    // only); the lower tiles stay in LDS for the factorisation
+  // The two roles are two separate code paths from here to the end of the kernel (each with its own copy of the retry loop and the
+  // same sequence of barriers): in one control flow graph the tile column of the column waves stays live through the chain wave's
+  // blocks and the other way round, and the 168 registers of a three-waves-per-SIMD launch do not hold both.
+  if (chain) {
+    __builtin_amdgcn_s_setprio(3);      // the chain's instructions go in front of its SIMD-mates' (an FP64 MFMA holds the SIMD's issue for its duration)
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      const int i = gm_opaque(i0), kq = gm_opaque(kq0);
+      stage();
+      GM_STAMP(0);
+      lds_barrier();                                                                     // b1
+      GM_STAMP(1);
+      // ---- delta_k = MF_{k+1} - A MF_k  (the chain wave has nothing else to do yet)
+      if (attempt == 0)
+        for (int s = lane; s < S; s += 64) {
+          int blk = 0;
+          while (ioff[blk + 1] <= s) ++blk;
+          const int row = s - ioff[blk];
+          const double* mf = b.MF + ((size_t)pb * T + k) * S;
+          double acc = mf[S + s];
+          for (int l = 0; l < ibsz[blk]; ++l) acc = fma(-sA[(size_t)blk * 16 + 4 * row + l], mf[ioff[blk] + l], acc);
+          b.dbuf[((size_t)pb * gp.chunk + kk) * S + s] = acc;
+        }
+      GM_STAMP(2);
+      lds_barrier();                                                                     // b2
+      lds_barrier();                                                                     // b3: PSkp complete
+      GM_STAMP(1);
+      if (!gm_chol_inv_tile(Lt + gm_tix(0, 0), Li, lane)) { if (lane == 0) flag[attempt] = 1; }
+      GM_STAMP(4);
+      lds_barrier();                                                                     // b4: inv(L_00) published
+      GM_STAMP(1);
 #pragma unroll 1
-    for (int I = 0; I < NTL; ++I) {
-      if (attempt == 1 && I < J) continue;
-      v4d ps;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int br = 4 * I + t;
-        const double bp = (gp.dbg & 32) ? 0.0 : bprime(br);
-        double v = 0.0;
-        // sum_l B'[r][(bc,l)] A_bc[ci][l]: the four columns of block bc sit in the four lanes of this lane's quad
-#pragma unroll
-        for (int l = 0; l < 4; ++l) {
-          const double bl = __shfl(bp, (lane & ~3) | l, 64);
-          if (bc < M) v = fma(bl, sA[(size_t)bc * 16 + 4 * ci + l], v);
-        }
-        const bool rowok = br < M && kq < ibsz[br < M ? br : 0];
-        if (rowok && colok && br == bc) {
-          v += mdl[mdl_Q(sh) + (size_t)br * 16 + 4 * kq + ci];
-          if (attempt == 1 && kq == ci) v += 0.01 * 0.5;        // sqrt(1e-4)*diag(rand): deterministic 0.5 in place of rand
-        }
-        if (!(rowok && colok)) v = (16 * I + 4 * t + kq == 16 * J + i) ? 1.0 : 0.0;      // padding: identity
-        ps[t] = v;
-        if (attempt == 0 && !(gp.dbg & 8)) {
-          double d = 0.0;
-          if (rowok && colok) d = pf_elem(PFk1, br, bc, kq, ci) - v;
-          Dout[(16 * I + 4 * t + kq) * Sp + 16 * J + i] = d;
-        }
-      }
-      if (I >= J) gm_store_acc(Lt + gm_tix(I, J), ps, i, kq);
-    }
-    __syncthreads();
-    // ---- right-looking Cholesky on 16x16 tiles
-    for (int j = 0; j < NTL; ++j) {
-      if (J == j) {
-        if (!(gp.dbg & 1) && !gm_chol16(Lt + gm_tix(j, j), Li + (size_t)j * 256, rdv, lane)) { if (lane == 0) flag[attempt] = 1; }
-      }
-      __syncthreads();
-      // panel: L_Ij = A_Ij inv(L_jj)'  (wave I, I > j)
-      if (J > j) {
-        v4d acc = {0.0, 0.0, 0.0, 0.0};
-        acc = gm_mma_xyT(Lt + gm_tix(J, j), Li + (size_t)j * 256, i, kq, acc, false);
-        gm_store_acc(Lt + gm_tix(J, j), acc, i, kq);
-      }
-      __syncthreads();
-      // trailing update: A_IK -= L_Ij L_Kj', j < K <= I, tiles dealt round robin over the waves
-      if (!(gp.dbg & 4)) {
-        int cnt = 0;
-        for (int I = j + 1; I < NTL; ++I)
-          for (int K = j + 1; K <= I; ++K, ++cnt) {
-            if (cnt % NTL != J) continue;
-            v4d acc = gm_load_acc(Lt + gm_tix(I, K), i, kq);
-            acc = gm_mma_xyT(Lt + gm_tix(I, j), Lt + gm_tix(K, j), i, kq, acc, true);
-            gm_store_acc(Lt + gm_tix(I, K), acc, i, kq);
+      for (int J = 0; J < NTL; ++J) {
+        if (J + 1 < NTL) {
+          double* s10 = Lt + gm_tix(J + 1, J);
+          double* s11 = Lt + gm_tix(J + 1, J + 1);
+          v4d a1 = gm_load_acc(s10, i, kq), a2 = gm_load_acc(s11, i, kq);
+          if (J >= 1) {      // column J-1 (finished by the other waves in the interval before)
+            a1 = gm_mma_xyT(Lt + gm_tix(J + 1, J - 1), Lt + gm_tix(J, J - 1), i, kq, a1, true);
+            a2 = gm_mma_xyT(Lt + gm_tix(J + 1, J - 1), Lt + gm_tix(J + 1, J - 1), i, kq, a2, true);
           }
+          gm_store_acc(s10, a1, i, kq);
+          gm_wave_fence();
+          v4d l = {0.0, 0.0, 0.0, 0.0};
+          l = gm_mma_xyT(s10, Li + (size_t)J * 256, i, kq, l, false);       // L_{J+1,J} = A_{J+1,J} inv(L_JJ)'
+          gm_store_acc(s10, l, i, kq);
+          gm_wave_fence();
+          a2 = gm_mma_xyT(s10, s10, i, kq, a2, true);
+          gm_store_acc(s11, a2, i, kq);
+          gm_wave_fence();
+          GM_STAMP(5);
+          if (!gm_chol_inv_tile(s11, Li + (size_t)(J + 1) * 256, lane)) { if (lane == 0) flag[attempt] = 1; }
+          GM_STAMP(6);
+        }
+        lds_barrier();
+        GM_STAMP(8);
       }
-      __syncthreads();
+      if (flag[attempt] == 0) break;
+      lds_barrier();
     }
-    failed = (flag[attempt] != 0);
-    if (!failed) break;
-    __syncthreads();
+    GM_STAMP(9);
+    if (stamp) atomicAdd(&gp.stamps[16 + 12], 1ull);
+    return;
   }
-  if (tid == 0) {
+
+  // ================================================= column waves =================================================
+  v4d Y[NTL];
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    const int i = gm_opaque(i0), kq = gm_opaque(kq0);
+    const int ci = i & 3;
+    const int bcc = bcin ? 4 * c + (i >> 2) : 0;                  // (clamped: lanes of padding columns read block 0 and are masked)
+    stage();
+    GM_STAMP(0);
+    lds_barrier();                                                                       // b1
+    GM_STAMP(1);
+    {
+      // ---- B' = A PS_k, tile column c: element (16I + 4t + kq, 16c + i) = row kq of block br = 4I+t times column ci of PS(br, bc).
+      // Half a tile row at a time, its PS entries and rows of A in flight together.  Tiles below the diagonal tile read the stored
+      // lower tile (br, bc) -- element 4l + ci, four 8-byte reads a quarter-tile apart; tiles above it the mirror tile (bc, br) --
+      // elements 4ci + l, two 16-byte reads; the diagonal tile selects per lane.
+      const int lane_lo = (ci >> 1) * 128 + (ci & 1);            // offset of element ci inside a stored tile (pf_off)
+      const int lane_up = ci * 256;                               // offset of element 4 ci
+      const int Tbc = bcc * (bcc + 1) / 2;
+      const double* arow = sA + 4 * kq;
+#pragma unroll
+      for (int I = 0; I < NTL; ++I) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          double p[2][4];
+          double2 a01[2], a23[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int br = 4 * I + 2 * h + u, brc = br < M ? br : 0;      // (uniform)
+            const double2* ap = reinterpret_cast<const double2*>(arow + brc * 16);
+            a01[u] = ap[0]; a23[u] = ap[1];
+          }
+          if (I > c) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const int br = 4 * I + 2 * h + u, brc = br < M ? br : 0;
+              const double* q = Lt + gm_tpart(brc * (brc + 1) / 2 + bcc) + lane_lo;
+#pragma unroll
+              for (int l = 0; l < 4; ++l) p[u][l] = q[l * 256];
+            }
+          } else if (I < c) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const int br = 4 * I + 2 * h + u, brc = br < M ? br : 0;
+              const double2* q = reinterpret_cast<const double2*>(Lt + gm_tpart(Tbc + brc) + lane_up);
+              const double2 d0 = q[0], d1 = q[64];
+              p[u][0] = d0.x; p[u][1] = d0.y; p[u][2] = d1.x; p[u][3] = d1.y;
+            }
+          } else {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const int br = 4 * I + 2 * h + u, brc = br < M ? br : 0;
+              const bool lo = brc >= bcc;
+              const double* q = Lt + (lo ? gm_tpart(brc * (brc + 1) / 2 + bcc) + lane_lo : gm_tpart(Tbc + brc) + lane_up);
+              p[u][0] = q[0]; p[u][1] = q[lo ? 256 : 1]; p[u][2] = q[lo ? 512 : 128]; p[u][3] = q[lo ? 768 : 129];
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int t = 2 * h + u;
+            double v = a01[u].x * p[u][0];
+            v = fma(a01[u].y, p[u][1], v); v = fma(a23[u].x, p[u][2], v); v = fma(a23[u].y, p[u][3], v);
+            v = (((rowbits >> (4 * I + t)) & 1ull) && colok) ? v : 0.0;
+            gm_pin(v);
+            Y[I][t] = v;
+          }
+          __builtin_amdgcn_sched_barrier(0);      // half a tile row at a time: the reads of all ten rows hoisted together spill
+        }
+      }
+    }
+    GM_STAMP(2);
+    lds_barrier();                                                                       // b2: the staged PS_k is dead
+    GM_STAMP(1);
+    double dpf[ND][4];
+    {
+      // ---- PSkp = B' A' + Q (+ jitter), lower tiles (I >= c) -> LDS.  sum_l B'[r][(bc,l)] A_bc[ci][l]: the four columns of block bc
+      // sit in the four lanes of this lane's quad
+      double abc[4];
+      {
+        const double2* ap = reinterpret_cast<const double2*>(sA + bcc * 16 + 4 * ci);
+        const double2 a0 = ap[0], a1 = ap[1];
+        abc[0] = a0.x; abc[1] = a0.y; abc[2] = a1.x; abc[3] = a1.y;
+      }
+#pragma unroll
+      for (int I = 0; I < NTL; ++I) {
+        if (I < c) continue;
+        v4d ps;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const double bp = Y[I][t];
+          const double b0 = gm_quad<0x00>(bp), b1 = gm_quad<0x55>(bp), b2 = gm_quad<0xAA>(bp), b3 = gm_quad<0xFF>(bp);
+          double v = abc[0] * b0;
+          v = fma(abc[1], b1, v); v = fma(abc[2], b2, v); v = fma(abc[3], b3, v);
+          ps[t] = (((rowbits >> (4 * I + t)) & 1ull) && colok) ? v : 0.0;
+        }
+        if (I == c) {      // the diagonal tile: Q (+ jitter) on the diagonal blocks, identity in the padding
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const bool ok = ((rowbits >> (4 * I + t)) & 1ull) && colok;
+            if (ok && t == (i >> 2)) ps[t] += (attempt == 1 && kq == ci) ? qd + 0.01 * 0.5 : qd;      // sqrt(1e-4)*diag(rand): deterministic 0.5 in place of rand
+            if (!ok && t == diag_t) ps[t] = 1.0;
+          }
+        }
+        gm_store_acc(Lt + gm_tix(I, c), ps, i, kq);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // ---- PS_{k+1} for Delta: the loads go out now (indices clamped into the stored tiles: the padding is masked below) and land
+      // while the chain wave factors tile 0
+      if (attempt == 0) {
+#pragma unroll
+        for (int n = 0; n < ND; ++n) {
+          const int q = c + NTL * n;
+          int I = 0, K = 0;
+          if (q < NTOT) dtile(q, I, K);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int br = 4 * I + t, bcK = 4 * K + (i >> 2);
+            dpf[n][t] = pf_elem(PFk1, br < M ? br : M - 1, bcK < M ? bcK : M - 1, kq, i & 3);
+          }
+        }
+      }
+    }
+    GM_STAMP(3);
+    lds_barrier();                                                                       // b3: PSkp complete
+    GM_STAMP(1);
+    if (attempt == 0) {
+      // ---- Delta_k = PS_{k+1} - PSkp, tiles dealt round robin over the column waves
+      for (int n0 = 0; n0 * NTL + c < NTOT; n0 += ND) {
+#pragma unroll
+        for (int n = 0; n < ND; ++n) {
+          const int q = c + NTL * (n0 + n);
+          if (q >= NTOT) continue;
+          int I, K;
+          dtile(q, I, K);
+          const v4d pk = (I >= K) ? gm_load_acc(Lt + gm_tix(I, K), i, kq) : gm_load_accT(Lt + gm_tix(K, I), i, kq);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const bool ok = ((rowbits >> (4 * I + t)) & 1ull) && ((colbits >> K) & 1u);
+            const int br = 4 * I + t, bcK = 4 * K + (i >> 2);
+            const double pf1 = (n0 == 0) ? dpf[n][t] : pf_elem(PFk1, br < M ? br : M - 1, bcK < M ? bcK : M - 1, kq, i & 3);
+            const double d = ok ? pf1 - pk[t] : 0.0;
+            if (gp.dpacked) Dout[(size_t)(I * (I + 1) / 2 + K) * 256 + (4 * t + kq) * 16 + i] = d;
+            else Dout[(size_t)(16 * I + 4 * t + kq) * Sp + 16 * K + i] = d;
+          }
+        }
+      }
+    }
+    GM_STAMP(4);
+    lds_barrier();                                                                       // b4: inv(L_00) published, Delta has read PSkp
+    GM_STAMP(1);
+    // ---- NTL intervals, one barrier each
+#pragma unroll
+    for (int J = 0; J < NTL; ++J) {
+      // trailing update with column J-1 (+ the panel product for the tiles of column J); the chain wave owns (J+1,J), (J+1,J+1)
+      int cnt = 0;
+      for (int K = J; K < (J == 0 ? 1 : NTL); ++K)
+        for (int I = K; I < NTL; ++I) {
+          if (I == K && (K == J || K == J + 1)) continue;
+          if (K == J && I == J + 1) continue;
+          if ((cnt++) % NTL != c) continue;
+          double* slot = Lt + gm_tix(I, K);
+          v4d acc = gm_load_acc(slot, i, kq);
+          if (J >= 1) acc = gm_mma_xyT(Lt + gm_tix(I, J - 1), Lt + gm_tix(K, J - 1), i, kq, acc, true);
+          if (K == J) {
+            gm_store_acc(slot, acc, i, kq);
+            gm_wave_fence();
+            v4d z = {0.0, 0.0, 0.0, 0.0};
+            acc = gm_mma_xyT(slot, Li + (size_t)J * 256, i, kq, z, false);
+          }
+          gm_store_acc(slot, acc, i, kq);
+        }
+      GM_STAMP(5);
+      // forward solve, row J: Y_J = inv(L_JJ) (B'_J - sum_{K<J} L_JK Y_K)
+      {
+        v4d acc = Y[J];
+#pragma unroll
+        for (int K = 0; K < NTL; ++K)
+          if (K < J) acc = gm_mma_xb(Lt + gm_tix(J, K), Y[K], i, kq, acc, true);
+        v4d y = {0.0, 0.0, 0.0, 0.0};
+        Y[J] = gm_mma_xb(Li + (size_t)J * 256, acc, i, kq, y, false);
+      }
+      GM_STAMP(7);
+      lds_barrier();
+      GM_STAMP(8);
+    }
+    if (flag[attempt] == 0) break;
+    lds_barrier();
+  }
+  if (w == 0 && lane == 0) {
     if (flag[0]) atomicAdd(&b.counters[(size_t)pb * 4 + 0], 1ull);
     if (flag[0] && flag[1]) atomicAdd(&b.counters[(size_t)pb * 4 + 3], 1ull);
   }
+  GM_STAMP(9);
+  const int i = gm_opaque(i0), kq = gm_opaque(kq0);
 
-  // ---- B' again, now into the registers it stays in through both solves (PS_k comes from L2 this time)
-  v4d R[NTL];
+  // ---- backward: W_I = inv(L_II)' (Y_I - sum_{K>I} L_KI' W_K)
 #pragma unroll
-  for (int I = 0; I < NTL; ++I) {
+  for (int I = NTL - 1; I >= 0; --I) {
+    v4d acc = Y[I];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) R[I][t] = (gp.dbg & 64) ? 1.0 : bprime(4 * I + t);
+    for (int K = 0; K < NTL; ++K)
+      if (K > I) { acc = gm_mma_xTb(Lt + gm_tix(K, I), Y[K], i, kq, acc, true); if (K & 1) __builtin_amdgcn_sched_barrier(0); }
+    v4d wv = {0.0, 0.0, 0.0, 0.0};
+    Y[I] = gm_mma_xTb(Li + (size_t)I * 256, acc, i, kq, wv, false);
     __builtin_amdgcn_sched_barrier(0);
   }
-  // ---- forward: Y_I = inv(L_II) (B'_I - sum_{K<I} L_IK Y_K)   (tile column J, no synchronisation)
-  if (!(gp.dbg & 2)) {
-#pragma unroll
-    for (int I = 0; I < NTL; ++I) {
-      v4d acc = R[I];
-#pragma unroll
-      for (int K = 0; K < NTL; ++K)
-        if (K < I) { acc = gm_mma_xb(Lt + gm_tix(I, K), R[K], i, kq, acc, true); if (K & 1) __builtin_amdgcn_sched_barrier(0); }
-      v4d y = {0.0, 0.0, 0.0, 0.0};
-      R[I] = gm_mma_xb(Li + (size_t)I * 256, acc, i, kq, y, false);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // ---- backward: W_I = inv(L_II)' (Y_I - sum_{K>I} L_KI' W_K)
-#pragma unroll
-    for (int I = NTL - 1; I >= 0; --I) {
-      v4d acc = R[I];
-#pragma unroll
-      for (int K = 0; K < NTL; ++K)
-        if (K > I) { acc = gm_mma_xTb(Lt + gm_tix(K, I), R[K], i, kq, acc, true); if (K & 1) __builtin_amdgcn_sched_barrier(0); }
-      v4d w = {0.0, 0.0, 0.0, 0.0};
-      R[I] = gm_mma_xTb(Li + (size_t)I * 256, acc, i, kq, w, false);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  // ---- G = W': G[16J + i][16I + 4t + kq] = W_I[4t+kq][i] (32-byte runs); padding rows / columns cleaned
-  const int gbase = (16 * J + i) * Sp + kq;
+  GM_STAMP(10);
+  // ---- G = W': G[16c + i][16I + 4t + kq] = W_I[4t+kq][i] (32-byte runs); padding rows / columns cleaned
+  const int gbase = (16 * c + i) * Sp + kq;
 #pragma unroll
   for (int I = 0; I < NTL; ++I) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int br = 4 * I + t;
-      const bool rowok = br < M && kq < ibsz[br < M ? br : 0];
-      if (!(gp.dbg & 16)) Gout[gbase + 16 * I + 4 * t] = (rowok && colok) ? R[I][t] : 0.0;
-    }
+    for (int t = 0; t < 4; ++t) Gout[gbase + 16 * I + 4 * t] = (((rowbits >> (4 * I + t)) & 1ull) && colok) ? Y[I][t] : 0.0;
   }
+  GM_STAMP(11);
+  if (stamp) atomicAdd(&gp.stamps[12], 1ull);
+#undef GM_STAMP
 }
 
 }  // namespace nagp

@@ -1532,9 +1532,9 @@ def test_ekf_gradient_consistent_form_equals_central_differences_of_the_energy()
 
 @pytest.mark.parametrize('D,N', [(3, 2), (16, 3), (22, 4), (32, 6)])
 def test_mfma_gain_kernel_equals_the_valu_gain_kernel(D, N):
-    """rts_gain_mfma_kernel (16x16 tiles on the matrix cores, opt-in: NAGP_GAIN_MFMA=1) against the default 4x4-tile kernel on the
-    same plans: Sp = 32, 80, 112, 160 (2, 5, 7, 10 waves), two problems, chunks of 24 steps, a missing observation -- every output
-    to rounding, the jitter counters identical."""
+    """rts_gain_mfma_kernel (16x16 tiles on the matrix cores, the default when the smoother passes take dense operands) against the
+    4x4-tile VALU kernel (NAGP_NO_GAIN_MFMA=1) on the same plans: Sp = 32, 80, 112, 160 (3, 6, 8, 11 waves), two problems, chunks of
+    24 steps, a missing observation -- every output to rounding, the jitter counters identical."""
     T = 60
     probs, ys = [], []
     for q in range(2):
@@ -1545,12 +1545,12 @@ def test_mfma_gain_kernel_equals_the_valu_gain_kernel(D, N):
     mom = Mom('likModulatorNMFPower', p_cubature=3); d = np.array([0.6, 0.5])
     res = {}
     for mode in ('mfma', 'valu'):
-        if mode == 'mfma': os.environ['NAGP_GAIN_MFMA'] = '1'
+        if mode == 'valu': os.environ['NAGP_NO_GAIN_MFMA'] = '1'
         try:
             plan = Plan(L.KIND_GF_EP, probs, T, mom=mom, ep_fraction=0.5, ep_damping=d, ep_itts=2, chunk=24)
             plan.upload(ys); plan.execute(); res[mode] = plan.download(); plan.close()
         finally:
-            os.environ.pop('NAGP_GAIN_MFMA', None)
+            os.environ.pop('NAGP_NO_GAIN_MFMA', None)
     for q in range(2):
         a, v = res['mfma'][q], res['valu'][q]
         for f, tol in (('Eft', 1e-9), ('Varft', 1e-9), ('MS', 1e-9), ('lZ', 1e-9), ('ttau', 1e-7), ('tnu', 1e-7)):

@@ -11,7 +11,8 @@
 //   * the inverse X = L^-1 rides along (it is not on the chain): unscaled rows U_i = e_i - sum_{k<i} L_ik X_k, X_k = r_k U_k;
 //     at column j every lane i > j takes  U_i -= (l_ij r_j) U_j  with U_j broadcast from lane j, again one DPP broadcast and one multiply-add per
 //     entry; the rows are scaled by their own r at the end.
-// 120 + 136 broadcast + multiply-add pairs and 16 reciprocal square roots per tile: 2 690 cycles measured (tools/ubench/chol16.hip).  The panel products and both triangular solves of the gain
+// 120 + 136 broadcast + multiply-add pairs and 16 reciprocal square roots per tile: 2.26 us per tile on a lone wave by the event clock
+// (tools/ubench/chol16.hip; ~840 instructions).  The panel products and both triangular solves of the gain
 // kernel multiply by inv(L_JJ) on the matrix cores instead of substituting through L_JJ, so the factor itself is never stored.
 #pragma once
 #include "nagp_dev.hpp"
@@ -29,10 +30,17 @@ __device__ __forceinline__ double c16_nbk(double v, int k) {
     case 12: return c16_nb<12>(v); case 13: return c16_nb<13>(v); case 14: return c16_nb<14>(v); default: return c16_nb<15>(v);
   }
 }
-// d -= (lane K's a) * b  (v_mov_b64_dpp + v_fma_f64; the fused v_fmac_f64_dpp through inline asm measured SLOWER -- 4 480 against
-// 2 690 cycles per tile, tools/ubench/chol16.hip: the wait states of a DPP operand have to be inside the string for every statement)
+// d -= (lane K's a) * b  (v_mov_b64_dpp + v_fma_f64; the fused v_fmac_f64_dpp through inline asm, -DNAGP_C16_ASM, measured SLOWER -- 2.63 against
+// 2.26 us per tile, tools/ubench/chol16.hip: the wait states of a DPP operand have to be inside the string for every statement)
+#ifdef NAGP_C16_ASM
+template <int K>
+__device__ __forceinline__ void c16_fmsub(double& d, double a, double b) {
+  asm("s_nop 1\n\tv_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(a), "v"(b), "n"(K));
+}
+#else
 template <int K>
 __device__ __forceinline__ void c16_fmsub(double& d, double a, double b) { d = fma(-c16_nb<K>(a), b, d); }
+#endif
 __device__ __forceinline__ void c16_fmsubk(double& d, double a, double b, int k) {
   switch (k) {
     case 0: c16_fmsub<0>(d, a, b); break; case 1: c16_fmsub<1>(d, a, b); break; case 2: c16_fmsub<2>(d, a, b); break;

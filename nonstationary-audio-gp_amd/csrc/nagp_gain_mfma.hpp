@@ -85,6 +85,11 @@ __device__ __forceinline__ v4d gm_load_acc(const double* Tl, int i, int kq) {
   for (int t = 0; t < 4; ++t) v[t] = Tl[(4 * t + kq) * 16 + pi];
   return v;
 }
+// store the accumulator TRANSPOSED: element (4t+kq, i) of the accumulator becomes element (i, 4t+kq) of the stored tile
+__device__ __forceinline__ void gm_store_accT(double* Tl, v4d v, int i, int kq) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) Tl[i * 16 + gm_p(4 * t + kq)] = v[t];
+}
 // the transposed tile in accumulator layout: element (4t+kq, i) of Tl'
 __device__ __forceinline__ v4d gm_load_accT(const double* Tl, int i, int kq) {
   v4d v;
@@ -105,6 +110,7 @@ __device__ __forceinline__ void gm_pin(double& v) { asm volatile("" : "+v"(v)); 
 __device__ __forceinline__ int gm_opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 
 // the chain wave: tile T (LDS, lower part meaningful) -> inv(chol(T)) into Ti (LDS, full tile, zeros above the diagonal)
+// (measured as a non-inlined function: 6 900 instead of 6 400 cycles per tile -- inlined it stays)
 __device__ __forceinline__ bool gm_chol_inv_tile(const double* T, double* Ti, int lane) {
   const int row = lane & 15;
   double a[16], x[16];
@@ -185,7 +191,6 @@ __global__ void __launch_bounds__(64 * (NTL + 1)) rts_gain_mfma_kernel(Shape sh,
     const int bs = (q == 0) ? sh.bsz[4 * K] : (q == 1) ? sh.bsz[4 * K + 1] : (q == 2) ? sh.bsz[4 * K + 2] : sh.bsz[4 * K + 3];
     if (4 * K + q < M && (i0 & 3) < bs) colbits |= 1u << K;
   }
-  for (int q = tid; q < M * 16; q += NT) sA[q] = mdl[mdl_A(sh) + q];
   if (tid < MAXM) {
     int bs = 0, of = 0;
 #pragma unroll
@@ -198,24 +203,37 @@ __global__ void __launch_bounds__(64 * (NTL + 1)) rts_gain_mfma_kernel(Shape sh,
   const int bc0 = 4 * c + (i0 >> 2);                              // block of this lane's column (column waves)
   const bool bcin = !chain && bc0 < M;
   const bool colok = !chain && ((colbits >> c) & 1u);
-  const double qd = colok ? mdl[mdl_Q(sh) + (size_t)bc0 * 16 + 4 * kq0 + (i0 & 3)] : 0.0;      // entry (kq, ci) of this column's diagonal block of Q
+  double qd = 0.0;                                                // entry (kq, ci) of this column's diagonal block of Q (loaded beside the staged copy)
   const int diag_t = (((i0 - kq0) & 3) == 0 && i0 >= kq0) ? ((i0 - kq0) >> 2) : -1;             // register t with 4t + kq == i (the tile's diagonal)
   // staged copy of PS_k (the layout of PF: pf_off): every 16-byte piece of the step in flight at once
-  auto stage = [&]() {
+  // (the A blocks of the model and this lane's entry of Q ride along on the first attempt: every global load of the prologue is in
+  // flight at once, and nothing but kernel arguments is needed to issue them)
+  auto stage = [&](bool first) {
     const double2* src = reinterpret_cast<const double2*>(PFk);
     double2* dst = reinterpret_cast<double2*>(Lt);
     const int n2 = (int)(pf_step_doubles(sh) / 2);
     const int tq = gm_opaque(tid);      // (addresses formed here: hoisted out of the retry loop they are spilled, and every reload waits for the load before it)
-    static_assert(NLD <= 10, "gm_pin_all takes ten pieces");
+    static_assert(NLD <= 10, "the pin below takes ten pieces");
     double2 v[10];
 #pragma unroll
     for (int u = 0; u < 10; ++u) { const int q = tq + u * NT; v[u] = (u < NLD) ? src[q < n2 ? q : n2 - 1] : make_double2(0.0, 0.0); }      // unconditional loads
+    double2 va = make_double2(0.0, 0.0);
+    double vq = 0.0;
+    if (first) {
+      va = reinterpret_cast<const double2*>(mdl + mdl_A(sh))[tq < M * 8 ? tq : 0];
+      vq = mdl[mdl_Q(sh) + (size_t)(bcin ? bc0 : 0) * 16 + 4 * kq0 + (i0 & 3)];
+    }
     // ONE statement that needs all of them: the compiler otherwise sinks every load into the conditional store below -- load, wait, LDS
     // write, next load: ten HBM round trips in a row (38 k cycles of a 260 k-cycle step)
     asm volatile("" : "+v"(v[0].x), "+v"(v[0].y), "+v"(v[1].x), "+v"(v[1].y), "+v"(v[2].x), "+v"(v[2].y), "+v"(v[3].x), "+v"(v[3].y), "+v"(v[4].x), "+v"(v[4].y),
-                      "+v"(v[5].x), "+v"(v[5].y), "+v"(v[6].x), "+v"(v[6].y), "+v"(v[7].x), "+v"(v[7].y), "+v"(v[8].x), "+v"(v[8].y), "+v"(v[9].x), "+v"(v[9].y));
+                      "+v"(v[5].x), "+v"(v[5].y), "+v"(v[6].x), "+v"(v[6].y), "+v"(v[7].x), "+v"(v[7].y), "+v"(v[8].x), "+v"(v[8].y), "+v"(v[9].x), "+v"(v[9].y),
+                      "+v"(va.x), "+v"(va.y), "+v"(vq));
 #pragma unroll
     for (int u = 0; u < NLD; ++u) { const int q = tq + u * NT; if (q < n2) dst[q] = v[u]; }
+    if (first) {
+      if (tq < M * 8) reinterpret_cast<double2*>(sA)[tq] = va;
+      qd = colok ? vq : 0.0;
+    }
   };
 
   // The two roles are two separate code paths from here to the end of the kernel (each with its own copy of the retry loop and the
@@ -225,7 +243,7 @@ __global__ void __launch_bounds__(64 * (NTL + 1)) rts_gain_mfma_kernel(Shape sh,
     __builtin_amdgcn_s_setprio(3);      // the chain's instructions go in front of its SIMD-mates' (an FP64 MFMA holds the SIMD's issue for its duration)
     for (int attempt = 0; attempt < 2; ++attempt) {
       const int i = gm_opaque(i0), kq = gm_opaque(kq0);
-      stage();
+      stage(attempt == 0);
       GM_STAMP(0);
       lds_barrier();                                                                     // b1
       GM_STAMP(1);
@@ -288,7 +306,7 @@ __global__ void __launch_bounds__(64 * (NTL + 1)) rts_gain_mfma_kernel(Shape sh,
     const int i = gm_opaque(i0), kq = gm_opaque(kq0);
     const int ci = i & 3;
     const int bcc = bcin ? 4 * c + (i >> 2) : 0;                  // (clamped: lanes of padding columns read block 0 and are masked)
-    stage();
+    stage(attempt == 0);
     GM_STAMP(0);
     lds_barrier();                                                                       // b1
     GM_STAMP(1);
@@ -364,9 +382,13 @@ __global__ void __launch_bounds__(64 * (NTL + 1)) rts_gain_mfma_kernel(Shape sh,
         const double2 a0 = ap[0], a1 = ap[1];
         abc[0] = a0.x; abc[1] = a0.y; abc[2] = a1.x; abc[3] = a1.y;
       }
+      // tile (I, J), I > J, comes out of the registers of wave J (rows of tile row I of its column) or, transposed, of wave I (rows of
+      // tile row J of ITS column, PSkp is symmetric): dealt by the parity of I - J, five or six tiles per wave instead of ten on wave 0
+      // and one on the last
 #pragma unroll
       for (int I = 0; I < NTL; ++I) {
-        if (I < c) continue;
+        const bool mirror = I < c;                                // this wave forms tile (I, c) of the upper triangle and stores it as (c, I)
+        if (mirror ? (((c - I) & 1) != 0) : (I > c && ((I - c) & 1) == 0)) continue;
         v4d ps;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -384,7 +406,8 @@ __global__ void __launch_bounds__(64 * (NTL + 1)) rts_gain_mfma_kernel(Shape sh,
             if (!ok && t == diag_t) ps[t] = 1.0;
           }
         }
-        gm_store_acc(Lt + gm_tix(I, c), ps, i, kq);
+        if (mirror) gm_store_accT(Lt + gm_tix(c, I), ps, i, kq);
+        else gm_store_acc(Lt + gm_tix(I, c), ps, i, kq);
         __builtin_amdgcn_sched_barrier(0);
       }
       // ---- PS_{k+1} for Delta: the loads go out now (indices clamped into the stored tiles: the padding is masked below) and land
@@ -435,12 +458,16 @@ __global__ void __launch_bounds__(64 * (NTL + 1)) rts_gain_mfma_kernel(Shape sh,
 #pragma unroll
     for (int J = 0; J < NTL; ++J) {
       // trailing update with column J-1 (+ the panel product for the tiles of column J); the chain wave owns (J+1,J), (J+1,J+1)
+      // (dealt round robin over the column waves EXCEPT the one on the chain's SIMD -- wave 7, column 6, when there is one: every MFMA
+      // it issues holds that SIMD and delays the chain)
+      constexpr int NDEAL = (NTL >= 7) ? NTL - 1 : NTL;
+      const int cdeal = (NTL >= 7) ? (c == 6 ? -1 : (c > 6 ? c - 1 : c)) : c;
       int cnt = 0;
       for (int K = J; K < (J == 0 ? 1 : NTL); ++K)
         for (int I = K; I < NTL; ++I) {
           if (I == K && (K == J || K == J + 1)) continue;
           if (K == J && I == J + 1) continue;
-          if ((cnt++) % NTL != c) continue;
+          if ((cnt++) % NDEAL != cdeal) continue;
           double* slot = Lt + gm_tix(I, K);
           v4d acc = gm_load_acc(slot, i, kq);
           if (J >= 1) acc = gm_mma_xyT(Lt + gm_tix(I, J - 1), Lt + gm_tix(K, J - 1), i, kq, acc, true);

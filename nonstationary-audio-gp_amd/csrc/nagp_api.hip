@@ -17,6 +17,7 @@ NAGP_LIST_ALL(extern template __global__)
 #include <cstdlib>
 #include <chrono>
 #include <mutex>
+#include <set>
 #include <string>
 #include <functional>
 #include <thread>
@@ -27,6 +28,24 @@ NAGP_LIST_ALL(extern template __global__)
 using namespace nagp;
 
 static thread_local std::string g_last_error;
+
+// Developer switches and test hooks.  The library is meant to live inside a long-running host process (MATLAB): a stray NAGP_* variable
+// in that environment must not change what it computes, so NONE of them is read unless NAGP_DEVELOPER=1 is set as well (tests/conftest.py
+// and the scripts under tools/ set it; bench.py and the MEX gateway never do).  The switches that make results meaningless (phase-skipping
+// timing probes) and the test hooks that replace devices or fail allocations say so on stderr once when they are active.
+static const char* dev_env(const char* name) {
+  static const bool on = [] { const char* d = getenv("NAGP_DEVELOPER"); return d && d[0] == '1' && d[1] == 0; }();
+  if (!on) return nullptr;
+  const char* v = getenv(name);
+  if (v && (!strcmp(name, "NAGP_FILTER_DBG") || !strncmp(name, "NAGP_TEST_", 10))) {
+    static std::mutex mu; static std::set<std::string> said;
+    std::lock_guard<std::mutex> lk(mu);
+    if (said.insert(name).second)
+      fprintf(stderr, "[nagp] developer switch %s=%s is active (%s)\n", name, v,
+              !strcmp(name, "NAGP_FILTER_DBG") ? "phases of the filter step are skipped: results are garbage, timing only" : "test hook: devices / allocations are not the real ones");
+  }
+  return v;
+}
 
 #define HIP_TRY(expr)                                                                         \
   do {                                                                                        \
@@ -207,7 +226,7 @@ static void dfree(nagp_plan* p, double* ptr) {
 static bool build_mom_src(int B, const nagp_model* models, int D, int N, int n_pts, const std::vector<unsigned char>& code,
                           MomSrc& sc, std::vector<unsigned char>& blob) {
   sc = MomSrc{};
-  if (N < 2 || D < 2 || n_pts > 65535 || getenv("NAGP_NO_SRC")) return false;
+  if (N < 2 || D < 2 || n_pts > 65535 || dev_env("NAGP_NO_SRC")) return false;
   std::vector<int> par(D + N);
   for (int i = 0; i < D + N; ++i) par[i] = i;
   auto find = [&](int x) { while (par[x] != x) { par[x] = par[par[x]]; x = par[x]; } return x; };
@@ -435,7 +454,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     // ADF launches: <= 256 threads (512 registers per lane) whenever the tiles fit
     if (slots <= 1024 && sh.S <= 256) { p->TPT_a = slots <= 256 ? 1 : (slots <= 512 ? 2 : (slots <= 768 ? 3 : 4)); p->NT_a = 256; p->LB_a = 256; }
     else { p->TPT_a = 4; p->NT_a = std::max(roundup64((slots + 3) / 4), roundup64(sh.S)); p->LB_a = 512; }
-    p->wide_l = (!ekf && slots > 512 && slots <= 1024 && !getenv("NAGP_NO_WIDE")) ? 1 : 0;
+    p->wide_l = (!ekf && slots > 512 && slots <= 1024 && !dev_env("NAGP_NO_WIDE")) ? 1 : 0;
     p->NT_l = p->wide_l ? roundup64(slots) : p->NT_f;
     // fixed-site launches with one tile per thread: whole waves beyond the tile threads for the state lanes (gf_filter_kernel: soff)
     p->NT_fl = p->NT_f;
@@ -501,7 +520,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     mc.n_pts = o->n_pts; mc.cdim = o->cub_dim; mc.D = sh.D; mc.wn = p->d_wn;
     mc.jitter = (o->lik_kind == NAGP_LIK_POWER) ? 1e-8 : 1e-10;
     mc.DG = 1; mc.cache_tabs = 0; mc.store_a = 0; mc.stamps = nullptr;
-    if (o->lik_kind == NAGP_LIK_POWER_NMF && o->cub_dim <= MSP_MAXCD && !getenv("NAGP_NO_SPARSE")) {
+    if (o->lik_kind == NAGP_LIK_POWER_NMF && o->cub_dim <= MSP_MAXCD && !dev_env("NAGP_NO_SPARSE")) {
       // sparse-point form: needs the coordinate value 0 and <= MSP_NZ non-centre coordinates per sigma point
       int c0 = -1;
       for (size_t ci = 0; ci < xd.size(); ++ci) if (xd[ci] == 0.0) c0 = (int)ci;
@@ -533,7 +552,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
           }
       }
     }
-    if (o->lik_kind == NAGP_LIK_POWER_NMF_SQRT && o->cub_dim <= MSQ_MAXCD && sh.D <= MSQ_MAXD && !getenv("NAGP_NO_SPARSE")) {
+    if (o->lik_kind == NAGP_LIK_POWER_NMF_SQRT && o->cub_dim <= MSQ_MAXCD && sh.D <= MSQ_MAXD && !dev_env("NAGP_NO_SPARSE")) {
       // staged form of the square-root amplitudes: needs the coordinate value 0 (the marginal sums leave the centre to a difference),
       // the marginal lists of the packed form (<= 16 per marginal wave, <= 64 members each) and <= 320 sigma points
       int c0 = -1;
@@ -587,7 +606,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
   // smoother chunk: the unit of the (G, Delta) buffers and of the filter -> smoother pipeline.  About a dozen chunks per sweep
   // (the tail the pipeline cannot hide is one chunk's gain + compose), at least 2048 steps each, at most what one buffer may take.
   {
-    const int64_t n_ch = getenv("NAGP_CHUNKS") ? std::max(1, atoi(getenv("NAGP_CHUNKS"))) : 12;     // developer switch
+    const int64_t n_ch = dev_env("NAGP_CHUNKS") ? std::max(1, atoi(dev_env("NAGP_CHUNKS"))) : 12;     // developer switch
     p->chunk = (o->chunk > 0) ? o->chunk : (int)std::min<int64_t>(T, std::max<int64_t>(2048, (T + n_ch - 1) / n_ch));
   }
   if (p->chunk > T) p->chunk = (int)T;
@@ -596,16 +615,16 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
   if (o->kind != NAGP_KIND_IHGP) {
     {   // FP64 MFMA smoother for padded dimensions up to 96 (set NAGP_NO_MFMA=1 to force the VALU passes)
       const int Sp = ((4 * sh.M + 15) / 16) * 16;
-      if (Sp <= 96 && !getenv("NAGP_NO_MFMA")) p->mfma_sp = Sp;
+      if (Sp <= 96 && !dev_env("NAGP_NO_MFMA")) p->mfma_sp = Sp;
       // 96 < Sp <= 160: state and G no longer fit LDS side by side; column-owner kernels
       // (a sweep that stores the smoothed covariances runs the VALU passes instead: see run_smoother)
-      else if (Sp <= 160 && !getenv("NAGP_NO_MFMA") && !getenv("NAGP_NO_MFMA_BIG")) { p->mfma_sp = Sp; p->big_sp = 1; }
+      else if (Sp <= 160 && !dev_env("NAGP_NO_MFMA") && !dev_env("NAGP_NO_MFMA_BIG")) { p->mfma_sp = Sp; p->big_sp = 1; }
     }
     const size_t mat = p->mfma_sp ? (size_t)p->mfma_sp * p->mfma_sp : (size_t)nt * 16;     // (4M)^2 <= Sp^2: the tile-major form fits the dense slot
     // column-owner passes (96 < Sp <= 160) read the symmetric Delta through its lower 16x16 tiles only: the slots hold it packed
     // (Sp = 160: 315 KB per step instead of 410 -- eight chunks of the 8-segment cfg5 plan keep their slot where six did).  Not when a
     // sweep stores smoothed covariances (its VALU passes use the tile-major layout of the same slots) or with the opt-in MFMA gain kernel.
-    p->dpacked = (p->big_sp && !p->want_PS && !getenv("NAGP_DENSE_DELTA")) ? 1 : 0;
+    p->dpacked = (p->big_sp && !p->want_PS && !dev_env("NAGP_DENSE_DELTA")) ? 1 : 0;
     p->gstep = p->mfma_sp ? gd_step_doubles(p->mfma_sp, p->dpacked) : 2 * mat;
     const double per_step = (double)B * ((double)p->gstep + sh.S) * 8.0;                   // one step of a (G, Delta, delta) chunk buffer
     {
@@ -644,7 +663,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     // Chunk-pipelined schedule: needs >= 2 chunks and >= 2 chunk buffers.  The compose results (Phi, C, c of every span) are kept
     // per chunk; the (G, Delta, delta) buffers are kept for as many chunks as the free memory holds, the rest recompute their
     // gains after the filter (slot 0 is the scratch).
-    p->pipeline = p->need_PF && p->nc >= 2 && !getenv("NAGP_NO_PIPELINE");
+    p->pipeline = p->need_PF && p->nc >= 2 && !dev_env("NAGP_NO_PIPELINE");
     const int n_sets = p->pipeline ? p->nc : 1;
     for (int c = 0; c < n_sets; ++c) {
       double *a1 = nullptr, *a2 = nullptr, *a3 = nullptr, *a4 = nullptr, *a5 = nullptr;
@@ -674,12 +693,12 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
         const double avail = (double)free_b - 2.0 * 1073741824.0 - 0.03 * (double)total_b;     // head-room for the runtime, RCCL, other plans
         n_slots = (int)std::max(1.0, std::min((double)(p->nc - 1), std::floor((avail - slot_bytes / 8.0) / slot_bytes)));   // full chunks: nc - 1
       }
-      if (const char* e = getenv("NAGP_PIPELINE_SLOTS")) n_slots = std::max(1, std::min(p->nc - 1, atoi(e)));   // developer switch (tests: partial retention)
+      if (const char* e = dev_env("NAGP_PIPELINE_SLOTS")) n_slots = std::max(1, std::min(p->nc - 1, atoi(e)));   // developer switch (tests: partial retention)
       if (n_slots < 2) { p->pipeline = false; n_slots = 1; }
     }
     p->mat_doubles = mat;
     auto add_slot = [&](int cap_steps) -> int {
-      if (const char* e = getenv("NAGP_TEST_SLOT_ENOMEM"))          // test hook: the (n+1)-th slot allocation of a plan fails
+      if (const char* e = dev_env("NAGP_TEST_SLOT_ENOMEM"))          // test hook: the (n+1)-th slot allocation of a plan fails
         if ((int)p->slotG.size() >= atoi(e)) return NAGP_ENOMEM;
       double *g = nullptr, *d = nullptr;
       int st = dalloc(p, &g, (size_t)B * cap_steps * p->gstep, true);
@@ -721,7 +740,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     // per chunk, the chunks the filter finishes LAST take theirs from there -- recycled slot j (the chunk with n_slots + j full chunks
     // before it in time) occupies doubles [pf_step + j * chunk * gstep, pf_step + (j+1) * chunk * gstep) of every problem's PF; all of
     // it must lie below the first step of that chunk.  All-or-nothing: a chunk left without a slot would read PF again.
-    if (p->pipeline && p->dpacked && n_slots < p->nc - 1 && !getenv("NAGP_NO_RECYCLE")) {
+    if (p->pipeline && p->dpacked && n_slots < p->nc - 1 && !dev_env("NAGP_NO_RECYCLE")) {
       std::vector<int64_t> k0s;      // first step of the chunks, latest first (the cuts of sweep_begin)
       for (int64_t k1 = T - 1; k1 > 0;) { const int nk = chunk_len(p, k1, k0s.empty()); k0s.push_back(k1 - nk); k1 -= nk; }
       const int ncs = (int)k0s.size(), need = (ncs - 1) - n_slots;
@@ -763,7 +782,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
       PLAN_HIP(hipHostMalloc(reinterpret_cast<void**>(&p->h_tab), (size_t)(p->nc + 1) * sizeof(ChunkTab), hipHostMallocMapped | hipHostMallocCoherent));
       PLAN_HIP(hipEventCreateWithFlags(&p->ev_filter, hipEventDisableTiming));
       PLAN_HIP(hipEventCreateWithFlags(&p->ev_s2, hipEventDisableTiming));
-      if (p->opts.kind == NAGP_KIND_GF_EP && !getenv("NAGP_NO_XSWEEP")) {
+      if (p->opts.kind == NAGP_KIND_GF_EP && !dev_env("NAGP_NO_XSWEEP")) {
         for (int c = 0; c < p->nc + 1; ++c) { hipEvent_t e = nullptr; PLAN_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); p->ev_chunk.push_back(e); }
         PLAN_HIP(hipEventCreateWithFlags(&p->ev_red, hipEventDisableTiming));
         p->xsweep = true;
@@ -771,7 +790,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
       PLAN_HIP(hipHostMalloc(reinterpret_cast<void**>(&p->h_progress), (size_t)B * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent));
       std::memset(p->h_progress, 0, (size_t)B * sizeof(unsigned long long));
     }
-    if (getenv("NAGP_STAMPS")) fprintf(stderr, "[nagp plan] smoother: chunk %d, %d chunk(s) per sweep, %d (G,Delta) buffer(s) of %.2f GiB (+ %d recycled from PF), pipelined %d\n", p->chunk, p->nc, n_slots, per_step * p->chunk / 1073741824.0, p->n_recycled, (int)p->pipeline);
+    if (dev_env("NAGP_STAMPS")) fprintf(stderr, "[nagp plan] smoother: chunk %d, %d chunk(s) per sweep, %d (G,Delta) buffer(s) of %.2f GiB (+ %d recycled from PF), pipelined %d\n", p->chunk, p->nc, n_slots, per_step * p->chunk / 1073741824.0, p->n_recycled, (int)p->pipeline);
   } else {
     PLAN_TRY(dalloc(p, &p->d_lZs, BT));
     PLAN_TRY(dalloc(p, &p->d_vprev, (size_t)B * sh.M));
@@ -837,11 +856,11 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     if (ihgp_filter_lds_doubles(sh, t, p->tb.NG, p->hph_lds, p->kb_ih) * sizeof(double) > 156 * 1024) t.cache_tabs = 0;
     p->cache_f = t.cache_tabs; p->sta_f = t.store_a;
     p->lds_ih = ihgp_filter_lds_doubles(sh, t, p->tb.NG, p->hph_lds, p->kb_ih) * sizeof(double);
-    if (getenv("NAGP_STAMPS")) fprintf(stderr, "[nagp plan] ihgp filter: LDS %zu B, hph table in LDS %d, cubature tables in LDS %d, block-structured mom %d, mom LDS %zu B\n", p->lds_ih, p->hph_lds, p->cache_f, p->src_f, mom_lds_doubles(t) * sizeof(double));
+    if (dev_env("NAGP_STAMPS")) fprintf(stderr, "[nagp plan] ihgp filter: LDS %zu B, hph table in LDS %d, cubature tables in LDS %d, block-structured mom %d, mom LDS %zu B\n", p->lds_ih, p->hph_lds, p->cache_f, p->src_f, mom_lds_doubles(t) * sizeof(double));
     // the ADF sweep in the sparse-point form (ihgp_adf_kernel): plain NMF likelihood, <= 320 sigma points, unstructured Wnmf
     if (p->sp.enabled && !p->src_f && sh.M <= 64 && sh.D <= 4 * MSP_DT && o->n_pts <= MSP_NT + 64 && (o->n_pts + 3) / 4 <= MSP_NW * MSP_NST) {
       p->kb_sp = IH_KB; p->hph_sp = 1;
-      if (const char* e = getenv("NAGP_IH_KB")) p->kb_sp = std::max(1, std::min(IH_KB, atoi(e)));   // developer switch: steps per I/O block
+      if (const char* e = dev_env("NAGP_IH_KB")) p->kb_sp = std::max(1, std::min(IH_KB, atoi(e)));   // developer switch: steps per I/O block
       auto need = [&]() { return ihgp_adf_lds_doubles(sh, o->cub_dim, p->tb.NG, p->hph_sp, p->kb_sp) * sizeof(double) + 16; };
       if (need() > 156 * 1024) p->kb_sp = 8;
       if (need() > 156 * 1024) p->hph_sp = 0;
@@ -855,14 +874,14 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
         }
         // role-specialised waves: two serial + six worker waves, one sigma point per worker lane, <= 80 MFMA steps
         const size_t need8 = ihgp_adf8_lds_doubles(sh, o->cub_dim, p->tb.NG, p->hph_sp, p->kb_sp) * sizeof(double) + 16;
-        const char* er = getenv("NAGP_IH_ROLES");
+        const char* er = dev_env("NAGP_IH_ROLES");
         if (o->n_pts <= 64 * MSR_NWK && (o->n_pts + 3) / 4 <= 4 * MSR_NST && need8 <= 156 * 1024 && !(er && er[0] == '0')) {
           p->sp_ih8 = 1; p->lds_sp8 = need8;
           // packed form (eight points per MFMA step, g1 / g2 from marginal sums): <= 6 components, <= 16 marginals per marginal wave, each of <= 64 members
           {
             const int CDp = o->cub_dim, ndp = mc.nd;
             bool pk = CDp <= 6 && (ndp - 1) * ((CDp + 1) / 2) <= 16 && (ndp - 1) * CDp <= MSR_NMARG && (o->n_pts + 7) / 8 <= 40 && p->sp_maxmem <= 4 * MSR_NMEM;   // 3 of 8 slots <= MSR_NSTP steps
-            const char* ep = getenv("NAGP_IH_PACK");
+            const char* ep = dev_env("NAGP_IH_PACK");
             if (ep && ep[0] == '0') pk = false;
             p->sp_pack = pk ? 1 : 0;
           }
@@ -876,7 +895,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     // likModulatorPreCalcwn: the role-specialised sweep of nagp_momsq.hpp
     if (p->sq_ok && !p->src_f && sh.M <= 64) {
       p->kb_sq = IH_KB; p->hph_sq = 1;
-      if (const char* e = getenv("NAGP_IH_KB")) p->kb_sq = std::max(1, std::min(IH_KB, atoi(e)));
+      if (const char* e = dev_env("NAGP_IH_KB")) p->kb_sq = std::max(1, std::min(IH_KB, atoi(e)));
       auto needq = [&]() { return ihgp_adf8sq_lds_doubles(sh, o->cub_dim, p->tb.NG, p->hph_sq, p->kb_sq) * sizeof(double) + 16; };
       if (needq() > 156 * 1024) p->kb_sq = 8;
       if (needq() > 156 * 1024) p->hph_sq = 0;
@@ -889,8 +908,8 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
         }
       }
     }
-    if (getenv("NAGP_STAMPS")) fprintf(stderr, "[nagp plan] ihgp ADF sweep, square-root amplitudes in the staged form: %d (LDS %zu B, ring %d steps, hph table in LDS %d)\n", p->sq_ih, p->lds_sq, p->kb_sq, p->hph_sq);
-    if (getenv("NAGP_STAMPS")) fprintf(stderr, "[nagp plan] ihgp ADF sweep in the sparse-point form: %d (LDS %zu B, ring %d steps, hph table in LDS %d), role-specialised waves %d (LDS %zu B), packed MFMA steps %d\n", p->sp_ih, p->lds_sp, p->kb_sp, p->hph_sp, p->sp_ih8, p->lds_sp8, p->sp_pack);
+    if (dev_env("NAGP_STAMPS")) fprintf(stderr, "[nagp plan] ihgp ADF sweep, square-root amplitudes in the staged form: %d (LDS %zu B, ring %d steps, hph table in LDS %d)\n", p->sq_ih, p->lds_sq, p->kb_sq, p->hph_sq);
+    if (dev_env("NAGP_STAMPS")) fprintf(stderr, "[nagp plan] ihgp ADF sweep in the sparse-point form: %d (LDS %zu B, ring %d steps, hph table in LDS %d), role-specialised waves %d (LDS %zu B), packed MFMA steps %d\n", p->sp_ih, p->lds_sp, p->kb_sp, p->hph_sp, p->sp_ih8, p->lds_sp8, p->sp_pack);
 #define SL(V) PLAN_TRY(set_lds(ihgp_filter_kernel<V, false>, p->lds_ih))
 #define SLS(V) PLAN_TRY(set_lds(ihgp_filter_kernel<V, true>, p->lds_ih))
     if (p->src_f) { NAGP_MV_SWITCH9(mom_variant(mc), SLS) } else { NAGP_MV_SWITCH9(mom_variant(mc), SL) }
@@ -915,32 +934,32 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     if (filter_lds_doubles(sh, t, ekf ? 1 : 0, p->kb_f) * sizeof(double) > cap) p->kb_f = 2;      // 59 .. 63 sites: the W panel alone is 110 - 127 KB
     if (filter_lds_doubles(sh, t, ekf ? 1 : 0, p->kb_f) * sizeof(double) > cap) p->kb_f = 1;
     if (filter_lds_doubles(sh, t, ekf ? 1 : 0, p->kb_f) * sizeof(double) > cap) t.chunk_cap = 256;   // ut7 / ut9 in nine dimensions at 57 sites: 256 points per pass
-    if (const char* e = getenv("NAGP_MOM_CHUNK")) t.chunk_cap = std::max(64, atoi(e));      // developer switch
+    if (const char* e = dev_env("NAGP_MOM_CHUNK")) t.chunk_cap = std::max(64, atoi(e));      // developer switch
     p->chunk_cap_f = t.chunk_cap;
-    if (const char* e = getenv("NAGP_KB_F")) p->kb_f = std::max(1, std::min(16, atoi(e)));      // developer switches: the fall-backs of LDS-tight shapes
-    if (getenv("NAGP_NO_CACHE_TABS")) { t.cache_tabs = 0; t.store_a = 0; }
+    if (const char* e = dev_env("NAGP_KB_F")) p->kb_f = std::max(1, std::min(16, atoi(e)));      // developer switches: the fall-backs of LDS-tight shapes
+    if (dev_env("NAGP_NO_CACHE_TABS")) { t.cache_tabs = 0; t.store_a = 0; }
     p->cache_f = t.cache_tabs; p->sta_f = t.store_a;
     p->lds_filter = filter_lds_doubles(sh, t, ekf ? 1 : 0, p->kb_f) * sizeof(double);
     // pipelined plans: the filter's workgroup asks for the whole LDS of its CU, so that no workgroup of the smoother kernels running
     // beside it on the second stream is placed on the same CU (the filter is the critical path; its time is latency, not occupancy)
     if (p->pipeline && B <= 128 && p->lds_filter < 160 * 1024) p->lds_filter = 160 * 1024;     // (never BELOW what the kernel needs: set_lds refuses > 160 KiB)
-    if (getenv("NAGP_STAMPS")) fprintf(stderr, "[nagp plan] gf filter: LDS %zu B, ring %d steps, cubature tables in LDS %d, mom LDS %zu B, sparse-point ADF %d\n", p->lds_filter, p->kb_f, p->cache_f, ekf ? (size_t)0 : mom_lds_doubles(t) * sizeof(double), p->sp_gf);
+    if (dev_env("NAGP_STAMPS")) fprintf(stderr, "[nagp plan] gf filter: LDS %zu B, ring %d steps, cubature tables in LDS %d, mom LDS %zu B, sparse-point ADF %d\n", p->lds_filter, p->kb_f, p->cache_f, ekf ? (size_t)0 : mom_lds_doubles(t) * sizeof(double), p->sp_gf);
     // ADF sweep with role-specialised waves (nagp_gfadf8.hpp): 512 threads, <= 2 lower tiles per thread, the role layout's limits
     // (one sigma point per worker lane, <= 80 MFMA steps; packed form as in the IHGP sweep)
     if (p->sp_gf && sh.M * (sh.M + 1) / 2 <= 2 * MSR_NT && sh.S <= MSR_NT && o->n_pts <= 64 * MSR_NWK && (o->n_pts + 3) / 4 <= 4 * MSR_NST &&
-        !getenv("NAGP_NO_GF_ROLES")) {
+        !dev_env("NAGP_NO_GF_ROLES")) {
       // tiles per thread / who owns them: 1 or 2 on the six worker waves (<= 384 / 768 lower tiles), else 2 on all eight waves
       const int nlow8 = sh.M * (sh.M + 1) / 2, ntw = MSR_NT - 64 * MSR_W0;
       p->a8_tpt = (nlow8 <= ntw) ? 1 : 2; p->a8_st = (nlow8 <= 2 * ntw) ? 0 : 1;
-      if (getenv("NAGP_A8_ST")) { p->a8_tpt = 2; p->a8_st = 1; }       // developer switch: tiles on all eight waves
+      if (dev_env("NAGP_A8_ST")) { p->a8_tpt = 2; p->a8_st = 1; }       // developer switch: tiles on all eight waves
       p->kb_a8 = 16;
       while (p->kb_a8 > 2 && gf_adf8_lds_doubles(sh, o->cub_dim, p->kb_a8) * sizeof(double) > cap) p->kb_a8 /= 2;
-      if (const char* e = getenv("NAGP_KB_A8")) p->kb_a8 = std::max(2, std::min(16, atoi(e) & ~1));
+      if (const char* e = dev_env("NAGP_KB_A8")) p->kb_a8 = std::max(2, std::min(16, atoi(e) & ~1));
       const size_t need = gf_adf8_lds_doubles(sh, o->cub_dim, p->kb_a8) * sizeof(double);
       if (need <= cap) {
         const int CDp = o->cub_dim, ndp = mc.nd;
         bool pk = CDp <= 6 && (ndp - 1) * ((CDp + 1) / 2) <= 16 && (ndp - 1) * CDp <= MSR_NMARG && (o->n_pts + 7) / 8 <= 40 && p->sp_maxmem <= 4 * MSR_NMEM;
-        const char* ep = getenv("NAGP_IH_PACK");
+        const char* ep = dev_env("NAGP_IH_PACK");
         if (ep && ep[0] == '0') pk = false;
         p->a8_gf = 1; p->a8_pack = pk ? 1 : 0; p->lds_a8 = need;
         if (p->pipeline && B <= 128) p->lds_a8 = 160 * 1024;      // (the whole LDS of the CU, as for the other filter launches below)
@@ -954,7 +973,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
 #undef SA8
       }
     }
-    if (getenv("NAGP_STAMPS")) fprintf(stderr, "[nagp plan] gf ADF sweep with role-specialised waves: %d (tiles per thread %d, ring %d steps, LDS %zu B, packed MFMA steps %d)\n", p->a8_gf, p->a8_tpt, p->kb_a8, p->lds_a8, p->a8_pack);
+    if (dev_env("NAGP_STAMPS")) fprintf(stderr, "[nagp plan] gf ADF sweep with role-specialised waves: %d (tiles per thread %d, ring %d steps, LDS %zu B, packed MFMA steps %d)\n", p->a8_gf, p->a8_tpt, p->kb_a8, p->lds_a8, p->a8_pack);
     p->lds_gain = ((p->TPT == 1) ? gain_lds_doubles_staged(sh) : gain_lds_doubles(sh)) * sizeof(double);     // (rts_gain_kernel: STAGE)
     p->lds_scan = span_lds_doubles(sh, p->LP1, p->LP2) * sizeof(double);
     if (ekf) {
@@ -1003,7 +1022,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
 #undef SL4
 #undef SL5
     }
-    if (nt > 1024 && nt <= 1536 && sh.M * (sh.M + 1) / 2 <= 768 && sh.S <= 768 && !getenv("NAGP_NO_GAIN768")) {
+    if (nt > 1024 && nt <= 1536 && sh.M * (sh.M + 1) / 2 <= 768 && sh.S <= 768 && !dev_env("NAGP_NO_GAIN768")) {
       p->gain768 = 1;
       p->lds_gain = gain_lds_doubles_staged(sh) * sizeof(double);
       PLAN_TRY(set_lds(rts_gain_kernel<2, 768>, p->lds_gain));
@@ -1016,7 +1035,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
       default: PLAN_TRY(set_lds(rts_gain_kernel<8>, p->lds_gain)); PLAN_TRY(set_lds(rts_compose_kernel<8>, p->lds_scan)); PLAN_TRY(set_lds(rts_boundary_kernel<8>, p->lds_scan)); PLAN_TRY(set_lds(rts_apply_kernel<8>, p->lds_scan)); break;
     }
   }
-  if (!ekf && o->kind == NAGP_KIND_GF_EP && o->mode == NAGP_MODE_PREDICT && !(o->flags & NAGP_FLAG_MIXTURE_RULE) && 4 * sh.M <= 160 && getenv("NAGP_LIN_MFMA")) {
+  if (!ekf && o->kind == NAGP_KIND_GF_EP && o->mode == NAGP_MODE_PREDICT && !(o->flags & NAGP_FLAG_MIXTURE_RULE) && 4 * sh.M <= 160 && dev_env("NAGP_LIN_MFMA")) {
     // fixed-site steps (sweeps >= 2) on the matrix cores: the plain predict-mode rule only.  Opt-in: measured on MI355X the step is
     // 13.7 us against 10.4 us of the 4x4-tile VALU kernel at S = 146 (6.2 against 3.85 at S = 73) -- DESIGN section 8
     const int ntl = (4 * sh.M + 15) / 16;
@@ -1030,7 +1049,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
   }
   // rts_gain_mfma_kernel (16x16 tiles on the matrix cores, the dependence chain of the blocked Cholesky on a wave of its own) serves every
   // plan whose smoother passes take dense (G, Delta); NAGP_NO_GAIN_MFMA=1 (developer switch) keeps the 4x4-tile VALU kernel
-  if (p->mfma_sp && !getenv("NAGP_NO_GAIN_MFMA")) {
+  if (p->mfma_sp && !dev_env("NAGP_NO_GAIN_MFMA")) {
     p->gain_mfma = 1;
     const size_t lg = gainm_lds_doubles(p->mfma_sp / 16, sh) * sizeof(double);
 #define SETG(N) PLAN_TRY(set_lds(rts_gain_mfma_kernel<N>, lg))
@@ -1064,7 +1083,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
 #undef SL
     // site refresh in the staged sparse-point form (the conditions of the ADF launches: likModulatorNMFPower on a fully symmetric rule)
     if (p->sp.enabled && !p->src_ep && sh.M <= 64 && sh.D <= 4 * MSP_DT && o->cub_dim <= MSP_MAXCD && o->n_pts <= MSP_NT + 64 &&
-        (o->n_pts + 3) / 4 <= MSP_NW * MSP_NST && !getenv("NAGP_NO_SPARSE_EP")) {
+        (o->n_pts + 3) / 4 <= MSP_NW * MSP_NST && !dev_env("NAGP_NO_SPARSE_EP")) {
       p->sp_ep = 1;
       p->lds_ep_sp = ep_sp_lds_doubles(sh, o->cub_dim) * sizeof(double);
 #define SLS(V) PLAN_TRY(set_lds(ep_site_sp_kernel<V>, p->lds_ep_sp))
@@ -1072,7 +1091,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
 #undef SLS
     }
     // ... and with likModulatorPreCalcwn in the staged form of nagp_momsq.hpp
-    if (p->sq_ok && !p->src_ep && sh.M <= 64 && !getenv("NAGP_NO_SPARSE_EP")) {
+    if (p->sq_ok && !p->src_ep && sh.M <= 64 && !dev_env("NAGP_NO_SPARSE_EP")) {
       p->sq_ep = 1;
       p->lds_ep_sq = ep_sq_lds_doubles(sh, o->cub_dim) * sizeof(double);
 #define SLQ(V) PLAN_TRY(set_lds(ep_site_sq_kernel<V>, p->lds_ep_sq))
@@ -1152,12 +1171,12 @@ static int launch_filter(nagp_plan* p, const FilterPar& fp_in) {
   FilterPar fp = fp_in;
   fp.kb = p->kb_f;
   if (p->pipeline && fp.store_PF) { fp.progress = p->h_progress; fp.progress_every = 256; }
-  if (const char* e = getenv("NAGP_FILTER_DBG")) fp.dbg = atoi(e);   // developer switch: see FilterPar::dbg
+  if (const char* e = dev_env("NAGP_FILTER_DBG")) fp.dbg = atoi(e);   // developer switch: see FilterPar::dbg
   const bool ekf = p->opts.kind == NAGP_KIND_GIEKF;
   MomCfg mc = p->mc; mc.DG = p->DG_f; mc.cache_tabs = p->cache_f; mc.store_a = p->sta_f; mc.chunk_cap = p->chunk_cap_f;
   mc.sp = p->sp_gf ? p->sp : MomSp{};
   if (p->sq_gf) { mc.sq_form = 1; mc.sp.c0 = p->sq_c0; mc.store_a = 0; }
-  if (getenv("NAGP_STAMPS")) mc.stamps = reinterpret_cast<unsigned long long*>(p->d_stamps);   // developer diagnostics
+  if (dev_env("NAGP_STAMPS")) mc.stamps = reinterpret_cast<unsigned long long*>(p->d_stamps);   // developer diagnostics
   const bool adf = ekf || fp.mom_all || fp.k_end == p->sh.T;   // launches that may call mom (or the EKF filter)
   int nt_ekf = p->NT_f;
   if (ekf && p->NT_f + 64 <= 512 && p->sh.N <= 64) { nt_ekf = p->NT_f + 64; fp.spl_wave = 1; }   // one extra wave for the link
@@ -1335,7 +1354,7 @@ static void sweep_begin(nagp_plan* p, SweepCtx& sc, bool write_PSs) {
 static void gain_map(const Shape& sh, GainPar& gp) {
   const int M = sh.M, nB = (sh.ntiles + 63) / 64, nlow = M * (M + 1) / 2, nL = (nlow + 63) / 64;
   gp.use_map = 0;
-  if (nB > 24 || nL > 12 || !getenv("NAGP_GAIN_MAP")) return;      // opt-in: measured without effect (profiles/r04_gain_phases.txt)
+  if (nB > 24 || nL > 12 || !dev_env("NAGP_GAIN_MAP")) return;      // opt-in: measured without effect (profiles/r04_gain_phases.txt)
   for (int w = 0; w < 12; ++w) { gp.gmapB[0][w] = gp.gmapB[1][w] = gp.gmapL[w] = -1; }
   double load[12];
   auto colB = [&](int g) { return ((double)g * 64 + 32) / M; };                 // column of the middle tile of a B group
@@ -1366,8 +1385,8 @@ static int launch_gain_chunk(nagp_plan* p, const SweepCtx& sc, int c, int slot, 
   const Shape& sh = p->sh; const ChunkGeom& g = sc.ch[c];
   GainPar gp{};
   gp.k0 = g.k0; gp.nk = g.nk; gp.chunk = p->slot_cap[slot]; gp.dense_sp = (sc.mode != SM_VALU) ? p->mfma_sp : 0;
-  gp.dbg = getenv("NAGP_GAINM_DBG") ? atoi(getenv("NAGP_GAINM_DBG")) : 0;
-  if (getenv("NAGP_STAMPS") && p->d_gstamps) gp.stamps = reinterpret_cast<unsigned long long*>(p->d_gstamps);
+  gp.dbg = dev_env("NAGP_GAINM_DBG") ? atoi(dev_env("NAGP_GAINM_DBG")) : 0;
+  if (dev_env("NAGP_STAMPS") && p->d_gstamps) gp.stamps = reinterpret_cast<unsigned long long*>(p->d_gstamps);
   gp.use_map = 0;
   if (p->gain768) gain_map(sh, gp);
   gp.dpacked = (sc.mode == SM_BIG) ? p->dpacked : 0;
@@ -1763,7 +1782,7 @@ static int exec_gf(nagp_plan* p) {
             fp.k_begin = xs_ch[c].k0; fp.k_end = xs_ch[c].k0 + xs_ch[c].nk;
             RUN(launch_filter(p, fp));
           }
-          HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_red, 0));      // (the lZ sum reads lZ[T-1], which the ADF step rewrites)
+          HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_red, 0));      // (the lZ sum reads lZ[T-1], which the ADF step rewrites; the fixed-site launches in front of it, k_end < T, do not write lZ at all)
           xs_pending = false;
         } else {
           fp.k_end = sh.T - 1;
@@ -1896,7 +1915,7 @@ static int exec_ihgp(nagp_plan* p) {
   }
   MomCfg mcf = p->mc; mcf.DG = p->DG_f; mcf.cache_tabs = p->cache_f; mcf.store_a = p->sta_f;
   if (p->src_f) mcf.src = p->src_all;
-  if (getenv("NAGP_STAMPS")) mcf.stamps = reinterpret_cast<unsigned long long*>(p->d_stamps);   // developer diagnostics
+  if (dev_env("NAGP_STAMPS")) mcf.stamps = reinterpret_cast<unsigned long long*>(p->d_stamps);   // developer diagnostics
   auto affine = [&](int mode, int64_t kend, int itt) -> int {
     if (kend <= 0) return NAGP_OK;
     AffPar ap{};
@@ -1922,7 +1941,7 @@ static int exec_ihgp(nagp_plan* p) {
     if (itt > 1) RUN(affine(0, sh.T - 1, itt));
     IhgpPar ip{itt, p->damping[itt - 1], itt == 1 ? 1 : 0, (itt == 1) ? (int64_t)0 : (int64_t)(sh.T - 1)};
     ip.hph_lds = p->hph_lds; ip.kb = p->kb_ih;
-    if (const char* e = getenv("NAGP_STAMP_WORKER")) ip.dbg_wave = atoi(e);
+    if (const char* e = dev_env("NAGP_STAMP_WORKER")) ip.dbg_wave = atoi(e);
     ip.w_old = 1.0 - ip.ep_damp; ip.w_new = mix ? ip.ep_damp / o.ep_fraction : ip.ep_damp; ip.mom_alpha = mix ? o.ep_fraction : 1.0;
     {
       Timed t(p, itt == 1 ? NAGP_K_FILTER : NAGP_K_FILTER_LIN);
@@ -2014,7 +2033,7 @@ extern "C" int nagp_plan_execute(nagp_plan* p) {
   }
   HIP_TRY(hipEventRecord(p->ev_t1, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
-  if (getenv("NAGP_STAMPS") && p->d_gstamps && p->opts.kind != NAGP_KIND_IHGP) {
+  if (dev_env("NAGP_STAMPS") && p->d_gstamps && p->opts.kind != NAGP_KIND_IHGP) {
     unsigned long long g[32];
     if (hipMemcpy(g, p->d_gstamps, sizeof g, hipMemcpyDeviceToHost) == hipSuccess && p->gain_mfma && g[12]) {
       static const char* nm[12] = {"staging", "prologue barriers", "B' | delta_k", "PSkp", "Delta | tile 0", "trailing | 4 products", "factor+invert", "forward row", "interval barrier", "retry check", "backward", "G store"};
@@ -2028,7 +2047,7 @@ extern "C" int nagp_plan_execute(nagp_plan* p) {
       fprintf(stderr, "[nagp stamps] rts_gain_kernel, cycles per workgroup (thread 0 of %llu sampled): prologue %llu | diagonal tiles %llu | column solves %llu | trailing updates %llu | backward solve %llu | G store %llu\n",
               g[6], g[0] / g[6], g[1] / g[6], g[2] / g[6], g[3] / g[6], g[4] / g[6], g[5] / g[6]);
   }
-  if (getenv("NAGP_STAMPS") && p->d_stamps) {
+  if (dev_env("NAGP_STAMPS") && p->d_stamps) {
     unsigned long long st[24];
     if (hipMemcpy(st, p->d_stamps, sizeof st, hipMemcpyDeviceToHost) == hipSuccess) {
       if (p->opts.kind == NAGP_KIND_IHGP)
@@ -2304,7 +2323,7 @@ extern "C" int nagp_fastfb_run(int32_t S, const double* A, const double* AKHA, c
   // spans of the parallel-in-time form (needs two more S x S work matrices in LDS: S <= 64); short series run as one span
   const size_t lds_c = fb_compose_lds_doubles(S) * sizeof(double);
   int ns = 1;
-  if (lds_c <= 160 * 1024 && T >= 2048 && !getenv("NAGP_FB_SEQUENTIAL")) ns = (int)std::min<int64_t>(512, T / 128);
+  if (lds_c <= 160 * 1024 && T >= 2048 && !dev_env("NAGP_FB_SEQUENTIAL")) ns = (int)std::min<int64_t>(512, T / 128);
   const int64_t L = (T + ns - 1) / ns;
   ns = (int)((T + L - 1) / L);
   const size_t SS = (size_t)S * S, SP = (size_t)S + 4;
@@ -2453,8 +2472,8 @@ extern "C" int nagp_batch_run(int32_t n_problems, const nagp_model* models, cons
   // propagation run for n devices; device d's plan lives on physical device d mod (real devices) (every worker stops at its first device
   // call on a machine without one) and the nlZ sums are added on the host in device order instead of by RCCL (one card cannot hold two
   // ranks of a communicator).  NAGP_TEST_FAIL_DEVICE=d -- worker d reports NAGP_EHIP before it creates its plan.
-  const int fake = getenv("NAGP_TEST_FAKE_DEVICES") ? std::max(0, atoi(getenv("NAGP_TEST_FAKE_DEVICES"))) : 0;
-  const int fail_dev = getenv("NAGP_TEST_FAIL_DEVICE") ? atoi(getenv("NAGP_TEST_FAIL_DEVICE")) : -1;
+  const int fake = dev_env("NAGP_TEST_FAKE_DEVICES") ? std::max(0, atoi(dev_env("NAGP_TEST_FAKE_DEVICES"))) : 0;
+  const int fail_dev = dev_env("NAGP_TEST_FAIL_DEVICE") ? atoi(dev_env("NAGP_TEST_FAIL_DEVICE")) : -1;
   ndev = fake ? fake : ndev_real;
   if (ndev < 1) FAIL(NAGP_ENODEVICE, "no HIP device visible");
   if (n_gpus > ndev) FAIL(NAGP_EINVAL, "n_gpus = %d but %d device(s) visible", n_gpus, ndev);
@@ -2510,7 +2529,7 @@ extern "C" int nagp_batch_run(int32_t n_problems, const nagp_model* models, cons
   std::vector<double> total(I, 0.0);
   if (fake && G > 1) {
     for (int d = 0; d < G; ++d) for (int i = 0; i < I; ++i) total[i] += part[d][i];
-  } else if (G > 1 || getenv("NAGP_FORCE_RCCL")) {
+  } else if (G > 1 || dev_env("NAGP_FORCE_RCCL")) {
     const int st = allreduce_nlz(G, I, part, total);
     if (st != NAGP_OK) return st;
   } else {

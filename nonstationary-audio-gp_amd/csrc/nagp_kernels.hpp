@@ -750,9 +750,11 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
     // ---- flush the ring
     if constexpr (MEAS == 0 && MV >= 0) {
       for (int i = tid; i < nb; i += NT) g_lZ[k0 + i] = (rZ[i] < 0.0) ? rlZ[i] : log(rZ[i]);
-    } else {
-      for (int i = tid; i < nb; i += NT) g_lZ[k0 + i] = rlZ[i];   // no mom in this instantiation
+    } else if constexpr (MEAS == 1) {
+      for (int i = tid; i < nb; i += NT) g_lZ[k0 + i] = rlZ[i];   // (the EKF energy of the nlml pass travels through rlZ)
     }
+    // (MEAS == 0, MV < 0: the fixed-site launches never call mom and leave lZ alone -- in the cross-sweep schedule they run on the main
+    // stream while the reduction of the previous sweep's lZ is still reading it on the side stream; nagp_api.hip, ev_red)
     for (int i = tid; i < nb * M; i += NT) {
       if (MEAS == 0) {
         g_tt[(size_t)k0 * M + i] = rtt[i]; g_tn[(size_t)k0 * M + i] = rtn[i];

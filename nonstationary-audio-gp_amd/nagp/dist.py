@@ -101,6 +101,29 @@ def world_size():
     return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
 
 
+def backend_id():
+    """'nccl' (RCCL on ROCm), 'gloo', ... as torch.distributed reports it; 'none' without a process group."""
+    import torch.distributed as dist
+    return str(dist.get_backend()) if (dist.is_available() and dist.is_initialized()) else 'none'
+
+
+def gather_device_ids(local_rank):
+    """['rank r: <PCI bus id> <device name>'] of every rank's GPU (all-gathered): N ranks on N physical devices show N different bus ids."""
+    import torch
+    import torch.distributed as dist
+    me = 'no GPU'
+    if torch.cuda.is_available():
+        pr = torch.cuda.get_device_properties(local_rank)
+        bus = getattr(pr, 'pci_bus_id', None)
+        pci = ('%04x:%02x:%02x' % (getattr(pr, 'pci_domain_id', 0), bus, getattr(pr, 'pci_device_id', 0))) if bus is not None else str(getattr(pr, 'uuid', 'unknown'))
+        me = '%s %s' % (pci, pr.name)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        out = [None] * dist.get_world_size()
+        dist.all_gather_object(out, me)
+        return ['rank %d: %s' % (r, v) for r, v in enumerate(out)]
+    return ['rank 0: %s' % me]
+
+
 def backend_name():
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():

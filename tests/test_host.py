@@ -202,6 +202,35 @@ def test_batch_run_host_logic_for_several_devices_without_the_hardware(G, monkey
     monkeypatch.delenv('NAGP_TEST_FAIL_DEVICE')
 
 
+def test_developer_switches_and_test_hooks_are_ignored_without_nagp_developer():
+    """A stray NAGP_TEST_FAKE_DEVICES in the environment of a host process must not map 'devices' onto nothing: without NAGP_DEVELOPER=1
+    the library reads none of its switches (here: on a machine without a GPU the fake devices do not exist and the call is refused with
+    'no HIP device visible'; with NAGP_DEVELOPER=1 the same call gets as far as the workers' first device call)."""
+    if nagp.lib().nagp_device_count() > 0:
+        pytest.skip('a GPU is visible')
+    code = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], 'nonstationary-audio-gp_amd'))
+import numpy as np, nagp
+from nagp import harness, Mom, ss as pss, _lib as L
+pr = harness.nmf_problem(3, 2, 12, 40)
+probs = [(pss.ss_blocks_nmf(pr['param1'], pr['param2'], 'matern32', 'matern52'), pr['W'], np.log(pr['w_lik']))] * 4
+try:
+    nagp.batch_run(L.KIND_GF_EP, probs, [pr['y']] * 4, 12, n_gpus=2, mom=Mom('likModulatorNMFPower', p_cubature=5), ep_fraction=0.5, ep_damping=0.5 * np.ones(2), ep_itts=2)
+except nagp.NagpError as e:
+    print('ERR', e)
+"""
+    outs = {}
+    for dev in ('0', '1'):
+        env = dict(os.environ, NAGP_TEST_FAKE_DEVICES='4'); env.pop('NAGP_DEVELOPER', None)
+        if dev == '1':
+            env['NAGP_DEVELOPER'] = '1'
+        r = subprocess.run([sys.executable, '-c', code, ROOT], env=env, capture_output=True, text=True, timeout=300)
+        outs[dev] = r.stdout + r.stderr
+    assert 'no HIP device visible' in outs['0'] and 'device 0: ' not in outs['0'] and 'developer switch' not in outs['0'], outs['0']
+    assert 'device 0: ' in outs['1'] and 'developer switch NAGP_TEST_FAKE_DEVICES=4 is active' in outs['1'], outs['1']
+
+
 def test_measmodel_handle_raises_the_documented_error():
     H = np.zeros((5, 7)); H[np.arange(5), [0, 1, 2, 3, 5]] = 1.0
     mm = nagp.MeasModel(H, np.ones((3, 2)), 3, 2)

@@ -1,4 +1,5 @@
 #!/bin/bash
+export NAGP_DEVELOPER=1      # developer tool: libnagp.so reads its switches only with this set
 # same-box A/B of several builds of libnagp.so: tools/ab_libs.sh "bench args" rounds lib1.so lib2.so ...
 # The candidates are selected through NAGP_LIB (nagp/_lib.py); the in-tree library is never touched.
 cd "$(dirname "$0")/.." || exit 1

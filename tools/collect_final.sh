@@ -1,4 +1,5 @@
 #!/bin/bash
+export NAGP_DEVELOPER=1      # developer tool: libnagp.so reads its switches only with this set
 # tools/collect_final.sh -- after `gpurun -- bash tools/final_measurements.sh`: copy the merged summaries from gpurun_out/ into profiles/
 cd "$(dirname "$0")/.." || exit 1
 cp gpurun_out/pmc_traffic.json profiles/pmc_traffic.json

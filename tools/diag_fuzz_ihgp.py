@@ -1,6 +1,7 @@
 """Re-run ONE draw of tools/gpu_fuzz.py (main family) through ihgp_ep_modulator_nmf with the kernel-selection switches,
 against the oracle and the oracle's own sensitivity (developer tool):   python tools/diag_fuzz_ihgp.py [seed] [index]"""
 import os, sys
+os.environ.setdefault('NAGP_DEVELOPER', '1')      # developer tool: libnagp.so reads its switches only with this set
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'nonstationary-audio-gp_amd')); sys.path.insert(0, os.path.join(ROOT, 'tools'))
 import numpy as np

@@ -1,4 +1,5 @@
 #!/bin/bash
+export NAGP_DEVELOPER=1      # developer tool: libnagp.so reads its switches only with this set
 # tools/final_measurements.sh -- everything DESIGN.md section 5 cites, in one GPU call (run from the repository root on the GPU box):
 # PMC traffic + kernel statistics (tools/pmc_run.sh), rocprofv3 kernel traces -> pipeline timelines, then the default bench line.
 # Outputs under gpurun_out/ (copy the summaries into profiles/).

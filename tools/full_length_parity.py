@@ -5,7 +5,8 @@ chunk-pipelined schedule, the parallel-in-time scans -- against the COMPILED res
 
     python tools/full_length_parity.py [--cases cfg3,cfg2,cfg4,cfg5seg] [--out profiles/r04_full_length_parity.txt]
 
-cases (bench.py WORKLOADS, seed 1000 = the segment rank 0 times):
+cases (bench.py WORKLOADS, seed 1000 = the segment rank 0 times; cfg2audio / cfg4audio = bench.py's cfg2 / cfg4 themselves: the decoded audio
+files BASELINE names, cfg2 with the drivers' damping 0.1):
   cfg3     ihgp_ep_modulator_nmf, T = 200 000, 32 ch / 6 comps, p = 7, 3 sweeps          (north_star's target sentence)
   cfg2     gf_ep_modulator_nmf, T = 84 010 (the length of audio/speech_74.wav; prior sample), 16 ch / 3 comps, p = 9, 3 sweeps
   cfg4     gf_giekf_modulator_nmf, T = 88 200 (the length of audio/stim312_wind.wav; prior sample), 24 ch / 3 comps, g_iter = 3, l_iter = 1
@@ -19,6 +20,7 @@ Reference loops: gf_ep_modulator_nmf.m:126-283, ihgp_ep_modulator_nmf.m:233-442,
 """
 import argparse
 import os
+os.environ.setdefault('NAGP_DEVELOPER', '1')      # developer tool: libnagp.so reads its switches only with this set
 import sys
 import threading
 import time
@@ -34,11 +36,13 @@ CASES = {
     'cfg2': dict(fam='gf', D=16, N=3, T=84010, p=9, recipe='demo_nmf', balance=False),
     'cfg4': dict(fam='giekf', D=24, N=3, T=88200, p=9, recipe='demo_nmf', balance=True),
     'cfg5seg': dict(fam='gf', D=32, N=6, T=20000, p=7, recipe='constraints', balance=True),
-    # INFORMATIVE only (script mode, --audio): bench.py's cfg2 / cfg4 inputs, the decoded audio files BASELINE names, with the bench's untrained
-    # hyper-parameters -- the reference algorithm itself is ill-conditioned there (the oracle moves by tens of per cent under a 1e-13 relative
-    # change of y: printed next to the GPU - CPU difference), so nothing is asserted on them
-    'cfg2audio': dict(fam='gf', D=16, N=3, T=84010, p=9, recipe='demo_nmf', balance=False, audio='speech_74', informative=True),
-    'cfg4audio': dict(fam='giekf', D=24, N=3, T=88200, p=9, recipe='demo_nmf', balance=True, audio='stim312_wind', informative=True),
+    # bench.py's cfg2 / cfg4 inputs: the decoded audio files BASELINE names (tests/golden/audio_*.npz).  cfg2 runs with the damping of the
+    # reference's speech drivers (experiments/noise_reduction_speech.m:29: ep_damping = 0.1): with 0.5 the reference algorithm itself is
+    # chaotic on this file (the oracle's Eft moves by 50 % under a 1e-13 relative change of y), with 0.1 it moves by 1e-13 -- so THIS is
+    # the input bench.py times and the tests assert on.  The chaotic recipe stays as an informative case (script mode, --audio).
+    'cfg2audio': dict(fam='gf', D=16, N=3, T=84010, p=9, recipe='demo_nmf', balance=False, audio='speech_74', damping=0.1),
+    'cfg4audio': dict(fam='giekf', D=24, N=3, T=88200, p=9, recipe='demo_nmf', balance=True, audio='stim312_wind'),
+    'cfg2audio_d05': dict(fam='gf', D=16, N=3, T=84010, p=9, recipe='demo_nmf', balance=False, audio='speech_74', informative=True),
     # bench.py's cfg3_sqrt: the same model with experiments/likModulatorPreCalcwn.m (sqrt amplitudes, softplus(g - 1), ut7 passed in precomputed)
     'cfg3sqrt': dict(fam='ihgp', D=32, N=6, T=200000, p=7, recipe='constraints', balance=True, lik='sqrt', link_shift=1.0, damping=0.1),
 }
@@ -199,8 +203,8 @@ def bit_equal(a, b, fields=('Eft', 'Varft', 'ttau', 'tnu', 'lZ', 'nlZ', 'maxDiff
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--cases', default='cfg3,cfg2,cfg4,cfg5seg,cfg3sqrt')
-    ap.add_argument('--out', default=os.path.join(ROOT, 'profiles', 'r04_full_length_parity.txt'))
+    ap.add_argument('--cases', default='cfg3,cfg2,cfg4,cfg5seg,cfg3sqrt,cfg2audio,cfg4audio')
+    ap.add_argument('--out', default=os.path.join(ROOT, 'profiles', 'r05_full_length_parity.txt'))
     ap.add_argument('--audio', action='store_true', help='also the informative audio-input section (four more CPU legs)')
     a = ap.parse_args()
     names = [n for n in a.cases.split(',') if n]
@@ -211,7 +215,7 @@ def main():
     legs = CpuLegs(names, probs).start()
     la = lb = None
     if a.audio:      # the informative audio legs run beside the others from the start (eight more minutes of CPU otherwise)
-        an = ['cfg2audio', 'cfg4audio']
+        an = ['cfg2audio_d05', 'cfg2audio', 'cfg4audio']
         pa = {n: problem(n) for n in an}
         pb = {}
         for n in an:
@@ -246,8 +250,9 @@ def main():
     if a.audio:
         # informative: the audio files BASELINE names with the bench's untrained hyper-parameters.  GPU - CPU next to the ORACLE's own movement
         # under y -> y (1 + 1e-13) (tools/fuzz_conditioning.py's criterion): where the reference algorithm itself is chaotic nothing can be asserted.
-        lines += ['# INFORMATIVE (nothing asserted): bench.py inputs cfg2 / cfg4 = the decoded audio files BASELINE names, untrained hyper-parameters of the bench.',
+        lines += ['# CONDITIONING of the reference algorithm on the audio inputs (cfg2audio_d05 = the round-4 bench recipe, damping 0.5: nothing can be asserted on it).',
                   '# "oracle moves" = the sequential CPU algorithm on y against itself on y (1 + 1e-13): the conditioning of the reference algorithm on this input.', '']
+        cond = {}
         for n in an:
             c = CASES[n]
             out, dt = gpu_run(n, pa[n])
@@ -259,6 +264,12 @@ def main():
                 lines.append('    %-8s gpu - cpu %.3e      oracle moves %.3e      largest |value| %.3e' % (k, _rel(g, ra[k]), _rel(rb[k], ra[k]), float(np.nanmax(np.abs(ra[k])))))
             lines.append('    outputs finite: %s' % bool(np.all(np.isfinite(out.Eft)) and np.all(np.isfinite(out.Varft))))
             lines.append('')
+            cond[n] = dict(fn={'gf': 'gf_ep_modulator_nmf', 'giekf': 'gf_giekf_modulator_nmf'}[c['fam']], audio=c['audio'] + '.wav', T=c['T'], ep_damping=c.get('damping', 0.5),
+                           oracle_moves={k: _rel(rb[k], ra[k]) for k in keys}, gpu_minus_cpu={k: _rel(getattr(out, k), ra[k]) for k in keys})
+        import json
+        with open(os.path.join(ROOT, 'tests', 'golden', 'audio_conditioning.json'), 'w') as fh:      # bench.py prints it next to cfg2 / cfg4
+            json.dump(dict(note='sequential CPU algorithm (oracle/cpu) on y against itself on y (1 + 1e-13): tools/full_length_parity.py --audio',
+                           source_hash=nagp._lib.source_hash(), cases=cond), fh, indent=1, default=lambda o: o.tolist() if hasattr(o, 'tolist') else float(o))
     lines.append('# wall time of this script: %.0f s; all within tolerance: %s' % (time.perf_counter() - t_all, ok))
     txt = '\n'.join(lines) + '\n'
     os.makedirs(os.path.dirname(a.out), exist_ok=True)

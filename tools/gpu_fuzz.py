@@ -3,6 +3,7 @@ function families (developer tool; the fixed-seed subset in tests/ is what the s
 python tools/gpu_fuzz.py [n_cases] [seed]
 python tools/gpu_fuzz.py widened [n_cases] [seed]     # mixtures (block-structured cubature included) and the EKF objective"""
 import os, sys, time
+os.environ.setdefault('NAGP_DEVELOPER', '1')      # developer tool: libnagp.so reads its switches only with this set
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'nonstationary-audio-gp_amd')); sys.path.insert(0, os.path.join(ROOT, 'tools'))
 import numpy as np
@@ -11,11 +12,32 @@ from nagp import harness, Mom, SSHandle, cubature
 from oracle import gf_ep as ogf, ihgp as oih, giekf as oek, lik as olik, mixture as omx
 
 
+NOT_COMPARED = -1.0      # both sides entirely NaN: there is nothing to compare (counted and printed, never taken for agreement)
+
+
 def rel(a, b):
     a = np.asarray(a, float); b = np.asarray(b, float)
     if not np.array_equal(np.isnan(a), np.isnan(b)):
         return np.inf
+    if a.size and np.all(np.isnan(b)):
+        return NOT_COMPARED
     return float(np.nanmax(np.abs(a - b)) / (np.nanmax(np.abs(b)) + 1e-300)) if a.size else 0.0
+
+
+def tally(res, worst, skipped):
+    """flag of one draw; the worst figures ignore NOT_COMPARED entries, which are counted per key instead"""
+    bad = False
+    for k, v in res.items():
+        if v == NOT_COMPARED:
+            skipped[k] = skipped.get(k, 0) + 1
+        else:
+            worst[k] = max(worst.get(k, 0.0), v)
+            bad = bad or not (v <= 1e-7)          # (NaN fails too)
+    return bad
+
+
+def fmt(res):
+    return ' '.join('%s %s' % (k, 'all-NaN:not-compared' if v == NOT_COMPARED else '%.1e' % v) for k, v in res.items())
 
 
 from gpu_fuzz_draws import draw, moms, draw_widened   # the draws live in a GPU-free module (tools/fuzz_conditioning.py shares them)
@@ -157,18 +179,16 @@ def one_widened(rng, raw=False):
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'widened':
         n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-        rng = np.random.default_rng(int(sys.argv[3]) if len(sys.argv) > 3 else 0); worst = {}; t0 = time.time()
+        rng = np.random.default_rng(int(sys.argv[3]) if len(sys.argv) > 3 else 0); worst = {}; skipped = {}; t0 = time.time()
         for c in range(n):
             desc, res, _ = one_widened(rng)
-            flag = ' <<<<' if max(res.values()) > 1e-7 else ''
-            print('%3d %-100s %s%s' % (c, desc, ' '.join('%s %.1e' % kv for kv in res.items()), flag)); sys.stdout.flush()
-            for k, v in res.items():
-                worst[k] = max(worst.get(k, 0.0), v)
-        print('worst', worst, '%.0fs' % (time.time() - t0))
+            flag = ' <<<<' if tally(res, worst, skipped) else ''
+            print('%3d %-100s %s%s' % (c, desc, fmt(res), flag)); sys.stdout.flush()
+        print('worst', worst, 'not compared (all-NaN on both sides)', skipped, '%.0fs' % (time.time() - t0))
         sys.exit(0)
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    rng = np.random.default_rng(seed); worst = {}; t0 = time.time()
+    rng = np.random.default_rng(seed); worst = {}; skipped = {}; t0 = time.time()
     only = int(sys.argv[3]) if len(sys.argv) > 3 else -1
     for c in range(n):
         desc, res, cfg = one(rng)
@@ -176,8 +196,6 @@ if __name__ == '__main__':
             if c == only:
                 print(desc, res); diagnose_ihgp(cfg)
             continue
-        flag = ' <<<<' if max(res.values()) > 1e-7 else ''
-        print('%3d %-70s %s%s' % (c, desc, ' '.join('%s %.1e' % kv for kv in res.items()), flag)); sys.stdout.flush()
-        for k, v in res.items():
-            worst[k] = max(worst.get(k, 0.0), v)
-    print('worst', worst, '%.0fs' % (time.time() - t0))
+        flag = ' <<<<' if tally(res, worst, skipped) else ''
+        print('%3d %-70s %s%s' % (c, desc, fmt(res), flag)); sys.stdout.flush()
+    print('worst', worst, 'not compared (all-NaN on both sides)', skipped, '%.0fs' % (time.time() - t0))

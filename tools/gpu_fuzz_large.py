@@ -2,6 +2,7 @@
 768-thread gain kernel, two / three tiles per thread in the filters), both EP families, one or two problems per plan, small
 chunks (developer tool):   python tools/gpu_fuzz_large.py [n_cases] [seed]"""
 import os, sys, time
+os.environ.setdefault('NAGP_DEVELOPER', '1')      # developer tool: libnagp.so reads its switches only with this set
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'nonstationary-audio-gp_amd'))
 import numpy as np

@@ -3,6 +3,7 @@ number of (G, Delta) buffers, sweeps, missing data; every output of the pipeline
 (NAGP_NO_PIPELINE=1), and the serial plan is the one the oracle tests pin.
 python tools/gpu_fuzz_schedules.py [n_cases] [seed]"""
 import os, sys, time
+os.environ.setdefault('NAGP_DEVELOPER', '1')      # developer tool: libnagp.so reads its switches only with this set
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'nonstationary-audio-gp_amd'))
 import numpy as np

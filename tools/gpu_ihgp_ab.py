@@ -1,6 +1,7 @@
 """Developer probe: the IHGP ADF sweep in the sparse-point form (ihgp_adf_kernel) against the generic kernel
 (NAGP_NO_SPARSE=1) on the same inputs.  python tools/gpu_ihgp_ab.py [T] [D N p ...]"""
 import os, sys
+os.environ.setdefault('NAGP_DEVELOPER', '1')      # developer tool: libnagp.so reads its switches only with this set
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'nonstationary-audio-gp_amd'))
 import numpy as np, nagp

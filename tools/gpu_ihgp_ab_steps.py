@@ -1,5 +1,6 @@
 """Developer probe: per-step divergence between the generic and the sparse-point IHGP ADF sweep (one sweep)."""
 import os, sys
+os.environ.setdefault('NAGP_DEVELOPER', '1')      # developer tool: libnagp.so reads its switches only with this set
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'nonstationary-audio-gp_amd'))
 import numpy as np, nagp

@@ -1,4 +1,5 @@
 #!/bin/bash
+export NAGP_DEVELOPER=1      # developer tool: libnagp.so reads its switches only with this set
 # tools/pmc_mfma.sh -- matrix-core counters of ONE execute per workload (north_star: "MFMA-busy counters against peak"); run on the GPU box
 # from the repository root:      bash tools/pmc_mfma.sh r04 cfg5_fill cfg2_batch cfg3_batch cfg3_sqrt
 # rocprofv3 --pmc only (no trace flags; the program directly behind --).  Summaries -> profiles/<tag>_pmc_mfma_<workload>.txt

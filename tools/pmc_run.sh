@@ -1,4 +1,5 @@
 #!/bin/bash
+export NAGP_DEVELOPER=1      # developer tool: libnagp.so reads its switches only with this set
 # tools/pmc_run.sh -- HBM traffic (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, no trace flags) and the kernel
 # statistics (rocprofv3 --kernel-trace --stats) of ONE execute of the benched build, per workload; run on the GPU box from the
 # repository root:      bash tools/pmc_run.sh r02 cfg3 cfg2

@@ -7,9 +7,31 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'nonstationary-audio-gp_amd'))
-DOMINANT = {'cfg3': ('ihgp_adf8_kernel', 'ihgp_adf_kernel', 'ihgp_filter_kernel'), 'cfg2': ('gf_filter_kernel<1, 0, 3, 256',), 'cfg5': ('gf_filter_kernel<3, 0, 6, 256',),
-            'cfg4': ('gf_filter_kernel<1, 1, 0',), 'cfg3_sqrt': ('ihgp_adf8sq_kernel',)}
-SHAPES = {'cfg2': (84010, 1), 'cfg3': (200000, 1), 'cfg4': (88200, 1), 'cfg5': (100000, 8), 'cfg3_sqrt': (200000, 1)}
+SHAPES = {'cfg2': (84010, 1), 'cfg3': (200000, 1), 'cfg4': (88200, 1), 'cfg5': (100000, 8), 'cfg3_sqrt': (200000, 1),
+          'cfg5_fill': (12500, 32), 'cfg2_batch': (4000, 128), 'cfg3_batch': (4000, 256)}
+
+
+def category(name):
+    """The timing category (nagp_plan_timings: filter, filter_lin, gain, scan, epsite, reduce) a kernel belongs to -- bench.py looks the traffic
+    of its dominant CATEGORY up, whatever instantiations happened to serve it (round 4: a hard-coded instantiation name went stale when the
+    default kernel changed)."""
+    import re
+    if 'rts_gain' in name:
+        return 'gain'
+    if any(k in name for k in ('rts_compose', 'rts_boundary', 'rts_apply', 'rts_big', 'ihgp_aff', 'ihgp_scan')):
+        return 'scan'
+    if 'ep_site' in name:
+        return 'epsite'
+    if 'sum_kernel' in name:
+        return 'reduce'
+    if 'gf_filter_lin' in name:
+        return 'filter_lin'
+    m = re.search(r'gf_filter_kernel<\s*(-?\d+)\s*,\s*(-?\d+)\s*,\s*(-?\d+)', name)
+    if m:
+        return 'filter_lin' if (int(m.group(2)) == 0 and int(m.group(3)) < 0) else 'filter'       # MEAS == 0, MV = -1: the fixed-site launches
+    if any(k in name for k in ('gf_adf8', 'ihgp_adf', 'ihgp_filter', 'ekf_grad', 'iekf')):
+        return 'filter'
+    return 'other'
 
 
 def per_kernel(d):
@@ -50,23 +72,24 @@ def main():
         for f in glob.glob(os.path.join(a.stats, '**', '*kernel_stats.csv'), recursive=True):
             shutil.copy(f, os.path.join(ROOT, 'profiles', '%s_kernel_stats_%s.csv' % (a.tag, a.workload)))
     from nagp import _lib as L
-    keys = DOMINANT.get(a.workload, ())
-    fetch = sum(v for (c, nm), (v, n) in tot.items() if c == 'FETCH_SIZE' and any(k in nm for k in keys))
-    write = sum(v for (c, nm), (v, n) in tot.items() if c == 'WRITE_SIZE' and any(k in nm for k in keys))
-    names = sorted({nm for (c, nm) in tot if any(k in nm for k in keys)})
+    cats = defaultdict(lambda: dict(fetch=0.0, write=0.0, kernels=set()))
+    for (c, nm), (v, n) in tot.items():
+        e = cats[category(nm)]
+        e['fetch' if c == 'FETCH_SIZE' else 'write'] += v
+        e['kernels'].add(nm.split('(')[0][:90])
     jp = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     try:
         with open(jp) as fh:
             js = json.load(fh)
     except (OSError, ValueError):
         js = {}
-    js['_comment'] = ('HBM bytes of the dominant kernel, summed over its dispatches of ONE execute (bench.py divides by its launches per execute), from rocprofv3 --pmc '
+    js['_comment'] = ('HBM bytes per timing category (filter, filter_lin, gain, scan, epsite: tools/pmc_summary.py category()), summed over the dispatches of ONE execute (bench.py divides by its launches per execute), from rocprofv3 --pmc '
                       'FETCH_SIZE / WRITE_SIZE, separate passes (tools/pmc_run.sh); FETCH_SIZE x2 (gfx950); bench.py reports roofline.traffic only when source_hash matches the loaded library')
-    js[a.workload] = dict(kernel=', '.join(names), fetch_bytes_per_execute=fetch, write_bytes_per_execute=write, source=os.path.relpath(out, ROOT),
-                          source_hash=L.source_hash(), T=SHAPES[a.workload][0], segments=SHAPES[a.workload][1] if a.workload == 'cfg5' else 1)
+    js[a.workload] = dict(by_category={k: dict(fetch_bytes_per_execute=e['fetch'], write_bytes_per_execute=e['write'], kernels=sorted(e['kernels'])) for k, e in sorted(cats.items())},
+                          source=os.path.relpath(out, ROOT), source_hash=L.source_hash(), T=SHAPES[a.workload][0], segments=SHAPES[a.workload][1])
     with open(jp, 'w') as fh:
         json.dump(js, fh, indent=1)
-    print('profiles/pmc_traffic.json <-', a.workload, 'fetch %.4f GB write %.4f GB' % (fetch / 1e9, write / 1e9))
+    print('profiles/pmc_traffic.json <-', a.workload, {k: 'fetch %.3f GB write %.3f GB' % (e['fetch'] / 1e9, e['write'] / 1e9) for k, e in cats.items()})
 
 
 if __name__ == '__main__':

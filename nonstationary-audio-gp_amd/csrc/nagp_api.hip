@@ -1400,7 +1400,8 @@ static int launch_gain_chunk(nagp_plan* p, const SweepCtx& sc, int c, int slot, 
   if (gp.dense_sp && p->gain_mfma) {
     const int ntl = p->mfma_sp / 16;
     const size_t lg = gainm_lds_doubles(ntl, sh) * sizeof(double);
-#define LG(N) hipLaunchKernelGGL((rts_gain_mfma_kernel<N>), gr, dim3(64 * (N + 1)), lg, st, sh, b, gp)
+    const dim3 gr8((unsigned)((g.nk + 7) / 8 * 8), (unsigned)p->B);      // (the steps of one XCD contiguous: nagp_gain_mfma.hpp)
+#define LG(N) hipLaunchKernelGGL((rts_gain_mfma_kernel<N>), gr8, dim3(64 * (N + 1)), lg, st, sh, b, gp)
     switch (ntl) { case 1: LG(1); break; case 2: LG(2); break; case 3: LG(3); break; case 4: LG(4); break; case 5: LG(5); break;
                    case 6: LG(6); break; case 7: LG(7); break; case 8: LG(8); break; case 9: LG(9); break; default: LG(10); break; }
 #undef LG

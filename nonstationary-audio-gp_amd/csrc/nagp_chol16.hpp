@@ -8,10 +8,11 @@
 //     broadcasts act inside a row of 16 lanes, and redundancy costs nothing on a lone wave);
 //   * column j:  p = a_jj of lane j (v_mov_b64_dpp row_newbcast:j),  r = 1/sqrt(p) (v_rsq_f64 + two Newton steps),  l_ij = a_ij r,
 //     trailing update  a_ik -= l_ij l_kj  with l_kj = lane k's l_.j through one DPP broadcast per (j, k);
-//   * the inverse X = L^-1 rides along (it is not on the chain): unscaled rows U_i = e_i - sum_{k<i} L_ik X_k, X_k = r_k U_k;
-//     at column j every lane i > j takes  U_i -= (l_ij r_j) U_j  with U_j broadcast from lane j, again one DPP broadcast and one multiply-add per
-//     entry; the rows are scaled by their own r at the end.
-// 120 + 136 broadcast + multiply-add pairs and 16 reciprocal square roots per tile: 2.26 us per tile on a lone wave by the event clock
+//   * the inverse X = L^-1 rides along: unscaled rows U_i = e_i - sum_{k<i} L_ik X_k, X_k = r_k U_k; at column j every lane i > j
+//     takes  U_i -= (l_ij r_j) U_j  with U_j broadcast from lane j, one DPP broadcast and one multiply-add per entry -- and the four lane
+//     rows, which all know L, each keep a QUARTER of the columns of X (column 4r + g in register r of lane row g); the rows are
+//     scaled by their own r at the end.
+// 120 + 40 broadcast + multiply-add pairs and 16 reciprocal square roots per tile (120 + 136 with the inverse kept redundantly: 2.26 us per tile on a lone wave by the event clock
 // (tools/ubench/chol16.hip; ~840 instructions).  The panel products and both triangular solves of the gain
 // kernel multiply by inv(L_JJ) on the matrix cores instead of substituting through L_JJ, so the factor itself is never stored.
 #pragma once
@@ -52,12 +53,14 @@ __device__ __forceinline__ void c16_fmsubk(double& d, double a, double b, int k)
   }
 }
 
-// a[c] = entry (row, c) of the symmetric positive definite tile (only c <= row is read).  On return x[c] = entry (row, c) of
-// inv(L), L = chol(tile, 'lower'); entries above the diagonal are exact zeros.  Returns false (to every lane) when a pivot was not
-// positive (NaN included): the caller reports it (jitter retry, gf_ep_modulator_nmf.m:214-221).
-__device__ __forceinline__ bool chol16_inv_rows(double (&a)[16], double (&x)[16], int row) {
+// a[c] = entry (row, c) of the symmetric positive definite tile (only c <= row is read), identical in the four 16-lane rows of the wave.
+// On return x[r] = entry (row, 4r + g) of inv(L), L = chol(tile, 'lower'), g = lane >> 4: the INVERSE is split over the four lane rows by
+// columns -- a DPP broadcast stays inside a lane row, and lane j of row g holds exactly the columns of U_j that row needs -- so the 136
+// broadcast + multiply-add pairs of the redundant form are 40.  Entries above the diagonal are exact zeros.  Returns false (to every
+// lane) when a pivot was not positive (NaN included): the caller reports it (jitter retry, gf_ep_modulator_nmf.m:214-221).
+__device__ __forceinline__ bool chol16_inv_rows(double (&a)[16], double (&x)[4], int row, int g) {
 #pragma unroll
-  for (int c = 0; c < 16; ++c) x[c] = (c == row) ? 1.0 : 0.0;
+  for (int r = 0; r < 4; ++r) x[r] = (4 * r + g == row) ? 1.0 : 0.0;
   bool ok = true;
   double rown = 1.0;
 #pragma unroll
@@ -71,11 +74,15 @@ __device__ __forceinline__ bool chol16_inv_rows(double (&a)[16], double (&x)[16]
 #pragma unroll
     for (int k = j + 1; k < 16; ++k) c16_fmsubk(a[k], lj, lj, k);            // a_ik -= l_kj l_ij
     const double am = (row > j) ? lj * r : 0.0;
+    // U_i -= (l_ij r_j) U_j over the columns c = 4r + g <= j of this lane row
 #pragma unroll
-    for (int c = 0; c <= j; ++c) c16_fmsubk(x[c], x[c], am, j);              // U_i -= (l_ij r_j) U_j
+    for (int rr = 0; rr < 4; ++rr) {
+      if (4 * rr + 3 <= j) c16_fmsubk(x[rr], x[rr], am, j);                    // (every lane row)
+      else if (4 * rr <= j) c16_fmsubk(x[rr], x[rr], (4 * rr + g <= j) ? am : 0.0, j);
+    }
   }
 #pragma unroll
-  for (int c = 0; c < 16; ++c) x[c] *= rown;
+  for (int r = 0; r < 4; ++r) x[r] *= rown;
   return ok;
 }
 

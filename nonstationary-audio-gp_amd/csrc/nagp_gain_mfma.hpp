@@ -112,8 +112,8 @@ __device__ __forceinline__ int gm_opaque(int v) { asm volatile("" : "+v"(v)); re
 // the chain wave: tile T (LDS, lower part meaningful) -> inv(chol(T)) into Ti (LDS, full tile, zeros above the diagonal)
 // (measured as a non-inlined function: 6 900 instead of 6 400 cycles per tile -- inlined it stays)
 __device__ __forceinline__ bool gm_chol_inv_tile(const double* T, double* Ti, int lane) {
-  const int row = lane & 15;
-  double a[16], x[16];
+  const int row = lane & 15, g = lane >> 4;
+  double a[16], x[4];
   const double2* src = reinterpret_cast<const double2*>(T + row * 16);
 #pragma unroll
   for (int m = 0; m < 8; ++m) {      // positions 2m, 2m+1 hold columns 4(q&3) + (q>>2)
@@ -121,13 +121,11 @@ __device__ __forceinline__ bool gm_chol_inv_tile(const double* T, double* Ti, in
     a[4 * ((2 * m) & 3) + ((2 * m) >> 2)] = v.x;
     a[4 * ((2 * m + 1) & 3) + ((2 * m + 1) >> 2)] = v.y;
   }
-  const bool ok = chol16_inv_rows(a, x, row);
-  if (lane < 16) {
-    double2* dst = reinterpret_cast<double2*>(Ti + row * 16);
-#pragma unroll
-    for (int m = 0; m < 8; ++m)
-      dst[m] = make_double2(x[4 * ((2 * m) & 3) + ((2 * m) >> 2)], x[4 * ((2 * m + 1) & 3) + ((2 * m + 1) >> 2)]);
-  }
+  const bool ok = chol16_inv_rows(a, x, row, g);
+  // lane row g holds columns g, 4+g, 8+g, 12+g of its row of the inverse: positions 4g .. 4g+3 of the stored row -- 32 contiguous bytes
+  double2* dst = reinterpret_cast<double2*>(Ti + row * 16 + 4 * g);
+  dst[0] = make_double2(x[0], x[1]);
+  dst[1] = make_double2(x[2], x[3]);
   return __ballot(!ok) == 0ull;
 }
 
@@ -149,7 +147,12 @@ __global__ void __launch_bounds__(64 * (NTL + 1)) rts_gain_mfma_kernel(Shape sh,
   const int c = (w > CW) ? w - 1 : w;                             // tile column of a column wave
   const int S = sh.S, M = sh.M;
   const int64_t T = sh.T;
-  const int kk = blockIdx.x, pb = blockIdx.y;
+  // Workgroups go to the eight XCDs round robin in dispatch order, and each XCD has an L2 of its own.  Step k reads PS_k AND PS_{k+1}
+  // (Delta_k), so consecutive steps on consecutive XCDs fetch every filtered covariance from HBM twice; with the steps of an XCD contiguous
+  // (launch: gridDim.x = nk rounded up to a multiple of eight) the second reader finds it in its L2.
+  const int pb = blockIdx.y;
+  const int kk = (int)(blockIdx.x & 7u) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+  if (kk >= gp.nk) return;
   const int64_t k = gp.k0 + kk;
   const double* mdl = b.model + (size_t)pb * mdl_size(sh);
   double* Lt = lds;                                               // lower tiles of PSkp -> L; before that: PS_k in the layout of PF
@@ -163,7 +166,7 @@ __global__ void __launch_bounds__(64 * (NTL + 1)) rts_gain_mfma_kernel(Shape sh,
   // workgroup -- slot 0 staging | 1 barrier waits of the prologue | 2 B' (chain: delta_k) | 3 PSkp | 4 Delta (chain: tile 0) | 5 trailing tasks
   // (chain: its four products) | 6 chain: factor + invert | 7 forward row | 8 interval barrier wait | 9 flag, retry | 10 backward | 11 G store
   // | 12 workgroups sampled
-  const bool stamp = gp.stamps && lane == 0 && (w == 0 || chain) && (blockIdx.x & 63) == 0;
+  const bool stamp = gp.stamps && lane == 0 && (w == 0 || chain) && (kk & 63) == 0;
   unsigned long long st_a = stamp ? __builtin_readcyclecounter() : 0ull;
 #define GM_STAMP(slot) do { if (stamp) { const unsigned long long st_b = __builtin_readcyclecounter(); atomicAdd(&gp.stamps[(chain ? 16 : 0) + (slot)], st_b - st_a); st_a = st_b; } } while (0)
 

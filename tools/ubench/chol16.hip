@@ -7,24 +7,21 @@
 #include "nagp_chol16.hpp"
 using namespace nagp;
 __global__ void __launch_bounds__(64) k(const double* tiles, double* inv, long long* t, int ntile, int reps) {
-  const int lane = threadIdx.x & 63, row = lane & 15;
+  const int lane = threadIdx.x & 63, row = lane & 15, g = lane >> 4;
   long long cyc = 0;
   for (int rep = 0; rep < reps; ++rep)
     for (int q = 0; q < ntile; ++q) {
-      double a[16], x[16];
+      double a[16], x[4];
 #pragma unroll
       for (int c = 0; c < 16; ++c) a[c] = tiles[(size_t)q * 256 + row * 16 + c];
       __builtin_amdgcn_s_waitcnt(0);
       const long long c0 = clock64();
-      const bool ok = chol16_inv_rows(a, x, row);
-      asm volatile("" :: "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(x[8]), "v"(x[9]), "v"(x[10]), "v"(x[11]),
-                   "v"(x[12]), "v"(x[13]), "v"(x[14]), "v"(x[15]), "v"((int)ok));      // every output exists before the second clock read
+      const bool ok = chol16_inv_rows(a, x, row, g);
+      asm volatile("" :: "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"((int)ok));
       const long long c1 = clock64();
       cyc += c1 - c0;
-      if (lane < 16) {
 #pragma unroll
-        for (int c = 0; c < 16; ++c) inv[(size_t)q * 256 + row * 16 + c] = ok ? x[c] : -1.0;
-      }
+      for (int r = 0; r < 4; ++r) inv[(size_t)q * 256 + row * 16 + 4 * r + g] = ok ? x[r] : -1.0;      // lane row g: columns 4r + g
     }
   if (threadIdx.x == 0 && blockIdx.x == 0) t[0] = cyc;
 }

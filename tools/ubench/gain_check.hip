@@ -86,7 +86,7 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int rep = 0; rep < 3; ++rep) {
     hipEventRecord(e0);
-    launch_n(ntl, dim3(nk, 1), lds, sh, b, gp);
+    launch_n(ntl, dim3((nk + 7) / 8 * 8, 1), lds, sh, b, gp);
     hipEventRecord(e1); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double flop = 2.33 * (double)S * S * S * 2 * nk;

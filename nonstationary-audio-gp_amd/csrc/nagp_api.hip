@@ -84,6 +84,8 @@ struct nagp_plan {
   int big_sp = 0;       // 1: Sp > 96, the column-owner kernels of nagp_mfma_big.hpp
   int gain768 = 0;      // rts_gain_kernel<2, 768>: 1025..1536 tiles with a lower triangle of <= 768 tiles
   int gain_mfma = 0;    // dense (G, Delta) output through rts_gain_mfma_kernel<Sp/16> (nagp_gain_mfma.hpp)
+  int gain_inv = 0;     // ... in its explicit-inverse form G = A^-1 - (A^-1 Q) PSkp^-1 (every block of A comfortably invertible)
+  double* d_ainv = nullptr;      // [B][M][32]: per block A^-1 and A^-1 Q (GainPar::ainv)
   int lin_mfma = 0;     // fixed-site filter launches through gf_filter_lin_mfma_kernel<NTL> (nagp_filter_mfma.hpp); = NTL
   size_t lds_lin = 0;
   size_t gbuf_doubles = 0;
@@ -1052,7 +1054,53 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
   if (p->mfma_sp && !dev_env("NAGP_NO_GAIN_MFMA")) {
     p->gain_mfma = 1;
     const size_t lg = gainm_lds_doubles(p->mfma_sp / 16, sh) * sizeof(double);
-#define SETG(N) PLAN_TRY(set_lds(rts_gain_mfma_kernel<N>, lg))
+    // The explicit-inverse form needs A^-1 per block.  It is used when EVERY block of every problem of the plan is comfortably
+    // invertible -- |A_b^-1|_inf <= 8: A_b = expm(F_b dt) with dt = one sample is a slightly damped rotation for every kernel the
+    // drivers use; a block with a length-scale below a sample would amplify the rounding error of PSkp^-1 by its |A_b^-1|, and such
+    // plans keep the solve form (G = PS_k A' / L' / L, no inverse of A anywhere).  NAGP_GAIN_FORM=solve|inv (developer switch) forces one.
+    {
+      std::vector<double> ha((size_t)B * sh.M * 32, 0.0);
+      double worst = 0.0; bool singular = false;
+      for (int q = 0; q < B; ++q)
+        for (int n = 0; n < sh.M; ++n) {
+          const int bs = sh.bsz[n];
+          const double* A0 = hm.data() + (size_t)q * msz + mdl_A(sh) + (size_t)n * 16;
+          const double* Q0 = hm.data() + (size_t)q * msz + mdl_Q(sh) + (size_t)n * 16;
+          double a[16], x[16];
+          for (int e = 0; e < 16; ++e) { a[e] = A0[e]; x[e] = 0.0; }
+          for (int i = 0; i < bs; ++i) x[4 * i + i] = 1.0;
+          for (int col = 0; col < bs; ++col) {      // Gauss-Jordan, partial pivoting
+            int piv = col;
+            for (int r = col + 1; r < bs; ++r) if (std::fabs(a[4 * r + col]) > std::fabs(a[4 * piv + col])) piv = r;
+            if (!(std::fabs(a[4 * piv + col]) > 0.0)) { singular = true; break; }
+            for (int j = 0; j < 4; ++j) { std::swap(a[4 * col + j], a[4 * piv + j]); std::swap(x[4 * col + j], x[4 * piv + j]); }
+            const double d = 1.0 / a[4 * col + col];
+            for (int j = 0; j < 4; ++j) { a[4 * col + j] *= d; x[4 * col + j] *= d; }
+            for (int r = 0; r < bs; ++r)
+              if (r != col) { const double f = a[4 * r + col]; for (int j = 0; j < 4; ++j) { a[4 * r + j] -= f * a[4 * col + j]; x[4 * r + j] -= f * x[4 * col + j]; } }
+          }
+          double* o = ha.data() + ((size_t)q * sh.M + n) * 32;
+          for (int i = 0; i < bs; ++i) {
+            double rs = 0.0;
+            for (int j = 0; j < bs; ++j) {
+              o[4 * i + j] = x[4 * i + j]; rs += std::fabs(x[4 * i + j]);
+              double wv = 0.0;
+              for (int l = 0; l < bs; ++l) wv += x[4 * i + l] * Q0[4 * l + j];
+              o[16 + 4 * i + j] = wv;
+            }
+            worst = std::max(worst, rs);
+          }
+        }
+      const char* form = dev_env("NAGP_GAIN_FORM");
+      p->gain_inv = (!singular && std::isfinite(worst) && (worst <= 8.0 || (form && !strcmp(form, "inv")))) ? 1 : 0;
+      if (form && !strcmp(form, "solve")) p->gain_inv = 0;
+      if (p->gain_inv) {
+        PLAN_TRY(dalloc(p, &p->d_ainv, ha.size(), false));
+        PLAN_HIP(hipMemcpyAsync(p->d_ainv, ha.data(), ha.size() * sizeof(double), hipMemcpyHostToDevice, p->stream));
+        PLAN_HIP(hipStreamSynchronize(p->stream));
+      }
+    }
+#define SETG(N) PLAN_TRY(set_lds((rts_gain_mfma_kernel<N, false>), lg)); PLAN_TRY(set_lds((rts_gain_mfma_kernel<N, true>), lg))
     switch (p->mfma_sp / 16) { case 1: SETG(1); break; case 2: SETG(2); break; case 3: SETG(3); break; case 4: SETG(4); break; case 5: SETG(5); break;
                                case 6: SETG(6); break; case 7: SETG(7); break; case 8: SETG(8); break; case 9: SETG(9); break; default: SETG(10); break; }
 #undef SETG
@@ -1401,7 +1449,9 @@ static int launch_gain_chunk(nagp_plan* p, const SweepCtx& sc, int c, int slot, 
     const int ntl = p->mfma_sp / 16;
     const size_t lg = gainm_lds_doubles(ntl, sh) * sizeof(double);
     const dim3 gr8((unsigned)((g.nk + 7) / 8 * 8), (unsigned)p->B);      // (the steps of one XCD contiguous: nagp_gain_mfma.hpp)
-#define LG(N) hipLaunchKernelGGL((rts_gain_mfma_kernel<N>), gr8, dim3(64 * (N + 1)), lg, st, sh, b, gp)
+    gp.ainv = p->gain_inv ? p->d_ainv : nullptr;
+#define LG(N) do { if (p->gain_inv) hipLaunchKernelGGL((rts_gain_mfma_kernel<N, true>), gr8, dim3(64 * (N + 1)), lg, st, sh, b, gp); \
+                   else hipLaunchKernelGGL((rts_gain_mfma_kernel<N, false>), gr8, dim3(64 * (N + 1)), lg, st, sh, b, gp); } while (0)
     switch (ntl) { case 1: LG(1); break; case 2: LG(2); break; case 3: LG(3); break; case 4: LG(4); break; case 5: LG(5); break;
                    case 6: LG(6); break; case 7: LG(7); break; case 8: LG(8); break; case 9: LG(9); break; default: LG(10); break; }
 #undef LG

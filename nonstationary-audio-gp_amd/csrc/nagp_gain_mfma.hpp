@@ -129,10 +129,43 @@ __device__ __forceinline__ bool gm_chol_inv_tile(const double* T, double* Ti, in
   return __ballot(!ok) == 0ull;
 }
 
+// Which tile column a column wave owns.  In the solve form every column is the same work and the order is the identity.  In the
+// explicit-inverse form column c is a triangle of (NTL - c)(NTL - c + 1)/2 tile products, in the forward rows and again in the backward
+// solve, and a wave's SIMD is fixed by its index (waves go to the four SIMDs round robin; wave 3 is the chain): the largest column goes to
+// the chain's SIMD-mate (wave 7: the chain needs its SIMD least while the others solve backward), the rest largest first to the SIMD
+// with the least work so far -- {55}, {45,10,1}, {36,15,3}, {28,21,6} at ten columns instead of {55,28,6}, {45,21,3}, {36,15,1}, {10}.
+struct GmColMap { int col[12]; };
+template <int NTL, bool INV>
+constexpr GmColMap gm_col_map() {
+  GmColMap m{};
+  constexpr int CW = (NTL >= 4) ? 3 : NTL, NWV = NTL + 1;
+  for (int w = 0; w < 12; ++w) m.col[w] = -1;
+  if (!INV) { for (int w = 0; w < NWV; ++w) m.col[w] = (w == CW) ? -1 : (w > CW ? w - 1 : w); return m; }
+  int load[4] = {0, 0, 0, 0};
+  int next = 0;
+  if (NWV > 7) { m.col[7] = 0; load[3] += NTL * (NTL + 1) / 2; next = 1; }
+  for (int c = next; c < NTL; ++c) {
+    int best = -1;
+    for (int w = 0; w < NWV; ++w) {
+      if (w == CW || m.col[w] >= 0) continue;
+      if (best < 0 || load[w & 3] < load[best & 3]) best = w;
+    }
+    m.col[best] = c; load[best & 3] += (NTL - c) * (NTL - c + 1) / 2;
+  }
+  return m;
+}
+
 // LDS offset (doubles) of the first element of tile t in the layout of PF (pf_off(t, 0))
 __device__ __forceinline__ int gm_tpart(int t) { return ((t >> 6) << 10) + ((t & 63) << 1); }
 
-template <int NTL>
+// INV: the gain through the explicit inverse.  With X = PSkp^-1 and PS_k A' = A^-1 (PSkp - Q):  G = PS_k A' X = A^-1 - (A^-1 Q) X.  A and Q are
+// block diagonal, so once X is known G is a 4x4-block operation on it -- and X costs HALF the solves: the tile columns of L^-1 (forward
+// substitution on the identity: column c starts at tile row c) and of X = L'^-1 L^-1 (backward substitution, needed for tile rows >= c only,
+// X being symmetric) are triangles, 220 + 220 tile products at ten tile columns instead of 550 + 550; B' = A PS_k is not formed at all
+// (PSkp alone, for the 55 lower tiles).  The host enables it when every block of A is comfortably invertible (GainPar::ainv holds
+// A^-1 and A^-1 Q per block; |A_b^-1| <= 8: the error of G is that of X times |A^-1|) -- otherwise, and for any caller that passes no
+// inverses, the solve form below runs.
+template <int NTL, bool INV>
 __global__ void __launch_bounds__(64 * (NTL + 1)) rts_gain_mfma_kernel(Shape sh, Bufs b, GainPar gp) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   constexpr int Sp = 16 * NTL, NT = 64 * (NTL + 1), NLOW = NTL * (NTL + 1) / 2;
@@ -144,7 +177,10 @@ __global__ void __launch_bounds__(64 * (NTL + 1)) rts_gain_mfma_kernel(Shape sh,
   // column wave instead of two (an FP64 MFMA holds its SIMD's issue for its duration: every MFMA of a SIMD-mate delays the chain)
   constexpr int CW = (NTL >= 4) ? 3 : NTL;
   const bool chain = (w == CW);
-  const int c = (w > CW) ? w - 1 : w;                             // tile column of a column wave
+  constexpr GmColMap CMAP = gm_col_map<NTL, INV>();
+  int c = 0;                                                      // tile column of a column wave (gm_col_map)
+#pragma unroll
+  for (int q = 0; q < NTL + 1; ++q) if (q == w && CMAP.col[q] >= 0) c = CMAP.col[q];
   const int S = sh.S, M = sh.M;
   const int64_t T = sh.T;
   // Workgroups go to the eight XCDs round robin in dispatch order, and each XCD has an L2 of its own.  Step k reads PS_k AND PS_{k+1}
@@ -313,6 +349,9 @@ __global__ void __launch_bounds__(64 * (NTL + 1)) rts_gain_mfma_kernel(Shape sh,
     GM_STAMP(0);
     lds_barrier();                                                                       // b1
     GM_STAMP(1);
+    // INV: only the tiles of PSkp this wave forms are computed (tile row I of B' = A PS_k, then PSkp(I, c) = B' A_c' by quad broadcasts),
+    // kept in registers until the staged copy is dead
+    const auto mine = [&](int I) -> bool { return (I < c) ? (((c - I) & 1) == 0) : (I == c || ((I - c) & 1) != 0); };
     {
       // ---- B' = A PS_k, tile column c: element (16I + 4t + kq, 16c + i) = row kq of block br = 4I+t times column ci of PS(br, bc).
       // Half a tile row at a time, its PS entries and rows of A in flight together.  Tiles below the diagonal tile read the stored
@@ -324,6 +363,7 @@ __global__ void __launch_bounds__(64 * (NTL + 1)) rts_gain_mfma_kernel(Shape sh,
       const double* arow = sA + 4 * kq;
 #pragma unroll
       for (int I = 0; I < NTL; ++I) {
+        if (INV && !mine(I)) continue;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           double p[2][4];
@@ -391,7 +431,7 @@ __global__ void __launch_bounds__(64 * (NTL + 1)) rts_gain_mfma_kernel(Shape sh,
 #pragma unroll
       for (int I = 0; I < NTL; ++I) {
         const bool mirror = I < c;                                // this wave forms tile (I, c) of the upper triangle and stores it as (c, I)
-        if (mirror ? (((c - I) & 1) != 0) : (I > c && ((I - c) & 1) == 0)) continue;
+        if (!mine(I)) continue;
         v4d ps;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -461,10 +501,11 @@ __global__ void __launch_bounds__(64 * (NTL + 1)) rts_gain_mfma_kernel(Shape sh,
 #pragma unroll
     for (int J = 0; J < NTL; ++J) {
       // trailing update with column J-1 (+ the panel product for the tiles of column J); the chain wave owns (J+1,J), (J+1,J+1)
-      // (dealt round robin over the column waves EXCEPT the one on the chain's SIMD -- wave 7, column 6, when there is one: every MFMA
+      // (dealt round robin over the column waves EXCEPT the one on the chain's SIMD -- wave 7 when there is one: every MFMA
       // it issues holds that SIMD and delays the chain)
       constexpr int NDEAL = (NTL >= 7) ? NTL - 1 : NTL;
-      const int cdeal = (NTL >= 7) ? (c == 6 ? -1 : (c > 6 ? c - 1 : c)) : c;
+      constexpr int MATE = (NTL >= 7) ? CMAP.col[7] : -1;          // the column of the chain's SIMD-mate
+      const int cdeal = (NTL >= 7) ? (c == MATE ? -1 : (c > MATE ? c - 1 : c)) : c;
       int cnt = 0;
       for (int K = J; K < (J == 0 ? 1 : NTL); ++K)
         for (int I = K; I < NTL; ++I) {
@@ -484,13 +525,32 @@ __global__ void __launch_bounds__(64 * (NTL + 1)) rts_gain_mfma_kernel(Shape sh,
         }
       GM_STAMP(5);
       // forward solve, row J: Y_J = inv(L_JJ) (B'_J - sum_{K<J} L_JK Y_K)
-      {
+      if constexpr (!INV) {
         v4d acc = Y[J];
 #pragma unroll
         for (int K = 0; K < NTL; ++K)
           if (K < J) acc = gm_mma_xb(Lt + gm_tix(J, K), Y[K], i, kq, acc, true);
         v4d y = {0.0, 0.0, 0.0, 0.0};
         Y[J] = gm_mma_xb(Li + (size_t)J * 256, acc, i, kq, y, false);
+      } else {
+        // tile column c of L^-1 (right-hand side: the identity): zero above tile row c, inv(L_cc) in it, a forward row below
+        if (J == c) Y[J] = gm_load_acc(Li + (size_t)J * 256, i, kq);
+        else if (J > c) {
+          // (the products of a row are independent of each other: three accumulators in turn -- the first tile columns hold most of the
+          // triangle and have their SIMD almost to themselves, where one accumulator chain runs at the latency of a dependent MFMA)
+          v4d acc = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int K = 0; K < NTL; ++K)
+            if (K < J && K >= c) {
+              if (K % 3 == 0) acc = gm_mma_xb(Lt + gm_tix(J, K), Y[K], i, kq, acc, true);
+              else if (K % 3 == 1) acc1 = gm_mma_xb(Lt + gm_tix(J, K), Y[K], i, kq, acc1, true);
+              else acc2 = gm_mma_xb(Lt + gm_tix(J, K), Y[K], i, kq, acc2, true);
+            }
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[t] += acc1[t] + acc2[t];
+          v4d y = {0.0, 0.0, 0.0, 0.0};
+          Y[J] = gm_mma_xb(Li + (size_t)J * 256, acc, i, kq, y, false);
+        }
       }
       GM_STAMP(7);
       lds_barrier();
@@ -506,6 +566,7 @@ __global__ void __launch_bounds__(64 * (NTL + 1)) rts_gain_mfma_kernel(Shape sh,
   GM_STAMP(9);
   const int i = gm_opaque(i0), kq = gm_opaque(kq0);
 
+  if constexpr (!INV) {
   // ---- backward: W_I = inv(L_II)' (Y_I - sum_{K>I} L_KI' W_K)
 #pragma unroll
   for (int I = NTL - 1; I >= 0; --I) {
@@ -524,6 +585,70 @@ __global__ void __launch_bounds__(64 * (NTL + 1)) rts_gain_mfma_kernel(Shape sh,
   for (int I = 0; I < NTL; ++I) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) Gout[gbase + 16 * I + 4 * t] = (((rowbits >> (4 * I + t)) & 1ull) && colok) ? Y[I][t] : 0.0;
+  }
+  } else {
+  // ---- the block operands of G = A^-1 - (A^-1 Q) X: loaded now, they land under the backward solve
+  const double* ai = gp.ainv + (size_t)pb * M * 32;
+  const int bci = bcin ? 4 * c + (i >> 2) : 0;
+  double wd[NTL], wq[4];
+  // (after a jitter retry the matrix that was inverted is PSkp + J, J = 0.005 I, while PS_k A' is still A^-1 (PSkp - Q): the reference's
+  // G = PS_k A' / chol(PSkp + J) is then A^-1 - A^-1 (Q + J) X, i.e. the block factor gains 0.005 A^-1)
+  const double jit = (flag[0] != 0) ? 0.01 * 0.5 : 0.0;
+#pragma unroll
+  for (int I = 0; I < NTL; ++I) {                                                                                                          // (A^-1 (Q + J))_br [i & 3][kq]
+    const int br = 4 * I + (i >> 2);
+    const double* e = ai + (size_t)(br < M ? br : 0) * 32 + 4 * (i & 3) + kq;
+    wd[I] = fma(jit, e[0], e[16]);
+  }
+#pragma unroll
+  for (int l = 0; l < 4; ++l) { const double* e = ai + (size_t)bci * 32 + 4 * (i & 3) + l; wq[l] = fma(jit, e[0], e[16]); }                // (A^-1 (Q + J))_bc [ci][l]
+  const double aid = ai[(size_t)bci * 32 + 4 * kq + (i & 3)];                                                                              // (A^-1)_bc [kq][ci]
+  // ---- backward, tile rows >= c: X_I = inv(L_II)' (Y_I - sum_{K>I} L_KI' X_K)
+#pragma unroll
+  for (int I = NTL - 1; I >= 0; --I) {
+    if (I < c) continue;
+    v4d acc = Y[I], acc1 = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int K = 0; K < NTL; ++K)
+      if (K > I) {
+        if (K % 3 == 0) acc = gm_mma_xTb(Lt + gm_tix(K, I), Y[K], i, kq, acc, true);
+        else if (K % 3 == 1) acc1 = gm_mma_xTb(Lt + gm_tix(K, I), Y[K], i, kq, acc1, true);
+        else acc2 = gm_mma_xTb(Lt + gm_tix(K, I), Y[K], i, kq, acc2, true);
+      }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] += acc1[t] + acc2[t];
+    v4d wv = {0.0, 0.0, 0.0, 0.0};
+    Y[I] = gm_mma_xTb(Li + (size_t)I * 256, acc, i, kq, wv, false);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  GM_STAMP(10);
+  // ---- G from the lower tiles X(I, c), I >= c, of this wave.  Tile (I, c) of G = [I == c] A^-1 - blockdiag(A^-1 Q)_I X(I, c): one product
+  // on the matrix cores with the block-diagonal factor as the A operand (k-step s carries block s: one value per lane), stored as
+  // 128-byte rows; tile (c, I), I > c, = -(A^-1 Q)_c X(c, I) = -(A^-1 Q)_c X(I, c)': the four columns of a block sit in a quad, stored
+  // as 32-byte runs.
+#pragma unroll
+  for (int I = 0; I < NTL; ++I) {
+    if (I < c) continue;
+    v4d acc = {0.0, 0.0, 0.0, 0.0};
+    if (I == c) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = (t == (i >> 2)) ? aid : 0.0;
+    }
+#pragma unroll
+    for (int sx = 0; sx < 4; ++sx) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(((i >> 2) == sx) ? -wd[I] : 0.0, Y[I][sx], acc, 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const bool ok = ((rowbits >> (4 * I + t)) & 1ull) && colok;
+      Gout[(size_t)(16 * I + 4 * t + kq) * Sp + 16 * c + i] = ok ? acc[t] : 0.0;
+      if (I > c) {
+        const double xv = Y[I][t];
+        const double b0 = gm_quad<0x00>(xv), b1 = gm_quad<0x55>(xv), b2 = gm_quad<0xAA>(xv), b3 = gm_quad<0xFF>(xv);
+        double g = wq[0] * b0;
+        g = fma(wq[1], b1, g); g = fma(wq[2], b2, g); g = fma(wq[3], b3, g);
+        Gout[(size_t)(16 * c + i) * Sp + 16 * I + 4 * t + kq] = ok ? -g : 0.0;
+      }
+    }
+  }
   }
   GM_STAMP(11);
   if (stamp) atomicAdd(&gp.stamps[12], 1ull);

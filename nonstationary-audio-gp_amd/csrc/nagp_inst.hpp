@@ -74,11 +74,27 @@
 
 // RTS gain on the matrix cores (dense output), Sp = 16 .. 160
 #define NAGP_LIST_GAINM(P)                                                                                                 \
-  P void nagp::rts_gain_mfma_kernel<1>(nagp::Shape, nagp::Bufs, nagp::GainPar); P void nagp::rts_gain_mfma_kernel<2>(nagp::Shape, nagp::Bufs, nagp::GainPar);   \
-  P void nagp::rts_gain_mfma_kernel<3>(nagp::Shape, nagp::Bufs, nagp::GainPar); P void nagp::rts_gain_mfma_kernel<4>(nagp::Shape, nagp::Bufs, nagp::GainPar);   \
-  P void nagp::rts_gain_mfma_kernel<5>(nagp::Shape, nagp::Bufs, nagp::GainPar); P void nagp::rts_gain_mfma_kernel<6>(nagp::Shape, nagp::Bufs, nagp::GainPar);   \
-  P void nagp::rts_gain_mfma_kernel<7>(nagp::Shape, nagp::Bufs, nagp::GainPar); P void nagp::rts_gain_mfma_kernel<8>(nagp::Shape, nagp::Bufs, nagp::GainPar);   \
-  P void nagp::rts_gain_mfma_kernel<9>(nagp::Shape, nagp::Bufs, nagp::GainPar); P void nagp::rts_gain_mfma_kernel<10>(nagp::Shape, nagp::Bufs, nagp::GainPar);
+  P void nagp::rts_gain_mfma_kernel<1, false>(nagp::Shape, nagp::Bufs, nagp::GainPar); \
+  P void nagp::rts_gain_mfma_kernel<2, false>(nagp::Shape, nagp::Bufs, nagp::GainPar); \
+  P void nagp::rts_gain_mfma_kernel<3, false>(nagp::Shape, nagp::Bufs, nagp::GainPar); \
+  P void nagp::rts_gain_mfma_kernel<4, false>(nagp::Shape, nagp::Bufs, nagp::GainPar); \
+  P void nagp::rts_gain_mfma_kernel<5, false>(nagp::Shape, nagp::Bufs, nagp::GainPar); \
+  P void nagp::rts_gain_mfma_kernel<6, false>(nagp::Shape, nagp::Bufs, nagp::GainPar); \
+  P void nagp::rts_gain_mfma_kernel<7, false>(nagp::Shape, nagp::Bufs, nagp::GainPar); \
+  P void nagp::rts_gain_mfma_kernel<8, false>(nagp::Shape, nagp::Bufs, nagp::GainPar); \
+  P void nagp::rts_gain_mfma_kernel<9, false>(nagp::Shape, nagp::Bufs, nagp::GainPar); \
+  P void nagp::rts_gain_mfma_kernel<10, false>(nagp::Shape, nagp::Bufs, nagp::GainPar);
+#define NAGP_LIST_GAINI(P)                                                                                                 \
+  P void nagp::rts_gain_mfma_kernel<1, true>(nagp::Shape, nagp::Bufs, nagp::GainPar); \
+  P void nagp::rts_gain_mfma_kernel<2, true>(nagp::Shape, nagp::Bufs, nagp::GainPar); \
+  P void nagp::rts_gain_mfma_kernel<3, true>(nagp::Shape, nagp::Bufs, nagp::GainPar); \
+  P void nagp::rts_gain_mfma_kernel<4, true>(nagp::Shape, nagp::Bufs, nagp::GainPar); \
+  P void nagp::rts_gain_mfma_kernel<5, true>(nagp::Shape, nagp::Bufs, nagp::GainPar); \
+  P void nagp::rts_gain_mfma_kernel<6, true>(nagp::Shape, nagp::Bufs, nagp::GainPar); \
+  P void nagp::rts_gain_mfma_kernel<7, true>(nagp::Shape, nagp::Bufs, nagp::GainPar); \
+  P void nagp::rts_gain_mfma_kernel<8, true>(nagp::Shape, nagp::Bufs, nagp::GainPar); \
+  P void nagp::rts_gain_mfma_kernel<9, true>(nagp::Shape, nagp::Bufs, nagp::GainPar); \
+  P void nagp::rts_gain_mfma_kernel<10, true>(nagp::Shape, nagp::Bufs, nagp::GainPar);
 
 // MFMA smoother passes for 96 < Sp <= 160
 #define NAGP_LIST_BIG_N(P, NTL)                                                                                            \
@@ -155,4 +171,4 @@
 
 #define NAGP_LIST_ALL(P)                                                                                                   \
   NAGP_LIST_GF_ADF1(P) NAGP_LIST_GF_ADF2(P) NAGP_LIST_GF_ADF3(P) NAGP_LIST_GF_ADF4(P) NAGP_LIST_GF_ADF5(P)               \
-  NAGP_LIST_GF_SP12(P) NAGP_LIST_GF_SP34(P) NAGP_LIST_GF_SQ12(P) NAGP_LIST_GF_SQ34(P) NAGP_LIST_GF_REST(P) NAGP_LIST_SMOOTH(P) NAGP_LIST_SMOOTH8(P) NAGP_LIST_BIG(P) NAGP_LIST_GAINM(P) NAGP_LIST_FLM(P) NAGP_LIST_EP(P) NAGP_LIST_EPS(P) NAGP_LIST_EPQ(P) NAGP_LIST_IH0(P) NAGP_LIST_IH1(P) NAGP_LIST_IHA(P) NAGP_LIST_IHA8(P) NAGP_LIST_IHA8Q(P) NAGP_LIST_GF_A81(P) NAGP_LIST_GF_A82(P) NAGP_LIST_GF_A83(P)
+  NAGP_LIST_GF_SP12(P) NAGP_LIST_GF_SP34(P) NAGP_LIST_GF_SQ12(P) NAGP_LIST_GF_SQ34(P) NAGP_LIST_GF_REST(P) NAGP_LIST_SMOOTH(P) NAGP_LIST_SMOOTH8(P) NAGP_LIST_BIG(P) NAGP_LIST_GAINM(P) NAGP_LIST_GAINI(P) NAGP_LIST_FLM(P) NAGP_LIST_EP(P) NAGP_LIST_EPS(P) NAGP_LIST_EPQ(P) NAGP_LIST_IH0(P) NAGP_LIST_IH1(P) NAGP_LIST_IHA(P) NAGP_LIST_IHA8(P) NAGP_LIST_IHA8Q(P) NAGP_LIST_GF_A81(P) NAGP_LIST_GF_A82(P) NAGP_LIST_GF_A83(P)

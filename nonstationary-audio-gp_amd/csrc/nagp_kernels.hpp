@@ -796,6 +796,7 @@ struct GainPar {
   // early with late groups (nagp_api.hip: gain_map, NAGP_GAIN_MAP=1).  Measured WITHOUT effect -- the trailing phase is bound by the LDS
   // operand reads and the SIMDs' FP64 issue of ALL active tiles, not by the slowest wave (profiles/r04_gain_phases.txt): opt-in.
   signed char gmapB[2][12], gmapL[12]; int use_map;
+  const double* ainv;           // rts_gain_mfma_kernel<.., true>: [B][M][32] per block A^-1 (16) and A^-1 Q (16), zero padded (host: gain_inverse_blocks)
   unsigned long long* stamps;   // developer diagnostics (NAGP_STAMPS): cycles of thread 0 of every 64th workgroup per phase of rts_gain_kernel:
                 // [0] prologue (loads, B = PS A', PSkp, Delta) [1] diagonal tiles [2] column solves [3] trailing updates [4] backward
                 // solve [5] G store [6] workgroups sampled

@@ -1565,18 +1565,47 @@ def test_mfma_gain_kernel_equals_the_valu_gain_kernel(D, N):
         probs.append((blk, pr['W'], np.log(pr['w_lik']))); ys.append(y)
     mom = Mom('likModulatorNMFPower', p_cubature=3); d = np.array([0.6, 0.5])
     res = {}
-    for mode in ('mfma', 'valu'):
+    for mode in ('mfma', 'solve', 'valu'):      # the default (explicit-inverse form: these blocks of A are well conditioned), its solve form, the VALU kernel
         if mode == 'valu': os.environ['NAGP_NO_GAIN_MFMA'] = '1'
+        if mode == 'solve': os.environ['NAGP_GAIN_FORM'] = 'solve'
         try:
             plan = Plan(L.KIND_GF_EP, probs, T, mom=mom, ep_fraction=0.5, ep_damping=d, ep_itts=2, chunk=24)
             plan.upload(ys); plan.execute(); res[mode] = plan.download(); plan.close()
         finally:
-            os.environ.pop('NAGP_NO_GAIN_MFMA', None)
+            os.environ.pop('NAGP_NO_GAIN_MFMA', None); os.environ.pop('NAGP_GAIN_FORM', None)
     for q in range(2):
-        a, v = res['mfma'][q], res['valu'][q]
-        for f, tol in (('Eft', 1e-9), ('Varft', 1e-9), ('MS', 1e-9), ('lZ', 1e-9), ('ttau', 1e-7), ('tnu', 1e-7)):
-            assert rel(getattr(a, f), getattr(v, f)) < tol, (q, f)
-        assert relz(a.nlZ, v.nlZ) < 1e-10 and np.array_equal(a.counters, v.counters)
+        for mode in ('mfma', 'solve'):
+            a, v = res[mode][q], res['valu'][q]
+            for f, tol in (('Eft', 1e-9), ('Varft', 1e-9), ('MS', 1e-9), ('lZ', 1e-9), ('ttau', 1e-7), ('tnu', 1e-7)):
+                assert rel(getattr(a, f), getattr(v, f)) < tol, (q, f, mode)
+            assert relz(a.nlZ, v.nlZ) < 1e-10 and np.array_equal(a.counters, v.counters)
+    assert not np.array_equal(res['mfma'][0].MS, res['solve'][0].MS)      # (two different arithmetic routes: equal to rounding, not bit for bit)
+
+
+def test_gain_kernel_keeps_the_solve_form_when_a_block_of_A_is_badly_conditioned():
+    """The explicit-inverse form of the gain (G = A^-1 - A^-1 Q PSkp^-1) multiplies the rounding error of PSkp^-1 by |A_b^-1|; a sub-band
+    with a length-scale far below one sample has A_b ~ exp(-50) and the plan must keep the solve form.  Parity with the oracle at the
+    usual tolerance, and -- forced onto the inverse form (NAGP_GAIN_FORM=inv) -- visibly worse or not finite, which is what the guard is for."""
+    D, N, T = 6, 2, 80
+    pr = harness.nmf_problem(D, N, T, 8800)
+    p1 = pr['param1'].copy(); p1[D + 1] = 0.02          # length-scale of sub-band 1: 0.02 samples
+    blk = pss.ss_blocks_nmf(p1, pr['param2'], 'matern32', 'matern52')
+    mom = Mom('likModulatorNMFPower', p_cubature=5); d = 0.5 * np.ones(2)
+    w = pr['w'].copy(); w[1 + D + 1] = np.log(0.02)
+    t = np.arange(1, T + 1.0)
+    o = ogf.gf_ep_modulator_nmf(w, t, pr['y'], None, olik.Mom(olik.LIK_POWER_NMF, p=5), t, 'matern32', 'matern52', 1, D, N, 0.5, d, 2)
+    out = {}
+    for form in ('auto', 'inv'):
+        if form == 'inv': os.environ['NAGP_GAIN_FORM'] = 'inv'
+        try:
+            plan = Plan(L.KIND_GF_EP, [(blk, pr['W'], np.log(pr['w_lik']))], T, mom=mom, ep_fraction=0.5, ep_damping=d, ep_itts=2, chunk=24)
+            plan.upload([pr['y']]); plan.execute(); out[form] = plan.download()[0]; plan.close()
+        finally:
+            os.environ.pop('NAGP_GAIN_FORM', None)
+    assert rel(out['auto'].Eft, o[0]) < TOL_MEAN and rel(out['auto'].Varft, o[1]) < TOL_MEAN and relz(out['auto'].nlZ, o[5]['nlZ']) < TOL_LOGZ
+    with np.errstate(all='ignore'):      # (here A_b ~ 1e-36: A_b^-1 overflows the products and the forced inverse form returns NaN)
+        bad = np.max(np.abs(out['inv'].Eft - o[0])) / np.max(np.abs(o[0]))
+    assert not (bad < TOL_MEAN)
 
 
 @pytest.mark.parametrize('D,N,k1', [(3, 2, 'matern32'), (16, 3, 'matern32'), (22, 4, 'exp'), (32, 6, 'matern32')])

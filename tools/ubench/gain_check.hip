@@ -1,7 +1,7 @@
 // Standalone check and timing of rts_gain_mfma_kernel (nagp_gain_mfma.hpp) against a host computation in double: random SPD
 // filtered covariances in the compact layout of PF, block-diagonal A, Q; one launch over nk steps.  Developer tool.
 // build: hipcc -O3 --offload-arch=gfx950 -std=c++17 -I nonstationary-audio-gp_amd/csrc -I include -o tools/ubench/gain_check tools/ubench/gain_check.hip
-// run:   tools/ubench/gain_check [M=38] [nk=2048] [dpacked=1] [nbad=0: steps whose PSkp is made indefinite] [two=0: 2-state blocks]
+// run:   tools/ubench/gain_check [M=38] [nk=2048] [dpacked=1] [inv=0: 1 = the explicit-inverse form] [two=0: 2-state blocks]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -11,20 +11,21 @@
 using namespace nagp;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return 1; } } while (0)
 
-template <int N> static void launch(dim3 gr, size_t lds, const Shape& sh, const Bufs& b, const GainPar& gp) {
-  hipFuncSetAttribute(reinterpret_cast<const void*>(rts_gain_mfma_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((rts_gain_mfma_kernel<N>), gr, dim3(64 * (N + 1)), lds, 0, sh, b, gp);
+template <int N, bool INV> static void launch(dim3 gr, size_t lds, const Shape& sh, const Bufs& b, const GainPar& gp) {
+  hipFuncSetAttribute(reinterpret_cast<const void*>(rts_gain_mfma_kernel<N, INV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((rts_gain_mfma_kernel<N, INV>), gr, dim3(64 * (N + 1)), lds, 0, sh, b, gp);
 }
-static void launch_n(int ntl, dim3 gr, size_t lds, const Shape& sh, const Bufs& b, const GainPar& gp) {
-  switch (ntl) { case 1: launch<1>(gr, lds, sh, b, gp); break; case 2: launch<2>(gr, lds, sh, b, gp); break; case 3: launch<3>(gr, lds, sh, b, gp); break;
-    case 4: launch<4>(gr, lds, sh, b, gp); break; case 5: launch<5>(gr, lds, sh, b, gp); break; case 6: launch<6>(gr, lds, sh, b, gp); break;
-    case 7: launch<7>(gr, lds, sh, b, gp); break; case 8: launch<8>(gr, lds, sh, b, gp); break; case 9: launch<9>(gr, lds, sh, b, gp); break;
-    default: launch<10>(gr, lds, sh, b, gp); break; }
+template <bool INV> static void launch_n(int ntl, dim3 gr, size_t lds, const Shape& sh, const Bufs& b, const GainPar& gp) {
+  switch (ntl) { case 1: launch<1, INV>(gr, lds, sh, b, gp); break; case 2: launch<2, INV>(gr, lds, sh, b, gp); break; case 3: launch<3, INV>(gr, lds, sh, b, gp); break;
+    case 4: launch<4, INV>(gr, lds, sh, b, gp); break; case 5: launch<5, INV>(gr, lds, sh, b, gp); break; case 6: launch<6, INV>(gr, lds, sh, b, gp); break;
+    case 7: launch<7, INV>(gr, lds, sh, b, gp); break; case 8: launch<8, INV>(gr, lds, sh, b, gp); break; case 9: launch<9, INV>(gr, lds, sh, b, gp); break;
+    default: launch<10, INV>(gr, lds, sh, b, gp); break; }
 }
 
 int main(int argc, char** argv) {
   const int M = argc > 1 ? atoi(argv[1]) : 38, nk = argc > 2 ? atoi(argv[2]) : 2048, dpacked = argc > 3 ? atoi(argv[3]) : 1;
   const int two = argc > 5 ? atoi(argv[5]) : 0;
+  const int inv = argc > 4 ? atoi(argv[4]) : 0;      // 1: the explicit-inverse form (rts_gain_mfma_kernel<.., true>)
   const int dbg = argc > 6 ? atoi(argv[6]) : 0;
   Shape sh{};
   sh.M = M; sh.D = M - 2; sh.N = 2; sh.ntiles = M * M;
@@ -34,7 +35,7 @@ int main(int argc, char** argv) {
   const int T = nk + 1; sh.T = T;
   const int Sp = ((4 * M + 15) / 16) * 16, ntl = Sp / 16;
   const size_t pfs = pf_step_doubles(sh), gstep = gd_step_doubles(Sp, dpacked), SS = (size_t)Sp * Sp;
-  printf("M %d S %d Sp %d ntl %d nk %d dpacked %d  lds %zu bytes\n", M, S, Sp, ntl, nk, dpacked, gainm_lds_doubles(ntl, sh) * 8);
+  printf("M %d S %d Sp %d ntl %d nk %d dpacked %d form %s  lds %zu bytes\n", M, S, Sp, ntl, nk, dpacked, inv ? "explicit inverse" : "solves", gainm_lds_doubles(ntl, sh) * 8);
   srand(7);
   auto rnd = [] { return rand() / (double)RAND_MAX - 0.5; };
   // model: A, Q blocks (zero outside bs x bs)
@@ -79,14 +80,36 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&d_G, (size_t)nk * gstep * 8)); CK(hipMalloc(&d_d, (size_t)nk * S * 8)); CK(hipMalloc(&d_cnt, 32));
   CK(hipMemcpy(d_mdl, mdl.data(), mdl.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(d_PF, PF.data(), PF.size() * 8, hipMemcpyHostToDevice));
   CK(hipMemcpy(d_MF, MF.data(), MF.size() * 8, hipMemcpyHostToDevice)); CK(hipMemset(d_cnt, 0, 32)); CK(hipMemset(d_G, 0xff, (size_t)nk * gstep * 8));
+  // per block A^-1 and A^-1 Q (zero padded), as nagp_api.hip: gain_inverse_blocks
+  std::vector<double> ainv((size_t)M * 32, 0.0);
+  for (int m = 0; m < M; ++m) {
+    const int bs = sh.bsz[m];
+    double a[16], x[16];
+    for (int i = 0; i < 16; ++i) { a[i] = 0; x[i] = 0; }
+    for (int i = 0; i < bs; ++i) for (int j = 0; j < bs; ++j) a[4 * i + j] = mdl[mdl_A(sh) + m * 16 + 4 * i + j];
+    for (int i = 0; i < bs; ++i) x[4 * i + i] = 1.0;
+    for (int col = 0; col < bs; ++col) {      // Gauss-Jordan with partial pivoting
+      int piv = col; for (int r = col + 1; r < bs; ++r) if (fabs(a[4 * r + col]) > fabs(a[4 * piv + col])) piv = r;
+      for (int j = 0; j < 4; ++j) { std::swap(a[4 * col + j], a[4 * piv + j]); std::swap(x[4 * col + j], x[4 * piv + j]); }
+      const double d = 1.0 / a[4 * col + col];
+      for (int j = 0; j < 4; ++j) { a[4 * col + j] *= d; x[4 * col + j] *= d; }
+      for (int r = 0; r < bs; ++r) if (r != col) { const double f = a[4 * r + col]; for (int j = 0; j < 4; ++j) { a[4 * r + j] -= f * a[4 * col + j]; x[4 * r + j] -= f * x[4 * col + j]; } }
+    }
+    for (int i = 0; i < bs; ++i) for (int j = 0; j < bs; ++j) {
+      ainv[(size_t)m * 32 + 4 * i + j] = x[4 * i + j];
+      double w = 0; for (int l = 0; l < bs; ++l) w += x[4 * i + l] * mdl[mdl_Q(sh) + m * 16 + 4 * l + j];
+      ainv[(size_t)m * 32 + 16 + 4 * i + j] = w;
+    }
+  }
+  double* d_ainv; CK(hipMalloc(&d_ainv, ainv.size() * 8)); CK(hipMemcpy(d_ainv, ainv.data(), ainv.size() * 8, hipMemcpyHostToDevice));
   b.model = d_mdl; b.PF = d_PF; b.MF = d_MF; b.Gbuf = d_G; b.dbuf = d_d; b.counters = d_cnt; b.gpstride = 0;
-  GainPar gp{}; gp.k0 = 0; gp.nk = nk; gp.chunk = nk; gp.dense_sp = Sp; gp.dpacked = dpacked; gp.dbg = dbg;
+  GainPar gp{}; gp.k0 = 0; gp.nk = nk; gp.chunk = nk; gp.dense_sp = Sp; gp.dpacked = dpacked; gp.dbg = dbg; gp.ainv = d_ainv;
   unsigned long long* d_st; CK(hipMalloc(&d_st, 32 * 8)); CK(hipMemset(d_st, 0, 32 * 8)); gp.stamps = d_st;
   const size_t lds = gainm_lds_doubles(ntl, sh) * 8;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int rep = 0; rep < 3; ++rep) {
     hipEventRecord(e0);
-    launch_n(ntl, dim3((nk + 7) / 8 * 8, 1), lds, sh, b, gp);
+    if (inv) launch_n<true>(ntl, dim3((nk + 7) / 8 * 8, 1), lds, sh, b, gp); else launch_n<false>(ntl, dim3((nk + 7) / 8 * 8, 1), lds, sh, b, gp);
     hipEventRecord(e1); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double flop = 2.33 * (double)S * S * S * 2 * nk;

@@ -1,8 +1,8 @@
 """ORACLE (test infrastructure only -- never imported by the product path).
 
 CPU restatement of the reference's `mom` callbacks (tilted-distribution moments by cubature).
-PARITY UNPINNED (no reference fixtures); self-pinned by finite-difference checks in
-tests/test_oracle_lik.py.
+PARITY UNPINNED (no reference fixtures); self-pinned by tests/test_oracle_selfpins.py
+(test_mom_derivatives_vs_finite_differences, test_ep_with_gaussian_site_is_exact_gp_regression).
 
 Follows (file:line under /root/reference/matlab):
   likModulatorPower.m:25-100            (one modulator per sub-band, jitter 1e-8)

@@ -3,7 +3,7 @@
 CPU restatement of the reference's sigma-point / quadrature table builders.
 PARITY UNPINNED: the reference ships no golden vectors for these and MATLAB/Octave
 are not available, so this file is pinned only by its own mathematical
-self-checks (tests/test_oracle_selfpins.py: test_cubature_weights_and_polynomial_exactness, test_ut9_typo_is_reproduced).
+self-checks (tests/test_oracle_selfpins.py: test_cubature_polynomial_exactness, test_ut9_sign_typo_only_touches_centre_weight).
 
 Follows (file:line under /root/reference/matlab):
   symmetric-cubature-rules/utp_ws.m:3-14

@@ -96,7 +96,8 @@ def _tu_hash(f, extra=''):
     """hash of one translation unit: its own text, every header of csrc/ and include/nagp.h, the flags"""
     import hashlib
     h = hashlib.sha256(extra.encode())
-    names = [f] + sorted(x for x in os.listdir(CSRC) if x.endswith(('.hpp', '.h')))
+    # (nagp_api_*.hpp are the parts of the ONE host translation unit nagp_api.hip: no other unit includes them)
+    names = [f] + sorted(x for x in os.listdir(CSRC) if x.endswith(('.hpp', '.h')) and (f == 'nagp_api.hip' or not x.startswith('nagp_api_')))
     for n in names:
         with open(os.path.join(CSRC, n), 'rb') as fh:
             h.update(n.encode()); h.update(fh.read())

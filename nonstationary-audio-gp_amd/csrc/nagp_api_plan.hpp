@@ -254,8 +254,13 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
   if (o->kind != NAGP_KIND_IHGP) {
     {   // FP64 MFMA smoother for padded dimensions up to 96 (set NAGP_NO_MFMA=1 to force the VALU passes)
       const int Sp = ((4 * sh.M + 15) / 16) * 16;
-      if (Sp <= 96 && !dev_env("NAGP_NO_MFMA")) p->mfma_sp = Sp;
-      // 96 < Sp <= 160: state and G no longer fit LDS side by side; column-owner kernels
+      // Sp >= 80 (five tile columns and more): the column-owner kernels of nagp_mfma_big.hpp -- one wave per tile column, the symmetric state
+      // in LDS as its lower tiles, G streamed, two workgroups per CU at Sp = 80 / 96; below that the four-wave kernels with G and the state
+      // side by side in LDS.  (Round 5: at Sp = 80 the column-owner passes take cfg2_batch from 508 to 444 ms, span passes 428 -> 235 ms, once
+      // their span count knows that a CU holds two of their workgroups; NAGP_BIG_MIN_SP=97 restores the round-4 split.)
+      const int big_min = dev_env("NAGP_BIG_MIN_SP") ? std::max(80, atoi(dev_env("NAGP_BIG_MIN_SP"))) : 80;
+      if (Sp < big_min && Sp <= 96 && !dev_env("NAGP_NO_MFMA")) p->mfma_sp = Sp;
+      // Sp <= 160: state and G do not fit LDS side by side (or, from Sp = 80, are better off apart); column-owner kernels
       // (a sweep that stores the smoothed covariances runs the VALU passes instead: see run_smoother)
       else if (Sp <= 160 && !dev_env("NAGP_NO_MFMA") && !dev_env("NAGP_NO_MFMA_BIG")) { p->mfma_sp = Sp; p->big_sp = 1; }
     }
@@ -745,7 +750,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
   if (p->big_sp) {
 #define SETB(N) PLAN_TRY(set_lds(rts_big_kernel<N, 0>, p->lds_mfma)); PLAN_TRY(set_lds(rts_big_kernel<N, 1>, p->lds_mfma)); \
     PLAN_TRY(set_lds(rts_big_kernel<N, 2>, p->lds_mfma)); PLAN_TRY(set_lds(rts_big_phi_kernel<N>, p->lds_mfma))
-    switch (p->mfma_sp / 16) { case 7: SETB(7); break; case 8: SETB(8); break; case 9: SETB(9); break; default: SETB(10); break; }
+    switch (p->mfma_sp / 16) { case 5: SETB(5); break; case 6: SETB(6); break; case 7: SETB(7); break; case 8: SETB(8); break; case 9: SETB(9); break; default: SETB(10); break; }
 #undef SETB
   } else if (p->mfma_sp) {
 #define SETM(N) PLAN_TRY(set_lds(rts_compose_mfma_kernel<N>, p->lds_mfma)); PLAN_TRY(set_lds(rts_boundary_mfma_kernel<N>, p->lds_mfma)); PLAN_TRY(set_lds(rts_apply_mfma_kernel<N>, p->lds_mfma))

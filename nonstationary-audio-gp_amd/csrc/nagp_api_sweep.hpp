@@ -144,7 +144,8 @@ static void sweep_begin(nagp_plan* p, SweepCtx& sc, bool write_PSs) {
       ns = (int)std::lround((double)nk / Lstar);
       ns = std::max(1, std::min(std::min(ns, p->ns_max), (nk + 7) / 8));
     } else if (sc.mode == SM_BIG) {
-      const int n_cu = std::max(32, 256 - p->B);
+      const int per_cu = std::max(1, (int)((160 * 1024) / std::max<size_t>(p->lds_mfma, 1)));      // workgroups of the column-owner passes a CU holds (LDS)
+      const int n_cu = std::max(32, 256 - p->B) * per_cu;
       double best = 1e300; ns = 1;
       for (int c = 1; c <= std::max(1, std::min(p->ns_max, (nk + 7) / 8)); ++c) {
         const int L = (nk + c - 1) / c, cc = (nk + L - 1) / L;
@@ -290,7 +291,7 @@ static int launch_compose_chunk(nagp_plan* p, const SweepCtx& sc, int c, int slo
 #define LB(N) do { \
       hipLaunchKernelGGL((rts_big_phi_kernel<N>), gr, bl, p->lds_mfma, st, sh, b, mp); \
       hipLaunchKernelGGL((rts_big_kernel<N, 0>), gr, bl, p->lds_mfma, st, sh, b, mp); } while (0)
-    switch (ntl) { case 7: LB(7); break; case 8: LB(8); break; case 9: LB(9); break; default: LB(10); break; }
+    switch (ntl) { case 5: LB(5); break; case 6: LB(6); break; case 7: LB(7); break; case 8: LB(8); break; case 9: LB(9); break; default: LB(10); break; }
 #undef LB
   } else if (sc.mode == SM_MFMA) {
     MfmaPar mp = mfma_par(p, sc, c, slot);
@@ -321,7 +322,7 @@ static int launch_boundary_chunk(nagp_plan* p, const SweepCtx& sc, int c, int sl
     const int ntl = p->mfma_sp / 16;
     dim3 bl(64 * ntl);
 #define LB(N) hipLaunchKernelGGL((rts_big_kernel<N, 1>), g2, bl, p->lds_mfma, st, sh, b, mp)
-    switch (ntl) { case 7: LB(7); break; case 8: LB(8); break; case 9: LB(9); break; default: LB(10); break; }
+    switch (ntl) { case 5: LB(5); break; case 6: LB(6); break; case 7: LB(7); break; case 8: LB(8); break; case 9: LB(9); break; default: LB(10); break; }
 #undef LB
   } else if (sc.mode == SM_MFMA) {
     MfmaPar mp = mfma_par(p, sc, c, slot);
@@ -349,7 +350,7 @@ static int launch_apply_chunk(nagp_plan* p, const SweepCtx& sc, int c, int slot,
     const int ntl = p->mfma_sp / 16;
     dim3 gr(g.ns, p->B), bl(64 * ntl);
 #define LB(N) hipLaunchKernelGGL((rts_big_kernel<N, 2>), gr, bl, p->lds_mfma, st, sh, b, mp)
-    switch (ntl) { case 7: LB(7); break; case 8: LB(8); break; case 9: LB(9); break; default: LB(10); break; }
+    switch (ntl) { case 5: LB(5); break; case 6: LB(6); break; case 7: LB(7); break; case 8: LB(8); break; case 9: LB(9); break; default: LB(10); break; }
 #undef LB
   } else if (sc.mode == SM_MFMA) {
     MfmaPar mp = mfma_par(p, sc, c, slot);
@@ -425,7 +426,7 @@ static int launch_apply_merged(nagp_plan* p, const SweepCtx& sc, int n_own, hipS
     const int ntl = p->mfma_sp / 16;
     dim3 bl(64 * ntl);
 #define LB(N) hipLaunchKernelGGL((rts_big_kernel<N, 2>), gr, bl, p->lds_mfma, st, sh, b, mp)
-    switch (ntl) { case 7: LB(7); break; case 8: LB(8); break; case 9: LB(9); break; default: LB(10); break; }
+    switch (ntl) { case 5: LB(5); break; case 6: LB(6); break; case 7: LB(7); break; case 8: LB(8); break; case 9: LB(9); break; default: LB(10); break; }
 #undef LB
   } else if (sc.mode == SM_MFMA) {
     MfmaPar mp = mfma_par(p, sc, 0, sc.slot_of[0]); mp.tab = p->h_tab; mp.ntab = n_own;

@@ -102,7 +102,7 @@
   P void nagp::rts_big_kernel<NTL, 1>(nagp::Shape, nagp::Bufs, nagp::MfmaPar);                                           \
   P void nagp::rts_big_kernel<NTL, 2>(nagp::Shape, nagp::Bufs, nagp::MfmaPar);                                           \
   P void nagp::rts_big_phi_kernel<NTL>(nagp::Shape, nagp::Bufs, nagp::MfmaPar);
-#define NAGP_LIST_BIG(P) NAGP_LIST_BIG_N(P, 7) NAGP_LIST_BIG_N(P, 8) NAGP_LIST_BIG_N(P, 9) NAGP_LIST_BIG_N(P, 10)
+#define NAGP_LIST_BIG(P) NAGP_LIST_BIG_N(P, 5) NAGP_LIST_BIG_N(P, 6) NAGP_LIST_BIG_N(P, 7) NAGP_LIST_BIG_N(P, 8) NAGP_LIST_BIG_N(P, 9) NAGP_LIST_BIG_N(P, 10)
 
 // site refresh and mom on its own
 #define NAGP_LIST_EP_V(P, V)                                                                                               \

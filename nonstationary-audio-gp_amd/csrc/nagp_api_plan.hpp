@@ -39,9 +39,14 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
   sh.S = m0.S; sh.M = m0.M; sh.D = m0.D; sh.N = (o->lik_kind == NAGP_LIK_POWER && !ekf) ? m0.D : m0.N;
   sh.T = T; sh.ntiles = m0.M * m0.M;
   for (int n = 0; n <= m0.M; ++n) sh.off[n] = m0.block_offsets[n];
+  sh.BS = 4; sh.Ms = m0.M;
+  for (int n = 0; n < MAXM; ++n) sh.part[n] = -1;
+  const bool ih_kind = (o->kind == NAGP_KIND_IHGP);
   for (int n = 0; n < m0.M; ++n) {
     sh.bsz[n] = sh.off[n + 1] - sh.off[n];
-    if (sh.bsz[n] < 1 || sh.bsz[n] > 4) { const int bsn = sh.bsz[n]; delete p; FAIL(NAGP_EUNSUPPORTED, "block %d has size %d (supported: 1..4)", n, bsn); }
+    // blocks of 5 .. 8 states (Matern-5/2 and -7/2 sub-bands): the infinite-horizon plans keep them whole (BS = 8)
+    if (sh.bsz[n] < 1 || sh.bsz[n] > (ih_kind ? 8 : 4)) { const int bsn = sh.bsz[n]; delete p; FAIL(NAGP_EUNSUPPORTED, "block %d has size %d (supported: 1..%d)", n, bsn, ih_kind ? 8 : 4); }
+    if (sh.bsz[n] > 4) sh.BS = 8;
   }
   if (sh.off[0] != 0 || sh.off[m0.M] != m0.S) { delete p; FAIL(NAGP_EINVAL, "block_offsets do not span 0..S"); }
   for (int q = 0; q < B; ++q) {   // every pointer the packing below dereferences
@@ -109,15 +114,15 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
   for (int q = 0; q < B; ++q) {
     const nagp_model& mq = models[q];
     double* d = hm.data() + (size_t)q * msz;
-    const int S = sh.S;
+    const int S = sh.S, BSr = sh.BS, BS2 = sh.BS * sh.BS;
     for (int n = 0; n < sh.M; ++n) {
       const int o0 = sh.off[n], bs = sh.bsz[n];
       for (int i = 0; i < bs; ++i)
         for (int j = 0; j < bs; ++j) {
           const size_t src = (size_t)(o0 + i) + (size_t)S * (o0 + j);   // column-major
-          d[mdl_A(sh) + (size_t)n * 16 + 4 * i + j] = mq.A[src];
-          d[mdl_Q(sh) + (size_t)n * 16 + 4 * i + j] = mq.Q[src];
-          d[mdl_P(sh) + (size_t)n * 16 + 4 * i + j] = mq.Pinf[src];
+          d[mdl_A(sh) + (size_t)n * BS2 + BSr * i + j] = mq.A[src];
+          d[mdl_Q(sh) + (size_t)n * BS2 + BSr * i + j] = mq.Q[src];
+          d[mdl_P(sh) + (size_t)n * BS2 + BSr * i + j] = mq.Pinf[src];
         }
       d[mdl_h(sh) + n] = mq.h_val[n];
       p->h_hval[(size_t)q * sh.M + n] = mq.h_val[n];
@@ -459,15 +464,15 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
         for (int g = 0; g < NG; ++g) {
           const double* ppr = pp + (size_t)g * bs * bs;          // column-major bs x bs
           d[itab_hph(sh, NG) + (size_t)n * NG + g] = h * h * ppr[0];
-          for (int i = 0; i < bs; ++i) d[itab_wcol(sh, NG) + ((size_t)n * NG + g) * 4 + i] = h * ppr[i];
+          for (int i = 0; i < bs; ++i) d[itab_wcol(sh, NG) + ((size_t)n * NG + g) * sh.BS + i] = h * ppr[i];
           const double* pgr = pg + (size_t)g * 2 * bs * bs;      // [PS2(:)' G(:)']
           d[itab_v(sh, NG) + (size_t)n * NG + g] = h * h * pgr[0];
           for (int i = 0; i < bs; ++i)
             for (int j = 0; j < bs; ++j)
-              d[itab_g(sh, NG) + ((size_t)n * NG + g) * 16 + 4 * i + j] = pgr[bs * bs + i + bs * j];
+              d[itab_g(sh, NG) + ((size_t)n * NG + g) * sh.BS * sh.BS + sh.BS * i + j] = pgr[bs * bs + i + bs * j];
         }
         d[itab_hph0(sh, NG) + n] = h * h * mq.Pinf[(size_t)o0 + (size_t)sh.S * o0];
-        for (int i = 0; i < bs; ++i) d[itab_wcol0(sh, NG) + (size_t)n * 4 + i] = h * mq.Pinf[(size_t)(o0 + i) + (size_t)sh.S * o0];
+        for (int i = 0; i < bs; ++i) d[itab_wcol0(sh, NG) + (size_t)n * sh.BS + i] = h * mq.Pinf[(size_t)(o0 + i) + (size_t)sh.S * o0];
       }
     }
     PLAN_TRY(dalloc(p, &p->d_tab, ht.size(), false));
@@ -488,7 +493,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     p->DG_f = pick_DG(o->lik_kind, o->n_pts, p->NT_ih, sh.D, o->cub_dim);
     MomCfg t = mc; t.DG = p->DG_f; t.cache_tabs = 1; t.store_a = (o->lik_kind == NAGP_LIK_POWER_NMF_SQRT) ? 1 : 0;
     p->kb_ih = IH_KB;
-    if (p->src_all.n_src >= 2) {   // block-structured Wnmf: the tuple tables must be resident (a shorter I/O ring makes room)
+    if (p->src_all.n_src >= 2 && sh.BS == 4) {   // block-structured Wnmf: the tuple tables must be resident (a shorter I/O ring makes room)
       t.src = p->src_all;
       while (p->kb_ih > 4 && ihgp_filter_lds_doubles(sh, t, p->tb.NG, 0, p->kb_ih) * sizeof(double) > 156 * 1024) p->kb_ih /= 2;
       if (ihgp_filter_lds_doubles(sh, t, p->tb.NG, 0, p->kb_ih) * sizeof(double) <= 156 * 1024) p->src_f = 1;
@@ -502,7 +507,8 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     p->lds_ih = ihgp_filter_lds_doubles(sh, t, p->tb.NG, p->hph_lds, p->kb_ih) * sizeof(double);
     if (dev_env("NAGP_STAMPS")) fprintf(stderr, "[nagp plan] ihgp filter: LDS %zu B, hph table in LDS %d, cubature tables in LDS %d, block-structured mom %d, mom LDS %zu B\n", p->lds_ih, p->hph_lds, p->cache_f, p->src_f, mom_lds_doubles(t) * sizeof(double));
     // the ADF sweep in the sparse-point form (ihgp_adf_kernel): plain NMF likelihood, <= 320 sigma points, unstructured Wnmf
-    if (p->sp.enabled && !p->src_f && sh.M <= 64 && sh.D <= 4 * MSP_DT && o->n_pts <= MSP_NT + 64 && (o->n_pts + 3) / 4 <= MSP_NW * MSP_NST) {
+    // (plans with a block of 5 .. 8 states, BS = 8: the general kernels only -- ihgp_filter_kernel<MV, false, 8> for every sweep, ihgp_scan_kernel<8> backward)
+    if (sh.BS == 4 && p->sp.enabled && !p->src_f && sh.M <= 64 && sh.D <= 4 * MSP_DT && o->n_pts <= MSP_NT + 64 && (o->n_pts + 3) / 4 <= MSP_NW * MSP_NST) {
       p->kb_sp = IH_KB; p->hph_sp = 1;
       if (const char* e = dev_env("NAGP_IH_KB")) p->kb_sp = std::max(1, std::min(IH_KB, atoi(e)));   // developer switch: steps per I/O block
       auto need = [&]() { return ihgp_adf_lds_doubles(sh, o->cub_dim, p->tb.NG, p->hph_sp, p->kb_sp) * sizeof(double) + 16; };
@@ -537,7 +543,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
       }
     }
     // likModulatorPreCalcwn: the role-specialised sweep of nagp_momsq.hpp
-    if (p->sq_ok && !p->src_f && sh.M <= 64) {
+    if (sh.BS == 4 && p->sq_ok && !p->src_f && sh.M <= 64) {
       p->kb_sq = IH_KB; p->hph_sq = 1;
       if (const char* e = dev_env("NAGP_IH_KB")) p->kb_sq = std::max(1, std::min(IH_KB, atoi(e)));
       auto needq = [&]() { return ihgp_adf8sq_lds_doubles(sh, o->cub_dim, p->tb.NG, p->hph_sq, p->kb_sq) * sizeof(double) + 16; };
@@ -556,9 +562,11 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     if (dev_env("NAGP_STAMPS")) fprintf(stderr, "[nagp plan] ihgp ADF sweep in the sparse-point form: %d (LDS %zu B, ring %d steps, hph table in LDS %d), role-specialised waves %d (LDS %zu B), packed MFMA steps %d\n", p->sp_ih, p->lds_sp, p->kb_sp, p->hph_sp, p->sp_ih8, p->lds_sp8, p->sp_pack);
 #define SL(V) PLAN_TRY(set_lds(ihgp_filter_kernel<V, false>, p->lds_ih))
 #define SLS(V) PLAN_TRY(set_lds(ihgp_filter_kernel<V, true>, p->lds_ih))
-    if (p->src_f) { NAGP_MV_SWITCH9(mom_variant(mc), SLS) } else { NAGP_MV_SWITCH9(mom_variant(mc), SL) }
+#define SL8(V) PLAN_TRY(set_lds(ihgp_filter_kernel<V, false, 8>, p->lds_ih))
+    if (sh.BS == 8) { NAGP_MV_SWITCH9(mom_variant(mc), SL8) } else if (p->src_f) { NAGP_MV_SWITCH9(mom_variant(mc), SLS) } else { NAGP_MV_SWITCH9(mom_variant(mc), SL) }
 #undef SL
 #undef SLS
+#undef SL8
   } else {
     if (!ekf) p->DG_f = pick_DG(o->lik_kind, o->n_pts, p->NT_a, sh.D, o->cub_dim);
     MomCfg t = mc; t.DG = p->DG_f; t.cache_tabs = ekf ? 0 : 1; t.store_a = (!ekf && o->lik_kind == NAGP_LIK_POWER_NMF_SQRT) ? 1 : 0;

@@ -778,8 +778,9 @@ static int exec_ihgp(nagp_plan* p) {
   for (int itt = 1; itt <= I; ++itt) {
     // forward: sweep 1 is the sequential ADF filter; later sweeps have fixed sites for k < T-1 (an affine
     // recursion, run parallel in time) and one ADF step at k = T-1
-    if (itt > 1) RUN(affine(0, sh.T - 1, itt));
-    IhgpPar ip{itt, p->damping[itt - 1], itt == 1 ? 1 : 0, (itt == 1) ? (int64_t)0 : (int64_t)(sh.T - 1)};
+    const bool seq = sh.BS == 8;      // blocks of 5 .. 8 states: the sequential kernels do every sweep (the affine scans hold 4 x 4 maps)
+    if (itt > 1 && !seq) RUN(affine(0, sh.T - 1, itt));
+    IhgpPar ip{itt, p->damping[itt - 1], itt == 1 ? 1 : 0, (itt == 1 || seq) ? (int64_t)0 : (int64_t)(sh.T - 1)};
     ip.hph_lds = p->hph_lds; ip.kb = p->kb_ih;
     if (const char* e = dev_env("NAGP_STAMP_WORKER")) ip.dbg_wave = atoi(e);
     ip.w_old = 1.0 - ip.ep_damp; ip.w_new = mix ? ip.ep_damp / o.ep_fraction : ip.ep_damp; ip.mom_alpha = mix ? o.ep_fraction : 1.0;
@@ -802,6 +803,10 @@ static int exec_ihgp(nagp_plan* p) {
         else switch (mcf.cdim) { case 1: LA(1); break; case 2: LA(2); break; case 3: LA(3); break; case 4: LA(4); break; case 5: LA(5); break; case 6: LA(6); break; default: LA(7); break; }
 #undef LA
 #undef LA8
+      } else if (seq) {
+#define LI8(V) hipLaunchKernelGGL((ihgp_filter_kernel<V, false, 8>), dim3(B), dim3(p->NT_ih), p->lds_ih, p->stream, sh, p->b, mcf, p->tb, ip)
+        NAGP_MV_SWITCH9(mom_variant(mcf), LI8)
+#undef LI8
       } else if (p->src_f) { NAGP_MV_SWITCH9(mom_variant(mcf), LIS) } else { NAGP_MV_SWITCH9(mom_variant(mcf), LI) }
 #undef LI
 #undef LIS
@@ -811,10 +816,11 @@ static int exec_ihgp(nagp_plan* p) {
     RUN(seed_last_step(p));
     // backward mean recursion (parallel in time); red[1], red[2] = maxDiffM, maxDiffP
     hipLaunchKernelGGL(zero_maxdiff_kernel, dim3((B + 255) / 256), dim3(256), 0, p->stream, p->b.red, B);
-    if (sh.T > 1) RUN(affine(1, sh.T - 1, itt));
-    else {   // no smoothing step: P = zeros (ihgp_ep_modulator_nmf.m:364) -> maxDiffP = |H PSP H'|
+    if (sh.T > 1 && !seq) RUN(affine(1, sh.T - 1, itt));
+    else {   // T = 1, no smoothing step: P = zeros (ihgp_ep_modulator_nmf.m:364) -> maxDiffP = |H PSP H'|   (or a plan of the sequential kernels)
       Timed t(p, NAGP_K_SCAN);
-      hipLaunchKernelGGL(ihgp_scan_kernel, dim3(B), dim3(64), 0, p->stream, sh, p->b, p->tb, p->d_vprev);
+      if (seq) hipLaunchKernelGGL(ihgp_scan_kernel<8>, dim3(B), dim3(64), 0, p->stream, sh, p->b, p->tb, p->d_vprev);
+      else hipLaunchKernelGGL(ihgp_scan_kernel<4>, dim3(B), dim3(64), 0, p->stream, sh, p->b, p->tb, p->d_vprev);
     }
     if (itt < I) {
       RUN(zero_async(p, p->d_lZs, (size_t)B * sh.T * sizeof(double)));

@@ -12,9 +12,9 @@ namespace nagp {
 
 // Device look-up tables of ONE problem (all doubles), derived on the host from PPlist / PGlist:
 //   hph[M][NG]      h_n^2 * PP(1,1)             (diag(H*PP*H'))
-//   wcol[M][NG][4]  h_n * PP(:,1)               (W(ii,n) = PP(ii,ii) * H(n,ii)')
-//   hph0[M], wcol0[M][4]  the same from Pinf (k = 1 of the reference uses PP = Pinf)
-//   gtab[M][NG][16] smoother gain block G (row-major, zero padded)
+//   wcol[M][NG][BS] h_n * PP(:,1)               (W(ii,n) = PP(ii,ii) * H(n,ii)')          BS = Shape::BS: 4, or 8 when a block has 5 .. 8 states
+//   hph0[M], wcol0[M][BS] the same from Pinf (k = 1 of the reference uses PP = Pinf)
+//   gtab[M][NG][BS*BS] smoother gain block G (row-major, zero padded)
 //   vtab[M][NG]     h_n^2 * PS2(1,1)            (diag(H*P*H') of the looked-up smoother covariance)
 struct IhgpTabs {
   int NG;
@@ -25,10 +25,10 @@ struct IhgpTabs {
 };
 __host__ __device__ inline size_t itab_hph(const Shape&, int) { return 0; }
 __host__ __device__ inline size_t itab_wcol(const Shape& s, int NG) { return (size_t)s.M * NG; }
-__host__ __device__ inline size_t itab_hph0(const Shape& s, int NG) { return (size_t)s.M * NG * 5; }
-__host__ __device__ inline size_t itab_wcol0(const Shape& s, int NG) { return (size_t)s.M * NG * 5 + s.M; }
-__host__ __device__ inline size_t itab_g(const Shape& s, int NG) { return (size_t)s.M * NG * 5 + 5 * (size_t)s.M; }
-__host__ __device__ inline size_t itab_v(const Shape& s, int NG) { return itab_g(s, NG) + (size_t)s.M * NG * 16; }
+__host__ __device__ inline size_t itab_hph0(const Shape& s, int NG) { return (size_t)s.M * NG * (1 + s.BS); }
+__host__ __device__ inline size_t itab_wcol0(const Shape& s, int NG) { return (size_t)s.M * NG * (1 + s.BS) + s.M; }
+__host__ __device__ inline size_t itab_g(const Shape& s, int NG) { return (size_t)s.M * NG * (1 + s.BS) + (1 + s.BS) * (size_t)s.M; }
+__host__ __device__ inline size_t itab_v(const Shape& s, int NG) { return itab_g(s, NG) + (size_t)s.M * NG * s.BS * s.BS; }
 __host__ __device__ inline size_t itab_size(const Shape& s, int NG) { return itab_v(s, NG) + (size_t)s.M * NG; }
 
 // [~,ind] = min(abs(r-R)): first minimiser; NaN / +-Inf distances everywhere -> index 0 (SURVEY C-4)
@@ -117,7 +117,8 @@ __device__ __forceinline__ int nearest_idx_lds(const double* r, int NG, double l
 // coalesced transfers once per block, so the sequential loop body contains no global-memory waits
 // except the (L2-resident) table gather.
 // SRC: the block-structured mom path (source-separation mixtures) and a run-time ring depth; compiled out otherwise
-template <int MV, bool SRC>
+// BS: doubles per block row in the packed model and the tables (4; 8 for plans with a block of 5 .. 8 states)
+template <int MV, bool SRC, int BS = 4>
 __global__ void __launch_bounds__(MV >= 9 ? 512 : 256) ihgp_filter_kernel(Shape sh, Bufs b, MomCfg mc, IhgpTabs tb, IhgpPar ip) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int tid = threadIdx.x, NT = blockDim.x;
@@ -161,22 +162,28 @@ __global__ void __launch_bounds__(MV >= 9 ? 512 : 256) ihgp_filter_kernel(Shape 
   // thread n < M owns block n
   const int n = tid;
   const bool act = n < M;
-  double A4[16], mreg[4] = {0, 0, 0, 0};
+  double A4[BS * BS], mreg[BS];
+#pragma unroll
+  for (int i = 0; i < BS; ++i) mreg[i] = 0.0;
   double hn = 0.0;
   int o = 0, bs = 0;
   if (act) {
-    tile_load(A4, mdl + mdl_A(sh) + (size_t)n * 16);
+    if constexpr (BS == 4) tile_load(A4, mdl + mdl_A(sh) + (size_t)n * 16);
+    else {
+#pragma unroll
+      for (int e = 0; e < BS * BS; ++e) A4[e] = mdl[mdl_A(sh) + (size_t)n * BS * BS + e];
+    }
     hn = mdl[mdl_h(sh) + n];
     o = ioff[n]; bs = ibsz[n];
     if (ip.k_start > 0) {      // continue from the filtered mean of the previous step
       const double* mp = b.MF + ((size_t)pb * T + (ip.k_start - 1)) * S;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < BS; ++i)
         if (i < bs) mreg[i] = mp[o + i];
     } else if (ip.itt > 1) {   // m is NOT reset between sweeps (SURVEY C-22): smoothed mean at k=0
       const double* ms0 = b.MS + (size_t)pb * T * S;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < BS; ++i)
         if (i < bs) mreg[i] = ms0[o + i];
     }
   }
@@ -203,25 +210,27 @@ __global__ void __launch_bounds__(MV >= 9 ? 512 : 256) ihgp_filter_kernel(Shape 
     for (int kk = 0; kk < nb; ++kk) {
       const int64_t k = k0 + kk;
       const double yk = ry[kk];
-      double hph = 0.0, wc[4] = {0, 0, 0, 0}, Am[4] = {0, 0, 0, 0}, fmun = 0.0;
+      double hph = 0.0, wc[BS], Am[BS], fmun = 0.0;
+#pragma unroll
+      for (int i = 0; i < BS; ++i) { wc[i] = 0.0; Am[i] = 0.0; }
       if (act) {
         if (k > 0) {
           const int idx = nearest_idx_lds(rg, NG, tb.lr0, tb.inv_dlr, Rprev);
           hph = ip.hph_lds ? thph[n * NG + idx] : tab[itab_hph(sh, NG) + (size_t)n * NG + idx];
-          const double* w = tab + itab_wcol(sh, NG) + ((size_t)n * NG + idx) * 4;
+          const double* w = tab + itab_wcol(sh, NG) + ((size_t)n * NG + idx) * BS;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) wc[i] = w[i];
+          for (int i = 0; i < BS; ++i) wc[i] = w[i];
         } else {
           hph = tab[itab_hph0(sh, NG) + n];
-          const double* w = tab + itab_wcol0(sh, NG) + (size_t)n * 4;
+          const double* w = tab + itab_wcol0(sh, NG) + (size_t)n * BS;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) wc[i] = w[i];
+          for (int i = 0; i < BS; ++i) wc[i] = w[i];
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < BS; ++i) {
           double a = 0.0;
 #pragma unroll
-          for (int l = 0; l < 4; ++l) a = fma(A4[4 * i + l], mreg[l], a);
+          for (int l = 0; l < BS; ++l) a = fma(A4[BS * i + l], mreg[l], a);
           Am[i] = a;
         }
         fmun = hn * Am[0];
@@ -253,15 +262,15 @@ __global__ void __launch_bounds__(MV >= 9 ? 512 : 256) ihgp_filter_kernel(Shape 
         if (tnew == 0.0) {
           Rn = INFINITY;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) mreg[i] = Am[i];
+          for (int i = 0; i < BS; ++i) mreg[i] = Am[i];
         } else {
           const double den = hph + Rn;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) mreg[i] = Am[i] + (wc[i] / den) * (ys - fmun);
+          for (int i = 0; i < BS; ++i) mreg[i] = Am[i] + (wc[i] / den) * (ys - fmun);
         }
         rtt[kk * M + n] = tnew; rtn[kk * M + n] = nnew; rR[kk * M + n] = Rn;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < BS; ++i)
           if (i < bs) rMF[(size_t)kk * S + o + i] = mreg[i];
         rfm[kk * M + n] = hn * mreg[0];
         Rprev = Rn;
@@ -1098,6 +1107,7 @@ __global__ void __launch_bounds__(MSQ_NT) ihgp_adf8sq_kernel(Shape sh, Bufs b, M
 
 // Backward mean recursion: m <- MF_k + G (m - A MF_k) with (P,G) looked up from R(:,k)
 // (Inf -> last grid row, ihgp_ep_modulator_nmf.m:379-380).  One wave per problem, thread n = block n.
+template <int BS>
 static __global__ void __launch_bounds__(64) ihgp_scan_kernel(Shape sh, Bufs b, IhgpTabs tb, double* vprev /* [B][M] */) {
   const int n = threadIdx.x, pb = blockIdx.x;
   const int S = sh.S, M = sh.M, NG = tb.NG;
@@ -1106,8 +1116,11 @@ static __global__ void __launch_bounds__(64) ihgp_scan_kernel(Shape sh, Bufs b, 
   const double* tab = tb.base + (size_t)pb * itab_size(sh, NG);
   double mxM = 0.0, mxP = 0.0;
   if (n < M) {
-    double A4[16], mreg[4] = {0, 0, 0, 0};
-    tile_load(A4, mdl + mdl_A(sh) + (size_t)n * 16);
+    double A4[BS * BS], mreg[BS];
+#pragma unroll
+    for (int i = 0; i < BS; ++i) mreg[i] = 0.0;
+#pragma unroll
+    for (int e = 0; e < BS * BS; ++e) A4[e] = mdl[mdl_A(sh) + (size_t)n * BS * BS + e];
     const double hn = mdl[mdl_h(sh) + n];
     const int o = sh.off[n], bs = sh.bsz[n];
     const double* g_MF = b.MF + (size_t)pb * T * S;
@@ -1115,31 +1128,37 @@ static __global__ void __launch_bounds__(64) ihgp_scan_kernel(Shape sh, Bufs b, 
     const double* g_R = b.R + (size_t)pb * T * M;
     double* g_sm = b.sm + (size_t)pb * T * M;
     double* g_sv = b.sv + (size_t)pb * T * M;
-    for (int i = 0; i < bs; ++i) { mreg[i] = g_MF[(size_t)(T - 1) * S + o + i]; g_MS[(size_t)(T - 1) * S + o + i] = mreg[i]; }
+    #pragma unroll
+    for (int i = 0; i < BS; ++i) if (i < bs) { mreg[i] = g_MF[(size_t)(T - 1) * S + o + i]; g_MS[(size_t)(T - 1) * S + o + i] = mreg[i]; }
     double vlast = 0.0;   // P = zeros(size(A)) before the loop (:364)
     for (int64_t k = T - 2; k >= 0; --k) {
       const double Rk = g_R[(size_t)k * M + n];
       int idx = nearest_idx(tb, Rk);
       if (isinf(Rk)) idx = NG - 1;
-      double G4[16], mf[4] = {0, 0, 0, 0}, d[4];
-      tile_load(G4, tab + itab_g(sh, NG) + ((size_t)n * NG + idx) * 16);
-      vlast = tab[itab_v(sh, NG) + (size_t)n * NG + idx];
-      for (int i = 0; i < bs; ++i) mf[i] = g_MF[(size_t)k * S + o + i];
+      double G4[BS * BS], mf[BS], d[BS];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < BS; ++i) mf[i] = 0.0;
+#pragma unroll
+      for (int e = 0; e < BS * BS; ++e) G4[e] = tab[itab_g(sh, NG) + ((size_t)n * NG + idx) * BS * BS + e];
+      vlast = tab[itab_v(sh, NG) + (size_t)n * NG + idx];
+      #pragma unroll
+      for (int i = 0; i < BS; ++i) if (i < bs) mf[i] = g_MF[(size_t)k * S + o + i];
+#pragma unroll
+      for (int i = 0; i < BS; ++i) {
         double a = mreg[i];
 #pragma unroll
-        for (int l = 0; l < 4; ++l) a = fma(-A4[4 * i + l], mf[l], a);
+        for (int l = 0; l < BS; ++l) a = fma(-A4[BS * i + l], mf[l], a);
         d[i] = a;
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < BS; ++i) {
         double a = mf[i];
 #pragma unroll
-        for (int l = 0; l < 4; ++l) a = fma(G4[4 * i + l], d[l], a);
+        for (int l = 0; l < BS; ++l) a = fma(G4[BS * i + l], d[l], a);
         mreg[i] = a;
       }
-      for (int i = 0; i < bs; ++i) g_MS[(size_t)k * S + o + i] = mreg[i];
+      #pragma unroll
+      for (int i = 0; i < BS; ++i) if (i < bs) g_MS[(size_t)k * S + o + i] = mreg[i];
       const double mnew = hn * mreg[0];
       mxM = fmax(mxM, fabs(g_sm[(size_t)k * M + n] - mnew));
       g_sm[(size_t)k * M + n] = mnew;

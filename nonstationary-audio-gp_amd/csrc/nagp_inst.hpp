@@ -133,6 +133,13 @@
   P void nagp::ihgp_filter_kernel<6, SRC> NAGP_SIG_IH; P void nagp::ihgp_filter_kernel<7, SRC> NAGP_SIG_IH;              \
   P void nagp::ihgp_filter_kernel<8, SRC> NAGP_SIG_IH; P void nagp::ihgp_filter_kernel<9, SRC> NAGP_SIG_IH;
 #define NAGP_LIST_IH0(P) NAGP_LIST_IH_S(P, false)
+// ... with blocks of 5 .. 8 states
+#define NAGP_LIST_IH8(P)                                                                                                   \
+  P void nagp::ihgp_filter_kernel<0, false, 8> NAGP_SIG_IH; P void nagp::ihgp_filter_kernel<1, false, 8> NAGP_SIG_IH;    \
+  P void nagp::ihgp_filter_kernel<2, false, 8> NAGP_SIG_IH; P void nagp::ihgp_filter_kernel<3, false, 8> NAGP_SIG_IH;    \
+  P void nagp::ihgp_filter_kernel<4, false, 8> NAGP_SIG_IH; P void nagp::ihgp_filter_kernel<5, false, 8> NAGP_SIG_IH;    \
+  P void nagp::ihgp_filter_kernel<6, false, 8> NAGP_SIG_IH; P void nagp::ihgp_filter_kernel<7, false, 8> NAGP_SIG_IH;    \
+  P void nagp::ihgp_filter_kernel<8, false, 8> NAGP_SIG_IH; P void nagp::ihgp_filter_kernel<9, false, 8> NAGP_SIG_IH;
 #define NAGP_LIST_IH1(P) NAGP_LIST_IH_S(P, true)
 #define NAGP_SIG_IHA (nagp::Shape, nagp::Bufs, nagp::MomCfg, nagp::MomSp, nagp::IhgpTabs, nagp::IhgpPar)
 #define NAGP_LIST_IHA(P)                                                                                                   \
@@ -171,4 +178,4 @@
 
 #define NAGP_LIST_ALL(P)                                                                                                   \
   NAGP_LIST_GF_ADF1(P) NAGP_LIST_GF_ADF2(P) NAGP_LIST_GF_ADF3(P) NAGP_LIST_GF_ADF4(P) NAGP_LIST_GF_ADF5(P)               \
-  NAGP_LIST_GF_SP12(P) NAGP_LIST_GF_SP34(P) NAGP_LIST_GF_SQ12(P) NAGP_LIST_GF_SQ34(P) NAGP_LIST_GF_REST(P) NAGP_LIST_SMOOTH(P) NAGP_LIST_SMOOTH8(P) NAGP_LIST_BIG(P) NAGP_LIST_GAINM(P) NAGP_LIST_GAINI(P) NAGP_LIST_FLM(P) NAGP_LIST_EP(P) NAGP_LIST_EPS(P) NAGP_LIST_EPQ(P) NAGP_LIST_IH0(P) NAGP_LIST_IH1(P) NAGP_LIST_IHA(P) NAGP_LIST_IHA8(P) NAGP_LIST_IHA8Q(P) NAGP_LIST_GF_A81(P) NAGP_LIST_GF_A82(P) NAGP_LIST_GF_A83(P)
+  NAGP_LIST_GF_SP12(P) NAGP_LIST_GF_SP34(P) NAGP_LIST_GF_SQ12(P) NAGP_LIST_GF_SQ34(P) NAGP_LIST_GF_REST(P) NAGP_LIST_SMOOTH(P) NAGP_LIST_SMOOTH8(P) NAGP_LIST_BIG(P) NAGP_LIST_GAINM(P) NAGP_LIST_GAINI(P) NAGP_LIST_FLM(P) NAGP_LIST_EP(P) NAGP_LIST_EPS(P) NAGP_LIST_EPQ(P) NAGP_LIST_IH0(P) NAGP_LIST_IH8(P) NAGP_LIST_IH1(P) NAGP_LIST_IHA(P) NAGP_LIST_IHA8(P) NAGP_LIST_IHA8Q(P) NAGP_LIST_GF_A81(P) NAGP_LIST_GF_A82(P) NAGP_LIST_GF_A83(P)

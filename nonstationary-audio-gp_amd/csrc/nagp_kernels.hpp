@@ -21,17 +21,28 @@ struct Shape {
   int64_t T;
   int off[MAXM + 1];
   int bsz[MAXM];
+  // Blocks of more than four states (Matern-5/2 or -7/2 sub-bands, ss_modulators_nmf.m:13-33 with cf_matern52_to_ss.m:93-121):
+  //   infinite-horizon plans keep a block per thread, BS = 8 doubles per block row in the packed model and the tables (4 otherwise);
+  //   full-covariance plans split such a block over TWO tile rows -- its first four states stay in tile row n, the rest become tile
+  //   row part[n] behind the Ms real sites ("tail rows": no measurement, h = 0, sites fixed at zero) -- and A, Q, Pinf gain the cross
+  //   tiles of the pair (mdl_Ax ...).  Ms = number of real sites (= M when no block is split), part[n] = -1 for an unsplit block.
+  int BS;
+  int Ms;
+  signed char part[MAXM];
 };
 
-// per-problem packed model (doubles): A blocks [M][16] | Q blocks [M][16] | Pinf blocks [M][16] |
-// h_val [M] | W [D][N] row-major | sn2
+// per-problem packed model (doubles): A blocks [M][BS^2] | Q blocks [M][BS^2] | Pinf blocks [M][BS^2] |
+// h_val [M] | W [D][N] row-major | sn2 | split blocks only: cross tiles A(n, part[n]) [M][16] | Q(n, part[n]) [M][16] | Pinf(n, part[n]) [M][16]
 __host__ __device__ inline size_t mdl_A(const Shape&) { return 0; }
-__host__ __device__ inline size_t mdl_Q(const Shape& s) { return (size_t)s.M * 16; }
-__host__ __device__ inline size_t mdl_P(const Shape& s) { return (size_t)s.M * 32; }
-__host__ __device__ inline size_t mdl_h(const Shape& s) { return (size_t)s.M * 48; }
-__host__ __device__ inline size_t mdl_W(const Shape& s) { return (size_t)s.M * 49; }
-__host__ __device__ inline size_t mdl_sn2(const Shape& s) { return (size_t)s.M * 49 + (size_t)s.D * s.N; }
-__host__ __device__ inline size_t mdl_size(const Shape& s) { return ((mdl_sn2(s) + 1 + 1) / 2) * 2; }
+__host__ __device__ inline size_t mdl_Q(const Shape& s) { return (size_t)s.M * s.BS * s.BS; }
+__host__ __device__ inline size_t mdl_P(const Shape& s) { return (size_t)s.M * 2 * s.BS * s.BS; }
+__host__ __device__ inline size_t mdl_h(const Shape& s) { return (size_t)s.M * 3 * s.BS * s.BS; }
+__host__ __device__ inline size_t mdl_W(const Shape& s) { return (size_t)s.M * (3 * s.BS * s.BS + 1); }
+__host__ __device__ inline size_t mdl_sn2(const Shape& s) { return mdl_W(s) + (size_t)s.D * s.N; }
+__host__ __device__ inline size_t mdl_Ax(const Shape& s) { return ((mdl_sn2(s) + 1 + 1) / 2) * 2; }
+__host__ __device__ inline size_t mdl_Qx(const Shape& s) { return mdl_Ax(s) + (size_t)s.M * 16; }
+__host__ __device__ inline size_t mdl_Px(const Shape& s) { return mdl_Ax(s) + (size_t)s.M * 32; }
+__host__ __device__ inline size_t mdl_size(const Shape& s) { return mdl_Ax(s) + ((s.Ms < s.M) ? (size_t)s.M * 48 : 0); }
 
 struct Bufs {
   const double* model;  // [B][mdl_size]

@@ -13,6 +13,8 @@ using namespace nagp;
 
 template <int N, bool INV> static void launch(dim3 gr, size_t lds, const Shape& sh, const Bufs& b, const GainPar& gp) {
   hipFuncSetAttribute(reinterpret_cast<const void*>(rts_gain_mfma_kernel<N, INV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static bool said = false;
+  if (!said) { int nb = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rts_gain_mfma_kernel<N, INV>, 64 * (N + 1), lds); hipFuncAttributes fa; hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(rts_gain_mfma_kernel<N, INV>)); printf("occupancy: %d workgroup(s) per CU; %d registers, %zu B scratch per lane\n", nb, fa.numRegs, (size_t)fa.localSizeBytes); said = true; }
   hipLaunchKernelGGL((rts_gain_mfma_kernel<N, INV>), gr, dim3(64 * (N + 1)), lds, 0, sh, b, gp);
 }
 template <bool INV> static void launch_n(int ntl, dim3 gr, size_t lds, const Shape& sh, const Bufs& b, const GainPar& gp) {
@@ -28,7 +30,7 @@ int main(int argc, char** argv) {
   const int inv = argc > 4 ? atoi(argv[4]) : 0;      // 1: the explicit-inverse form (rts_gain_mfma_kernel<.., true>)
   const int dbg = argc > 6 ? atoi(argv[6]) : 0;
   Shape sh{};
-  sh.M = M; sh.D = M - 2; sh.N = 2; sh.ntiles = M * M;
+  sh.M = M; sh.D = M - 2; sh.N = 2; sh.ntiles = M * M; sh.BS = 4; sh.Ms = M;
   int S = 0;
   for (int m = 0; m < M; ++m) { sh.bsz[m] = (two && m < M - 2) ? 2 : ((m % 5 == 4) ? 3 : 4); sh.off[m] = S; S += sh.bsz[m]; }
   sh.off[M] = S; sh.S = S;

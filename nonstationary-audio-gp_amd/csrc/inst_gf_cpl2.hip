@@ -1,0 +1,3 @@
+// one group of kernel instantiations of libnagp.so (see nagp_inst.hpp)
+#include "nagp_inst.hpp"
+NAGP_LIST_GF_CPL2(template __global__)

@@ -71,6 +71,8 @@ struct EvRec { int kid; hipEvent_t a, b; };
 
 struct nagp_plan {
   Shape sh{};
+  std::vector<int> perm;   // plans with split blocks: device state index -> the caller's state index (empty otherwise)
+  int Mu = 0;              // ... and the caller's number of sites (sh.Ms)
   nagp_opts opts{};
   std::vector<double> damping;
   int B = 0;

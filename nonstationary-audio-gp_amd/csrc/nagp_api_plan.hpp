@@ -45,8 +45,9 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
   for (int n = 0; n < m0.M; ++n) {
     sh.bsz[n] = sh.off[n + 1] - sh.off[n];
     // blocks of 5 .. 8 states (Matern-5/2 and -7/2 sub-bands): the infinite-horizon plans keep them whole (BS = 8)
-    if (sh.bsz[n] < 1 || sh.bsz[n] > (ih_kind ? 8 : 4)) { const int bsn = sh.bsz[n]; delete p; FAIL(NAGP_EUNSUPPORTED, "block %d has size %d (supported: 1..%d)", n, bsn, ih_kind ? 8 : 4); }
-    if (sh.bsz[n] > 4) sh.BS = 8;
+    // (and the full-covariance plans split them over two tile rows, below)
+    if (sh.bsz[n] < 1 || sh.bsz[n] > 8) { const int bsn = sh.bsz[n]; delete p; FAIL(NAGP_EUNSUPPORTED, "block %d has size %d (supported: 1..8)", n, bsn); }
+    if (sh.bsz[n] > 4 && ih_kind) sh.BS = 8;
   }
   if (sh.off[0] != 0 || sh.off[m0.M] != m0.S) { delete p; FAIL(NAGP_EINVAL, "block_offsets do not span 0..S"); }
   for (int q = 0; q < B; ++q) {   // every pointer the packing below dereferences
@@ -63,6 +64,55 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     for (int n = 0; same && n <= m0.M; ++n) same = mq.block_offsets[n] == m0.block_offsets[n];
     if (!same) { delete p; FAIL(NAGP_EINVAL, "problem %d has a different shape", q); }
   }
+  // ---- full-covariance plans with blocks of 5 .. 8 states: the DEVICE VIEW of the models.  Block n keeps its first four states in tile
+  // row n; the rest become tile row Mu + e behind the Mu real sites (Shape::part pairs the two).  The states are renumbered tile row by
+  // tile row (perm: device index -> caller's index); A, Q, Pinf are permuted accordingly, the tail rows get h = 0, and everything below
+  // this point -- packing, buffers, kernels -- sees Md = Mu + E "sites" of at most four states whose last E never carry a measurement.
+  std::vector<nagp_model> dmods;
+  std::vector<std::vector<double>> dstore;
+  std::vector<int32_t> doff;
+  {
+    int E = 0;
+    for (int n = 0; n < m0.M; ++n) if (sh.bsz[n] > 4) ++E;
+    if (!ih_kind && E > 0) {
+      const int Mu = m0.M, Md = Mu + E, S = m0.S;
+      if (Md > MAXM) { delete p; FAIL(NAGP_EUNSUPPORTED, "M=%d sites with %d blocks of more than four states: more than %d tile rows", Mu, E, MAXM); }
+      std::vector<int> start(Md), size(Md);
+      int e = 0;
+      for (int n = 0; n < Mu; ++n) {
+        const int bs = sh.bsz[n];
+        start[n] = sh.off[n]; size[n] = std::min(bs, 4);
+        if (bs > 4) { const int t = Mu + e++; start[t] = sh.off[n] + 4; size[t] = bs - 4; sh.part[n] = (signed char)t; sh.part[t] = (signed char)n; }
+      }
+      p->perm.resize(S); p->Mu = Mu;
+      doff.resize(Md + 1);
+      int pos = 0;
+      for (int r = 0; r < Md; ++r) { doff[r] = pos; for (int i = 0; i < size[r]; ++i) p->perm[pos++] = start[r] + i; }
+      doff[Md] = pos;
+      sh.M = Md; sh.Ms = Mu; sh.ntiles = Md * Md;
+      for (int r = 0; r <= Md; ++r) sh.off[r] = doff[r];
+      for (int r = 0; r < Md; ++r) sh.bsz[r] = size[r];
+      dmods.assign(models, models + B);
+      dstore.resize((size_t)B * 4);
+      for (int q = 0; q < B; ++q) {
+        const nagp_model& mq = models[q];
+        auto permuted = [&](const double* X, std::vector<double>& out) {
+          out.resize((size_t)S * S);
+          for (int j = 0; j < S; ++j)
+            for (int i = 0; i < S; ++i) out[(size_t)i + (size_t)S * j] = X[(size_t)p->perm[i] + (size_t)S * p->perm[j]];
+        };
+        permuted(mq.A, dstore[(size_t)q * 4 + 0]); permuted(mq.Q, dstore[(size_t)q * 4 + 1]); permuted(mq.Pinf, dstore[(size_t)q * 4 + 2]);
+        std::vector<double>& hv = dstore[(size_t)q * 4 + 3];
+        hv.assign(Md, 0.0);
+        for (int n = 0; n < Mu; ++n) hv[n] = mq.h_val[n];
+        dmods[q].M = Md; dmods[q].block_offsets = doff.data();
+        dmods[q].A = dstore[(size_t)q * 4 + 0].data(); dmods[q].Q = dstore[(size_t)q * 4 + 1].data(); dmods[q].Pinf = dstore[(size_t)q * 4 + 2].data();
+        dmods[q].h_val = hv.data();
+      }
+      models = dmods.data();
+    }
+  }
+  const bool split = sh.Ms < sh.M;
   if (!ekf) p->damping.assign(o->ep_damping, o->ep_damping + o->ep_itts);
   p->want_PS = true;   // smoothed covariances are cheap to keep only if asked; decided at download (see below)
 
@@ -103,6 +153,8 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     // fixed-site launches with one tile per thread: whole waves beyond the tile threads for the state lanes (gf_filter_kernel: soff)
     p->NT_fl = p->NT_f;
     if (!ekf && p->TPT_f == 1 && roundup64(slots) + roundup64(sh.S) <= 512) p->NT_fl = std::max(p->NT_f, roundup64(slots) + roundup64(sh.S));
+    // split blocks: every filter launch has the geometry of the fixed-site one (gf_filter_kernel<TPT_f, ., ., 512, 0, true>)
+    if (split) { p->TPT_a = p->TPT_f; p->NT_a = p->NT_f; p->LB_a = 512; p->wide_l = 0; p->NT_l = p->NT_f; p->NT_fl = p->NT_f; }
   }
   p->want_PS = (o->flags & 0x4u) != 0;
   p->need_PF = (o->kind != NAGP_KIND_IHGP) && !(o->mode == NAGP_MODE_NLML && (o->ep_itts == 1 || ekf));
@@ -126,6 +178,16 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
         }
       d[mdl_h(sh) + n] = mq.h_val[n];
       p->h_hval[(size_t)q * sh.M + n] = mq.h_val[n];
+      if (split && sh.part[n] >= 0) {      // cross tiles of the pair: X(rows of n, columns of part[n])
+        const int pn = sh.part[n], op = sh.off[pn], bp = sh.bsz[pn];
+        for (int i = 0; i < bs; ++i)
+          for (int j = 0; j < bp; ++j) {
+            const size_t src = (size_t)(o0 + i) + (size_t)S * (op + j);
+            d[mdl_Ax(sh) + (size_t)n * 16 + 4 * i + j] = mq.A[src];
+            d[mdl_Qx(sh) + (size_t)n * 16 + 4 * i + j] = mq.Q[src];
+            d[mdl_Px(sh) + (size_t)n * 16 + 4 * i + j] = mq.Pinf[src];
+          }
+      }
     }
     if (mq.Wnmf && (ekf || o->lik_kind != NAGP_LIK_POWER))
       for (int dd = 0; dd < sh.D; ++dd)
@@ -571,13 +633,13 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     if (!ekf) p->DG_f = pick_DG(o->lik_kind, o->n_pts, p->NT_a, sh.D, o->cub_dim);
     MomCfg t = mc; t.DG = p->DG_f; t.cache_tabs = ekf ? 0 : 1; t.store_a = (!ekf && o->lik_kind == NAGP_LIK_POWER_NMF_SQRT) ? 1 : 0;
     // ADF launches in the sparse-point form (256-thread launches, <= 320 sigma points)
-    if (!ekf && p->sp.enabled && p->LB_a == 256 && p->NT_a == MSP_NT && sh.M <= 64 && sh.D <= 4 * MSP_DT && o->n_pts <= MSP_NT + 64 &&
+    if (!split && !ekf && p->sp.enabled && p->LB_a == 256 && p->NT_a == MSP_NT && sh.M <= 64 && sh.D <= 4 * MSP_DT && o->n_pts <= MSP_NT + 64 &&
         (o->n_pts + 3) / 4 <= MSP_NW * MSP_NST) {
       p->sp_gf = 1; t.sp = p->sp;
     }
     // ... or with likModulatorPreCalcwn in the staged form of nagp_momsq.hpp
-    if (!ekf && p->sq_ok && !p->src_all.n_src && p->LB_a == 256 && p->NT_a == 256 && sh.M <= 64) { p->sq_gf = 1; t.sq_form = 1; t.store_a = 0; }
-    const size_t cap = 156 * 1024;
+    if (!split && !ekf && p->sq_ok && !p->src_all.n_src && p->LB_a == 256 && p->NT_a == 256 && sh.M <= 64) { p->sq_gf = 1; t.sq_form = 1; t.store_a = 0; }
+    const size_t cap = 156 * 1024 - filter_cpl_doubles(sh) * sizeof(double);      // (split blocks: the exchange buffer and the cross tiles in front)
     p->kb_f = 16;
     if (filter_lds_doubles(sh, t, ekf ? 1 : 0, p->kb_f) * sizeof(double) > cap) p->kb_f = 8;
     if (filter_lds_doubles(sh, t, ekf ? 1 : 0, p->kb_f) * sizeof(double) > cap) p->kb_f = 4;
@@ -591,7 +653,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     if (const char* e = dev_env("NAGP_KB_F")) p->kb_f = std::max(1, std::min(16, atoi(e)));      // developer switches: the fall-backs of LDS-tight shapes
     if (dev_env("NAGP_NO_CACHE_TABS")) { t.cache_tabs = 0; t.store_a = 0; }
     p->cache_f = t.cache_tabs; p->sta_f = t.store_a;
-    p->lds_filter = filter_lds_doubles(sh, t, ekf ? 1 : 0, p->kb_f) * sizeof(double);
+    p->lds_filter = (filter_lds_doubles(sh, t, ekf ? 1 : 0, p->kb_f) + filter_cpl_doubles(sh)) * sizeof(double);
     // pipelined plans: the filter's workgroup asks for the whole LDS of its CU, so that no workgroup of the smoother kernels running
     // beside it on the second stream is placed on the same CU (the filter is the critical path; its time is latency, not occupancy)
     if (p->pipeline && B <= 128 && p->lds_filter < 160 * 1024) p->lds_filter = 160 * 1024;     // (never BELOW what the kernel needs: set_lds refuses > 160 KiB)
@@ -626,8 +688,36 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
       }
     }
     if (dev_env("NAGP_STAMPS")) fprintf(stderr, "[nagp plan] gf ADF sweep with role-specialised waves: %d (tiles per thread %d, ring %d steps, LDS %zu B, packed MFMA steps %d)\n", p->a8_gf, p->a8_tpt, p->kb_a8, p->lds_a8, p->a8_pack);
-    p->lds_gain = ((p->TPT == 1) ? gain_lds_doubles_staged(sh) : gain_lds_doubles(sh)) * sizeof(double);     // (rts_gain_kernel: STAGE)
+    p->lds_gain = (((p->TPT == 1) ? gain_lds_doubles_staged(sh) : gain_lds_doubles(sh)) + gain_cpl_doubles(sh)) * sizeof(double);     // (rts_gain_kernel: STAGE)
     p->lds_scan = span_lds_doubles(sh, p->LP1, p->LP2) * sizeof(double);
+    if (split) {
+      if (p->TPT > 4) { nagp_plan_destroy(p); FAIL(NAGP_EUNSUPPORTED, "split blocks: more than 2048 tiles (%d tile rows)", sh.M); }
+      if (ekf) {
+        switch (p->TPT_f) {
+          case 1: PLAN_TRY(set_lds((gf_filter_kernel<1, 1, 0, 512, 0, true>), p->lds_filter)); break;
+          case 2: PLAN_TRY(set_lds((gf_filter_kernel<2, 1, 0, 512, 0, true>), p->lds_filter)); break;
+          default: PLAN_TRY(set_lds((gf_filter_kernel<4, 1, 0, 512, 0, true>), p->lds_filter)); break;
+        }
+      } else {
+#define SLC1(V) PLAN_TRY(set_lds((gf_filter_kernel<1, 0, V, 512, 0, true>), p->lds_filter))
+#define SLC2(V) PLAN_TRY(set_lds((gf_filter_kernel<2, 0, V, 512, 0, true>), p->lds_filter))
+#define SLC4(V) PLAN_TRY(set_lds((gf_filter_kernel<4, 0, V, 512, 0, true>), p->lds_filter))
+        switch (p->TPT_f) {
+          case 1: NAGP_MV_SWITCH(mom_variant(mc), SLC1) SLC1(-1); break;
+          case 2: NAGP_MV_SWITCH(mom_variant(mc), SLC2) SLC2(-1); break;
+          default: NAGP_MV_SWITCH(mom_variant(mc), SLC4) SLC4(-1); break;
+        }
+#undef SLC1
+#undef SLC2
+#undef SLC4
+      }
+      switch (p->TPT) {
+        case 1: PLAN_TRY(set_lds((rts_gain_kernel<1, 512, true>), p->lds_gain)); break;
+        case 2: PLAN_TRY(set_lds((rts_gain_kernel<2, 512, true>), p->lds_gain)); break;
+        case 3: PLAN_TRY(set_lds((rts_gain_kernel<3, 512, true>), p->lds_gain)); break;
+        default: PLAN_TRY(set_lds((rts_gain_kernel<4, 512, true>), p->lds_gain)); break;
+      }
+    }
     if (ekf) {
       switch (p->TPT_f) {
         case 1: PLAN_TRY(set_lds(gf_filter_kernel<1, 1, 0>, p->lds_filter)); break;
@@ -674,7 +764,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
 #undef SL4
 #undef SL5
     }
-    if (nt > 1024 && nt <= 1536 && sh.M * (sh.M + 1) / 2 <= 768 && sh.S <= 768 && !dev_env("NAGP_NO_GAIN768")) {
+    if (!split && nt > 1024 && nt <= 1536 && sh.M * (sh.M + 1) / 2 <= 768 && sh.S <= 768 && !dev_env("NAGP_NO_GAIN768")) {
       p->gain768 = 1;
       p->lds_gain = gain_lds_doubles_staged(sh) * sizeof(double);
       PLAN_TRY(set_lds(rts_gain_kernel<2, 768>, p->lds_gain));
@@ -687,7 +777,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
       default: PLAN_TRY(set_lds(rts_gain_kernel<8>, p->lds_gain)); PLAN_TRY(set_lds(rts_compose_kernel<8>, p->lds_scan)); PLAN_TRY(set_lds(rts_boundary_kernel<8>, p->lds_scan)); PLAN_TRY(set_lds(rts_apply_kernel<8>, p->lds_scan)); break;
     }
   }
-  if (!ekf && o->kind == NAGP_KIND_GF_EP && o->mode == NAGP_MODE_PREDICT && !(o->flags & NAGP_FLAG_MIXTURE_RULE) && 4 * sh.M <= 160 && dev_env("NAGP_LIN_MFMA")) {
+  if (!split && !ekf && o->kind == NAGP_KIND_GF_EP && o->mode == NAGP_MODE_PREDICT && !(o->flags & NAGP_FLAG_MIXTURE_RULE) && 4 * sh.M <= 160 && dev_env("NAGP_LIN_MFMA")) {
     // fixed-site steps (sweeps >= 2) on the matrix cores: the plain predict-mode rule only.  Opt-in: measured on MI355X the step is
     // 13.7 us against 10.4 us of the 4x4-tile VALU kernel at S = 146 (6.2 against 3.85 at S = 73) -- DESIGN section 8
     const int ntl = (4 * sh.M + 15) / 16;
@@ -701,7 +791,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
   }
   // rts_gain_mfma_kernel (16x16 tiles on the matrix cores, the dependence chain of the blocked Cholesky on a wave of its own) serves every
   // plan whose smoother passes take dense (G, Delta); NAGP_NO_GAIN_MFMA=1 (developer switch) keeps the 4x4-tile VALU kernel
-  if (p->mfma_sp && !dev_env("NAGP_NO_GAIN_MFMA")) {
+  if (p->mfma_sp && !split && !dev_env("NAGP_NO_GAIN_MFMA")) {      // (split blocks: the VALU kernel knows the cross tiles of A)
     p->gain_mfma = 1;
     const size_t lg = gainm_lds_doubles(p->mfma_sp / 16, sh) * sizeof(double);
     // The explicit-inverse form needs A^-1 per block.  It is used when EVERY block of every problem of the plan is comfortably
@@ -780,7 +870,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     NAGP_MV_SWITCH9(mom_variant(mc), SL)
 #undef SL
     // site refresh in the staged sparse-point form (the conditions of the ADF launches: likModulatorNMFPower on a fully symmetric rule)
-    if (p->sp.enabled && !p->src_ep && sh.M <= 64 && sh.D <= 4 * MSP_DT && o->cub_dim <= MSP_MAXCD && o->n_pts <= MSP_NT + 64 &&
+    if (!split && p->sp.enabled && !p->src_ep && sh.M <= 64 && sh.D <= 4 * MSP_DT && o->cub_dim <= MSP_MAXCD && o->n_pts <= MSP_NT + 64 &&
         (o->n_pts + 3) / 4 <= MSP_NW * MSP_NST && !dev_env("NAGP_NO_SPARSE_EP")) {
       p->sp_ep = 1;
       p->lds_ep_sp = ep_sp_lds_doubles(sh, o->cub_dim) * sizeof(double);
@@ -789,7 +879,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
 #undef SLS
     }
     // ... and with likModulatorPreCalcwn in the staged form of nagp_momsq.hpp
-    if (p->sq_ok && !p->src_ep && sh.M <= 64 && !dev_env("NAGP_NO_SPARSE_EP")) {
+    if (!split && p->sq_ok && !p->src_ep && sh.M <= 64 && !dev_env("NAGP_NO_SPARSE_EP")) {
       p->sq_ep = 1;
       p->lds_ep_sq = ep_sq_lds_doubles(sh, o->cub_dim) * sizeof(double);
 #define SLQ(V) PLAN_TRY(set_lds(ep_site_sq_kernel<V>, p->lds_ep_sq))
@@ -843,8 +933,18 @@ extern "C" int nagp_plan_upload_sites(nagp_plan* p, const double* const* ttau0, 
     if (st == NAGP_OK) st = dalloc(p, &p->d_tn0, (size_t)p->B * n, false);
     if (st != NAGP_OK) return st;
   }
+  std::vector<double> wide;      // split blocks: the caller's Mu columns per step, zero sites on the tail rows
   for (int q = 0; q < p->B; ++q) {
     if (!ttau0[q] || !tnu0[q]) FAIL(NAGP_EINVAL, "problem %d: NULL site array", q);
+    if (!p->perm.empty()) {
+      const int Md = p->sh.M, Mu = p->Mu;
+      wide.assign(2 * n, 0.0);
+      for (int64_t k = 0; k < p->sh.T; ++k)
+        for (int i = 0; i < Mu; ++i) { wide[(size_t)k * Md + i] = ttau0[q][(size_t)k * Mu + i]; wide[n + (size_t)k * Md + i] = tnu0[q][(size_t)k * Mu + i]; }
+      HIP_TRY(hipMemcpy(p->d_tt0 + (size_t)q * n, wide.data(), n * sizeof(double), hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(p->d_tn0 + (size_t)q * n, wide.data() + n, n * sizeof(double), hipMemcpyHostToDevice));
+      continue;
+    }
     HIP_TRY(hipMemcpyAsync(p->d_tt0 + (size_t)q * n, ttau0[q], n * sizeof(double), hipMemcpyHostToDevice, p->stream));
     HIP_TRY(hipMemcpyAsync(p->d_tn0 + (size_t)q * n, tnu0[q], n * sizeof(double), hipMemcpyHostToDevice, p->stream));
   }

@@ -18,6 +18,21 @@ static int launch_filter(nagp_plan* p, const FilterPar& fp_in) {
   if (ekf && p->NT_f + 64 <= 512 && p->sh.N <= 64) { nt_ekf = p->NT_f + 64; fp.spl_wave = 1; }   // one extra wave for the link
   Timed t(p, adf ? NAGP_K_FILTER : NAGP_K_FILTER_LIN);
   dim3 g(p->B), bl(p->NT_f);
+  if (p->sh.Ms < p->sh.M) {      // split blocks: one geometry (the fixed-site one) for every launch, the general mom code
+    fp.cpl_doubles = (int)filter_cpl_doubles(p->sh);
+    mc.sp = MomSp{};
+#define LFC(TP, ME, V) hipLaunchKernelGGL((gf_filter_kernel<TP, ME, V, 512, 0, true>), g, dim3(ekf ? nt_ekf : p->NT_f), p->lds_filter, p->stream, p->sh, p->b, mc, fp)
+#define LFC1(V) LFC(1, 0, V)
+#define LFC2(V) LFC(2, 0, V)
+#define LFC4(V) LFC(4, 0, V)
+    if (ekf) switch (p->TPT_f) { case 1: LFC(1, 1, 0); break; case 2: LFC(2, 1, 0); break; default: LFC(4, 1, 0); break; }
+    else if (adf) switch (p->TPT_f) { case 1: NAGP_MV_SWITCH(mom_variant(mc), LFC1) break; case 2: NAGP_MV_SWITCH(mom_variant(mc), LFC2) break; default: NAGP_MV_SWITCH(mom_variant(mc), LFC4) break; }
+    else switch (p->TPT_f) { case 1: LFC1(-1); break; case 2: LFC2(-1); break; default: LFC4(-1); break; }
+#undef LFC
+#undef LFC1
+#undef LFC2
+#undef LFC4
+  } else
   if (ekf) {
 #define LF(TP) hipLaunchKernelGGL((gf_filter_kernel<TP, 1, 0>), g, dim3(nt_ekf), p->lds_filter, p->stream, p->sh, p->b, mc, fp)
     switch (p->TPT_f) { case 1: LF(1); break; case 2: LF(2); break; default: LF(4); break; }
@@ -244,6 +259,15 @@ static int launch_gain_chunk(nagp_plan* p, const SweepCtx& sc, int c, int slot, 
     switch (ntl) { case 1: LG(1); break; case 2: LG(2); break; case 3: LG(3); break; case 4: LG(4); break; case 5: LG(5); break;
                    case 6: LG(6); break; case 7: LG(7); break; case 8: LG(8); break; case 9: LG(9); break; default: LG(10); break; }
 #undef LG
+  } else
+  if (sh.Ms < sh.M) {      // split blocks
+    gp.cpl_doubles = (int)gain_cpl_doubles(sh);
+    switch (p->TPT) {
+      case 1: hipLaunchKernelGGL((rts_gain_kernel<1, 512, true>), gr, bl, p->lds_gain, st, sh, b, gp); break;
+      case 2: hipLaunchKernelGGL((rts_gain_kernel<2, 512, true>), gr, bl, p->lds_gain, st, sh, b, gp); break;
+      case 3: hipLaunchKernelGGL((rts_gain_kernel<3, 512, true>), gr, bl, p->lds_gain, st, sh, b, gp); break;
+      default: hipLaunchKernelGGL((rts_gain_kernel<4, 512, true>), gr, bl, p->lds_gain, st, sh, b, gp); break;
+    }
   } else
   if (p->gain768) hipLaunchKernelGGL((rts_gain_kernel<2, 768>), gr, dim3(768), p->lds_gain, st, sh, b, gp);
   else switch (p->TPT) {
@@ -945,6 +969,32 @@ extern "C" int nagp_plan_download(nagp_plan* p, nagp_out* outs) {
   for (int q = 0; q < p->B; ++q) {
     nagp_out& o = outs[q];
     const size_t oM = (size_t)q * T * M, oS = (size_t)q * T * S;
+    if (!p->perm.empty()) {
+      // split blocks: the device keeps Md = M tile rows of which the caller's Mu sites are the first, and numbers the states tile row by
+      // tile row (perm: device index -> the caller's)
+      const int Mu = p->Mu;
+      std::vector<double> w;
+      auto sites = [&](double* dst, const double* src) -> int {
+        if (!dst) return NAGP_OK;
+        w.resize((size_t)T * M);
+        HIP_TRY(hipMemcpy(w.data(), src, w.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int64_t k = 0; k < T; ++k)
+          for (int i = 0; i < Mu; ++i) dst[(size_t)k * Mu + i] = w[(size_t)k * M + i];
+        return NAGP_OK;
+      };
+      auto states = [&](double* dst, const double* src) -> int {
+        if (!dst) return NAGP_OK;
+        w.resize((size_t)T * S);
+        HIP_TRY(hipMemcpy(w.data(), src, w.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int64_t k = 0; k < T; ++k)
+          for (int i = 0; i < S; ++i) dst[(size_t)k * S + p->perm[i]] = w[(size_t)k * S + i];
+        return NAGP_OK;
+      };
+      HIP_TRY(hipStreamSynchronize(p->stream));
+      RUN(sites(o.Eft, p->b.sm + oM)); RUN(sites(o.Varft, p->b.sv + oM)); RUN(sites(o.ttau, p->b.ttau + oM)); RUN(sites(o.tnu, p->b.tnu + oM)); RUN(sites(o.R, p->b.R + oM));
+      RUN(states(o.MS, p->b.MS + oS)); RUN(states(o.MF, p->b.MF + oS));
+      if (o.lZ) HIP_TRY(hipMemcpy(o.lZ, p->b.lZ + (size_t)q * T, (size_t)T * sizeof(double), hipMemcpyDeviceToHost));
+    } else {
 #define D2H(dst, src, n) do { if (dst) HIP_TRY(hipMemcpyAsync(dst, src, (size_t)(n) * sizeof(double), hipMemcpyDeviceToHost, p->stream)); } while (0)
     D2H(o.Eft, p->b.sm + oM, T * M);
     D2H(o.MS, p->b.MS + oS, T * S);
@@ -955,6 +1005,7 @@ extern "C" int nagp_plan_download(nagp_plan* p, nagp_out* outs) {
     D2H(o.lZ, p->b.lZ + (size_t)q * T, T);
     if (!ihgp) D2H(o.Varft, p->b.sv + oM, T * M);
     HIP_TRY(hipStreamSynchronize(p->stream));
+    }
     if (ihgp && o.Varft) {
       // Varft = repmat(diag(H*P*H')) with the blocks last looked up (k = 0); abs() unless constraints variant
       std::vector<double> v0(M, 0.0);
@@ -991,7 +1042,11 @@ extern "C" int nagp_plan_download(nagp_plan* p, nagp_out* outs) {
             for (int Jb = 0; Jb < M; ++Jb) {
               const double* t16 = src + ((size_t)Ib * M + Jb) * 16;
               for (int i = 0; i < sh.bsz[Ib]; ++i)
-                for (int j = 0; j < sh.bsz[Jb]; ++j) dst[(size_t)(sh.off[Ib] + i) + (size_t)S * (sh.off[Jb] + j)] = t16[4 * i + j];
+                for (int j = 0; j < sh.bsz[Jb]; ++j) {
+                  const int r = sh.off[Ib] + i, c = sh.off[Jb] + j;
+                  if (p->perm.empty()) dst[(size_t)r + (size_t)S * c] = t16[4 * i + j];
+                  else dst[(size_t)p->perm[r] + (size_t)S * p->perm[c]] = t16[4 * i + j];
+                }
             }
         }
       }

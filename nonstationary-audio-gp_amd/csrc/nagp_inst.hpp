@@ -22,6 +22,21 @@
 #define NAGP_LIST_GF_ADF4(P) NAGP_LIST_GF_ADF(P, 4, 256)
 #define NAGP_LIST_GF_ADF5(P) NAGP_LIST_GF_ADF(P, 4, 512)
 
+// plans with split blocks (Shape::part): one geometry for the ADF, fixed-site and EKF launches; the VALU gain kernel with the cross tiles
+#define NAGP_LIST_GF_CPL(P, TPT)                                                                                                            \
+  P void nagp::gf_filter_kernel<TPT, 0, 0, 512, 0, true> NAGP_SIG_GF; P void nagp::gf_filter_kernel<TPT, 0, 1, 512, 0, true> NAGP_SIG_GF;   \
+  P void nagp::gf_filter_kernel<TPT, 0, 2, 512, 0, true> NAGP_SIG_GF; P void nagp::gf_filter_kernel<TPT, 0, 3, 512, 0, true> NAGP_SIG_GF;   \
+  P void nagp::gf_filter_kernel<TPT, 0, 4, 512, 0, true> NAGP_SIG_GF; P void nagp::gf_filter_kernel<TPT, 0, 5, 512, 0, true> NAGP_SIG_GF;   \
+  P void nagp::gf_filter_kernel<TPT, 0, 6, 512, 0, true> NAGP_SIG_GF; P void nagp::gf_filter_kernel<TPT, 0, 7, 512, 0, true> NAGP_SIG_GF;   \
+  P void nagp::gf_filter_kernel<TPT, 0, 8, 512, 0, true> NAGP_SIG_GF; P void nagp::gf_filter_kernel<TPT, 0, 9, 512, 0, true> NAGP_SIG_GF;   \
+  P void nagp::gf_filter_kernel<TPT, 0, -1, 512, 0, true> NAGP_SIG_GF; P void nagp::gf_filter_kernel<TPT, 1, 0, 512, 0, true> NAGP_SIG_GF;
+#define NAGP_LIST_GF_CPL1(P) NAGP_LIST_GF_CPL(P, 1)
+#define NAGP_LIST_GF_CPL2(P) NAGP_LIST_GF_CPL(P, 2)
+#define NAGP_LIST_GF_CPL4(P) NAGP_LIST_GF_CPL(P, 4)
+#define NAGP_LIST_GAIN_CPL(P)                                                                                                               \
+  P void nagp::rts_gain_kernel<1, 512, true>(nagp::Shape, nagp::Bufs, nagp::GainPar); P void nagp::rts_gain_kernel<2, 512, true>(nagp::Shape, nagp::Bufs, nagp::GainPar); \
+  P void nagp::rts_gain_kernel<3, 512, true>(nagp::Shape, nagp::Bufs, nagp::GainPar); P void nagp::rts_gain_kernel<4, 512, true>(nagp::Shape, nagp::Bufs, nagp::GainPar);
+
 // ADF launches in the sparse-point form (likModulatorNMFPower, 1..7 components), 256-thread launches
 #define NAGP_LIST_GF_SP(P, TPT)                                                                                            \
   P void nagp::gf_filter_kernel<TPT, 0, 1, 256, 1> NAGP_SIG_GF; P void nagp::gf_filter_kernel<TPT, 0, 2, 256, 1> NAGP_SIG_GF;    \
@@ -178,4 +193,4 @@
 
 #define NAGP_LIST_ALL(P)                                                                                                   \
   NAGP_LIST_GF_ADF1(P) NAGP_LIST_GF_ADF2(P) NAGP_LIST_GF_ADF3(P) NAGP_LIST_GF_ADF4(P) NAGP_LIST_GF_ADF5(P)               \
-  NAGP_LIST_GF_SP12(P) NAGP_LIST_GF_SP34(P) NAGP_LIST_GF_SQ12(P) NAGP_LIST_GF_SQ34(P) NAGP_LIST_GF_REST(P) NAGP_LIST_SMOOTH(P) NAGP_LIST_SMOOTH8(P) NAGP_LIST_BIG(P) NAGP_LIST_GAINM(P) NAGP_LIST_GAINI(P) NAGP_LIST_FLM(P) NAGP_LIST_EP(P) NAGP_LIST_EPS(P) NAGP_LIST_EPQ(P) NAGP_LIST_IH0(P) NAGP_LIST_IH8(P) NAGP_LIST_IH1(P) NAGP_LIST_IHA(P) NAGP_LIST_IHA8(P) NAGP_LIST_IHA8Q(P) NAGP_LIST_GF_A81(P) NAGP_LIST_GF_A82(P) NAGP_LIST_GF_A83(P)
+  NAGP_LIST_GF_SP12(P) NAGP_LIST_GF_SP34(P) NAGP_LIST_GF_SQ12(P) NAGP_LIST_GF_SQ34(P) NAGP_LIST_GF_REST(P) NAGP_LIST_SMOOTH(P) NAGP_LIST_SMOOTH8(P) NAGP_LIST_BIG(P) NAGP_LIST_GAINM(P) NAGP_LIST_GAINI(P) NAGP_LIST_FLM(P) NAGP_LIST_EP(P) NAGP_LIST_EPS(P) NAGP_LIST_EPQ(P) NAGP_LIST_IH0(P) NAGP_LIST_IH8(P) NAGP_LIST_IH1(P) NAGP_LIST_IHA(P) NAGP_LIST_IHA8(P) NAGP_LIST_IHA8Q(P) NAGP_LIST_GF_A81(P) NAGP_LIST_GF_A82(P) NAGP_LIST_GF_A83(P) NAGP_LIST_GF_CPL1(P) NAGP_LIST_GF_CPL2(P) NAGP_LIST_GF_CPL4(P) NAGP_LIST_GAIN_CPL(P)

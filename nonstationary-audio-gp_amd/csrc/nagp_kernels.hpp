@@ -96,6 +96,7 @@ struct FilterPar {
   int progress_every;      // publish when the step count crosses a multiple of this (and at the end of the launch)
   int dbg;                 // developer switch (NAGP_FILTER_DBG): skip phases to time the others -- results are garbage.
                            // 1: rank-M covariance update, 2: PF stores, 4: prediction congruence, 8: W panel writes, 16: mean update
+  int cpl_doubles;         // split blocks (Shape::part): doubles of the extra LDS region in FRONT of everything else (filter_cpl_doubles)
 };
 
 // The filtered covariance is symmetric: PF holds only the lower-triangular tiles, tile (I,J), I >= J, at tile index I(I+1)/2 + J.
@@ -162,6 +163,10 @@ struct TileOwner {
 // coalesced transfers once per block; the only global operations inside the sequential loop are the
 // fire-and-forget stores of the filtered covariance tiles.
 __host__ __device__ inline size_t filter_ring_doubles(const Shape& s, int kb) { return (size_t)kb * (5 * s.M + s.S + 3); }
+// split blocks: partner table [MAXM ints] | cross tiles of A [M][TS] | of Q [M][TS] | exchange buffer of the lower tiles [M(M+1)/2][TS]
+__host__ __device__ inline size_t filter_cpl_doubles(const Shape& s) {
+  return (s.Ms < s.M) ? (size_t)(MAXM / 2) + 2 * (size_t)s.M * TS + (size_t)(s.M * (s.M + 1) / 2) * TS : 0;
+}
 __host__ __device__ inline size_t filter_lds_doubles(const Shape& s, const MomCfg& mc, int meas, int kb) {
   size_t n = LDS_INT_DOUBLES + 2 * (size_t)s.M * TS + s.M + (size_t)s.D * s.N + s.S + 4 * (size_t)s.M * s.M +
              6 * (size_t)s.M + 2 * 68 + 8 + 2 /* the W panel starts on a 16-byte boundary */ + filter_ring_doubles(s, kb);
@@ -179,11 +184,20 @@ __host__ __device__ inline size_t filter_lds_doubles(const Shape& s, const MomCf
 // SP = 1: the ADF steps use the staged sparse-point form of likModulatorNMFPower (nagp_momsp.hpp) and the generic mom_eval is not
 // compiled into the instantiation at all (both side by side cost hundreds of registers); SP = 2: likModulatorPreCalcwn in the staged
 // form of nagp_momsq.hpp (flat layout), likewise without the generic code
-template <int TPT, int MEAS, int MV, int LB = 512, int SP = 0>
+// CPL: plans with split blocks (Shape::part): the prediction couples the two tile rows of a block -- every thread leaves its tiles in an LDS
+// exchange buffer and forms  P(I,J) <- sum_{a in {I, part I}} sum_{b in {J, part J}} A(I,a) P(a,b) A(J,b)'  from up to four of them --
+// and the tail rows behind the Ms real sites take no part in the site arithmetic (h = 0, sites fixed at zero)
+template <int TPT, int MEAS, int MV, int LB = 512, int SP = 0, bool CPL = false>
 __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg mc, FilterPar fp) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
+  extern __shared__ __attribute__((aligned(16))) double lds_raw[];
+  double* lds = lds_raw + (CPL ? fp.cpl_doubles : 0);
   const int tid = threadIdx.x, NT = blockDim.x;
   const int S = sh.S, M = sh.M, D = sh.D, KB = fp.kb;
+  const int Ms = CPL ? sh.Ms : M;      // real sites
+  int* ipart = reinterpret_cast<int*>(lds_raw);                  // CPL: [MAXM] partner tile row or -1
+  double* sAx = lds_raw + MAXM / 2;                              //      A(n, part n) [M][TS]
+  double* sQx = sAx + (size_t)M * TS;                            //      Q(n, part n) [M][TS]
+  double* sX = sQx + (size_t)M * TS;                             //      exchange buffer, lower tile t at t * TS
   const int64_t T = sh.T;
   const int pb = blockIdx.x;
   const double* mdl = b.model + (size_t)pb * mdl_size(sh);
@@ -228,6 +242,15 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
   for (int i = tid; i < M; i += NT) shv[i] = mdl[mdl_h(sh) + i];
   for (int i = tid; i < sh.D * sh.N; i += NT) sW[i] = mdl[mdl_W(sh) + i];
   for (int i = tid; i < 68; i += NT) { fmu[i] = 0.0; HPH[i] = 0.0; }
+  if constexpr (CPL && MEAS == 1)      // EKF: Jacobian entries and mean terms of the tail rows stay zero
+    for (int i = Ms + tid; i < M; i += NT) { ws[i] = 0.0; ws[(size_t)M + 2 * S + 2 * sh.N + i] = 0.0; }
+  if constexpr (CPL) {
+    for (int i = tid; i < M; i += NT) ipart[i] = sh.part[i];
+    for (int i = tid; i < M * 16; i += NT) {
+      sAx[(i >> 4) * TS + (i & 15)] = mdl[mdl_Ax(sh) + i];
+      sQx[(i >> 4) * TS + (i & 15)] = mdl[mdl_Qx(sh) + i];
+    }
+  }
   const double sn2 = mdl[mdl_sn2(sh)];
   // likModulatorNMFPower on a fully symmetric sigma-point set: the staged form of nagp_momsp.hpp (256-thread ADF launches)
   constexpr bool SPK = SP == 1 && (MEAS == 0 && MV >= 1 && MV <= MSP_MAXCD);
@@ -295,6 +318,8 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
         tile_load(P[q], st + (size_t)(own.I[q] * M + own.J[q]) * 16);
       else if (own.I[q] == own.J[q])
         tile_load(P[q], mdl + mdl_P(sh) + (size_t)own.I[q] * 16);
+      else if (CPL && sh.part[own.I[q]] == own.J[q])
+        tile_load(P[q], mdl + mdl_Px(sh) + (size_t)own.I[q] * 16);      // Pinf(rows of the tail row I, columns of its head row)
     }
   }
   for (int i = tid; i < S; i += NT)
@@ -318,6 +343,34 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
     my_o = ioff[myblk]; my_bs = ibsz[myblk];
   }
 
+  // CPL: the partner's share of row `row` of (A m) for block blk:  sum_l A(blk, part blk)[row][l] m[off(part blk) + l]
+  auto cross_mean = [&](int blk, int row) -> double {
+    double r = 0.0;
+    if constexpr (CPL) {
+      const int pp = ipart[blk];
+      if (pp >= 0) {
+        const double* ax = sAx + (size_t)blk * TS + 4 * row;
+        const double* mp_ = m + ioff[pp];
+        const int bp = ibsz[pp];
+#pragma unroll
+        for (int l = 0; l < 4; ++l)
+          if (l < bp) r = fma(ax[l], mp_[l], r);
+      }
+    }
+    return r;
+  };
+  // CPL: tile (a, c) of the symmetric matrix in the exchange buffer
+  auto x_tile = [&](double* t, int a, int c) {
+    if (a >= c) tile_load(t, sX + (size_t)(a * (a + 1) / 2 + c) * TS);
+    else {
+      double u[16];
+      tile_load(u, sX + (size_t)(c * (c + 1) / 2 + a) * TS);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[4 * i + j] = u[4 * j + i];
+    }
+  };
   const double* yv = b.y + (size_t)pb * T;
   double* g_tt = b.ttau + (size_t)pb * T * M;
   double* g_tn = b.tnu + (size_t)pb * T * M;
@@ -361,6 +414,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
 #pragma unroll
           for (int l = 0; l < 4; ++l)
             if (l < bs) rm = fma(a[l], mb[l], rm);
+          if constexpr (CPL) rm += cross_mean(myblk, myrow);
         } else {
           rm = m[sid];
         }
@@ -380,6 +434,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
 #pragma unroll
             for (int l = 0; l < 4; ++l)
               if (l < ibsz[blk]) g = fma(a[l], m[o_ + l], g);
+            if constexpr (CPL) g += cross_mean(blk, 0);
           } else {
             g = m[o_];
           }
@@ -389,12 +444,43 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
           spl0[sh.N + j] = eg / (eg + 1.0);
         }
       }
+      if constexpr (CPL) {
+        if (pred) {      // every tile into the exchange buffer (the readers of the previous step are five barriers back)
+#pragma unroll
+          for (int q = 0; q < TPT; ++q)
+            if (own.ok[q]) tile_store(sX + (size_t)(tid + q * NT) * TS, P[q]);
+          lds_barrier();
+        }
+      }
 #pragma unroll
       for (int q = 0; q < TPT; ++q) {
         if (own.ok[q]) {
           const int I = own.I[q], J = own.J[q];
           if (pred && !(fp.dbg & 4)) {
-            tile_congruence(P[q], sA + (size_t)I * TS, sA + (size_t)J * TS);
+            if constexpr (CPL) {
+              const int Ip = ipart[I], Jp = ipart[J];
+              double acc[16];
+              tile_zero(acc);
+              // acc += A(I,a) * ( P(a,J) A(J,J)' + P(a,Jp) A(J,Jp)' )
+              auto term = [&](int a, const double* Aia) {
+                double t1[16], pt[16];
+                tile_zero(t1);
+                x_tile(pt, a, J); tile_mma_nt(t1, pt, sA + (size_t)J * TS);
+                if (Jp >= 0) { x_tile(pt, a, Jp); tile_mma_nt(t1, pt, sAx + (size_t)J * TS); }
+                tile_mma(acc, Aia, t1);
+              };
+              term(I, sA + (size_t)I * TS);
+              if (Ip >= 0) term(Ip, sAx + (size_t)I * TS);
+#pragma unroll
+              for (int e = 0; e < 16; ++e) P[q][e] = acc[e];
+              if (J == Ip) {      // the pair's cross tile of Q (I = tail row, J = its head row)
+                const double* Qb = sQx + (size_t)I * TS;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) P[q][e] += Qb[e];
+              }
+            } else {
+              tile_congruence(P[q], sA + (size_t)I * TS, sA + (size_t)J * TS);
+            }
             if (I == J) {
               const double* Qb = sQ + (size_t)I * TS;
 #pragma unroll
@@ -418,6 +504,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
 #pragma unroll
                 for (int l = 0; l < 4; ++l)
                   if (l < ibsz[I]) f = fma(a[l], mb[l], f);
+                if constexpr (CPL) f += cross_mean(I, 0);
                 f *= hI;
               } else {
                 f = hI * m[ioff[I]];
@@ -428,9 +515,10 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
               bool formA = (t == 0.0);
               if (fp.legacy_update) {
                 double mn = max0(rtt[kk * M]);
-                for (int u = 1; u < M; ++u) mn = fmin(mn, max0(rtt[kk * M + u]));
+                for (int u = 1; u < Ms; ++u) mn = fmin(mn, max0(rtt[kk * M + u]));
                 formA = (mn == 0.0);
               }
+              if (CPL && I >= Ms) formA = true;      // tail rows (t = 0, h = 0): the form without 1 / t
               if (formA) { const double z = t * hp + 1.0; cA[I] = t / z; cm[I] = -(t * f - n_) / z; }
               else { const double s = 1.0 / (hp + 1.0 / t); cA[I] = s; cm[I] = s * (n_ / t - f); }
             }
@@ -476,11 +564,12 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
             }
             if constexpr (!SPK && !SQK) {
               mom_eval<MV, false, false>(mc, sW, pEP1, sn2, fp.mom_alpha, yk, fmu, HPH, ws, &misc[0], dl, d2l, stp);
-              if (tid < M) { d1v = dl[tid]; d2v = d2l[tid]; }
+              if (tid < Ms) { d1v = dl[tid]; d2v = d2l[tid]; }
               if (tid == 0) rZ[kk] = misc[0];
             }
             if (mc.stamps && tid == 0) st_a = __builtin_readcyclecounter();
-            if (tid < M) {
+            if (CPL && tid >= Ms && tid < M) { tt[tid] = 0.0; tn[tid] = 0.0; }      // tail rows: no site
+            if (tid < Ms) {
               const double d2 = d2v, d1 = d1v, hp = HPH[tid], f = fmu[tid];
               const double t_old = rtt[kk * M + tid], n_old = rtn[kk * M + tid];
               double tnew = fp.w_old * t_old + fp.w_new * (-d2 / (1.0 + d2 * hp));
@@ -499,9 +588,10 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
             bool formA = (t == 0.0);
             if (fp.legacy_update) {
               double mn = tt[0];
-              for (int q = 1; q < M; ++q) mn = fmin(mn, tt[q]);   // MATLAB min ignores NaN like fmin
+              for (int q = 1; q < Ms; ++q) mn = fmin(mn, tt[q]);   // MATLAB min ignores NaN like fmin
               formA = (mn == 0.0);
             }
+            if (CPL && tid >= Ms) formA = true;      // tail rows
             if (formA) {   // z = t*hp+1; K = W*(t/z); v = t*f - n; m -= W*(v/z); P -= K*W'
               const double z = t * hp + 1.0;
               cA[tid] = t / z;
@@ -620,7 +710,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
               z = group_sum(z, 8);
               if (sub == 0 && g < N) { part[D + g] = z * spl[N + g]; mp[D + g] = 0.0; }
             }
-            if (tid < (mod_w1 ? D : M)) {
+            if (tid < (mod_w1 ? D : Ms)) {
               double pv = 0.0;
               if (tid < D) {
                 for (int j0 = 0; j0 < N; j0 += 4) {      // (reads of four terms together; same order of the fused multiply-adds)
@@ -807,6 +897,7 @@ struct GainPar {
   // early with late groups (nagp_api.hip: gain_map, NAGP_GAIN_MAP=1).  Measured WITHOUT effect -- the trailing phase is bound by the LDS
   // operand reads and the SIMDs' FP64 issue of ALL active tiles, not by the slowest wave (profiles/r04_gain_phases.txt): opt-in.
   signed char gmapB[2][12], gmapL[12]; int use_map;
+  int cpl_doubles;              // split blocks (Shape::part): doubles of the extra LDS region in front of everything else (gain_cpl_doubles)
   const double* ainv;           // rts_gain_mfma_kernel<.., true>: [B][M][32] per block A^-1 (16) and A^-1 Q (16), zero padded (host: gain_inverse_blocks)
   unsigned long long* stamps;   // developer diagnostics (NAGP_STAMPS): cycles of thread 0 of every 64th workgroup per phase of rts_gain_kernel:
                 // [0] prologue (loads, B = PS A', PSkp, Delta) [1] diagonal tiles [2] column solves [3] trailing updates [4] backward
@@ -820,6 +911,8 @@ __host__ __device__ inline size_t gd_step_doubles(int Sp, int dpacked) {      //
 __host__ __device__ inline size_t gain_lds_doubles(const Shape& s) {
   return LDS_INT_DOUBLES + (size_t)s.M * 16 * 2 + 4 * (size_t)s.M * TS + 8;
 }
+// split blocks: partner table [MAXM ints] | cross tiles A(n, part n) [M][16]
+__host__ __device__ inline size_t gain_cpl_doubles(const Shape& s) { return (s.Ms < s.M) ? (size_t)(MAXM / 2) + (size_t)s.M * 16 : 0; }
 // the 768-thread instantiation (one workgroup per CU anyway) and the one-tile-per-thread one stage PS_k in LDS: its tiles are read three
 // times (PSkp by the lower owners, B = PS A' by the owners of (I,J) and of (J,I)), at 768 threads by lanes that have no registers to hoist the
 // loads with.  Measured (tools/ab_libs.sh, same box): gain launches of 32 x 12 500 steps at S = 146 899 -> ~780 ms (cfg5_fill 1 873 -> 1 755 ms,
@@ -897,9 +990,14 @@ __device__ __forceinline__ void tile_solve_L(double* t, const double* L) {
 // barrier-separated phases and lives on latency hiding across workgroups
 // LB = 768 (two tiles of B and ONE of the lower triangle per thread, 168 registers): the shapes with 1025 .. 1536 tiles whose lower
 // triangle fits 768 threads (32-channel / 6-component: 1444 and 741) -- three tiles per thread under the 512 bound spill ~280 registers
-template <int TPT, int LB = 512>
+// CPL: plans with split blocks (Shape::part): B = PS A' and PSkp = A B + Q with the cross tiles of the pairs,
+//   B(I,J) = PS(I,J) A(J,J)' + PS(I,Jp) A(J,Jp)' ,  PSkp(I,J) = A(I,I) B(I,J) + A(I,Ip) B(Ip,J)  (every thread forms the B tiles it needs itself)
+template <int TPT, int LB = 512, bool CPL = false>
 __global__ void __launch_bounds__(LB) __attribute__((amdgpu_waves_per_eu(LB > 512 ? 3 : (TPT == 1 ? 4 : 2)))) rts_gain_kernel(Shape sh, Bufs b, GainPar gp) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
+  extern __shared__ __attribute__((aligned(16))) double lds_raw[];
+  double* lds = lds_raw + (CPL ? gp.cpl_doubles : 0);
+  int* ipart = reinterpret_cast<int*>(lds_raw);      // CPL: [MAXM]
+  double* sAx = lds_raw + MAXM / 2;                  //      [M][16]
   const int tid = threadIdx.x, NT = blockDim.x;
   const int S = sh.S, M = sh.M;
   const int64_t T = sh.T;
@@ -1021,13 +1119,31 @@ __global__ void __launch_bounds__(LB) __attribute__((amdgpu_waves_per_eu(LB > 51
     }
   };
   // PSkp(I,J) = A_I PS(I,J) A_J' (+ Q, + the jitter of the second attempt), I >= J
-  auto pskp_tile = [&](double* Lq, int I, int J, bool jitter) {
-    double ps[16], bt[16];
+  // B(I,J) = PS(I,:) A(J,:)'
+  auto b_tile = [&](double* bt, int I, int J) {
+    double ps[16];
     pf_load(ps, PSk, I, J);
     tile_zero(bt);
     tile_mma_nt(bt, ps, sA + (size_t)J * 16);
+    if constexpr (CPL) {
+      const int Jp = ipart[J];
+      if (Jp >= 0) { pf_load(ps, PSk, I, Jp); tile_mma_nt(bt, ps, sAx + (size_t)J * 16); }
+    }
+  };
+  auto pskp_tile = [&](double* Lq, int I, int J, bool jitter) {
+    double bt[16];
+    b_tile(bt, I, J);
     tile_zero(Lq);
     tile_mma(Lq, sA + (size_t)I * 16, bt);
+    if constexpr (CPL) {
+      const int Ip = ipart[I];
+      if (Ip >= 0) { b_tile(bt, Ip, J); tile_mma(Lq, sAx + (size_t)I * 16, bt); }
+      if (J == Ip) {      // the pair's cross tile of Q
+        const double* Qx = mdl + mdl_Qx(sh) + (size_t)I * 16;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) Lq[e] += Qx[e];
+      }
+    }
     if (I == J) {
       const double* Qb = mdl + mdl_Q(sh) + (size_t)I * 16;
 #pragma unroll
@@ -1059,6 +1175,10 @@ __global__ void __launch_bounds__(LB) __attribute__((amdgpu_waves_per_eu(LB > 51
   for (int i = tid; i <= M; i += NT) ioff[i] = sh.off[i];
   for (int i = tid; i < M; i += NT) ibsz[i] = sh.bsz[i];
   for (int i = tid; i < M * 16; i += NT) sA[i] = mdl[mdl_A(sh) + i];
+  if constexpr (CPL) {
+    for (int i = tid; i < M; i += NT) ipart[i] = sh.part[i];
+    for (int i = tid; i < M * 16; i += NT) sAx[i] = mdl[mdl_Ax(sh) + i];
+  }
   if (tid == 0) { flag[0] = 0; flag[1] = 0; }
   lds_barrier();
 
@@ -1088,6 +1208,9 @@ __global__ void __launch_bounds__(LB) __attribute__((amdgpu_waves_per_eu(LB > 51
     if (own.ok[q]) {
       const int I = own.I[q], J = own.J[q];
       double ps[16];
+      if constexpr (CPL) {
+        b_tile(Bt[q], I, J);
+      } else {
       if constexpr (HOIST && !STAGE) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) ps[e] = Bt[q][e];
@@ -1096,14 +1219,19 @@ __global__ void __launch_bounds__(LB) __attribute__((amdgpu_waves_per_eu(LB > 51
         pf_load(ps, PSk, I, J);
       }
       tile_mma_nt(Bt[q], ps, sA + (size_t)J * 16);          // B = PS A'
+      }
       if constexpr (!SPLIT) {
         double pk[16];
+        if constexpr (CPL) {
+          pskp_tile(pk, I, J, false);
+        } else {
         tile_zero(pk);
         tile_mma(pk, sA + (size_t)I * 16, Bt[q]);           // PSkp = A B (+Q)
         if (I == J) {
           const double* Qb = mdl + mdl_Q(sh) + (size_t)I * 16;
 #pragma unroll
           for (int e = 0; e < 16; ++e) pk[e] += Qb[e];
+        }
         }
         double d[16];
 #pragma unroll
@@ -1120,6 +1248,11 @@ __global__ void __launch_bounds__(LB) __attribute__((amdgpu_waves_per_eu(LB > 51
     const double* mf = b.MF + ((size_t)pb * T + k) * S;
     double acc = mf[S + tid];
     for (int l = 0; l < ibsz[blk]; ++l) acc = fma(-sA[(size_t)blk * 16 + 4 * row + l], mf[ioff[blk] + l], acc);
+    if constexpr (CPL) {
+      const int pp = ipart[blk];
+      if (pp >= 0)
+        for (int l = 0; l < ibsz[pp]; ++l) acc = fma(-sAx[(size_t)blk * 16 + 4 * row + l], mf[ioff[pp] + l], acc);
+    }
     b.dbuf[((size_t)pb * gp.chunk + kk) * S + tid] = acc;
   }
 
@@ -1132,15 +1265,18 @@ __global__ void __launch_bounds__(LB) __attribute__((amdgpu_waves_per_eu(LB > 51
 #pragma unroll
       for (int q = 0; q < TPT; ++q)
         if (own.ok[q]) {
+          if constexpr (CPL) b_tile(Bt[q], own.I[q], own.J[q]);
+          else {
           double ps[16];
           pf_load(ps, PSk, own.I[q], own.J[q]);
           tile_zero(Bt[q]);
           tile_mma_nt(Bt[q], ps, sA + (size_t)own.J[q] * 16);
+          }
         }
 #pragma unroll
       for (int q = 0; q < TPL; ++q)
         if (low.ok[q]) {
-          if constexpr (SPLIT) pskp_tile(Lt[q], low.I[q], low.J[q], true);
+          if constexpr (SPLIT || CPL) pskp_tile(Lt[q], low.I[q], low.J[q], true);
           else {
             const int I = low.I[q];
             tile_zero(Lt[q]);
@@ -1699,7 +1835,7 @@ template <int MV>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) ep_site_kernel(Shape sh, Bufs b, MomCfg mc, EpPar ep) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int tid = threadIdx.x, NT = blockDim.x;
-  const int M = sh.M;
+  const int M = sh.M, Ms = sh.Ms;      // Ms < M: tail rows of split blocks behind the real sites (no site arithmetic there)
   const int64_t T = sh.T;
   const int pb = blockIdx.y;
   const double* mdl = b.model + (size_t)pb * mdl_size(sh);
@@ -1722,7 +1858,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) e
     if (yk != yk) continue;   // isnan(y_k): no EP update (uniform)
     const size_t ix = ((size_t)pb * T + k) * M + tid;
     double t_old = 0.0, n_old = 0.0, vcav = 0.0, mcav = 0.0;
-    if (tid < M) {
+    if (tid < Ms) {
       t_old = b.ttau[ix]; n_old = b.tnu[ix];
       const double vm = b.sv[ix], mm = b.sm[ix];
       vcav = 1.0 / (1.0 / vm - ep.alpha * t_old);
@@ -1731,7 +1867,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) e
     }
     lds_barrier();
     mom_eval<MV>(mc, sW, pEPa, sn2, ep.alpha, yk, mc_, vc_, ws, &misc[0], dl, d2l);
-    if (tid < M) {
+    if (tid < Ms) {
       const bool upd = vcav > 0.0;
       double tnew = t_old, nnew = n_old;
       if (upd) {
@@ -1746,7 +1882,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) e
     if (tid == 0 && ep.lZ_out) ep.lZ_out[(size_t)pb * T + k] = misc[0];
     lds_barrier();
   }
-  if (tid < M && n_clamped) atomicAdd(&b.counters[(size_t)pb * 4 + 1], n_clamped);
+  if (tid < Ms && n_clamped) atomicAdd(&b.counters[(size_t)pb * 4 + 1], n_clamped);
 }
 
 // The same refresh with likModulatorNMFPower in the staged sparse-point form of nagp_momsp.hpp (fully symmetric sigma-point sets,

@@ -19,7 +19,7 @@ static int launch_filter(nagp_plan* p, const FilterPar& fp_in) {
   Timed t(p, adf ? NAGP_K_FILTER : NAGP_K_FILTER_LIN);
   dim3 g(p->B), bl(p->NT_f);
   if (p->sh.Ms < p->sh.M) {      // split blocks: one geometry (the fixed-site one) for every launch, the general mom code
-    fp.cpl_doubles = (int)filter_cpl_doubles(p->sh);
+    fp.cpl_doubles = (int)filter_cpl_doubles(p->sh); fp.xbuf = p->d_xbuf;
     mc.sp = MomSp{};
 #define LFC(TP, ME, V) hipLaunchKernelGGL((gf_filter_kernel<TP, ME, V, 512, 0, true>), g, dim3(ekf ? nt_ekf : p->NT_f), p->lds_filter, p->stream, p->sh, p->b, mc, fp)
 #define LFC1(V) LFC(1, 0, V)
@@ -802,7 +802,8 @@ static int exec_ihgp(nagp_plan* p) {
   for (int itt = 1; itt <= I; ++itt) {
     // forward: sweep 1 is the sequential ADF filter; later sweeps have fixed sites for k < T-1 (an affine
     // recursion, run parallel in time) and one ADF step at k = T-1
-    const bool seq = sh.BS == 8;      // blocks of 5 .. 8 states: the sequential kernels do every sweep (the affine scans hold 4 x 4 maps)
+    const bool seq8 = sh.BS == 8;     // blocks of 5 .. 8 states: the sequential kernels do every sweep (the affine scans hold 4 x 4 maps)
+    const bool seq = seq8 || (dev_env("NAGP_IH_SEQ") && !p->sq_ih && !p->sp_ih && !p->src_f);      // (developer switch: the same schedule with 4-state blocks)
     if (itt > 1 && !seq) RUN(affine(0, sh.T - 1, itt));
     IhgpPar ip{itt, p->damping[itt - 1], itt == 1 ? 1 : 0, (itt == 1 || seq) ? (int64_t)0 : (int64_t)(sh.T - 1)};
     ip.hph_lds = p->hph_lds; ip.kb = p->kb_ih;
@@ -827,7 +828,7 @@ static int exec_ihgp(nagp_plan* p) {
         else switch (mcf.cdim) { case 1: LA(1); break; case 2: LA(2); break; case 3: LA(3); break; case 4: LA(4); break; case 5: LA(5); break; case 6: LA(6); break; default: LA(7); break; }
 #undef LA
 #undef LA8
-      } else if (seq) {
+      } else if (seq8) {
 #define LI8(V) hipLaunchKernelGGL((ihgp_filter_kernel<V, false, 8>), dim3(B), dim3(p->NT_ih), p->lds_ih, p->stream, sh, p->b, mcf, p->tb, ip)
         NAGP_MV_SWITCH9(mom_variant(mcf), LI8)
 #undef LI8
@@ -843,7 +844,7 @@ static int exec_ihgp(nagp_plan* p) {
     if (sh.T > 1 && !seq) RUN(affine(1, sh.T - 1, itt));
     else {   // T = 1, no smoothing step: P = zeros (ihgp_ep_modulator_nmf.m:364) -> maxDiffP = |H PSP H'|   (or a plan of the sequential kernels)
       Timed t(p, NAGP_K_SCAN);
-      if (seq) hipLaunchKernelGGL(ihgp_scan_kernel<8>, dim3(B), dim3(64), 0, p->stream, sh, p->b, p->tb, p->d_vprev);
+      if (seq8) hipLaunchKernelGGL(ihgp_scan_kernel<8>, dim3(B), dim3(64), 0, p->stream, sh, p->b, p->tb, p->d_vprev);
       else hipLaunchKernelGGL(ihgp_scan_kernel<4>, dim3(B), dim3(64), 0, p->stream, sh, p->b, p->tb, p->d_vprev);
     }
     if (itt < I) {

@@ -97,6 +97,7 @@ struct FilterPar {
   int dbg;                 // developer switch (NAGP_FILTER_DBG): skip phases to time the others -- results are garbage.
                            // 1: rank-M covariance update, 2: PF stores, 4: prediction congruence, 8: W panel writes, 16: mean update
   int cpl_doubles;         // split blocks (Shape::part): doubles of the extra LDS region in FRONT of everything else (filter_cpl_doubles)
+  double* xbuf;            // ... and the exchange buffer of the lower tiles in global memory, [B][M(M+1)/2][TS] (filter_cpl_xglobal), or nullptr: in the LDS
 };
 
 // The filtered covariance is symmetric: PF holds only the lower-triangular tiles, tile (I,J), I >= J, at tile index I(I+1)/2 + J.
@@ -164,8 +165,10 @@ struct TileOwner {
 // fire-and-forget stores of the filtered covariance tiles.
 __host__ __device__ inline size_t filter_ring_doubles(const Shape& s, int kb) { return (size_t)kb * (5 * s.M + s.S + 3); }
 // split blocks: partner table [MAXM ints] | cross tiles of A [M][TS] | of Q [M][TS] | exchange buffer of the lower tiles [M(M+1)/2][TS]
+// (the exchange buffer moves to global memory, FilterPar::xbuf, when it would take more than 48 KB of the LDS: more than 25 tile rows)
+__host__ __device__ inline bool filter_cpl_xglobal(const Shape& s) { return (size_t)(s.M * (s.M + 1) / 2) * TS * sizeof(double) > 48 * 1024; }
 __host__ __device__ inline size_t filter_cpl_doubles(const Shape& s) {
-  return (s.Ms < s.M) ? (size_t)(MAXM / 2) + 2 * (size_t)s.M * TS + (size_t)(s.M * (s.M + 1) / 2) * TS : 0;
+  return (s.Ms < s.M) ? (size_t)(MAXM / 2) + 2 * (size_t)s.M * TS + (filter_cpl_xglobal(s) ? 0 : (size_t)(s.M * (s.M + 1) / 2) * TS) : 0;
 }
 __host__ __device__ inline size_t filter_lds_doubles(const Shape& s, const MomCfg& mc, int meas, int kb) {
   size_t n = LDS_INT_DOUBLES + 2 * (size_t)s.M * TS + s.M + (size_t)s.D * s.N + s.S + 4 * (size_t)s.M * s.M +
@@ -197,7 +200,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
   int* ipart = reinterpret_cast<int*>(lds_raw);                  // CPL: [MAXM] partner tile row or -1
   double* sAx = lds_raw + MAXM / 2;                              //      A(n, part n) [M][TS]
   double* sQx = sAx + (size_t)M * TS;                            //      Q(n, part n) [M][TS]
-  double* sX = sQx + (size_t)M * TS;                             //      exchange buffer, lower tile t at t * TS
+  double* sX = (CPL && fp.xbuf) ? fp.xbuf + (size_t)blockIdx.x * (size_t)(M * (M + 1) / 2) * TS : sQx + (size_t)M * TS;      //      exchange buffer, lower tile t at t * TS (LDS, or global memory for many tile rows)
   const int64_t T = sh.T;
   const int pb = blockIdx.x;
   const double* mdl = b.model + (size_t)pb * mdl_size(sh);
@@ -449,7 +452,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
 #pragma unroll
           for (int q = 0; q < TPT; ++q)
             if (own.ok[q]) tile_store(sX + (size_t)(tid + q * NT) * TS, P[q]);
-          lds_barrier();
+          __syncthreads();      // (a full barrier: the buffer may live in global memory)
         }
       }
 #pragma unroll

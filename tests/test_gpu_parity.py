@@ -12,7 +12,7 @@ import pytest
 import nagp
 from nagp import harness, Mom, SSHandle, Plan, _lib as L
 from nagp import ss as pss
-from oracle import gf_ep as ogf, ihgp as oih, giekf as oek, lik as olik, fastfb as offb, mixture as omx
+from oracle import gf_ep as ogf, ihgp as oih, giekf as oek, lik as olik, fastfb as offb, mixture as omx, ss as oss
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), 'golden')
@@ -526,9 +526,135 @@ def test_full_length_cfg2_prefix_property_and_finiteness():
     assert np.all(np.isfinite(out.Eft)) and np.all(out.Varft > 0) and np.isfinite(out.nlZ[0])
 
 
+def test_golden_sixstate_matern52_subbands_all_three_families():
+    """kernel1 = 'matern52' (ss_modulators_nmf.m:13-33, cf_matern52_to_ss.m:93-121): 6-state sub-band blocks, D = 8, N = 3 -- the full-covariance
+    plans split each block over two tile rows, the infinite-horizon plans keep it whole (block stride 8)."""
+    g = gold('sixstate_matern52_subbands'); D, N = int(g['D']), int(g['N']); T = g['y'].size; t = np.arange(1, T + 1.0)
+    mom = Mom('likModulatorNMFPower', p_cubature=7); d = 0.5 * np.ones(3); k1 = k2 = 'matern52'
+    Eft, Varft, _, _, _, out = nagp.gf_ep_modulator_nmf(g['w'], t, g['y'], SSHandle(), mom, t, k1, k2, 1, D, N, 0.5, d, 3, nargout=6)
+    assert rel(Eft, g['gf_Eft']) < TOL_MEAN and rel(Varft, g['gf_Varft']) < TOL_MEAN and relz(out['nlZ'], g['gf_nlZ']) < TOL_LOGZ
+    assert rel(out['ttau'], g['gf_ttau']) < TOL_SITE and rel(out['tnu'], g['gf_tnu']) < TOL_SITE and rel(out['lZ'], g['gf_lZ']) < 1e-7
+    assert rel(out['maxDiffM'], g['gf_maxDiffM']) < 1e-6 and rel(out['maxDiffP'], g['gf_maxDiffP']) < 1e-6
+    assert out['counters']['nan_obs'] == 3 * 11 and out['counters']['chol_retries'] == 0
+    assert out['ttau'].shape == (D + N, T) and out['MS'].shape == (6 * D + 3 * N, T)
+    e, _ = nagp.gf_ep_modulator_nmf(g['w'], t, g['y'], SSHandle(), mom, None, k1, k2, 1, D, N, 0.5, d, 3)
+    assert abs(e - float(g['gf_edata_I3'])) < TOL_LOGZ * abs(e)
+    Eft, Varft, _, _, _, out = nagp.ihgp_ep_modulator_nmf(g['w'], t, g['y'], SSHandle(), mom, t, k1, k2, 1, D, N, 0.5, d, 3, nargout=6)
+    # two sets of look-up tables: the oracle's own (SciPy's DARE solver) and the host's (batched doubling) agree to 1e-8 .. 1e-6 on a 6-state block
+    # (steady-state covariances conditioned ~1e8), so logZ and the sites are held to 1e-6 / 1e-4 against the independent tables and the
+    # kernels are pinned by the oracle run on the HOST's tables (ihh_*)
+    assert rel(Eft, g['ih_Eft']) < TOL_MEAN and rel(Varft, g['ih_Varft']) < TOL_MEAN and relz(out['nlZ'], g['ih_nlZ']) < 1e-6
+    assert rel(out['ttau'], g['ih_ttau']) < 1e-4 and rel(out['tnu'], g['ih_tnu']) < 1e-4
+    assert rel(Eft, g['ihh_Eft']) < 1e-9 and rel(Varft, g['ihh_Varft']) < 1e-9 and relz(out['nlZ'], g['ihh_nlZ']) < TOL_LOGZ and rel(out['ttau'], g['ihh_ttau']) < 1e-4
+    Eft, Varft, _, _, _, out = nagp.gf_giekf_modulator_nmf(g['w'], t, g['y_ekf'], SSHandle(), None, t, k1, k2, 1, D, N, 3, 2, nargout=6)
+    assert rel(Eft, g['ekf_Eft']) < TOL_MEAN and rel(Varft, g['ekf_Varft']) < TOL_MEAN and rel(out['maxDiffP'], g['ekf_maxDiffP']) < 1e-6
+
+
+@pytest.mark.parametrize('k1', ['matern52', 'matern72'])
+def test_blocks_of_more_than_four_states_against_the_oracle(k1):
+    """6- and 8-state sub-band blocks through every entry point of the full-covariance path (EP predict / nlml, plain likelihood with M = 2D,
+    constraints variants, EKF smoother and energy), against the oracle on fresh problems."""
+    D, N, T = 5, 2, 160
+    pr = harness.nmf_problem(D, N, T, 9, 'constraints', kernel1=k1); t = np.arange(1, T + 1.0); y = pr['y'].copy(); y[50:58] = np.nan
+    mom = Mom('likModulatorNMFPower', p_cubature=7); om = olik.Mom(olik.LIK_POWER_NMF, p=7)
+    r = nagp.gf_ep_modulator_nmf(pr['w'], t, y, SSHandle(), mom, t, k1, 'matern52', 1, D, N, 0.5, [0.5, 0.4], 2, nargout=6)
+    o = ogf.gf_ep_modulator_nmf(pr['w'], t, y, None, om, t, k1, 'matern52', 1, D, N, 0.5, [0.5, 0.4], 2)
+    assert rel(r[0], o[0]) < TOL_MEAN and rel(r[1], o[1]) < TOL_MEAN and rel(r[5]['ttau'], o[5]['ttau']) < TOL_SITE and relz(r[5]['nlZ'], o[5]['nlZ']) < TOL_LOGZ
+    assert rel(r[5]['MS'], o[5]['MS']) < TOL_MEAN and rel(r[5]['PS'], np.transpose(o[5]['PS'], (1, 2, 0))) < TOL_MEAN      # (the caller's state order)
+    for I in (1, 3):
+        e, _ = nagp.gf_ep_modulator_nmf(pr['w'], t, y, SSHandle(), mom, None, k1, 'matern52', 1, D, N, 0.5, [0.5] * I, I)
+        eo, _ = ogf.gf_ep_modulator_nmf(pr['w'], t, y, None, om, None, k1, 'matern52', 1, D, N, 0.5, [0.5] * I, I)
+        assert abs(e - eo) < TOL_LOGZ * abs(eo)
+    cons = harness.CONSTRAINTS_DEMO(D); w, wf = harness.constrained_vectors(pr, cons, harness.TUNE_DEMO)
+    r = nagp.gf_ep_modulator_nmf_constraints(w, t, y, SSHandle(), mom, t, k1, 'matern52', 1, D, N, 0.5, 0.5 * np.ones(2), 2, cons, wf, harness.TUNE_DEMO, nargout=6)
+    o = ogf.gf_ep_modulator_nmf_constraints(w, t, y, None, om, t, k1, 'matern52', 1, D, N, 0.5, 0.5 * np.ones(2), 2, cons, wf, harness.TUNE_DEMO)
+    assert rel(r[0], o[0]) < TOL_MEAN and rel(r[1], o[1]) < TOL_MEAN and rel(r[5]['ttau'], o[5]['ttau']) < TOL_SITE
+    r = nagp.gf_giekf_modulator_nmf(pr['w'], t, pr['y'], SSHandle(), None, t, k1, 'matern52', 1, D, N, 2, 2, nargout=6)
+    o = oek.gf_giekf_modulator_nmf(pr['w'], t, pr['y'], None, None, t, k1, 'matern52', 1, D, N, 2, 2)
+    assert rel(r[0], o[0]) < TOL_MEAN and rel(r[1], o[1]) < TOL_MEAN and rel(r[5]['maxDiffP'], o[5]['maxDiffP']) < 1e-6
+    r = nagp.gf_giekf_modulator_nmf_constraints(w, t, pr['y'], SSHandle(), None, t, k1, 'matern52', 1, D, N, 3, 1, cons, wf, harness.TUNE_DEMO, nargout=6)
+    o = oek.gf_giekf_modulator_nmf_constraints(w, t, pr['y'], None, None, t, k1, 'matern52', 1, D, N, 3, 1, cons, wf, harness.TUNE_DEMO)
+    assert rel(r[0], o[0]) < TOL_MEAN and rel(r[1], o[1]) < TOL_MEAN
+    e, eg = nagp.gf_giekf_modulator_nmf_constraints(w, t, pr['y'], SSHandle(), None, None, k1, 'matern52', 1, D, N, 3, 2, cons, wf, harness.TUNE_DEMO, 'off')
+    eo, _ = oek.gf_giekf_modulator_nmf_constraints_nlml(w, t, pr['y'], k1, 'matern52', 1, D, N, cons, wf, harness.TUNE_DEMO)
+    assert abs(e - eo) < TOL_LOGZ * abs(eo)
+    # the plain likelihood: one modulator per sub-band, M = 2D sites, balanced blocks, prediction at the first step
+    D1, T1 = 4, 240
+    param = np.concatenate([np.full(D1, 0.1), [50.0, 40.0, 50.0, 40.0], [np.pi / 4, np.pi / 6, np.pi / 8, np.pi / 10], [2.0, 3.0, 2.0, 3.0], [500.0, 700.0, 500.0, 700.0]])
+    y1 = harness.sample_prior(pss.ss_blocks_nmf(param[:3 * D1], param[3 * D1:], k1, 'matern52'), None, T1, np.random.default_rng(3))
+    w1 = np.log(np.concatenate([[1e-5], param])); t1 = np.arange(1, T1 + 1.0)
+    r = nagp.gf_ep_modulator(w1, t1, y1, SSHandle('ss_modulators'), Mom('likModulatorPower', p_cubature=9), t1, k1, 'matern52', 1, 0.5, 0.3 * np.ones(3), 3, nargout=6)
+    o = ogf.gf_ep_modulator(w1, t1, y1, None, olik.Mom(olik.LIK_POWER, p=9), t1, k1, 'matern52', 1, 0.5, 0.3 * np.ones(3), 3)
+    assert rel(r[0], o[0]) < TOL_MEAN and rel(r[1], o[1]) < TOL_MEAN and rel(r[5]['ttau'], o[5]['ttau']) < TOL_SITE and relz(r[5]['nlZ'], o[5]['nlZ']) < TOL_LOGZ
+
+
+@pytest.mark.parametrize('k1', ['matern52', 'matern72'])
+def test_infinite_horizon_sweeps_with_blocks_of_more_than_four_states(k1):
+    """ihgp_ep_modulator_nmf{,_constraints} with 6- and 8-state sub-band blocks.  The steady-state covariances of such blocks are badly conditioned
+    (1e8 for Matern-5/2, 1e12 for an 8-state Matern-7/2 block): two DARE solvers with residuals of 1e-13 each (the oracle's SciPy one, the host's batched
+    doubling) give tables 1e-8 .. 1e-5 apart.  The kernels are pinned by the oracle run on the HOST's tables; the independent tables are held to what
+    their own agreement allows."""
+    D, N, T = 6, 2, 260
+    pr = harness.nmf_problem(D, N, T, 13, kernel1=k1); t = np.arange(1, T + 1.0); y = pr['y'].copy(); y[70:75] = np.nan
+    mom = Mom('likModulatorNMFPower', p_cubature=7); om = olik.Mom(olik.LIK_POWER_NMF, p=7); d = [0.5, 0.4, 0.3]
+    r = nagp.ihgp_ep_modulator_nmf(pr['w'], t, y, SSHandle(), mom, t, k1, 'matern52', 1, D, N, 0.5, d, 3, nargout=6)
+    o = oih.ihgp_ep_modulator_nmf(pr['w'], t, y, None, om, t, k1, 'matern52', 1, D, N, 0.5, d, 3)
+    if k1 == 'matern52':      # against the oracle's own tables (Matern-7/2: SciPy's solver itself warns "ill-conditioned, rcond = 8e-17" on these blocks
+        # and its tables are off by up to 10 % of the posterior mean on this instance -- nothing to hold the product to)
+        assert rel(r[0], o[0]) < TOL_MEAN and rel(r[1], o[1]) < TOL_MEAN and rel(r[5]['ttau'], o[5]['ttau']) < 1e-4 and relz(r[5]['nlZ'], o[5]['nlZ']) < 1e-6
+    from nagp import ihgp_tables
+    lik, p1, p2, W = oss.unpack_log(pr['w'], 1, D, N)
+    model = ogf.assemble(lik, p1, p2, W, k1, 'matern52', True, True)
+    blk = pss.balance_blocks(pss.ss_blocks_nmf(p1, p2, k1, 'matern52'))
+    A, Q, _ = pss.discretise(blk, symmetrize_Q=True)
+    r2, PP, ppo, PG, pgo = ihgp_tables.build_tables(A, Q, blk.offsets, blk.h_val)
+    PPl = [PP[ppo[n]:ppo[n] + 200 * blk.sizes[n] ** 2].reshape(200, -1) for n in range(D + N)]
+    PGl = [PG[pgo[n]:pgo[n] + 400 * blk.sizes[n] ** 2].reshape(200, -1) for n in range(D + N)]
+    res = oih.run_predict(model, y, om, 0.5, np.asarray(d), 3, tables=(oih.build_tables(model)[0], r2, PPl, PGl))      # ... and on the host's
+    assert rel(r[0], res['Eft']) < TOL_MEAN and rel(r[1], res['Varft']) < TOL_MEAN and rel(r[5]['ttau'], res['ttau']) < 1e-4 and relz(r[5]['nlZ'], res['nlZ']) < TOL_LOGZ
+    cons = harness.CONSTRAINTS_DEMO(D); prc = harness.nmf_problem(D, N, T, 13, 'constraints', kernel1=k1); w, wf = harness.constrained_vectors(prc, cons, harness.TUNE_DEMO)
+    if k1 == 'matern52':
+        r = nagp.ihgp_ep_modulator_nmf_constraints(w, t, prc['y'], SSHandle(), mom, t, k1, 'matern52', 1, D, N, 0.5, 0.3, 2, cons, wf, harness.TUNE_DEMO, nargout=6)
+        o = oih.ihgp_ep_modulator_nmf_constraints(w, t, prc['y'], None, om, t, k1, 'matern52', 1, D, N, 0.5, 0.3, 2, cons, wf, harness.TUNE_DEMO)
+        assert rel(r[0], o[0]) < TOL_MEAN and rel(r[1], o[1]) < TOL_MEAN and relz(r[5]['nlZ'], o[5]['nlZ']) < 1e-6
+
+
+def test_split_block_plans_batches_chunks_warm_starts_and_many_tile_rows():
+    """Plans with split blocks: a batch equals its single runs, a chunked pipelined smoother equals the oracle, sites round-trip through the warm start
+    in the caller's M columns, the exchange buffer in global memory (more than 25 tile rows: D = 16 -> 35, D = 20 -> 43) agrees with the oracle."""
+    k1 = 'matern52'; mom = Mom('likModulatorNMFPower', p_cubature=7); om = olik.Mom(olik.LIK_POWER_NMF, p=7)
+    for (D, N, T) in [(4, 2, 90), (16, 3, 30), (20, 3, 10)]:
+        probs, ys, orc = [], [], []
+        for sd in (1, 2):
+            pr = harness.nmf_problem(D, N, T, sd, kernel1=k1)
+            probs.append((pss.ss_blocks_nmf(pr['param1'], pr['param2'], k1, 'matern52'), pr['W'], np.log(pr['w_lik']))); ys.append(pr['y'])
+            orc.append(ogf.gf_ep_modulator_nmf(pr['w'], np.arange(1, T + 1.0), pr['y'], None, om, np.arange(1, T + 1.0), k1, 'matern52', 1, D, N, 0.5, [0.5, 0.5], 2))
+        plan = Plan(L.KIND_GF_EP, probs, T, mom=mom, ep_fraction=0.5, ep_damping=[0.5, 0.5], ep_itts=2, flags=0x4)
+        plan.upload(ys); plan.execute(); outs = plan.download(want_MS=True, want_PS=True, want_MF=True)
+        for q in range(2):
+            o = orc[q]
+            assert rel(outs[q].Eft, o[0]) < TOL_MEAN and rel(outs[q].Varft, o[1]) < TOL_MEAN and rel(outs[q].ttau, o[5]['ttau']) < TOL_SITE
+            assert rel(outs[q].MS, o[5]['MS']) < TOL_MEAN and rel(outs[q].MF, o[5]['MF']) < TOL_MEAN and rel(outs[q].PS, np.transpose(o[5]['PS'], (1, 2, 0))) < TOL_MEAN
+        if D == 4:
+            one = Plan(L.KIND_GF_EP, probs[1:], T, mom=mom, ep_fraction=0.5, ep_damping=[0.5, 0.5], ep_itts=2); one.upload(ys[1:]); one.execute(); o1 = one.download()[0]; one.close()
+            assert np.array_equal(o1.Eft, outs[1].Eft) and np.array_equal(o1.ttau, outs[1].ttau) and np.array_equal(o1.nlZ, outs[1].nlZ)
+        plan.close()
+    D, N, T = 6, 2, 700
+    pr = harness.nmf_problem(D, N, T, 4, kernel1=k1); t = np.arange(1, T + 1.0)
+    a = Plan(L.KIND_GF_EP, [(pss.ss_blocks_nmf(pr['param1'], pr['param2'], k1, 'matern52'), pr['W'], np.log(pr['w_lik']))], T, mom=mom, ep_fraction=0.5,
+             ep_damping=[0.5] * 3, ep_itts=3, chunk=128)
+    a.upload([pr['y']]); a.execute(); oa = a.download()[0]
+    o3 = ogf.gf_ep_modulator_nmf(pr['w'], t, pr['y'], None, om, t, k1, 'matern52', 1, D, N, 0.5, [0.5] * 3, 3)
+    assert rel(oa.Eft, o3[0]) < TOL_MEAN and rel(oa.Varft, o3[1]) < TOL_MEAN and rel(oa.ttau, o3[5]['ttau']) < TOL_SITE and relz(oa.nlZ, o3[5]['nlZ']) < TOL_LOGZ
+    assert oa.ttau.shape == (D + N, T)
+    a.upload_sites([oa.ttau], [oa.tnu]); a.execute(); ob = a.download()[0]; a.close()
+    assert np.all(np.isfinite(ob.Eft)) and ob.ttau.shape == (D + N, T) and not np.array_equal(ob.ttau, oa.ttau)
+
+
 def test_unsupported_shapes_are_refused_not_emulated():
-    D, N, T = 2, 1, 20
-    pr = harness.nmf_problem(D, N, T, 1, kernel1='matern52')              # 6-state sub-band blocks
+    # more tile rows (sites + split blocks) than the split-block kernels are instantiated for: 27 sites + 24 six-state sub-bands = 51 > 45
+    D, N, T = 24, 3, 8
+    pr = harness.nmf_problem(D, N, T, 1, kernel1='matern52')
     t = np.arange(1, T + 1.0)
     with pytest.raises(nagp.NagpError, match='unsupported'):
         nagp.gf_ep_modulator_nmf(pr['w'], t, pr['y'], SSHandle(), Mom('likModulatorNMFPower', p_cubature=5), t, 'matern52', 'matern52', 1, D, N, 0.5, [0.5], 1)

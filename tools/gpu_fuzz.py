@@ -54,11 +54,15 @@ def weak_checks(r, o):
     return dict(same_nan_pattern=bool(same_nan), ttau_nonneg=nonneg)
 
 
-def one(rng, raw=False):
+def one(rng, raw=False, k1_override=None):
     """raw=True: plain device-vs-oracle differences, nothing excused (the tests decide from the committed lists of
     tests/golden/fuzz_excused_*.json, which tools/fuzz_conditioning.py derives from the oracle alone)"""
-    c = draw(rng)
+    c = draw(rng, k1_override)
     D, N, T, p, k1, k2, itts, alpha, damp, pr, y = (c[k] for k in ('D', 'N', 'T', 'p', 'k1', 'k2', 'itts', 'alpha', 'damp', 'pr', 'y'))
+    # blocks of six / eight states: the infinite-horizon look-up tables of the host and of the oracle come from two DARE solvers and agree to
+    # 1e-8 .. 1e-5 only (steady-state covariances conditioned 1e8 .. 1e12) -- on such draws the oracle runs on the HOST's tables (the kernels are
+    # what is compared; key 'ihgp'), and the difference to the oracle's own tables is printed beside it
+    tol_ih = 1e-7
     t = np.arange(1, T + 1.0)
     mom, omom = moms(c)
     desc = 'D=%d N=%d T=%d p=%d %s %s(%g) %s/%s itts=%d alpha=%.2f' % (D, N, T, p, c['kind'], c['link'], c['shift'], k1, k2, itts, alpha)
@@ -80,9 +84,15 @@ def one(rng, raw=False):
     yi = pr['y']     # IHGP has no NaN test on y (C-3): feed complete data
     r = nagp.ihgp_ep_modulator_nmf(pr['w'], t, yi, SSHandle(), mom, t, k1, k2, 1, D, N, alpha, damp, itts, nargout=6)
     o = oih.ihgp_ep_modulator_nmf(pr['w'], t, yi, None, omom, t, k1, k2, 1, D, N, alpha, damp, itts)
+    if k1_override:
+        own = max(rel(r[0], o[0]), rel(r[1], o[1]), rel(r[5]['nlZ'], o[5]['nlZ']))
+        from gpu_fuzz_draws import oracle_ihgp_on_host_tables
+        oh = oracle_ihgp_on_host_tables(pr['w'], yi, omom, k1, k2, D, N, alpha, damp, itts)
+        o = (oh['Eft'], oh['Varft'], None, None, None, oh)
+        desc += ' [ihgp against the oracle\'s own tables: %.1e]' % own
     res['ihgp'] = max(rel(r[0], o[0]), rel(r[1], o[1]), rel(r[5]['nlZ'], o[5]['nlZ']))
     c['weak']['ihgp'] = weak_checks(r, o)
-    if res['ihgp'] > 1e-7 and not raw:
+    if res['ihgp'] > tol_ih and not raw:
         # is the instance itself unstable?  (site updates -d2/(1+d2*v) with 1+d2*v ~ 0 under full-EP cavities, or an
         # arg-min over the R grid sitting on a midpoint: the reference's own result then moves by percents under a
         # 1e-13 relative change of y, and there is nothing to compare)
@@ -190,12 +200,15 @@ if __name__ == '__main__':
             print('%3d %-100s %s%s' % (c, desc, fmt(res), flag)); sys.stdout.flush()
         print('worst', worst, 'not compared (all-NaN on both sides)', skipped, '%.0fs' % (time.time() - t0))
         sys.exit(0)
+    k1o = None
+    if '--k1' in sys.argv:      # python tools/gpu_fuzz.py 40 20271006 --k1 matern52 : every draw with six-state sub-band blocks
+        i = sys.argv.index('--k1'); k1o = sys.argv[i + 1]; del sys.argv[i:i + 2]
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     rng = np.random.default_rng(seed); worst = {}; skipped = {}; t0 = time.time()
     only = int(sys.argv[3]) if len(sys.argv) > 3 else -1
     for c in range(n):
-        desc, res, cfg = one(rng)
+        desc, res, cfg = one(rng, k1_override=k1o)
         if only >= 0:
             if c == only:
                 print(desc, res); diagnose_ihgp(cfg)

@@ -8,12 +8,14 @@ from nagp import harness, cubature
 from oracle import lik as olik
 
 
-def draw(rng):
+def draw(rng, k1_override=None):
+    """k1_override: sub-band kernel in place of the drawn one ('matern52' / 'matern72': blocks of six / eight states) -- the stream is consumed as usual"""
     D = int(rng.integers(2, 9)); N = int(rng.integers(1, 7)); T = int(rng.integers(20, 90))
     p = int(rng.choice([5, 7, 9] if N <= 4 else [7]))
     kind = str(rng.choice(['nmf', 'nmf', 'sqrt']))
     link = str(rng.choice(['softplus', 'softplus', 'exp'])); shift = float(rng.choice([0.0, 1.0])) if link == 'softplus' else 0.0
     k1 = str(rng.choice(['exp', 'matern32'])); k2 = str(rng.choice(['matern32', 'matern52']))
+    if k1_override: k1 = k1_override
     itts = int(rng.integers(1, 4)); alpha = float(rng.choice([0.5, 0.75, 1.0])); damp = rng.uniform(0.1, 0.6, itts)
     if itts > 1 and alpha == 1.0:
         # full-EP cavities 1/(1/v - ttau) are routinely near-singular (v_cav ~ 1e12 ... Inf, exp-link overflow to NaN): their
@@ -61,3 +63,18 @@ def draw_widened(rng):
     # the EKF-objective part of the draw (consumed here so that every user of the stream stays in step)
     eD = int(rng.integers(2, 12)); eN = int(rng.integers(1, 5)); eT = int(rng.integers(30, 200)); eseed = int(rng.integers(1, 10 ** 6))
     return dict(c=c, mp=mp, t=t, y=y, k1=k1, k2=k2, J=J, alpha=alpha, damp=damp, itts=itts, desc=desc, shapes=shapes, ekf=(eD, eN, eT, eseed))
+
+
+def oracle_ihgp_on_host_tables(w, y, omom, k1, k2, D, N, alpha, damp, itts):
+    """ihgp_ep_modulator_nmf of the oracle run on the look-up tables the HOST builds (nagp/ihgp_tables.py) instead of its own: the two DARE
+    solvers agree to 1e-8 .. 1e-5 on blocks of six / eight states, and this run compares the kernels alone.  Returns the oracle's result dict."""
+    from nagp import ihgp_tables, ss as pss
+    from oracle import ss as oss, gf_ep as ogf, ihgp as oih
+    lik, p1, p2, W = oss.unpack_log(w, 1, D, N)
+    model = ogf.assemble(lik, p1, p2, W, k1, k2, True, True)
+    blk = pss.balance_blocks(pss.ss_blocks_nmf(p1, p2, k1, k2))
+    A, Q, _ = pss.discretise(blk, symmetrize_Q=True)
+    r2, PP, ppo, PG, pgo = ihgp_tables.build_tables(A, Q, blk.offsets, blk.h_val)
+    PPl = [PP[ppo[n]:ppo[n] + 200 * blk.sizes[n] ** 2].reshape(200, -1) for n in range(D + N)]
+    PGl = [PG[pgo[n]:pgo[n] + 400 * blk.sizes[n] ** 2].reshape(200, -1) for n in range(D + N)]
+    return oih.run_predict(model, np.asarray(y, float), omom, alpha, np.asarray(damp, float), itts, tables=(oih.build_tables(model)[0], r2, PPl, PGl))

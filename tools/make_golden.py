@@ -4,6 +4,7 @@ no MATLAB/Octave).  Fixtures hold data only (inputs + expected outputs).
 
     python tools/make_golden.py            # everything
     python tools/make_golden.py widened    # only the fixtures of the widened rows (mixtures, EKF objective)
+    python tools/make_golden.py sixstate   # only the fixtures with Matern-5/2 sub-bands (6-state blocks), all three families
 """
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -54,6 +55,38 @@ def widened():
     save('ekf_objective_cfg4_shape', w=w, w_fixed=wf, y=pr['y'], D=D, N=N, constraints=cons, tune_hypers=np.array(tune), edata=e)
 
 
+def sixstate():
+    """kernel1 = 'matern52' (ss_modulators_nmf.m:13-33 with cf_matern52_to_ss.m:93-121): 6-state sub-band blocks, D = 8, N = 3, in the three families."""
+    D, N, T = 8, 3, 400; k1, k2 = 'matern52', 'matern52'
+    pr = harness.nmf_problem(D, N, T, 11, kernel1=k1); t = np.arange(1, T + 1.0)      # (seed: an instance on which the infinite-horizon sweeps are well-conditioned -- with seed 652 the reference algorithm itself amplifies a 1e-9 change of the DARE tables to O(1) by the second sweep)
+    y = pr['y'].copy(); y[120:131] = np.nan
+    om = olik.Mom(olik.LIK_POWER_NMF, p=7); d = 0.5 * np.ones(3)
+    o = ogf.gf_ep_modulator_nmf(pr['w'], t, y, None, om, t, k1, k2, 1, D, N, 0.5, d, 3)
+    e3, _ = ogf.gf_ep_modulator_nmf(pr['w'], t, y, None, om, None, k1, k2, 1, D, N, 0.5, d, 3)
+    oi = oih.ihgp_ep_modulator_nmf(pr['w'], t, y, None, om, t, k1, k2, 1, D, N, 0.5, d, 3)
+    # the same sweeps on the look-up tables the HOST builds (nagp/ihgp_tables.py, batched doubling; the oracle's own come from SciPy's DARE solver):
+    # a 6-state block's steady-state covariances are conditioned ~1e8, the two sets of tables agree to 1e-8 .. 1e-6, and this run isolates the kernels
+    from nagp import ihgp_tables, ss as pss
+    from oracle import ss as oss
+    lik, p1, p2, W = oss.unpack_log(pr['w'], 1, D, N)
+    model = ogf.assemble(lik, p1, p2, W, k1, k2, True, True)
+    blk = pss.balance_blocks(pss.ss_blocks_nmf(p1, p2, k1, k2))
+    A, Q, _ = pss.discretise(blk, symmetrize_Q=True)
+    r2, PP, ppo, PG, pgo = ihgp_tables.build_tables(A, Q, blk.offsets, blk.h_val)
+    PPl = [PP[ppo[n]:ppo[n] + 200 * blk.sizes[n] ** 2].reshape(200, -1) for n in range(D + N)]
+    PGl = [PG[pgo[n]:pgo[n] + 400 * blk.sizes[n] ** 2].reshape(200, -1) for n in range(D + N)]
+    oh = oih.run_predict(model, y, om, 0.5, d, 3, tables=(oih.build_tables(model)[0], r2, PPl, PGl))
+    oe = oek.gf_giekf_modulator_nmf(pr['w'], t, pr['y'], None, None, t, k1, k2, 1, D, N, 3, 2)
+    save('sixstate_matern52_subbands', w=pr['w'], y=y, y_ekf=pr['y'], D=D, N=N,
+         gf_Eft=o[0], gf_Varft=o[1], gf_lZ=o[5]['lZ'], gf_edata_I3=e3, **{'gf_' + k: v for k, v in keep(o[5]).items()},
+         ih_Eft=oi[0], ih_Varft=oi[1], ih_R=oi[5]['R'], **{'ih_' + k: v for k, v in keep(oi[5]).items()},
+         ihh_Eft=oh['Eft'], ihh_Varft=oh['Varft'], ihh_nlZ=oh['nlZ'], ihh_ttau=oh['ttau'],
+         ekf_Eft=oe[0], ekf_Varft=oe[1], ekf_maxDiffP=oe[5]['maxDiffP'])
+
+
+if len(sys.argv) > 1 and sys.argv[1] == 'sixstate':
+    sixstate()
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == 'widened':
     widened()
     sys.exit(0)
@@ -117,3 +150,4 @@ o = ogf.gf_ep_modulator_nmf(pr['w'], t, y, None, om, t, 'exp', 'matern52', 1, D,
 save('precalcwn_exp_subbands', w=pr['w'], y=y, D=D, N=N, wn=wn, xn_unscaled=xn, Eft=o[0], Varft=o[1], lZ=o[5]['lZ'], **keep(o[5]))
 print('done in %.0fs' % (time.time() - t0))
 widened()
+sixstate()

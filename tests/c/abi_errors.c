@@ -36,7 +36,7 @@ int main(void) {
   { nagp_model q = m; q.block_offsets = NULL; EXPECT(nagp_plan_create(&p, 1, &q, NULL, T, &o), NAGP_EINVAL); }
   { nagp_model q = m; q.Wnmf = NULL; EXPECT(nagp_plan_create(&p, 1, &q, NULL, T, &o), NAGP_EINVAL); }
   { nagp_model q = m; q.M = 65; EXPECT(nagp_plan_create(&p, 1, &q, NULL, T, &o), NAGP_EUNSUPPORTED); }
-  { int32_t big[M + 1] = {0, 5, 6, 7}; nagp_model q = m; q.block_offsets = big; EXPECT(nagp_plan_create(&p, 1, &q, NULL, T, &o), NAGP_EUNSUPPORTED); }  /* block of 5 */
+  { int32_t big[M + 1] = {0, 9, 10, 11}; nagp_model q = m; q.block_offsets = big; EXPECT(nagp_plan_create(&p, 1, &q, NULL, T, &o), NAGP_EUNSUPPORTED); }  /* block of 9 (blocks of 5 .. 8 states are split over two tile rows) */
   { int32_t gap[M + 1] = {1, 2, 4, 7}; nagp_model q = m; q.block_offsets = gap; EXPECT(nagp_plan_create(&p, 1, &q, NULL, T, &o), NAGP_EINVAL); }
   { nagp_model two[2]; int32_t other[M + 1] = {0, 3, 4, 7}; two[0] = m; two[1] = m; two[1].block_offsets = other;
     EXPECT(nagp_plan_create(&p, 2, two, NULL, T, &o), NAGP_EINVAL); }                                                    /* shapes differ */

@@ -67,7 +67,11 @@ typedef enum nagp_link { NAGP_LINK_SOFTPLUS = 0, NAGP_LINK_EXP = 1 } nagp_link;
  * State ordering and block structure as built by ss_modulators_nmf.m:128-132: M diagonal blocks,
  * block n spanning states block_offsets[n] .. block_offsets[n+1]-1 (0-based); A, Q, Pinf are
  * block-diagonal with these blocks (only the diagonal blocks are read); row n of H has its single
- * non-zero h_val[n] at column block_offsets[n] (1 before `balance`, a power of two after). */
+ * non-zero h_val[n] at column block_offsets[n] (1 before `balance`, a power of two after).
+ * Blocks hold 1 .. 8 states: 1 .. 4 for the kernels every driver uses (exp / Matern-3/2 sub-bands, Matern-5/2 modulators), 6 or 8 for
+ * Matern-5/2 / -7/2 sub-bands (ss_modulators_nmf.m:13-33, cf_matern52_to_ss.m:93-121, cf_matern72_to_ss.m:93-124).  The state order of
+ * every input and output is the caller's; how blocks of more than four states are laid out on the device is DESIGN.md section 3.
+ * Larger blocks (the SE kernel's 12-state form) are refused with NAGP_EUNSUPPORTED. */
 typedef struct nagp_model {
   int32_t S;                    /* state dimension */
   int32_t M;                    /* sites per step: D+N (NMF) or 2*D (gf_ep_modulator) */

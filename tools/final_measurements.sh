@@ -17,7 +17,8 @@ if [ "$part" = 1 ]; then
   cp profiles/${tag}_pmc_insts_cfg3.txt gpurun_out/ 2>/dev/null; cp profiles/pmc_traffic.json gpurun_out/pmc_traffic_part1.json
   echo FINAL_PART1_DONE
 else
-  cp gpurun_out/pmc_traffic_part1.json profiles/pmc_traffic.json 2>/dev/null
+  # (gpurun_out/ does not travel to the GPU box: between the two calls, copy the merged gpurun_out/pmc_traffic_part1.json over profiles/pmc_traffic.json HERE,
+  #  so that part 2 adds its workloads to part 1's records)
   bash tools/pmc_run.sh $tag cfg5_fill cfg2_batch > gpurun_out/${tag}_pmc2.log 2>&1 && tail -3 gpurun_out/${tag}_pmc2.log &&
   bash tools/pmc_mfma.sh $tag cfg5_fill cfg2_batch > gpurun_out/${tag}_pmcm.log 2>&1 && tail -3 gpurun_out/${tag}_pmcm.log &&
   for wl in cfg2 cfg4; do

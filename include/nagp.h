@@ -222,7 +222,8 @@ int nagp_giekf_nlml_grad(int32_t n_problems, const nagp_model* models, const dou
  * The caller keeps the set-up lines of the .m (dare, K, AKHA = A-K*H*A, HA = H*A, G = PF2*A'/PP) and passes the constant
  * matrices: A, AKHA, G are S x S column-major (G = NULL: filter only, the KF = 1 option); HA, K have S entries.
  * MS (S x T, column-major) receives the filtered / smoothed means, *sum_v2 the sum of squared innovations of the observed
- * steps (lik = -( T/2 log(2 pi S_inn) + sum_v2 / (2 S_inn) ), :80,:101,:158).  S <= 96 (both matrices live in LDS). */
+ * steps (lik = -( T/2 log(2 pi S_inn) + sum_v2 / (2 S_inn) ), :80,:101,:158).  S <= 256 (a thread per state; up to S = 96 both matrices of a pass live in the LDS and long series run parallel in time,
+ * beyond that they are read from global memory and the passes run sequentially: 32 Matern-3/2 channels = S 128). */
 int nagp_fastfb_run(int32_t S, const double* A, const double* AKHA, const double* HA, const double* K, const double* G,
                     const double* y, int64_t T, double* MS, double* sum_v2, int32_t device);
 

@@ -157,8 +157,10 @@ extern "C" int nagp_fastfb_run(int32_t S, const double* A, const double* AKHA, c
                                const double* y, int64_t T, double* MS, double* sum_v2, int32_t device) {
   if (!A || !AKHA || !HA || !K || !y || !MS) FAIL(NAGP_EINVAL, "null argument");
   if (S < 1 || T < 1) FAIL(NAGP_EINVAL, "bad sizes (S=%d T=%lld)", S, (long long)T);
-  const size_t lds = fb_lds_doubles(S) * sizeof(double);
-  if (S > 256 || lds > 160 * 1024) FAIL(NAGP_EUNSUPPORTED, "S=%d: the two constant S x S matrices do not fit the LDS (S <= 96)", S);
+  // S <= 96: both constant S x S matrices of a pass live in the LDS; 96 < S <= 256 (a thread per state): they stay in global memory (L2-resident)
+  const int mat_global = (fb_lds_doubles(S) * sizeof(double) > 160 * 1024) ? 1 : 0;
+  const size_t lds = fb_lds_doubles(S, mat_global) * sizeof(double);
+  if (S > 256) FAIL(NAGP_EUNSUPPORTED, "S=%d: the stationary filterbank runs a thread per state (S <= 256)", S);
   if (hipSetDevice(device) != hipSuccess) FAIL(NAGP_EHIP, "hipSetDevice(%d)", device);
   // spans of the parallel-in-time form (needs two more S x S work matrices in LDS: S <= 64); short series run as one span
   const size_t lds_c = fb_compose_lds_doubles(S) * sizeof(double);
@@ -186,7 +188,7 @@ extern "C" int nagp_fastfb_run(int32_t S, const double* A, const double* AKHA, c
   if (st == NAGP_OK && ns > 1) st = set_lds(fastfb_compose_kernel<true>, lds_c);
   if (st == NAGP_OK) {
     FbPar fp{S, T, dev + o_A, dev + o_B, dev + o_ha, dev + o_k, dev + o_y, dev + o_ms, dev + o_sv, L, ns, dev + o_phi,
-             ns > 1 ? dev + o_st : nullptr};
+             ns > 1 ? dev + o_st : nullptr, mat_global};
     if (ns > 1) {
       hipLaunchKernelGGL(fastfb_compose_kernel<false>, dim3(ns), dim3(256), lds_c, 0, fp);
       hipLaunchKernelGGL(fastfb_boundary_kernel<false>, dim3(1), dim3(256), 0, 0, fp);

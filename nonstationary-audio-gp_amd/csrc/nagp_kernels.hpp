@@ -2197,24 +2197,26 @@ struct FbPar {
   int ns;               // spans
   double* Phi;          // [ns][S][SP]  pass 1 out (row-major, SP = S + 4; column S = c_j)
   double* starts;       // [ns][S]      pass 2 out: value entering span j
+  int mat_global;       // filter / smoother pass: the two S x S matrices stay in global memory (L2-resident, coalesced column reads) -- S > 96, where they do not fit the LDS
 };
-__host__ __device__ inline size_t fb_lds_doubles(int S) { return 2 * (size_t)S * S + 5 * (size_t)S + (size_t)FB_CHK * (S + 1) + 8; }
+__host__ __device__ inline size_t fb_lds_doubles(int S, int mat_global = 0) { return (mat_global ? 0 : 2 * (size_t)S * S) + 5 * (size_t)S + (size_t)FB_CHK * (S + 1) + 8; }
 __host__ __device__ inline size_t fb_compose_lds_doubles(int S) { return 2 * (size_t)S * S + 2 * (size_t)(S + 4) * (S + 4) + 3 * (size_t)S + 8; }
 
 // pass 3 (and the whole job when ns == 1):  if ~isnan(y): v = y - HA*m; m = AKHA*m + K*y; else m = A*m
 static __global__ void __launch_bounds__(256) fastfb_filter_kernel(FbPar fp) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int tid = threadIdx.x, NT = blockDim.x, S = fp.S;
-  double* At = lds;                       // At[j*S + i] = A(i,j): the column-major input is already this layout
-  double* Bt = At + (size_t)S * S;
-  double* ha = Bt + (size_t)S * S;
+  const bool mg = fp.mat_global != 0;
+  const double* At = mg ? fp.A : lds;                       // At[j*S + i] = A(i,j): the column-major input is already this layout
+  const double* Bt = mg ? fp.B : lds + (size_t)S * S;
+  double* ha = lds + (mg ? 0 : 2 * (size_t)S * S);
   double* kg = ha + S;
   double* m0 = kg + S;
   double* m1 = m0 + S;
   double* yc = m1 + S + S;                // [FB_CHK]
   double* msc = yc + FB_CHK;              // [FB_CHK][S] staged output
   const int64_t ka = (int64_t)blockIdx.x * fp.L, kb = (ka + fp.L < fp.T) ? ka + fp.L : fp.T;
-  for (int e = tid; e < S * S; e += NT) { At[e] = fp.A[e]; Bt[e] = fp.B[e]; }
+  if (!mg) for (int e = tid; e < S * S; e += NT) { lds[e] = fp.A[e]; lds[(size_t)S * S + e] = fp.B[e]; }
   for (int i = tid; i < S; i += NT) { ha[i] = fp.HA[i]; kg[i] = fp.K[i]; m0[i] = fp.starts ? fp.starts[(size_t)blockIdx.x * S + i] : 0.0; }
   double sv2 = 0.0;
   __syncthreads();
@@ -2259,14 +2261,15 @@ static __global__ void __launch_bounds__(256) fastfb_filter_kernel(FbPar fp) {
 static __global__ void __launch_bounds__(256) fastfb_smoother_kernel(FbPar fp) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int tid = threadIdx.x, NT = blockDim.x, S = fp.S;
-  double* At = lds;
-  double* Gt = At + (size_t)S * S;
-  double* m = Gt + (size_t)S * S + 2 * (size_t)S;   // [S] current smoothed mean
+  const bool mg = fp.mat_global != 0;
+  const double* At = mg ? fp.A : lds;
+  const double* Gt = mg ? fp.B : lds + (size_t)S * S;
+  double* m = lds + (mg ? 0 : 2 * (size_t)S * S) + 2 * (size_t)S;   // [S] current smoothed mean
   double* dv = m + S;                                // [S] m - A*MS_k
   double* msc = dv + 2 * (size_t)S + FB_CHK;         // [FB_CHK][S]
   const int64_t n = fp.T - 1;
   const int64_t ka = (int64_t)blockIdx.x * fp.L, kb = (ka + fp.L < n) ? ka + fp.L : n;   // steps ka .. kb-1
-  for (int e = tid; e < S * S; e += NT) { At[e] = fp.A[e]; Gt[e] = fp.B[e]; }
+  if (!mg) for (int e = tid; e < S * S; e += NT) { lds[e] = fp.A[e]; lds[(size_t)S * S + e] = fp.B[e]; }
   for (int i = tid; i < S; i += NT) m[i] = fp.starts ? fp.starts[(size_t)blockIdx.x * S + i] : fp.MS[(size_t)(fp.T - 1) * S + i];
   __syncthreads();
   for (int64_t k1 = kb; k1 > ka; k1 -= FB_CHK) {            // steps k1-1 ... k1-nb, descending

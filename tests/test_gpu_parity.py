@@ -219,10 +219,11 @@ def test_ekf_update1_and_iekf_update1_standalone(iters):
 
 
 @pytest.mark.parametrize('kernel,D,T,KF', [('exp', 16, 3000, 0), ('matern32', 8, 1000, 0), ('matern52', 5, 700, 1), ('exp', 3, 1, 0),
-                                           ('exp', 48, 400, 0)])
+                                           ('exp', 48, 400, 0), ('matern32', 32, 500, 0), ('matern32', 60, 300, 1)])
 def test_stationary_filterbank_kalmanFastFB(kernel, D, T, KF):
     """[lik,Xfin,Pfin] = kernel_ss_kalmanFastFB(A,Q,C,P0,K,vary,y,verbose,KF) with the model of get_disc_model
-    (SURVEY 8f row f-2): missing samples, filter-only option, T = 1, S = 96 (the LDS limit)."""
+    (SURVEY 8f row f-2): missing samples, filter-only option, T = 1, S = 96 (both constant matrices in the LDS), S = 128 (32 Matern-3/2 channels) and
+    S = 240 (matrices read from global memory: a thread per state, S <= 256)."""
     rng = np.random.default_rng(D + T)
     lam = 1.0 / rng.uniform(20, 400, D); var = rng.uniform(0.1, 1.0, D); om = np.linspace(np.pi / 3, np.pi / 50, D)
     A, Q, H, Pinf, K, tau1 = nagp.get_disc_model(lam, var, om, D, kernel, 6)
@@ -242,7 +243,7 @@ def test_stationary_filterbank_kalmanFastFB(kernel, D, T, KF):
 
 
 def test_stationary_filterbank_refuses_what_does_not_fit():
-    A, Q, H, Pinf, K, _ = nagp.get_disc_model(np.full(50, 0.01), np.ones(50), np.linspace(1, 0.1, 50), 50, 'exp')   # S = 100
+    A, Q, H, Pinf, K, _ = nagp.get_disc_model(np.full(130, 0.01), np.ones(130), np.linspace(1, 0.1, 130), 130, 'exp')   # S = 260 > 256 (a thread per state)
     with pytest.raises(nagp.NagpError):
         nagp.kernel_ss_kalmanFastFB(A, Q, H, Pinf, K, 0.01, np.zeros(10))
 
@@ -649,6 +650,22 @@ def test_split_block_plans_batches_chunks_warm_starts_and_many_tile_rows():
     assert oa.ttau.shape == (D + N, T)
     a.upload_sites([oa.ttau], [oa.tnu]); a.execute(); ob = a.download()[0]; a.close()
     assert np.all(np.isfinite(ob.Eft)) and ob.ttau.shape == (D + N, T) and not np.array_equal(ob.ttau, oa.ttau)
+
+
+def test_mixture_variants_with_a_six_state_source():
+    """experiments/{gf,ihgp}_ep_mods_nmf_mixture.m with Matern-5/2 sub-bands in one of two stacked sources (the older EP rule: NAGP_FLAG_MIXTURE_RULE)."""
+    shapes = [(3, 1), (2, 2)]; k1 = ['matern52', 'matern32']; k2 = ['matern52', 'matern52']; T = 80
+    mp = harness.mixture_problem(shapes, T, 21, k1, k2); t = np.arange(1, T + 1.0)
+    y = mp['y'].copy(); y[30:36] = np.nan
+    mom = Mom('likModulatorNMFPower', p_cubature=7); om = olik.Mom(olik.LIK_POWER_NMF, p=7)
+    r = nagp.gf_ep_mods_nmf_mixture(mp['w'], t, y, SSHandle(), mom, t, k1, k2, 2, 0.75, 0.2, 4, nargout=6)
+    o = omx.gf_ep_mods_nmf_mixture(mp['w'], t, y, None, om, t, k1, k2, 2, 0.75, 0.2, 4)
+    assert rel(r[0], o[0]) < TOL_MEAN and rel(r[1], o[1]) < TOL_MEAN and rel(r[5]['ttau'], o[5]['ttau']) < TOL_SITE
+    # infinite horizon: two sweeps (by the fourth this instance divides by 1 + d2 v ~ 0 -- the mixtures' rule, DESIGN section 2 -- and amplifies the 1e-8 by which
+    # the two builders of the look-up tables differ on a six-state block to O(1))
+    r = nagp.ihgp_ep_mods_nmf_mixture(mp['w'], t, mp['y'], SSHandle(), mom, t, k1, k2, 2, 0.75, 0.2, 2, nargout=6)
+    o = omx.ihgp_ep_mods_nmf_mixture(mp['w'], t, mp['y'], None, om, t, k1, k2, 2, 0.75, 0.2, 2)
+    assert rel(r[0], o[0]) < TOL_MEAN and rel(r[1], o[1]) < TOL_MEAN and rel(r[5]['ttau'], o[5]['ttau']) < TOL_SITE
 
 
 def test_unsupported_shapes_are_refused_not_emulated():

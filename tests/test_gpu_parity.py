@@ -652,6 +652,23 @@ def test_split_block_plans_batches_chunks_warm_starts_and_many_tile_rows():
     assert np.all(np.isfinite(ob.Eft)) and ob.ttau.shape == (D + N, T) and not np.array_equal(ob.ttau, oa.ttau)
 
 
+@pytest.mark.parametrize('k1', ['matern52', 'matern72'])
+def test_split_blocks_edge_lengths_and_tiny_shapes(k1):
+    """T = 1, 2, 3 and lengths around the I/O ring, one sub-band / one modulator, NaN at both ends: full-covariance EP and EKF with split blocks."""
+    mom = Mom('likModulatorNMFPower', p_cubature=5); om = olik.Mom(olik.LIK_POWER_NMF, p=5)
+    for (D, N) in [(1, 1), (2, 3), (7, 1)]:
+        for T in (1, 2, 3, 17, 33):
+            pr = harness.nmf_problem(D, N, max(T, 8), 3 + D + T, kernel1=k1); t = np.arange(1, T + 1.0); y = pr['y'][:T].copy()
+            if T > 2: y[1] = np.nan
+            if T > 16: y[-1] = np.nan; y[0] = np.nan
+            r = nagp.gf_ep_modulator_nmf(pr['w'], t, y, SSHandle(), mom, t, k1, 'matern52', 1, D, N, 0.5, [0.5, 0.5], 2, nargout=6)
+            o = ogf.gf_ep_modulator_nmf(pr['w'], t, y, None, om, t, k1, 'matern52', 1, D, N, 0.5, [0.5, 0.5], 2)
+            assert rel(r[0], o[0]) < TOL_MEAN and rel(r[1], o[1]) < TOL_MEAN and rel(r[5]['ttau'], o[5]['ttau']) < TOL_SITE and relz(r[5]['nlZ'], o[5]['nlZ']) < TOL_LOGZ, (D, N, T)
+            r = nagp.gf_giekf_modulator_nmf(pr['w'], t, y, SSHandle(), None, t, k1, 'matern52', 1, D, N, 2, 2, nargout=2)
+            o = oek.gf_giekf_modulator_nmf(pr['w'], t, y, None, None, t, k1, 'matern52', 1, D, N, 2, 2)
+            assert rel(r[0], o[0]) < TOL_MEAN and rel(r[1], o[1]) < TOL_MEAN, (D, N, T)
+
+
 def test_mixture_variants_with_a_six_state_source():
     """experiments/{gf,ihgp}_ep_mods_nmf_mixture.m with Matern-5/2 sub-bands in one of two stacked sources (the older EP rule: NAGP_FLAG_MIXTURE_RULE)."""
     shapes = [(3, 1), (2, 2)]; k1 = ['matern52', 'matern32']; k2 = ['matern52', 'matern52']; T = 80

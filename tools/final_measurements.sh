@@ -21,7 +21,7 @@ else
   #  so that part 2 adds its workloads to part 1's records)
   bash tools/pmc_run.sh $tag cfg5_fill cfg2_batch > gpurun_out/${tag}_pmc2.log 2>&1 && tail -3 gpurun_out/${tag}_pmc2.log &&
   bash tools/pmc_mfma.sh $tag cfg5_fill cfg2_batch > gpurun_out/${tag}_pmcm.log 2>&1 && tail -3 gpurun_out/${tag}_pmcm.log &&
-  for wl in cfg2 cfg4; do
+  for wl in cfg2 cfg4 cfg2_batch; do
     d=gpurun_out/${tag}_trace_$wl; rm -rf $d
     rocprofv3 --kernel-trace --output-format csv -d $d -- python3 bench.py --workload $wl --steps 1 --warmup 0 --no-cpu-baseline --extras none > $d.log 2>&1 &&
     python3 tools/trace_timeline.py $d > gpurun_out/${tag}_pipeline_timeline_$wl.txt || exit 1

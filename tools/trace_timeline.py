@@ -5,7 +5,7 @@ import csv, glob, os, sys
 
 
 def short(name):
-    for key, lab in (('gf_filter_kernel', 'filter'), ('gf_adf8_kernel', 'filter'), ('gf_filter_lin_mfma_kernel', 'filter'), ('rts_gain_kernel', 'gain'), ('rts_big_phi_kernel', 'compose'), ('rts_compose', 'compose'),
+    for key, lab in (('gf_filter_kernel', 'filter'), ('gf_adf8_kernel', 'filter'), ('gf_filter_lin_mfma_kernel', 'filter'), ('rts_gain_kernel', 'gain'), ('rts_gain_mfma_kernel', 'gain'), ('rts_big_phi_kernel', 'compose'), ('rts_compose', 'compose'),
                      ('rts_boundary', 'boundary'), ('rts_apply', 'apply'), ('ep_site_', 'ep_site'), ('sum_kernel', 'reduce')):
         if key in name:
             if key == 'gf_filter_kernel':

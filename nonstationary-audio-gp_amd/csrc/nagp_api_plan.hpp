@@ -506,8 +506,8 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     PLAN_TRY(dalloc(p, &p->d_lZs, BT));
     PLAN_TRY(dalloc(p, &p->d_vprev, (size_t)B * sh.M));
     p->aff_L = 128; p->aff_ns = (int)((T + p->aff_L - 1) / p->aff_L);
-    PLAN_TRY(dalloc(p, &p->d_affspan, (size_t)B * p->aff_ns * sh.M * 20, false));
-    PLAN_TRY(dalloc(p, &p->d_affbnd, (size_t)B * p->aff_ns * sh.M * 4, false));
+    PLAN_TRY(dalloc(p, &p->d_affspan, (size_t)B * p->aff_ns * sh.M * (sh.BS * sh.BS + sh.BS), false));
+    PLAN_TRY(dalloc(p, &p->d_affbnd, (size_t)B * p->aff_ns * sh.M * sh.BS, false));
     // ---- IHGP tables: MATLAB layout -> device layout (see nagp_ihgp.hpp)
     const int NG = tables[0].n_grid;
     if (NG < 2) { nagp_plan_destroy(p); FAIL(NAGP_EINVAL, "n_grid < 2"); }
@@ -569,7 +569,7 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     p->lds_ih = ihgp_filter_lds_doubles(sh, t, p->tb.NG, p->hph_lds, p->kb_ih) * sizeof(double);
     if (dev_env("NAGP_STAMPS")) fprintf(stderr, "[nagp plan] ihgp filter: LDS %zu B, hph table in LDS %d, cubature tables in LDS %d, block-structured mom %d, mom LDS %zu B\n", p->lds_ih, p->hph_lds, p->cache_f, p->src_f, mom_lds_doubles(t) * sizeof(double));
     // the ADF sweep in the sparse-point form (ihgp_adf_kernel): plain NMF likelihood, <= 320 sigma points, unstructured Wnmf
-    // (plans with a block of 5 .. 8 states, BS = 8: the general kernels only -- ihgp_filter_kernel<MV, false, 8> for every sweep, ihgp_scan_kernel<8> backward)
+    // (plans with a block of 5 .. 8 states, BS = 8: the general ADF kernel ihgp_filter_kernel<MV, false, 8>; the affine scans are instantiated for both strides)
     if (sh.BS == 4 && p->sp.enabled && !p->src_f && sh.M <= 64 && sh.D <= 4 * MSP_DT && o->n_pts <= MSP_NT + 64 && (o->n_pts + 3) / 4 <= MSP_NW * MSP_NST) {
       p->kb_sp = IH_KB; p->hph_sp = 1;
       if (const char* e = dev_env("NAGP_IH_KB")) p->kb_sp = std::max(1, std::min(IH_KB, atoi(e)));   // developer switch: steps per I/O block

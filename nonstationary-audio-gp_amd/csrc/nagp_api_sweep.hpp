@@ -787,23 +787,20 @@ static int exec_ihgp(nagp_plan* p) {
     ap.spanbuf = p->d_affspan; ap.bnd = p->d_affbnd; ap.vprev = p->d_vprev;
     const dim3 g((unsigned)((ap.ns * sh.M + 255) / 256), B), bl(256);
     Timed t(p, mode == 0 ? NAGP_K_FILTER_LIN : NAGP_K_SCAN);
-    if (mode == 0) {
-      hipLaunchKernelGGL((ihgp_aff_compose_kernel<0>), g, bl, 0, p->stream, sh, p->b, p->tb, ap);
-      hipLaunchKernelGGL((ihgp_aff_boundary_kernel<0>), dim3(B), dim3(64), 0, p->stream, sh, p->b, ap, itt);
-      hipLaunchKernelGGL((ihgp_aff_apply_kernel<0>), g, bl, 0, p->stream, sh, p->b, p->tb, ap);
-    } else {
-      hipLaunchKernelGGL((ihgp_aff_compose_kernel<1>), g, bl, 0, p->stream, sh, p->b, p->tb, ap);
-      hipLaunchKernelGGL((ihgp_aff_boundary_kernel<1>), dim3(B), dim3(64), 0, p->stream, sh, p->b, ap, itt);
-      hipLaunchKernelGGL((ihgp_aff_apply_kernel<1>), g, bl, 0, p->stream, sh, p->b, p->tb, ap);
-    }
+#define LAFF(MO, BSV) do { hipLaunchKernelGGL((ihgp_aff_compose_kernel<MO, BSV>), g, bl, 0, p->stream, sh, p->b, p->tb, ap); \
+                           hipLaunchKernelGGL((ihgp_aff_boundary_kernel<MO, BSV>), dim3(B), dim3(64), 0, p->stream, sh, p->b, ap, itt); \
+                           hipLaunchKernelGGL((ihgp_aff_apply_kernel<MO, BSV>), g, bl, 0, p->stream, sh, p->b, p->tb, ap); } while (0)
+    if (sh.BS == 8) { if (mode == 0) LAFF(0, 8); else LAFF(1, 8); }      // (blocks of 5 .. 8 states: 8 x 8 maps per thread)
+    else { if (mode == 0) LAFF(0, 4); else LAFF(1, 4); }
+#undef LAFF
     HIP_TRY(hipGetLastError());
     return NAGP_OK;
   };
   for (int itt = 1; itt <= I; ++itt) {
     // forward: sweep 1 is the sequential ADF filter; later sweeps have fixed sites for k < T-1 (an affine
     // recursion, run parallel in time) and one ADF step at k = T-1
-    const bool seq8 = sh.BS == 8;     // blocks of 5 .. 8 states: the sequential kernels do every sweep (the affine scans hold 4 x 4 maps)
-    const bool seq = seq8 || (dev_env("NAGP_IH_SEQ") && !p->sq_ih && !p->sp_ih && !p->src_f);      // (developer switch: the same schedule with 4-state blocks)
+    const bool seq8 = sh.BS == 8;     // blocks of 5 .. 8 states: the general ADF kernel at block stride 8
+    const bool seq = dev_env("NAGP_IH_SEQ") && !p->sq_ih && !p->sp_ih && !p->src_f;      // developer switch: the sequential kernels (general ADF filter, ihgp_scan_kernel) for every sweep instead of the affine scans
     if (itt > 1 && !seq) RUN(affine(0, sh.T - 1, itt));
     IhgpPar ip{itt, p->damping[itt - 1], itt == 1 ? 1 : 0, (itt == 1 || seq) ? (int64_t)0 : (int64_t)(sh.T - 1)};
     ip.hph_lds = p->hph_lds; ip.kb = p->kb_ih;

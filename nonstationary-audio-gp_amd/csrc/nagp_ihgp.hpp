@@ -1187,13 +1187,13 @@ struct AffPar {
   int64_t kend;    // number of steps covered
   int L;           // span length
   int ns;          // spans
-  double* spanbuf; // [B][ns][M][20]  Phi (16) + c (4)
-  double* bnd;     // [B][ns][M][4]   value entering the span
+  double* spanbuf; // [B][ns][M][BS*BS + BS]  Phi + c   (BS = Shape::BS: 4, or 8 for blocks of 5 .. 8 states)
+  double* bnd;     // [B][ns][M][BS]   value entering the span
   double* vprev;   // [B][M] (smoother: previous sweep's marginal variance at k = 0)
 };
 
 // coefficients of step k for block n: x_new = F x + g
-template <int MODE>
+template <int MODE, int BS = 4>
 __device__ __forceinline__ void ihgp_coeffs(const Shape& sh, const Bufs& b, const IhgpTabs& tb, const double* tab,
                                             const double* A4, double hn, int n, int pb, int64_t k, int bs, int o,
                                             double* F, double* g, double& aux) {
@@ -1204,35 +1204,35 @@ __device__ __forceinline__ void ihgp_coeffs(const Shape& sh, const Bufs& b, cons
     const double tt = max0(b.ttau[ix]);
     if (tt == 0.0) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) F[e] = A4[e];
+      for (int e = 0; e < BS * BS; ++e) F[e] = A4[e];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) g[i] = 0.0;
+      for (int i = 0; i < BS; ++i) g[i] = 0.0;
       aux = INFINITY;                       // R(n,k) = inf
     } else {
       const double Rk = b.R[ix];
-      double hph, wc[4];
+      double hph, wc[BS];
       if (k > 0) {
         const double tprev = max0(b.ttau[ix - M]);
         const double Rprev = (tprev == 0.0) ? INFINITY : b.R[ix - M];
         const int idx = nearest_idx(tb, Rprev);
         hph = tab[itab_hph(sh, NG) + (size_t)n * NG + idx];
-        const double* w = tab + itab_wcol(sh, NG) + ((size_t)n * NG + idx) * 4;
+        const double* w = tab + itab_wcol(sh, NG) + ((size_t)n * NG + idx) * BS;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) wc[i] = w[i];
+        for (int i = 0; i < BS; ++i) wc[i] = w[i];
       } else {
         hph = tab[itab_hph0(sh, NG) + n];
-        const double* w = tab + itab_wcol0(sh, NG) + (size_t)n * 4;
+        const double* w = tab + itab_wcol0(sh, NG) + (size_t)n * BS;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) wc[i] = w[i];
+        for (int i = 0; i < BS; ++i) wc[i] = w[i];
       }
       const double den = hph + Rk;
       const double ys = b.tnu[ix] / tt;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < BS; ++i) {
         const double Ki = wc[i] / den;
         g[i] = Ki * ys;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) F[4 * i + j] = A4[4 * i + j] - Ki * hn * A4[j];
+        for (int j = 0; j < BS; ++j) F[BS * i + j] = A4[BS * i + j] - Ki * hn * A4[j];
       }
       aux = Rk;
     }
@@ -1240,25 +1240,28 @@ __device__ __forceinline__ void ihgp_coeffs(const Shape& sh, const Bufs& b, cons
     const double Rk = b.R[ix];
     int idx = nearest_idx(tb, Rk);
     if (isinf(Rk)) idx = NG - 1;
-    tile_load(F, tab + itab_g(sh, NG) + ((size_t)n * NG + idx) * 16);
+#pragma unroll
+    for (int e = 0; e < BS * BS; ++e) F[e] = tab[itab_g(sh, NG) + ((size_t)n * NG + idx) * BS * BS + e];
     aux = tab[itab_v(sh, NG) + (size_t)n * NG + idx];
-    double mf[4] = {0, 0, 0, 0}, amf[4];
+    double mf[BS], amf[BS];
+#pragma unroll
+    for (int i = 0; i < BS; ++i) mf[i] = 0.0;
     const double* mfp = b.MF + ((size_t)pb * T + k) * sh.S + o;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < BS; ++i)
       if (i < bs) mf[i] = mfp[i];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < BS; ++i) {
       double a = 0.0;
 #pragma unroll
-      for (int l = 0; l < 4; ++l) a = fma(A4[4 * i + l], mf[l], a);
+      for (int l = 0; l < BS; ++l) a = fma(A4[BS * i + l], mf[l], a);
       amf[i] = a;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < BS; ++i) {
       double a = mf[i];
 #pragma unroll
-      for (int l = 0; l < 4; ++l) a = fma(-F[4 * i + l], amf[l], a);
+      for (int l = 0; l < BS; ++l) a = fma(-F[BS * i + l], amf[l], a);
       g[i] = a;
     }
   }
@@ -1266,7 +1269,7 @@ __device__ __forceinline__ void ihgp_coeffs(const Shape& sh, const Bufs& b, cons
 
 // span j covers recursion steps [j*L, min((j+1)L, kend)) counted in recursion order; k = that index
 // (forward) or kend-1-index (backward).
-template <int MODE>
+template <int MODE, int BS = 4>
 __global__ void __launch_bounds__(256) ihgp_aff_compose_kernel(Shape sh, Bufs b, IhgpTabs tb, AffPar ap) {
   const int pb = blockIdx.y, M = sh.M;
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1274,75 +1277,83 @@ __global__ void __launch_bounds__(256) ihgp_aff_compose_kernel(Shape sh, Bufs b,
   const int j = gid / M, n = gid - j * M;
   const double* mdl = b.model + (size_t)pb * mdl_size(sh);
   const double* tab = tb.base + (size_t)pb * itab_size(sh, tb.NG);
-  double A4[16];
-  tile_load(A4, mdl + mdl_A(sh) + (size_t)n * 16);
+  double A4[BS * BS];
+#pragma unroll
+  for (int e = 0; e < BS * BS; ++e) A4[e] = mdl[mdl_A(sh) + (size_t)n * BS * BS + e];
   const double hn = mdl[mdl_h(sh) + n];
   const int bs = sh.bsz[n], o = sh.off[n];
-  double Phi[16], c[4] = {0, 0, 0, 0};
+  double Phi[BS * BS], c[BS];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) Phi[e] = ((e & 3) == (e >> 2)) ? 1.0 : 0.0;
+  for (int e = 0; e < BS * BS; ++e) Phi[e] = ((e % BS) == (e / BS)) ? 1.0 : 0.0;
+#pragma unroll
+  for (int i = 0; i < BS; ++i) c[i] = 0.0;
   const int64_t s0 = (int64_t)j * ap.L, s1 = (s0 + ap.L < ap.kend) ? s0 + ap.L : ap.kend;
   for (int64_t s = s0; s < s1; ++s) {
     const int64_t k = (MODE == 0) ? s : (ap.kend - 1 - s);
-    double F[16], g[4], aux;
-    ihgp_coeffs<MODE>(sh, b, tb, tab, A4, hn, n, pb, k, bs, o, F, g, aux);
-    double P2[16], c2[4];
+    double F[BS * BS], g[BS], aux;
+    ihgp_coeffs<MODE, BS>(sh, b, tb, tab, A4, hn, n, pb, k, bs, o, F, g, aux);
+    double P2[BS * BS], c2[BS];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < BS; ++i) {
       double a = g[i];
 #pragma unroll
-      for (int l = 0; l < 4; ++l) a = fma(F[4 * i + l], c[l], a);
+      for (int l = 0; l < BS; ++l) a = fma(F[BS * i + l], c[l], a);
       c2[i] = a;
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
+      for (int jj = 0; jj < BS; ++jj) {
         double q = 0.0;
 #pragma unroll
-        for (int l = 0; l < 4; ++l) q = fma(F[4 * i + l], Phi[4 * l + jj], q);
-        P2[4 * i + jj] = q;
+        for (int l = 0; l < BS; ++l) q = fma(F[BS * i + l], Phi[BS * l + jj], q);
+        P2[BS * i + jj] = q;
       }
     }
 #pragma unroll
-    for (int e = 0; e < 16; ++e) Phi[e] = P2[e];
+    for (int e = 0; e < BS * BS; ++e) Phi[e] = P2[e];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) c[i] = c2[i];
+    for (int i = 0; i < BS; ++i) c[i] = c2[i];
   }
-  double* out = ap.spanbuf + (((size_t)pb * ap.ns + j) * M + n) * 20;
-  tile_store(out, Phi);
+  double* out = ap.spanbuf + (((size_t)pb * ap.ns + j) * M + n) * (BS * BS + BS);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) out[16 + i] = c[i];
+  for (int e = 0; e < BS * BS; ++e) out[e] = Phi[e];
+#pragma unroll
+  for (int i = 0; i < BS; ++i) out[BS * BS + i] = c[i];
 }
 
-template <int MODE>
+template <int MODE, int BS = 4>
 __global__ void __launch_bounds__(64) ihgp_aff_boundary_kernel(Shape sh, Bufs b, AffPar ap, int itt) {
   const int n = threadIdx.x, pb = blockIdx.x, M = sh.M, S = sh.S;
   const int64_t T = sh.T;
   if (n >= M) return;
   const int bs = sh.bsz[n], o = sh.off[n];
-  double x[4] = {0, 0, 0, 0};
+  double x[BS];
+#pragma unroll
+  for (int i = 0; i < BS; ++i) x[i] = 0.0;
   if (MODE == 0) {            // filter of sweep itt >= 2 starts from the smoothed mean at k = 0 (SURVEY C-22)
     if (itt > 1)
-      for (int i = 0; i < bs; ++i) x[i] = b.MS[(size_t)pb * T * S + o + i];
+#pragma unroll
+      for (int i = 0; i < BS; ++i) if (i < bs) x[i] = b.MS[(size_t)pb * T * S + o + i];
   } else {                    // smoother starts from the last filtered mean
-    for (int i = 0; i < bs; ++i) x[i] = b.MF[((size_t)pb * T + (T - 1)) * S + o + i];
+#pragma unroll
+    for (int i = 0; i < BS; ++i) if (i < bs) x[i] = b.MF[((size_t)pb * T + (T - 1)) * S + o + i];
   }
   for (int j = 0; j < ap.ns; ++j) {
-    double* bj = ap.bnd + (((size_t)pb * ap.ns + j) * M + n) * 4;
-    const double* sp = ap.spanbuf + (((size_t)pb * ap.ns + j) * M + n) * 20;
-    double y[4];
+    double* bj = ap.bnd + (((size_t)pb * ap.ns + j) * M + n) * BS;
+    const double* sp = ap.spanbuf + (((size_t)pb * ap.ns + j) * M + n) * (BS * BS + BS);
+    double y[BS];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < BS; ++i) {
       bj[i] = x[i];
-      double a = sp[16 + i];
+      double a = sp[BS * BS + i];
 #pragma unroll
-      for (int l = 0; l < 4; ++l) a = fma(sp[4 * i + l], x[l], a);
+      for (int l = 0; l < BS; ++l) a = fma(sp[BS * i + l], x[l], a);
       y[i] = a;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) x[i] = y[i];
+    for (int i = 0; i < BS; ++i) x[i] = y[i];
   }
 }
 
-template <int MODE>
+template <int MODE, int BS = 4>
 __global__ void __launch_bounds__(256) ihgp_aff_apply_kernel(Shape sh, Bufs b, IhgpTabs tb, AffPar ap) {
   const int pb = blockIdx.y, M = sh.M, S = sh.S;
   const int64_t T = sh.T;
@@ -1352,34 +1363,35 @@ __global__ void __launch_bounds__(256) ihgp_aff_apply_kernel(Shape sh, Bufs b, I
     const int j = gid / M, n = gid - j * M;
     const double* mdl = b.model + (size_t)pb * mdl_size(sh);
     const double* tab = tb.base + (size_t)pb * itab_size(sh, tb.NG);
-    double A4[16];
-    tile_load(A4, mdl + mdl_A(sh) + (size_t)n * 16);
+    double A4[BS * BS];
+#pragma unroll
+    for (int e = 0; e < BS * BS; ++e) A4[e] = mdl[mdl_A(sh) + (size_t)n * BS * BS + e];
     const double hn = mdl[mdl_h(sh) + n];
     const int bs = sh.bsz[n], o = sh.off[n];
-    double x[4];
-    const double* bj = ap.bnd + (((size_t)pb * ap.ns + j) * M + n) * 4;
+    double x[BS];
+    const double* bj = ap.bnd + (((size_t)pb * ap.ns + j) * M + n) * BS;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) x[i] = bj[i];
+    for (int i = 0; i < BS; ++i) x[i] = bj[i];
     const int64_t s0 = (int64_t)j * ap.L, s1 = (s0 + ap.L < ap.kend) ? s0 + ap.L : ap.kend;
     for (int64_t s = s0; s < s1; ++s) {
       const int64_t k = (MODE == 0) ? s : (ap.kend - 1 - s);
-      double F[16], g[4], aux;
-      ihgp_coeffs<MODE>(sh, b, tb, tab, A4, hn, n, pb, k, bs, o, F, g, aux);
-      double y[4];
+      double F[BS * BS], g[BS], aux;
+      ihgp_coeffs<MODE, BS>(sh, b, tb, tab, A4, hn, n, pb, k, bs, o, F, g, aux);
+      double y[BS];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < BS; ++i) {
         double a = g[i];
 #pragma unroll
-        for (int l = 0; l < 4; ++l) a = fma(F[4 * i + l], x[l], a);
+        for (int l = 0; l < BS; ++l) a = fma(F[BS * i + l], x[l], a);
         y[i] = a;
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) x[i] = y[i];
+      for (int i = 0; i < BS; ++i) x[i] = y[i];
       const size_t ix = ((size_t)pb * T + k) * M + n;
       if (MODE == 0) {
         double* mfp = b.MF + ((size_t)pb * T + k) * S + o;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < BS; ++i)
           if (i < bs) mfp[i] = x[i];
         b.fm[ix] = hn * x[0];
         b.ttau[ix] = max0(b.ttau[ix]);     // the clamp of :274 is stored
@@ -1387,7 +1399,7 @@ __global__ void __launch_bounds__(256) ihgp_aff_apply_kernel(Shape sh, Bufs b, I
       } else {
         double* msp = b.MS + ((size_t)pb * T + k) * S + o;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < BS; ++i)
           if (i < bs) msp[i] = x[i];
         const double mnew = hn * x[0];
         mxM = fmax(mxM, fabs(b.sm[ix] - mnew));

@@ -73,7 +73,6 @@ struct nagp_plan {
   Shape sh{};
   std::vector<int> perm;   // plans with split blocks: device state index -> the caller's state index (empty otherwise)
   int Mu = 0;              // ... and the caller's number of sites (sh.Ms)
-  double* d_xbuf = nullptr; // ... and the filter's exchange buffer when it does not fit the LDS (FilterPar::xbuf)
   nagp_opts opts{};
   std::vector<double> damping;
   int B = 0;

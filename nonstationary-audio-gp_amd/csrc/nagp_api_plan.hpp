@@ -154,7 +154,8 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     p->NT_fl = p->NT_f;
     if (!ekf && p->TPT_f == 1 && roundup64(slots) + roundup64(sh.S) <= 512) p->NT_fl = std::max(p->NT_f, roundup64(slots) + roundup64(sh.S));
     // split blocks: every filter launch has the geometry of the fixed-site one (gf_filter_kernel<TPT_f, ., ., 512, 0, true>)
-    if (split) { p->TPT_a = p->TPT_f; p->NT_a = p->NT_f; p->LB_a = 512; p->wide_l = 0; p->NT_l = p->NT_f; p->NT_fl = p->NT_f; }
+    // (fixed-site launches of 513 .. 1024 lower tiles: one tile per thread under the 768- / 1024-thread bound, as for unsplit models)
+    if (split) { p->TPT_a = p->TPT_f; p->NT_a = p->NT_f; p->LB_a = 512; p->NT_l = p->wide_l ? roundup64(slots) : p->NT_f; p->NT_fl = p->NT_f; }
   }
   p->want_PS = (o->flags & 0x4u) != 0;
   p->need_PF = (o->kind != NAGP_KIND_IHGP) && !(o->mode == NAGP_MODE_NLML && (o->ep_itts == 1 || ekf));
@@ -691,7 +692,6 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     p->lds_gain = (((p->TPT == 1) ? gain_lds_doubles_staged(sh) : gain_lds_doubles(sh)) + gain_cpl_doubles(sh)) * sizeof(double);     // (rts_gain_kernel: STAGE)
     p->lds_scan = span_lds_doubles(sh, p->LP1, p->LP2) * sizeof(double);
     if (split) {
-      if (filter_cpl_xglobal(sh)) PLAN_TRY(dalloc(p, &p->d_xbuf, (size_t)B * (sh.M * (sh.M + 1) / 2) * TS, false));
       if (p->TPT > 4) { const int Mx = sh.M; nagp_plan_destroy(p); FAIL(NAGP_EUNSUPPORTED, "blocks of more than four states: %d tile rows (sites + split blocks), more than the 45 the split-block kernels are instantiated for", Mx); }
       if (ekf) {
         switch (p->TPT_f) {
@@ -708,6 +708,8 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
           case 2: NAGP_MV_SWITCH(mom_variant(mc), SLC2) SLC2(-1); break;
           default: NAGP_MV_SWITCH(mom_variant(mc), SLC4) SLC4(-1); break;
         }
+        if (p->wide_l && p->NT_l <= 768) PLAN_TRY(set_lds((gf_filter_kernel<1, 0, -1, 768, 0, true>), p->lds_filter));
+        else if (p->wide_l) PLAN_TRY(set_lds((gf_filter_kernel<1, 0, -1, 1024, 0, true>), p->lds_filter));
 #undef SLC1
 #undef SLC2
 #undef SLC4

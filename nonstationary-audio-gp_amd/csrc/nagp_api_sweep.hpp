@@ -19,7 +19,7 @@ static int launch_filter(nagp_plan* p, const FilterPar& fp_in) {
   Timed t(p, adf ? NAGP_K_FILTER : NAGP_K_FILTER_LIN);
   dim3 g(p->B), bl(p->NT_f);
   if (p->sh.Ms < p->sh.M) {      // split blocks: one geometry (the fixed-site one) for every launch, the general mom code
-    fp.cpl_doubles = (int)filter_cpl_doubles(p->sh); fp.xbuf = p->d_xbuf;
+    fp.cpl_doubles = (int)filter_cpl_doubles(p->sh); fp.cpl_chunk = filter_cpl_chunk(p->sh);
     mc.sp = MomSp{};
 #define LFC(TP, ME, V) hipLaunchKernelGGL((gf_filter_kernel<TP, ME, V, 512, 0, true>), g, dim3(ekf ? nt_ekf : p->NT_f), p->lds_filter, p->stream, p->sh, p->b, mc, fp)
 #define LFC1(V) LFC(1, 0, V)
@@ -27,6 +27,8 @@ static int launch_filter(nagp_plan* p, const FilterPar& fp_in) {
 #define LFC4(V) LFC(4, 0, V)
     if (ekf) switch (p->TPT_f) { case 1: LFC(1, 1, 0); break; case 2: LFC(2, 1, 0); break; default: LFC(4, 1, 0); break; }
     else if (adf) switch (p->TPT_f) { case 1: NAGP_MV_SWITCH(mom_variant(mc), LFC1) break; case 2: NAGP_MV_SWITCH(mom_variant(mc), LFC2) break; default: NAGP_MV_SWITCH(mom_variant(mc), LFC4) break; }
+    else if (p->wide_l && p->NT_l <= 768) hipLaunchKernelGGL((gf_filter_kernel<1, 0, -1, 768, 0, true>), g, dim3(p->NT_l), p->lds_filter, p->stream, p->sh, p->b, mc, fp);
+    else if (p->wide_l) hipLaunchKernelGGL((gf_filter_kernel<1, 0, -1, 1024, 0, true>), g, dim3(p->NT_l), p->lds_filter, p->stream, p->sh, p->b, mc, fp);
     else switch (p->TPT_f) { case 1: LFC1(-1); break; case 2: LFC2(-1); break; default: LFC4(-1); break; }
 #undef LFC
 #undef LFC1

@@ -33,6 +33,8 @@
 #define NAGP_LIST_GF_CPL1(P) NAGP_LIST_GF_CPL(P, 1)
 #define NAGP_LIST_GF_CPL2(P) NAGP_LIST_GF_CPL(P, 2)
 #define NAGP_LIST_GF_CPL4(P) NAGP_LIST_GF_CPL(P, 4)
+#define NAGP_LIST_GF_CPLW(P)                                                                                                               \
+  P void nagp::gf_filter_kernel<1, 0, -1, 768, 0, true> NAGP_SIG_GF; P void nagp::gf_filter_kernel<1, 0, -1, 1024, 0, true> NAGP_SIG_GF;
 #define NAGP_LIST_GAIN_CPL(P)                                                                                                               \
   P void nagp::rts_gain_kernel<1, 512, true>(nagp::Shape, nagp::Bufs, nagp::GainPar); P void nagp::rts_gain_kernel<2, 512, true>(nagp::Shape, nagp::Bufs, nagp::GainPar); \
   P void nagp::rts_gain_kernel<3, 512, true>(nagp::Shape, nagp::Bufs, nagp::GainPar); P void nagp::rts_gain_kernel<4, 512, true>(nagp::Shape, nagp::Bufs, nagp::GainPar);
@@ -193,4 +195,4 @@
 
 #define NAGP_LIST_ALL(P)                                                                                                   \
   NAGP_LIST_GF_ADF1(P) NAGP_LIST_GF_ADF2(P) NAGP_LIST_GF_ADF3(P) NAGP_LIST_GF_ADF4(P) NAGP_LIST_GF_ADF5(P)               \
-  NAGP_LIST_GF_SP12(P) NAGP_LIST_GF_SP34(P) NAGP_LIST_GF_SQ12(P) NAGP_LIST_GF_SQ34(P) NAGP_LIST_GF_REST(P) NAGP_LIST_SMOOTH(P) NAGP_LIST_SMOOTH8(P) NAGP_LIST_BIG(P) NAGP_LIST_GAINM(P) NAGP_LIST_GAINI(P) NAGP_LIST_FLM(P) NAGP_LIST_EP(P) NAGP_LIST_EPS(P) NAGP_LIST_EPQ(P) NAGP_LIST_IH0(P) NAGP_LIST_IH8(P) NAGP_LIST_IH1(P) NAGP_LIST_IHA(P) NAGP_LIST_IHA8(P) NAGP_LIST_IHA8Q(P) NAGP_LIST_GF_A81(P) NAGP_LIST_GF_A82(P) NAGP_LIST_GF_A83(P) NAGP_LIST_GF_CPL1(P) NAGP_LIST_GF_CPL2(P) NAGP_LIST_GF_CPL4(P) NAGP_LIST_GAIN_CPL(P)
+  NAGP_LIST_GF_SP12(P) NAGP_LIST_GF_SP34(P) NAGP_LIST_GF_SQ12(P) NAGP_LIST_GF_SQ34(P) NAGP_LIST_GF_REST(P) NAGP_LIST_SMOOTH(P) NAGP_LIST_SMOOTH8(P) NAGP_LIST_BIG(P) NAGP_LIST_GAINM(P) NAGP_LIST_GAINI(P) NAGP_LIST_FLM(P) NAGP_LIST_EP(P) NAGP_LIST_EPS(P) NAGP_LIST_EPQ(P) NAGP_LIST_IH0(P) NAGP_LIST_IH8(P) NAGP_LIST_IH1(P) NAGP_LIST_IHA(P) NAGP_LIST_IHA8(P) NAGP_LIST_IHA8Q(P) NAGP_LIST_GF_A81(P) NAGP_LIST_GF_A82(P) NAGP_LIST_GF_A83(P) NAGP_LIST_GF_CPL1(P) NAGP_LIST_GF_CPL2(P) NAGP_LIST_GF_CPL4(P) NAGP_LIST_GF_CPLW(P) NAGP_LIST_GAIN_CPL(P)

@@ -97,7 +97,7 @@ struct FilterPar {
   int dbg;                 // developer switch (NAGP_FILTER_DBG): skip phases to time the others -- results are garbage.
                            // 1: rank-M covariance update, 2: PF stores, 4: prediction congruence, 8: W panel writes, 16: mean update
   int cpl_doubles;         // split blocks (Shape::part): doubles of the extra LDS region in FRONT of everything else (filter_cpl_doubles)
-  double* xbuf;            // ... and the exchange buffer of the lower tiles in global memory, [B][M(M+1)/2][TS] (filter_cpl_xglobal), or nullptr: in the LDS
+  int cpl_chunk;           // ... and the tiles per phase of the exchange (filter_cpl_chunk)
 };
 
 // The filtered covariance is symmetric: PF holds only the lower-triangular tiles, tile (I,J), I >= J, at tile index I(I+1)/2 + J.
@@ -165,10 +165,11 @@ struct TileOwner {
 // fire-and-forget stores of the filtered covariance tiles.
 __host__ __device__ inline size_t filter_ring_doubles(const Shape& s, int kb) { return (size_t)kb * (5 * s.M + s.S + 3); }
 // split blocks: partner table [MAXM ints] | cross tiles of A [M][TS] | of Q [M][TS] | exchange buffer of the lower tiles [M(M+1)/2][TS]
-// (the exchange buffer moves to global memory, FilterPar::xbuf, when it would take more than 48 KB of the LDS: more than 25 tile rows)
-__host__ __device__ inline bool filter_cpl_xglobal(const Shape& s) { return (size_t)(s.M * (s.M + 1) / 2) * TS * sizeof(double) > 48 * 1024; }
+// (the exchange runs in filter_cpl_phases() phases of filter_cpl_chunk() tiles each, so that the buffer takes at most 48 KB of the LDS: one phase up to 25 tile rows)
+__host__ __device__ inline int filter_cpl_phases(const Shape& s) { return (int)(((size_t)(s.M * (s.M + 1) / 2) * TS * sizeof(double) + 48 * 1024 - 1) / (48 * 1024)); }
+__host__ __device__ inline int filter_cpl_chunk(const Shape& s) { const int ph = filter_cpl_phases(s); return (s.M * (s.M + 1) / 2 + ph - 1) / ph; }
 __host__ __device__ inline size_t filter_cpl_doubles(const Shape& s) {
-  return (s.Ms < s.M) ? (size_t)(MAXM / 2) + 2 * (size_t)s.M * TS + (filter_cpl_xglobal(s) ? 0 : (size_t)(s.M * (s.M + 1) / 2) * TS) : 0;
+  return (s.Ms < s.M) ? (size_t)(MAXM / 2) + 2 * (size_t)s.M * TS + (size_t)filter_cpl_chunk(s) * TS : 0;
 }
 __host__ __device__ inline size_t filter_lds_doubles(const Shape& s, const MomCfg& mc, int meas, int kb) {
   size_t n = LDS_INT_DOUBLES + 2 * (size_t)s.M * TS + s.M + (size_t)s.D * s.N + s.S + 4 * (size_t)s.M * s.M +
@@ -200,7 +201,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
   int* ipart = reinterpret_cast<int*>(lds_raw);                  // CPL: [MAXM] partner tile row or -1
   double* sAx = lds_raw + MAXM / 2;                              //      A(n, part n) [M][TS]
   double* sQx = sAx + (size_t)M * TS;                            //      Q(n, part n) [M][TS]
-  double* sX = (CPL && fp.xbuf) ? fp.xbuf + (size_t)blockIdx.x * (size_t)(M * (M + 1) / 2) * TS : sQx + (size_t)M * TS;      //      exchange buffer, lower tile t at t * TS (LDS, or global memory for many tile rows)
+  double* sX = sQx + (size_t)M * TS;                             //      exchange buffer: the lower tiles [lo, lo + fp.cpl_chunk) of one phase, tile t at (t - lo) * TS
   const int64_t T = sh.T;
   const int pb = blockIdx.x;
   const double* mdl = b.model + (size_t)pb * mdl_size(sh);
@@ -362,17 +363,20 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
     }
     return r;
   };
-  // CPL: tile (a, c) of the symmetric matrix in the exchange buffer
-  auto x_tile = [&](double* t, int a, int c) {
-    if (a >= c) tile_load(t, sX + (size_t)(a * (a + 1) / 2 + c) * TS);
+  // CPL: tile (a, c) of the symmetric matrix if it lies in the phase [lo, hi) of the exchange buffer (false: not in this phase)
+  auto x_tile = [&](double* t, int a, int c, int lo, int hi) -> bool {
+    const int ix = (a >= c) ? a * (a + 1) / 2 + c : c * (c + 1) / 2 + a;
+    if (ix < lo || ix >= hi) return false;
+    if (a >= c) tile_load(t, sX + (size_t)(ix - lo) * TS);
     else {
       double u[16];
-      tile_load(u, sX + (size_t)(c * (c + 1) / 2 + a) * TS);
+      tile_load(u, sX + (size_t)(ix - lo) * TS);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) t[4 * i + j] = u[4 * j + i];
     }
+    return true;
   };
   const double* yv = b.y + (size_t)pb * T;
   double* g_tt = b.ttau + (size_t)pb * T * M;
@@ -448,11 +452,48 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
         }
       }
       if constexpr (CPL) {
-        if (pred) {      // every tile into the exchange buffer (the readers of the previous step are five barriers back)
+        if (pred) {
+          // P(I,J) <- sum_{a in {I, part I}} sum_{b in {J, part J}} A(I,a) P(a,b) A(J,b)': the tiles travel through the exchange buffer in phases of
+          // fp.cpl_chunk lower tiles; every thread adds the terms whose source tile lies in the phase (the readers of the previous step's last phase
+          // are five barriers back)
+          double acc[TPT][16];
+#pragma unroll
+          for (int q = 0; q < TPT; ++q) tile_zero(acc[q]);
+          for (int lo = 0; lo < nlow; lo += fp.cpl_chunk) {
+            const int hi = (lo + fp.cpl_chunk < nlow) ? lo + fp.cpl_chunk : nlow;
+#pragma unroll
+            for (int q = 0; q < TPT; ++q) {
+              const int t = tid + q * NT;
+              if (own.ok[q] && t >= lo && t < hi) tile_store(sX + (size_t)(t - lo) * TS, P[q]);
+            }
+            lds_barrier();
+#pragma unroll
+            for (int q = 0; q < TPT; ++q) {
+              if (own.ok[q]) {
+                const int I = own.I[q], J = own.J[q], Ip = ipart[I], Jp = ipart[J];
+                auto term = [&](int a_, const double* Aia, int b_, const double* Ajb) {
+                  double pt[16], t1[16];
+                  if (!x_tile(pt, a_, b_, lo, hi)) return;
+                  tile_zero(t1);
+                  tile_mma_nt(t1, pt, Ajb);
+                  tile_mma(acc[q], Aia, t1);
+                };
+                term(I, sA + (size_t)I * TS, J, sA + (size_t)J * TS);
+                if (Jp >= 0) term(I, sA + (size_t)I * TS, Jp, sAx + (size_t)J * TS);
+                if (Ip >= 0) {
+                  term(Ip, sAx + (size_t)I * TS, J, sA + (size_t)J * TS);
+                  if (Jp >= 0) term(Ip, sAx + (size_t)I * TS, Jp, sAx + (size_t)J * TS);
+                }
+              }
+            }
+            if (hi < nlow) lds_barrier();      // the buffer is overwritten by the next phase
+          }
 #pragma unroll
           for (int q = 0; q < TPT; ++q)
-            if (own.ok[q]) tile_store(sX + (size_t)(tid + q * NT) * TS, P[q]);
-          __syncthreads();      // (a full barrier: the buffer may live in global memory)
+            if (own.ok[q] && !(fp.dbg & 4)) {
+#pragma unroll
+              for (int e = 0; e < 16; ++e) P[q][e] = acc[q][e];
+            }
         }
       }
 #pragma unroll
@@ -461,22 +502,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
           const int I = own.I[q], J = own.J[q];
           if (pred && !(fp.dbg & 4)) {
             if constexpr (CPL) {
-              const int Ip = ipart[I], Jp = ipart[J];
-              double acc[16];
-              tile_zero(acc);
-              // acc += A(I,a) * ( P(a,J) A(J,J)' + P(a,Jp) A(J,Jp)' )
-              auto term = [&](int a, const double* Aia) {
-                double t1[16], pt[16];
-                tile_zero(t1);
-                x_tile(pt, a, J); tile_mma_nt(t1, pt, sA + (size_t)J * TS);
-                if (Jp >= 0) { x_tile(pt, a, Jp); tile_mma_nt(t1, pt, sAx + (size_t)J * TS); }
-                tile_mma(acc, Aia, t1);
-              };
-              term(I, sA + (size_t)I * TS);
-              if (Ip >= 0) term(Ip, sAx + (size_t)I * TS);
-#pragma unroll
-              for (int e = 0; e < 16; ++e) P[q][e] = acc[e];
-              if (J == Ip) {      // the pair's cross tile of Q (I = tail row, J = its head row)
+              if (J == ipart[I]) {      // the pair's cross tile of Q (I = tail row, J = its head row)
                 const double* Qb = sQx + (size_t)I * TS;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) P[q][e] += Qb[e];

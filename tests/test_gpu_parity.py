@@ -622,7 +622,7 @@ def test_infinite_horizon_sweeps_with_blocks_of_more_than_four_states(k1):
 
 def test_split_block_plans_batches_chunks_warm_starts_and_many_tile_rows():
     """Plans with split blocks: a batch equals its single runs, a chunked pipelined smoother equals the oracle, sites round-trip through the warm start
-    in the caller's M columns, the exchange buffer in global memory (more than 25 tile rows: D = 16 -> 35, D = 20 -> 43) agrees with the oracle."""
+    in the caller's M columns, the tile exchange in two and three phases (more than 25 tile rows: D = 16 -> 35, D = 20 -> 43) agrees with the oracle."""
     k1 = 'matern52'; mom = Mom('likModulatorNMFPower', p_cubature=7); om = olik.Mom(olik.LIK_POWER_NMF, p=7)
     for (D, N, T) in [(4, 2, 90), (16, 3, 30), (20, 3, 10)]:
         probs, ys, orc = [], [], []

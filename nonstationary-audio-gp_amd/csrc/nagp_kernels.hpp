@@ -823,7 +823,7 @@ __global__ void __launch_bounds__(LB) gf_filter_kernel(Shape sh, Bufs b, MomCfg 
               if (it + 1 < fp.l_iter && myrow == 0) {
                 const double f = shv[myblk] * rm;
                 fmu[myblk] = f;
-                if (myblk >= D) {
+                if (myblk >= D && myblk < Ms) {      // a modulator row (the tail rows of split blocks lie behind the Ms real sites)
                   const double eg = exp(f);
                   spl[myblk - D] = log(1.0 + eg);
                   spl[N + myblk - D] = eg / (eg + 1.0);

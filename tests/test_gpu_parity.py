@@ -669,6 +669,18 @@ def test_split_blocks_edge_lengths_and_tiny_shapes(k1):
             assert rel(r[0], o[0]) < TOL_MEAN and rel(r[1], o[1]) < TOL_MEAN, (D, N, T)
 
 
+@pytest.mark.parametrize('k1,D,N', [('matern72', 8, 6), ('matern52', 5, 4)])
+def test_ekf_inner_iterations_with_split_blocks_and_many_modulators(k1, D, N):
+    """iekf_update1 with l_iter = 2, 3 on plans with split blocks: the state lanes that refresh softplus / sigmoid of the modulators for the next inner
+    iteration must leave the tail rows out (found by the fuzz draws with --k1 matern72: a tail row counted as a modulator overwrote the sigmoid table)."""
+    T = 70
+    pr = harness.nmf_problem(D, N, T, 31, kernel1=k1); t = np.arange(1, T + 1.0); y = pr['y'].copy(); y[[5, 6, 40, 69]] = np.nan
+    for (gi, li) in [(1, 2), (2, 2), (2, 3)]:
+        r = nagp.gf_giekf_modulator_nmf(pr['w'], t, y, SSHandle(), None, t, k1, 'matern32', 1, D, N, gi, li, nargout=2)
+        o = oek.gf_giekf_modulator_nmf(pr['w'], t, y, None, None, t, k1, 'matern32', 1, D, N, gi, li)
+        assert rel(r[0], o[0]) < TOL_MEAN and rel(r[1], o[1]) < TOL_MEAN, (gi, li)
+
+
 def test_mixture_variants_with_a_six_state_source():
     """experiments/{gf,ihgp}_ep_mods_nmf_mixture.m with Matern-5/2 sub-bands in one of two stacked sources (the older EP rule: NAGP_FLAG_MIXTURE_RULE)."""
     shapes = [(3, 1), (2, 2)]; k1 = ['matern52', 'matern32']; k2 = ['matern52', 'matern52']; T = 80

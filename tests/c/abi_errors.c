@@ -43,6 +43,13 @@ int main(void) {
   { nagp_model two[2]; two[0] = m; two[1] = m; two[1].Q = NULL; EXPECT(nagp_plan_create(&p, 2, two, NULL, T, &o), NAGP_EINVAL); }
   /* a well-formed request passes every host check and stops at the missing device */
   if (nagp_device_count() == 0) EXPECT(nagp_plan_create(&p, 1, &m, NULL, T, &o), NAGP_ENODEVICE);
+  /* ... and so does one with a block of five states: the host builds the device view of the model (a tail row behind the sites, permuted
+   * A / Q / Pinf, cross tiles) before it looks at the device -- under the sanitizer */
+  if (nagp_device_count() == 0) {
+    int32_t five[M + 1] = {0, 5, 6, 7}; nagp_model two[2]; two[0] = m; two[0].block_offsets = five; two[1] = two[0];
+    EXPECT(nagp_plan_create(&p, 2, two, NULL, T, &o), NAGP_ENODEVICE);
+    { nagp_opts q = o; q.kind = NAGP_KIND_GIEKF; q.l_iter = 2; EXPECT(nagp_plan_create(&p, 2, two, NULL, T, &q), NAGP_ENODEVICE); }
+  }
   EXPECT(nagp_ep_run(NULL, y, T, &o, &out), NAGP_EINVAL);
   EXPECT(nagp_ep_run(&m, NULL, T, &o, &out), NAGP_EINVAL);
   { nagp_opts q = o; q.kind = NAGP_KIND_IHGP; EXPECT(nagp_ep_run(&m, y, T, &q, &out), NAGP_EINVAL); }

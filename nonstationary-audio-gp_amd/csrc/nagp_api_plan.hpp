@@ -692,7 +692,6 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
     p->lds_gain = (((p->TPT == 1) ? gain_lds_doubles_staged(sh) : gain_lds_doubles(sh)) + gain_cpl_doubles(sh)) * sizeof(double);     // (rts_gain_kernel: STAGE)
     p->lds_scan = span_lds_doubles(sh, p->LP1, p->LP2) * sizeof(double);
     if (split) {
-      if (p->TPT > 4) { const int Mx = sh.M; nagp_plan_destroy(p); FAIL(NAGP_EUNSUPPORTED, "blocks of more than four states: %d tile rows (sites + split blocks), more than the 45 the split-block kernels are instantiated for", Mx); }
       if (ekf) {
         switch (p->TPT_f) {
           case 1: PLAN_TRY(set_lds((gf_filter_kernel<1, 1, 0, 512, 0, true>), p->lds_filter)); break;
@@ -718,7 +717,8 @@ extern "C" int nagp_plan_create(nagp_plan** out, int32_t B, const nagp_model* mo
         case 1: PLAN_TRY(set_lds((rts_gain_kernel<1, 512, true>), p->lds_gain)); break;
         case 2: PLAN_TRY(set_lds((rts_gain_kernel<2, 512, true>), p->lds_gain)); break;
         case 3: PLAN_TRY(set_lds((rts_gain_kernel<3, 512, true>), p->lds_gain)); break;
-        default: PLAN_TRY(set_lds((rts_gain_kernel<4, 512, true>), p->lds_gain)); break;
+        case 4: PLAN_TRY(set_lds((rts_gain_kernel<4, 512, true>), p->lds_gain)); break;
+        default: PLAN_TRY(set_lds((rts_gain_kernel<8, 512, true>), p->lds_gain)); break;      // (46 .. 64 tile rows: tiles in scratch, as for unsplit models)
       }
     }
     if (ekf) {

@@ -268,7 +268,8 @@ static int launch_gain_chunk(nagp_plan* p, const SweepCtx& sc, int c, int slot, 
       case 1: hipLaunchKernelGGL((rts_gain_kernel<1, 512, true>), gr, bl, p->lds_gain, st, sh, b, gp); break;
       case 2: hipLaunchKernelGGL((rts_gain_kernel<2, 512, true>), gr, bl, p->lds_gain, st, sh, b, gp); break;
       case 3: hipLaunchKernelGGL((rts_gain_kernel<3, 512, true>), gr, bl, p->lds_gain, st, sh, b, gp); break;
-      default: hipLaunchKernelGGL((rts_gain_kernel<4, 512, true>), gr, bl, p->lds_gain, st, sh, b, gp); break;
+      case 4: hipLaunchKernelGGL((rts_gain_kernel<4, 512, true>), gr, bl, p->lds_gain, st, sh, b, gp); break;
+      default: hipLaunchKernelGGL((rts_gain_kernel<8, 512, true>), gr, bl, p->lds_gain, st, sh, b, gp); break;
     }
   } else
   if (p->gain768) hipLaunchKernelGGL((rts_gain_kernel<2, 768>), gr, dim3(768), p->lds_gain, st, sh, b, gp);

@@ -37,7 +37,8 @@
   P void nagp::gf_filter_kernel<1, 0, -1, 768, 0, true> NAGP_SIG_GF; P void nagp::gf_filter_kernel<1, 0, -1, 1024, 0, true> NAGP_SIG_GF;
 #define NAGP_LIST_GAIN_CPL(P)                                                                                                               \
   P void nagp::rts_gain_kernel<1, 512, true>(nagp::Shape, nagp::Bufs, nagp::GainPar); P void nagp::rts_gain_kernel<2, 512, true>(nagp::Shape, nagp::Bufs, nagp::GainPar); \
-  P void nagp::rts_gain_kernel<3, 512, true>(nagp::Shape, nagp::Bufs, nagp::GainPar); P void nagp::rts_gain_kernel<4, 512, true>(nagp::Shape, nagp::Bufs, nagp::GainPar);
+  P void nagp::rts_gain_kernel<3, 512, true>(nagp::Shape, nagp::Bufs, nagp::GainPar); P void nagp::rts_gain_kernel<4, 512, true>(nagp::Shape, nagp::Bufs, nagp::GainPar); \
+  P void nagp::rts_gain_kernel<8, 512, true>(nagp::Shape, nagp::Bufs, nagp::GainPar);
 
 // ADF launches in the sparse-point form (likModulatorNMFPower, 1..7 components), 256-thread launches
 #define NAGP_LIST_GF_SP(P, TPT)                                                                                            \

@@ -166,7 +166,8 @@ struct TileOwner {
 __host__ __device__ inline size_t filter_ring_doubles(const Shape& s, int kb) { return (size_t)kb * (5 * s.M + s.S + 3); }
 // split blocks: partner table [MAXM ints] | cross tiles of A [M][TS] | of Q [M][TS] | exchange buffer of the lower tiles [M(M+1)/2][TS]
 // (the exchange runs in filter_cpl_phases() phases of filter_cpl_chunk() tiles each, so that the buffer takes at most 48 KB of the LDS: one phase up to 25 tile rows)
-__host__ __device__ inline int filter_cpl_phases(const Shape& s) { return (int)(((size_t)(s.M * (s.M + 1) / 2) * TS * sizeof(double) + 48 * 1024 - 1) / (48 * 1024)); }
+// (16 KB beyond 45 tile rows, where the panel W = P H' alone takes 65 KB and more)
+__host__ __device__ inline int filter_cpl_phases(const Shape& s) { const size_t bud = (s.M > 45) ? 16 * 1024 : 48 * 1024; return (int)(((size_t)(s.M * (s.M + 1) / 2) * TS * sizeof(double) + bud - 1) / bud); }
 __host__ __device__ inline int filter_cpl_chunk(const Shape& s) { const int ph = filter_cpl_phases(s); return (s.M * (s.M + 1) / 2 + ph - 1) / ph; }
 __host__ __device__ inline size_t filter_cpl_doubles(const Shape& s) {
   return (s.Ms < s.M) ? (size_t)(MAXM / 2) + 2 * (size_t)s.M * TS + (size_t)filter_cpl_chunk(s) * TS : 0;

@@ -624,7 +624,7 @@ def test_split_block_plans_batches_chunks_warm_starts_and_many_tile_rows():
     """Plans with split blocks: a batch equals its single runs, a chunked pipelined smoother equals the oracle, sites round-trip through the warm start
     in the caller's M columns, the tile exchange in two and three phases (more than 25 tile rows: D = 16 -> 35, D = 20 -> 43) agrees with the oracle."""
     k1 = 'matern52'; mom = Mom('likModulatorNMFPower', p_cubature=7); om = olik.Mom(olik.LIK_POWER_NMF, p=7)
-    for (D, N, T) in [(4, 2, 90), (16, 3, 30), (20, 3, 10)]:
+    for (D, N, T) in [(4, 2, 90), (16, 3, 30), (20, 3, 10), (24, 3, 6)]:      # (19, 35, 43, 51 tile rows: one, two, three exchange phases; eight tiles per thread in the gain kernel)
         probs, ys, orc = [], [], []
         for sd in (1, 2):
             pr = harness.nmf_problem(D, N, T, sd, kernel1=k1)
@@ -698,8 +698,8 @@ def test_mixture_variants_with_a_six_state_source():
 
 
 def test_unsupported_shapes_are_refused_not_emulated():
-    # more tile rows (sites + split blocks) than the split-block kernels are instantiated for: 27 sites + 24 six-state sub-bands = 51 > 45
-    D, N, T = 24, 3, 8
+    # more tile rows (sites + split blocks) than the filter's LDS holds (panel W = P H', exchange buffer, cubature workspace): 33 sites + 30 six-state sub-bands = 63
+    D, N, T = 30, 3, 8
     pr = harness.nmf_problem(D, N, T, 1, kernel1='matern52')
     t = np.arange(1, T + 1.0)
     with pytest.raises(nagp.NagpError, match='unsupported'):

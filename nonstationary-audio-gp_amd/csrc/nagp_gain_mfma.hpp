@@ -165,8 +165,12 @@ __device__ __forceinline__ int gm_tpart(int t) { return ((t >> 6) << 10) + ((t &
 // (PSkp alone, for the 55 lower tiles).  The host enables it when every block of A is comfortably invertible (GainPar::ainv holds
 // A^-1 and A^-1 Q per block; |A_b^-1| <= 8: the error of G is that of X times |A^-1|) -- otherwise, and for any caller that passes no
 // inverses, the solve form below runs.
+// Up to six tile columns the kernel is capped at 128 registers (four waves per SIMD; 30 / 53 registers spilled at NTL = 5 / 6): its LDS lets two workgroups
+// share a CU there (four at NTL = 3), but a workgroup of NTL + 1 waves puts two of them on the first SIMDs, and a second workgroup is only placed
+// beside it if EVERY SIMD can take its share -- at 164 registers (three waves per SIMD) the occupancy query says two, the hardware runs one
+// (profiles/r05_gain_mfma.txt: 31.5 -> 27.4 us per step and CU at Sp = 80, 13.4 -> 8.3 at Sp = 48; cfg2_batch 444 -> 404 ms).
 template <int NTL, bool INV>
-__global__ void __launch_bounds__(64 * (NTL + 1)) rts_gain_mfma_kernel(Shape sh, Bufs b, GainPar gp) {
+__global__ void __launch_bounds__(64 * (NTL + 1)) __attribute__((amdgpu_waves_per_eu(NTL <= 6 ? 4 : 1, NTL <= 6 ? 4 : 8))) rts_gain_mfma_kernel(Shape sh, Bufs b, GainPar gp) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   constexpr int Sp = 16 * NTL, NT = 64 * (NTL + 1), NLOW = NTL * (NTL + 1) / 2;
   constexpr int ND = 6;                                           // Delta tiles per column wave and round

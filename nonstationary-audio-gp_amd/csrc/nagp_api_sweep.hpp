@@ -546,7 +546,8 @@ static int launch_ep(nagp_plan* p, double alpha, double damp, int clamp, int wri
   if (ep.k_end <= ep.k_begin) return NAGP_OK;
   // ~8192 workgroups over all problems (32 per CU): enough to fill the chip, and the per-workgroup set-up (cubature tables, the static
   // addresses of the sparse-point stages) is amortised over the steps of a workgroup when many problems share the launch
-  ep.steps_per_wg = (int)std::max<int64_t>(1, ((int64_t)p->B * (sh.T - 1) + 8191) / 8192);
+  // (sized from the steps of THIS launch: in the cross-sweep form a launch covers one smoother chunk)
+  ep.steps_per_wg = (int)std::max<int64_t>(1, ((int64_t)p->B * (ep.k_end - ep.k_begin) + 8191) / 8192);
   ep.alpha = alpha; ep.clamp = clamp; ep.write_R = write_R; ep.lZ_out = lZ_out;
   if (mixture_rule(p)) { ep.w_old = 1.0 - damp; ep.w_new = damp / alpha; }
   else { ep.w_old = 1.0 - damp * alpha; ep.w_new = damp; }

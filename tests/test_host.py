@@ -34,7 +34,7 @@ def test_gauss_hermite_grid():
 
 
 @pytest.mark.parametrize('k1,k2,bal', [('matern32', 'matern52', False), ('matern32', 'matern52', True), ('exp', 'matern32', True),
-                                       ('matern32', 'matern72', True)])
+                                       ('matern32', 'matern72', True), ('matern52', 'matern52', True), ('matern72', 'matern32', False)])
 def test_blockwise_model_equals_dense_reference_construction(k1, k2, bal):
     pr = harness.nmf_problem(5, 2, 10, 11, kernel1=k1, kernel2=k2)
     F, L, Qc, H, Pinf = nagp.ss_modulators_nmf(pr['param1'], pr['param2'], k1, k2)
@@ -105,6 +105,30 @@ def test_ihgp_tables_match_oracle_tables():
         b = blk.sizes[n]
         assert np.allclose(PP[ppo[n]:ppo[n] + 200 * b * b].reshape(200, -1), PPl[n], rtol=1e-7, atol=1e-12)
         assert np.allclose(PG[pgo[n]:pgo[n] + 400 * b * b].reshape(200, -1), PGl[n], rtol=1e-6, atol=1e-12)
+
+
+@pytest.mark.parametrize('k1,tol_pp,tol_pg', [('matern52', 1e-6, 1e-5)])
+def test_ihgp_tables_of_six_state_blocks_match_the_oracle_within_their_conditioning(k1, tol_pp, tol_pg):
+    """Sub-band blocks of six states: the steady-state covariances are conditioned ~1e8, and the two DARE solvers (batched doubling on the host, SciPy's in
+    the oracle) agree to 1e-8 .. 1e-6 -- both solve the equation to 1e-12 of the covariance's size (checked here for the host's tables)."""
+    pr = harness.nmf_problem(3, 2, 5, 11, kernel1=k1)
+    lik, p1, p2, W = oss.unpack_log(pr['w'], 1, 3, 2)
+    model = ogf.assemble(lik, p1, p2, W, k1, 'matern52', True, True)
+    ilist, r, PPl, PGl = oih.build_tables(model)
+    blk = pss.balance_blocks(pss.ss_blocks_nmf(p1, p2, k1, 'matern52'))
+    A, Q, P = pss.discretise(blk, symmetrize_Q=True)
+    r2, PP, ppo, PG, pgo = ihgp_tables.build_tables(A, Q, blk.offsets, blk.h_val)
+    assert np.allclose(r, r2) and list(blk.sizes[:3]) == [6, 6, 6]
+    for n in range(5):
+        b = blk.sizes[n]; o = blk.offsets[n]
+        pp = PP[ppo[n]:ppo[n] + 200 * b * b].reshape(200, -1); pg = PG[pgo[n]:pgo[n] + 400 * b * b].reshape(200, -1)
+        assert np.abs(pp - PPl[n]).max() < tol_pp * np.abs(PPl[n]).max() and np.abs(pg - PGl[n]).max() < tol_pg * np.abs(PGl[n]).max()
+        Ab = A[o:o + b, o:o + b]; Qb = Q[o:o + b, o:o + b]; h = np.zeros((1, b)); h[0, 0] = blk.h_val[n]
+        for g in (0, 199):      # residual of the predictive DARE  P = A (P - P h' (h P h' + r)^-1 h P) A' + Q  at the two grid points that are knots of the solver (the rest is interpolated)
+            Pm = pp[g].reshape(b, b, order='F')
+            K = Pm @ h.T / (h @ Pm @ h.T + r2[g])
+            res = Ab @ (Pm - K @ h @ Pm) @ Ab.T + Qb - Pm
+            assert np.abs(res).max() < 1e-11 * np.abs(Pm).max(), (n, g)
 
 
 def test_mom_descriptor_validation():

@@ -1,7 +1,7 @@
 """Randomised check of the chunk-pipelined smoother schedule (developer tool): random shape, family, number of segments, chunk length,
 number of (G, Delta) buffers, sweeps, missing data; every output of the pipelined plan (with and without the cross-sweep form, NAGP_NO_XSWEEP=1) must equal the serial plan's bit for bit
 (NAGP_NO_PIPELINE=1), and the serial plan is the one the oracle tests pin.
-python tools/gpu_fuzz_schedules.py [n_cases] [seed]"""
+python tools/gpu_fuzz_schedules.py [n_cases] [seed] [--k1 matern52]"""
 import os, sys, time
 os.environ.setdefault('NAGP_DEVELOPER', '1')      # developer tool: libnagp.so reads its switches only with this set
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,13 +10,14 @@ import numpy as np
 import nagp
 from nagp import harness, Mom, Plan, _lib as L, ss as pss
 
-def run_cases(n, seed, verbose=True):
+def run_cases(n, seed, verbose=True, k1='matern32'):
     """-> number of cases whose pipelined outputs differ from the serial ones"""
     rng = np.random.default_rng(seed)
     bad = 0; t0 = time.time()
     for case in range(n):
         ekf = rng.random() < 0.25
         D = int(rng.choice([3, 8, 12, 16, 20, 24, 32, 36])); N = int(rng.integers(1, 7 if D >= 12 else 4))
+        if k1 != 'matern32': D = min(D, 20)      # blocks of six / eight states are split over two tile rows: sites + split blocks fit the filter's LDS up to ~54
         if D == 36: N = min(N, 8)
         T = int(rng.integers(40, 700)); B = int(rng.choice([1, 1, 2, 3, 5, 8]))
         chunk = int(rng.choice([0, 8, 16, 24, 50, 100, 200]))
@@ -26,8 +27,8 @@ def run_cases(n, seed, verbose=True):
         nlml = (not ekf) and (not want_ps) and rng.random() < 0.25      # energy mode: sweeps 1 .. I-1 filter + smooth + refresh, no filter in sweep I
         probs, ys = [], []
         for q in range(B):
-            pr = harness.nmf_problem(D, N, T, int(rng.integers(1, 1 << 30)), 'constraints')
-            blk = pss.balance_blocks(pss.ss_blocks_nmf(pr['param1'], pr['param2'], 'matern32', 'matern52'))
+            pr = harness.nmf_problem(D, N, T, int(rng.integers(1, 1 << 30)), 'constraints', kernel1=k1)
+            blk = pss.balance_blocks(pss.ss_blocks_nmf(pr['param1'], pr['param2'], k1, 'matern52'))
             y = pr['y'].copy()
             if rng.random() < 0.5: y[rng.integers(0, T, size=max(1, T // 40))] = np.nan
             probs.append((blk, pr['W'], np.log(pr['w_lik']))); ys.append(y)
@@ -62,4 +63,7 @@ def run_cases(n, seed, verbose=True):
 
 
 if __name__ == '__main__':
-    sys.exit(1 if run_cases(int(sys.argv[1]) if len(sys.argv) > 1 else 20, int(sys.argv[2]) if len(sys.argv) > 2 else 0) else 0)
+    k1 = 'matern32'
+    if '--k1' in sys.argv:      # python tools/gpu_fuzz_schedules.py 40 7 --k1 matern52 : the same draws with six-state sub-band blocks
+        i = sys.argv.index('--k1'); k1 = sys.argv[i + 1]; del sys.argv[i:i + 2]
+    sys.exit(1 if run_cases(int(sys.argv[1]) if len(sys.argv) > 1 else 20, int(sys.argv[2]) if len(sys.argv) > 2 else 0, k1=k1) else 0)

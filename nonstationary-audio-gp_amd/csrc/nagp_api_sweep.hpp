@@ -162,7 +162,10 @@ static void sweep_begin(nagp_plan* p, SweepCtx& sc, bool write_PSs) {
       ns = std::max(1, std::min(std::min(ns, p->ns_max), (nk + 7) / 8));
     } else if (sc.mode == SM_BIG) {
       const int per_cu = std::max(1, (int)((160 * 1024) / std::max<size_t>(p->lds_mfma, 1)));      // workgroups of the column-owner passes a CU holds (LDS)
-      const int n_cu = std::max(32, 256 - p->B) * per_cu;
+      // resident workgroups a launch can count on: the CUs the filter's workgroups do not hold (one workgroup per CU), or -- where two fit a CU --
+      // two on every CU (measured at 128 segments: 243 -> 180 ms against 225 with 384; the filter launches are short beside the passes there)
+      int n_cu = (per_cu >= 2) ? 256 * per_cu : std::max(32, 256 - p->B);
+      if (dev_env("NAGP_BIG_NCU")) n_cu = std::max(1, atoi(dev_env("NAGP_BIG_NCU")));      // developer switch
       double best = 1e300; ns = 1;
       for (int c = 1; c <= std::max(1, std::min(p->ns_max, (nk + 7) / 8)); ++c) {
         const int L = (nk + c - 1) / c, cc = (nk + L - 1) / L;

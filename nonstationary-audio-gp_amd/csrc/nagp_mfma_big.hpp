@@ -31,6 +31,11 @@ __host__ __device__ inline size_t big_lds_doubles(int NTL) {
 __device__ __forceinline__ int big_phys(int r, int c) { return r * 16 + ((((c >> 1) ^ (r >> 1)) & 7) << 1) + (c & 1); }
 __device__ __forceinline__ int big_tix(int K, int L) { return (K * (K + 1) / 2 + L) * 256; }   // K >= L
 
+// Five tile columns (Sp = 80, 74 KB of LDS): capped at 128 registers (up to 34 spilled) so that TWO workgroups share a CU -- five waves put two on the first
+// SIMD, and at 148 .. 170 registers (three waves per SIMD) the second workgroup is never placed there.  With the span count of a chunk chosen for 512 resident
+// workgroups (nagp_api_sweep.hpp, SM_BIG) the span passes of cfg2_batch take 243 -> 180 ms; either change alone: nothing (profiles/r05_gain_mfma.txt).
+#define BIG_REG_CAP(NTL) __attribute__((amdgpu_waves_per_eu((NTL) <= 5 ? 4 : 1, (NTL) <= 5 ? 4 : 8)))
+
 template <int NTL>
 struct BigCtx {
   int tid, wave, lane, i, kq;
@@ -203,7 +208,7 @@ __device__ __forceinline__ int big_vperm(int d) { const int cc = d & 15; return 
 
 // MODE 0: compose, C chain and c (pass 1) ; 1: boundary (pass 2) ; 2: apply (pass 3)
 template <int NTL, int MODE>
-__global__ void __launch_bounds__(64 * NTL) rts_big_kernel(Shape sh, Bufs b, MfmaPar sp) {
+__global__ void __launch_bounds__(64 * NTL) BIG_REG_CAP(NTL) rts_big_kernel(Shape sh, Bufs b, MfmaPar sp) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   constexpr int Sp = 16 * NTL, NT = 64 * NTL;
   BigCtx<NTL> c;
@@ -363,7 +368,7 @@ __global__ void __launch_bounds__(64 * NTL) rts_big_kernel(Shape sh, Bufs b, Mfm
 
 // ---- pass 1, Phi chain: Phi <- G Phi over the span, column J of Phi in the registers of wave J
 template <int NTL>
-__global__ void __launch_bounds__(64 * NTL) rts_big_phi_kernel(Shape sh, Bufs b, MfmaPar sp) {
+__global__ void __launch_bounds__(64 * NTL) BIG_REG_CAP(NTL) rts_big_phi_kernel(Shape sh, Bufs b, MfmaPar sp) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   constexpr int Sp = 16 * NTL, HALF = (NTL + 1) / 2, NPK = NTL - HALF;
   BigCtx<NTL> c;
